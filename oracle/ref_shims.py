@@ -1,0 +1,111 @@
+"""TEST INFRASTRUCTURE ONLY -- stand-ins that let the *real* reference import in the authoring container.
+
+The reference (`/root/reference`, xuelunshen/gim) imports two third-party packages on the gim_loftr
+path that are not installed here and cannot be installed (no network):
+
+  * kornia 0.6.10  -- `networks/loftr/utils/fine_matching.py:5-6` uses
+        kornia.geometry.subpix.dsnt.spatial_expectation2d   (line 49)
+        kornia.utils.grid.create_meshgrid                    (line 50)
+  * yacs           -- `networks/loftr/config.py:1` (`CfgNode`)
+
+`install()` registers minimal modules under those names in `sys.modules` (restating the published
+behaviour of the two kornia functions and a dict-backed CfgNode) and puts `/root/reference` on
+`sys.path`, so `oracle/make_golden.py` can run the reference's own modules to pin `oracle/loftr_oracle.py`.
+
+Nothing here is copied from the reference or from kornia/yacs sources; nothing here is imported by the
+product (`gim_amd/`).  `/root/reference` does not exist on the GPU box: only `oracle/make_golden.py`
+(run by hand in the authoring container) calls `install()`.
+"""
+import sys
+import types
+
+import torch
+
+REFERENCE_ROOT = "/root/reference"
+
+
+def _create_meshgrid(height, width, normalized_coordinates=True, device=None, dtype=torch.float32):
+    """kornia.utils.grid.create_meshgrid: [1,H,W,2] grid, last dim = (x, y), in [-1,1] if normalised."""
+    xs = torch.linspace(0, width - 1, width, device=device, dtype=dtype)
+    ys = torch.linspace(0, height - 1, height, device=device, dtype=dtype)
+    if normalized_coordinates:
+        xs = (xs / (width - 1) - 0.5) * 2
+        ys = (ys / (height - 1) - 0.5) * 2
+    gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+    return torch.stack([gx, gy], dim=-1).unsqueeze(0)
+
+
+def _spatial_expectation2d(inp, normalized_coordinates=True):
+    """kornia.geometry.subpix.dsnt.spatial_expectation2d: inp [B,N,H,W] (a distribution) -> [B,N,2] (x,y)."""
+    b, n, h, w = inp.shape
+    grid = _create_meshgrid(h, w, normalized_coordinates, inp.device).to(inp.dtype)
+    pos_x = grid[..., 0].reshape(-1)
+    pos_y = grid[..., 1].reshape(-1)
+    flat = inp.reshape(b, n, -1)
+    ex = torch.sum(pos_x * flat, -1, keepdim=True)
+    ey = torch.sum(pos_y * flat, -1, keepdim=True)
+    return torch.cat([ex, ey], -1).reshape(b, n, 2)
+
+
+class CfgNode(dict):
+    """Dict-backed stand-in for yacs.config.CfgNode (attribute access + clone), enough for
+    `networks/loftr/config.py:3-77`."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def clone(self):
+        out = CfgNode()
+        for k, v in self.items():
+            out[k] = v.clone() if isinstance(v, CfgNode) else v
+        return out
+
+
+def lower_config(cfg):
+    """Restates `networks/loftr/misc.py:13-16` (that module itself imports loguru / pytorch_lightning)."""
+    if not isinstance(cfg, CfgNode):
+        return cfg
+    return {k.lower(): lower_config(v) for k, v in cfg.items()}
+
+
+def install():
+    def mod(name):
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+        return m
+
+    if "kornia" not in sys.modules:
+        k = mod("kornia")
+        kg = mod("kornia.geometry")
+        ks = mod("kornia.geometry.subpix")
+        kd = mod("kornia.geometry.subpix.dsnt")
+        ku = mod("kornia.utils")
+        kug = mod("kornia.utils.grid")
+        kd.spatial_expectation2d = _spatial_expectation2d
+        ks.dsnt = kd
+        kg.subpix = ks
+        k.geometry = kg
+        kug.create_meshgrid = _create_meshgrid
+        ku.grid = kug
+        ku.create_meshgrid = _create_meshgrid
+        k.utils = ku
+    if "yacs" not in sys.modules:
+        y = mod("yacs")
+        yc = mod("yacs.config")
+        yc.CfgNode = CfgNode
+        y.config = yc
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+
+
+def reference_loftr_config():
+    """The effective gim_loftr config dict (`demo.py:333-335`: lower_config(get_cfg_defaults())['loftr'])."""
+    install()
+    from networks.loftr.config import get_cfg_defaults
+    return lower_config(get_cfg_defaults())["loftr"]

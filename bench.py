@@ -1,0 +1,162 @@
+"""gim_loftr throughput bench on MI355X (driver contract: see the repo prompt / DESIGN.md section 6).
+
+    python bench.py                       # 1 GPU, BASELINE config 2: gim_loftr 640x480 bf16, batch 8 pairs
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one LoFTR.forward (HIP path through the C ABI) over one batch of 8 synthetic 640x480 pairs that
+are already resident in HBM, including the match-count read-back the reference's contract has
+(coarse_matching.py:193).  Pairs shard embarrassingly across ranks (weak scaling: 8 pairs per rank per
+step); the only collective is one RCCL all-gather(v) of the packed matches at the end of the run.
+Rank 0 prints ONE JSON line.  `roofline` = all gim_conv2d_bn_act launches (the implicit-GEMM MFMA kernel:
+backbone convs + transformer linears, > 95 % of the step's FLOPs) timed live with HIP events on the launch
+stream in extra instrumented steps; `cpu_baseline` = the CPU oracle (a port of the reference's forward,
+pinned to it by golden vectors) timed on this host's cores on a bounded sample (1 pair).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+H, W = 480, 640
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense, MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="pairs per rank per step")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=1)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback in the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from gim_amd import ops
+    from gim_amd.loftr import LoFTR, get_cfg_defaults, lower_config
+    from gim_amd.runner import all_gather_matches, pack_matches
+
+    # random-init weights of the gim_loftr architecture (no checkpoint ships with the reference)
+    torch.manual_seed(0)
+    cfg = lower_config(get_cfg_defaults())["loftr"]
+    cfg["precision"] = args.precision
+    model = LoFTR(cfg).eval()
+    sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+
+    g = torch.Generator().manual_seed(1234 + rank)
+    nb = args.batch
+    c0 = torch.rand(nb, 3, H, W, generator=g).to(dev)
+    c1 = torch.rand(nb, 3, H, W, generator=g).to(dev)
+
+    def step():
+        d = {"image0": c0[:, :1], "image1": c1[:, :1], "color0": c0, "color1": c1}
+        model(d)
+        return d
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    rows = []
+    for s in range(args.steps):
+        d = step()
+        rows.append(pack_matches(d, [(s * world + rank) * nb + b for b in range(nb)]))
+    allrows = all_gather_matches(torch.cat(rows))  # the one collective: matches, for reporting
+    n_matches = int(allrows.shape[0])
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- live roofline of the dominant kernel (instrumented steps outside the timed region) --------
+    roof = None
+    if rank == 0:
+        ops.PROFILE = []
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in prof)
+        tot_fl = sum(f for _, _, f, _ in prof)
+        nlaunch = len(prof)
+        achieved = tot_fl / (tot_ms * 1e-3) / 1e12
+        peak = MFMA_PEAK_TFLOPS[args.precision]
+        by = {}
+        for e0, e1, f, lab in prof:
+            ms, fl = by.get(lab, (0.0, 0.0))
+            by[lab] = (ms + e0.elapsed_time(e1), fl + f)
+        top = sorted(by.items(), key=lambda kv: -kv[1][0])[:8]
+        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None,
+                "kernel": "igemm_kernel (gim_conv2d_bn_act)", "launches_per_step": nlaunch // 2,
+                "avg_launch_us": round(1e3 * tot_ms / nlaunch, 2),
+                "gflop_per_launch": round(tot_fl / nlaunch / 1e9, 3),
+                "kernel_ms_per_step": round(tot_ms / 2, 3),
+                "top_layers_ms_tflops": [[k, round(v[0] / 2, 3), round(v[1] / (v[0] * 1e-3) / 1e12, 1)] for k, v in top]}
+
+    # ---- CPU baseline: the oracle on this host's cores, bounded sample ------------------------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import loftr_oracle as O
+        ncore = os.cpu_count() or 1
+        torch.set_num_threads(ncore)
+        n = args.cpu_pairs
+        cc0, cc1 = c0[:n].cpu(), c1[:n].cpu()
+        tc = time.perf_counter()
+        with torch.no_grad():
+            O.loftr_forward(sd_cpu, {"image0": cc0[:, :1], "image1": cc1[:, :1], "color0": cc0, "color1": cc1})
+        tc = time.perf_counter() - tc
+        cpu = {"value": round(n / tc, 5), "unit": "pairs/s", "cores": ncore, "kind": "port",
+               "sample": f"{n} pair(s) 640x480 fp32, one un-warmed forward of oracle/loftr_oracle.py "
+                         f"(torch CPU, {ncore} threads), {tc:.1f} s"}
+
+    if rank == 0:
+        pairs = world * nb * args.steps
+        out = {
+            "metric": "image-pairs/sec at 640x480", "value": round(pairs / dt, 2), "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"gim_loftr {W}x{H}, batch {nb} pairs per GPU per step, random-init weights, "
+                                   f"uniform-noise images (device resident), outputs incl. match count read back",
+                       "pairs_per_step": world * nb, "matches_per_pair": round(n_matches / max(1, pairs), 2),
+                       "parallelism": f"pairs sharded over {world} GPU(s), no collective per step"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,89 @@
+"""ctypes binding of libgimhip.so (the C ABI declared in include/gim_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing the import fails loudly
+(`python -m gim_amd.build` or `__graft_entry__.build()` compiles it in-tree with hipcc).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgimhip.so")
+
+GIM_F32, GIM_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU1 = 0, 1, 2, 3
+
+c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+
+class ConvArgs(ctypes.Structure):
+    """struct gim_conv_args (include/gim_hip.h)."""
+    _fields_ = [
+        ("x", c_void_p), ("w", c_void_p), ("ktab", c_void_p), ("bias", c_void_p), ("res", c_void_p),
+        ("y", c_void_p), ("x_bytes", c_int64),
+        ("B", c_int), ("H", c_int), ("W", c_int), ("Ho", c_int), ("Wo", c_int),
+        ("stride", c_int), ("pad", c_int), ("ldx", c_int), ("ldy", c_int), ("ldres", c_int),
+        ("N", c_int), ("npad", c_int), ("kpad", c_int), ("act", c_int), ("res_mod", c_int),
+        ("dtype", c_int), ("out_dtype", c_int), ("res_dtype", c_int), ("use_lds_dma", c_int),
+    ]
+
+
+class CoarseArgs(ctypes.Structure):
+    """struct gim_coarse_args (include/gim_hip.h)."""
+    _fields_ = [
+        ("feat0", c_void_p), ("feat1", c_void_p), ("scale0", c_void_p), ("scale1", c_void_p),
+        ("ws", c_void_p), ("b_ids", c_void_p), ("i_ids", c_void_p), ("j_ids", c_void_p),
+        ("mconf", c_void_p), ("mkpts0_c", c_void_p), ("mkpts1_c", c_void_p), ("count", c_void_p),
+        ("N", c_int), ("L", c_int), ("S", c_int), ("C", c_int),
+        ("h0c", c_int), ("w0c", c_int), ("h1c", c_int), ("w1c", c_int),
+        ("cap", c_int), ("temperature", c_float), ("thr", c_float), ("border_rm", c_int),
+        ("scale", c_float),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/gim_hip.h
+PROTOTYPES = {
+    "gim_version": (c_int, []),
+    "gim_last_error": (ctypes.c_char_p, []),
+    "gim_ktile_bytes": (c_int, []),
+    "gim_npad_granule": (c_int, []),
+    "gim_nchw_to_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "gim_nhwc_to_nchw": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "gim_conv2d_bn_act": (c_int, [ctypes.POINTER(ConvArgs), c_void_p]),
+    "gim_upsample2x_add": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "gim_posenc_add": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
+    "gim_linear_attention_ws_bytes": (c_int64, [c_int] * 4),
+    "gim_linear_attention_kv": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),
+    "gim_linear_attention_apply": (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p]),
+    "gim_layernorm_residual": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_float, c_void_p]),
+    "gim_coarse_match_ws_bytes": (c_int64, [c_int] * 3),
+    "gim_coarse_match": (c_int, [ctypes.POINTER(CoarseArgs), c_void_p]),
+    "gim_coarse_conf_matrix": (c_int, [ctypes.POINTER(CoarseArgs), c_void_p, c_void_p]),
+    "gim_fine_gather": (c_int, [c_void_p] * 6 + [c_int] * 13 + [c_void_p]),
+    "gim_fine_match": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_float, c_int, c_void_p]),
+}
+
+
+class GimHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"libgimhip.so not found at {LIB_PATH}: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -m gim_amd.build` (needs hipcc, gfx950).")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib.gim_last_error()
+        raise GimHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,406 @@
+// Fused coarse matching for gfx950: dual-softmax + threshold + border + mutual-NN + ordered compaction
+// (networks/loftr/utils/coarse_matching.py:88-259) without ever writing the [N,L,S] matrix to HBM.
+//
+//   sim[n,i,j]  = (f0[n,i]/sqrt(C)) . (f1[n,j]/sqrt(C)) / T                       (coarse_matching.py:111,115)
+//   conf[n,i,j] = softmax_i(sim)[i,j] * softmax_j(sim)[i,j]                       (coarse_matching.py:118)
+//   match (i,j) <=> conf > thr, (i,j) off the border, conf == max_j conf[i,:], conf == max_i conf[:,j]
+//                                                                                 (coarse_matching.py:174-190)
+//   outputs ordered like torch.where(mask.max(dim=2)): ascending (n, i)           (coarse_matching.py:192-195)
+//
+// Pass A  (cm_stats):  128x128 similarity tiles on the fp32 MFMA (exact fp32: the parity bar asks for
+//          bit-exact indices against a CPU fp32 oracle, which bf16 operands cannot give -- SURVEY 7),
+//          tile staged in LDS, per-tile row/column (max, sum-exp) partials.
+// combine: partials -> per-row / per-column softmax statistics.
+// Pass B  (cm_cand):   tiles recomputed; conf evaluated only where the row factor alone already exceeds
+//          thr; elements with conf > thr become candidates (<= 4 per row, since sum_j softmax_j <= 1):
+//          atomicMax of conf into rowmax/colmax (positive floats order like their bit patterns).
+//          Restricting the maxima to candidates is exact: if conf[i,j] > thr and some conf[i,j'] >=
+//          conf[i,j], then (i,j') is a candidate too.
+// select:  candidate survives iff it equals both maxima and is off the border; ties -> smallest j
+//          (mask.max(dim=2) returns the first True).  compact: block scan per pair, ascending i.
+#include "igemm_mainloop.h"
+#include <limits.h>
+
+namespace {
+
+constexpr int BM = 128, BN = 128, WM = 2, WN = 2;
+constexpr int TLD = BN + 4;  // LDS similarity tile row stride in floats
+constexpr int TILE_SMEM = BM * TLD * 4 + (4 * 128 + 4 * 128) * 4;  // tile + reduction scratch
+static_assert(TILE_SMEM >= gim::mainloop_smem_bytes<BM, BN>(), "stage buffers must fit in the tile allocation");
+
+struct Cand { int i, j; float p; int pad; };
+
+struct CmWs {  // device pointers carved out of the caller's workspace
+    float2* rowpart;   // [N][ntS][L]
+    float2* colpart;   // [N][ntL][S]
+    float2* rowstat;   // [N][L]  (max, sum)
+    float2* colstat;   // [N][S]
+    unsigned* rowmaxP; // [N][L]
+    unsigned* colmaxP; // [N][S]
+    int* jsel;         // [N][L]
+    float* psel;       // [N][L]
+    int* lpos;         // [N][L]
+    int* ncand;        // [N]
+    Cand* cand;        // [N][capc]
+    int* ktab;         // dense K table for the mainloop
+    int ntL, ntS, capc;
+};
+
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t carve(CmWs& w, char* base, int N, int L, int S, int C) {
+    w.ntL = (L + BM - 1) / BM;
+    w.ntS = (S + BN - 1) / BN;
+    w.capc = 4 * L + 64;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + o : nullptr; o += al(bytes); return p; };
+    w.rowpart = (float2*)take((size_t)N * w.ntS * L * 8);
+    w.colpart = (float2*)take((size_t)N * w.ntL * S * 8);
+    w.rowstat = (float2*)take((size_t)N * L * 8);
+    w.colstat = (float2*)take((size_t)N * S * 8);
+    w.rowmaxP = (unsigned*)take((size_t)N * L * 4);
+    w.colmaxP = (unsigned*)take((size_t)N * S * 4);
+    w.jsel = (int*)take((size_t)N * L * 4);
+    w.psel = (float*)take((size_t)N * L * 4);
+    w.lpos = (int*)take((size_t)N * L * 4);
+    w.ncand = (int*)take((size_t)N * 4);
+    w.cand = (Cand*)take((size_t)N * w.capc * sizeof(Cand));
+    w.ktab = (int*)take((size_t)(C / 32 + 2) * 8 * 4);
+    return o;
+}
+
+struct CmGeom {
+    const float* feat0;
+    const float* feat1;
+    int N, L, S, C;
+    float inv_c, temperature, thr;
+};
+
+// similarity tile -> LDS (St[i][j], i = feat0 row, j = feat1 row), scaled like the reference
+template <int MODE>
+__device__ __forceinline__ void sim_tile_to_lds(const CmGeom& g, const int* ktab, int n, int m0, int n0, char* smem) {
+    gim::MainloopArgs ml;
+    ml.x = g.feat0 + (size_t)n * g.L * g.C;
+    ml.w = g.feat1 + (size_t)n * g.S * g.C;
+    ml.ktab = ktab;
+    ml.x_bytes = (unsigned)((size_t)g.L * g.C * 4);
+    ml.w_bytes = (unsigned)((size_t)g.S * g.C * 4);
+    ml.H = 1; ml.W = g.L; ml.Ho = 1; ml.Wo = g.L; ml.stride = 1; ml.pad = 0; ml.ldx = g.C;
+    ml.kpad = g.C; ml.M = g.L;
+    f32x16_t acc[2][2];
+    gim::igemm_mainloop<BM, BN, WM, WN, false, true>(ml, smem, m0, n0, acc);
+    // mainloop ends with a barrier: stage buffers are free, reuse them as the similarity tile
+    float* St = (float*)smem;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, lh = lane >> 5, wm = wave / WN, wn = wave - wm * WN;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i_loc = wm * 64 + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int j_loc = wn * 64 + i * 32 + rg * 8 + lh * 4;
+                float4 v;
+                v.x = (acc[i][j][rg * 4 + 0] * g.inv_c) / g.temperature;
+                v.y = (acc[i][j][rg * 4 + 1] * g.inv_c) / g.temperature;
+                v.z = (acc[i][j][rg * 4 + 2] * g.inv_c) / g.temperature;
+                v.w = (acc[i][j][rg * 4 + 3] * g.inv_c) / g.temperature;
+                *(float4*)(St + i_loc * TLD + j_loc) = v;
+            }
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) cm_stats_kernel(const CmGeom g, const CmWs w) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n = blockIdx.y;
+    const int mt = blockIdx.x / w.ntS, nt = blockIdx.x - mt * w.ntS;
+    const int m0 = mt * BM, n0 = nt * BN;
+    sim_tile_to_lds<0>(g, w.ktab, n, m0, n0, smem);
+    const float* St = (const float*)smem;
+    float* red = (float*)(smem + BM * TLD * 4);  // [4][128]: rowmax halves, rowsum halves
+    const int t = threadIdx.x, idx = t & 127, half = t >> 7;
+    const float NEG = -INFINITY;
+    // ---- rows: thread (row idx, column half) ----
+    {
+        float mx = NEG;
+        for (int jj = 0; jj < 64; jj += 4) {
+            const int j = half * 64 + jj;
+            const float4 v = *(const float4*)(St + idx * TLD + j);
+            if (n0 + j + 0 < g.S) mx = fmaxf(mx, v.x);
+            if (n0 + j + 1 < g.S) mx = fmaxf(mx, v.y);
+            if (n0 + j + 2 < g.S) mx = fmaxf(mx, v.z);
+            if (n0 + j + 3 < g.S) mx = fmaxf(mx, v.w);
+        }
+        red[half * 128 + idx] = mx;
+        __syncthreads();
+        const float m = fmaxf(red[idx], red[128 + idx]);
+        float z = 0.f;
+        for (int jj = 0; jj < 64; jj += 4) {
+            const int j = half * 64 + jj;
+            const float4 v = *(const float4*)(St + idx * TLD + j);
+            if (n0 + j + 0 < g.S) z += expf(v.x - m);
+            if (n0 + j + 1 < g.S) z += expf(v.y - m);
+            if (n0 + j + 2 < g.S) z += expf(v.z - m);
+            if (n0 + j + 3 < g.S) z += expf(v.w - m);
+        }
+        red[256 + half * 128 + idx] = z;
+        __syncthreads();
+        if (half == 0 && m0 + idx < g.L)
+            w.rowpart[((size_t)n * w.ntS + nt) * g.L + m0 + idx] = make_float2(m, red[256 + idx] + red[384 + idx]);
+        __syncthreads();
+    }
+    // ---- columns: thread (column idx, row half) ----
+    {
+        float mx = NEG;
+        for (int r = half * 64; r < half * 64 + 64; ++r)
+            if (m0 + r < g.L) mx = fmaxf(mx, St[r * TLD + idx]);
+        red[half * 128 + idx] = mx;
+        __syncthreads();
+        const float m = fmaxf(red[idx], red[128 + idx]);
+        float z = 0.f;
+        for (int r = half * 64; r < half * 64 + 64; ++r)
+            if (m0 + r < g.L) z += expf(St[r * TLD + idx] - m);
+        red[256 + half * 128 + idx] = z;
+        __syncthreads();
+        if (half == 0 && n0 + idx < g.S)
+            w.colpart[((size_t)n * w.ntL + mt) * g.S + n0 + idx] = make_float2(m, red[256 + idx] + red[384 + idx]);
+    }
+}
+
+// stat[n][x] = combine over tiles:  m = max m_t ; z = sum_t z_t * exp(m_t - m)   (ascending tile order)
+__global__ void cm_combine_kernel(const float2* __restrict__ part, float2* __restrict__ stat, int N, int len, int ntile) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * len) return;
+    const size_t n = idx / len, x = idx - n * len;
+    float m = -INFINITY;
+    for (int t = 0; t < ntile; ++t) m = fmaxf(m, part[(n * ntile + t) * len + x].x);
+    float z = 0.f;
+    for (int t = 0; t < ntile; ++t) {
+        const float2 p = part[(n * ntile + t) * len + x];
+        z += p.y * expf(p.x - m);
+    }
+    stat[idx] = make_float2(m, z);
+}
+
+__global__ void cm_init_kernel(const CmWs w, int N, int L, int S) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (size_t)N * L) { w.rowmaxP[idx] = 0u; w.jsel[idx] = INT_MAX; w.psel[idx] = 0.f; }
+    if (idx < (size_t)N * S) w.colmaxP[idx] = 0u;
+    if (idx < (size_t)N) w.ncand[idx] = 0;
+}
+
+__global__ void cm_ktab_kernel(int* ktab, int C) {  // dense table: K group g -> channel 4g; 2 padding slabs
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ng = (C / 32 + 2) * 8;
+    if (g < ng) ktab[g] = (g * 4 < C) ? g * 4 : (int)0xFF000000;
+}
+
+// MODE 0: emit candidates.  MODE 1: write the conf tile to `conf` (lazy data['conf_matrix']).
+template <int MODE>
+__global__ void __launch_bounds__(256) cm_cand_kernel(const CmGeom g, const CmWs w, float* __restrict__ conf) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n = blockIdx.y;
+    const int mt = blockIdx.x / w.ntS, nt = blockIdx.x - mt * w.ntS;
+    const int m0 = mt * BM, n0 = nt * BN;
+    sim_tile_to_lds<1>(g, w.ktab, n, m0, n0, smem);
+    const float* St = (const float*)smem;
+    float2* rs = (float2*)(smem + BM * TLD * 4);  // [128] row stats
+    float2* cs = rs + 128;                         // [128] col stats
+    const int t = threadIdx.x, idx = t & 127, half = t >> 7;
+    if (half == 0) rs[idx] = (m0 + idx < g.L) ? w.rowstat[(size_t)n * g.L + m0 + idx] : make_float2(0.f, 1.f);
+    else cs[idx] = (n0 + idx < g.S) ? w.colstat[(size_t)n * g.S + n0 + idx] : make_float2(0.f, 1.f);
+    __syncthreads();
+    const int i = m0 + idx;
+    if (i >= g.L) return;
+    const float2 r = rs[idx];
+    for (int jj = 0; jj < 64; ++jj) {
+        const int jl = half * 64 + jj, j = n0 + jl;
+        if (j >= g.S) break;
+        const float s = St[idx * TLD + jl];
+        const float pr = expf(s - r.x) / r.y;  // softmax over j (dim=2)
+        if (MODE == 1) {
+            const float2 c = cs[jl];
+            conf[((size_t)n * g.L + i) * g.S + j] = (expf(s - c.x) / c.y) * pr;
+        } else if (pr > g.thr) {
+            const float2 c = cs[jl];
+            const float pc = expf(s - c.x) / c.y;  // softmax over i (dim=1)
+            const float p = pc * pr;
+            if (p > g.thr) {
+                const unsigned pb = __float_as_uint(p);
+                atomicMax(&w.rowmaxP[(size_t)n * g.L + i], pb);
+                atomicMax(&w.colmaxP[(size_t)n * g.S + j], pb);
+                const int k = atomicAdd(&w.ncand[n], 1);
+                if (k < w.capc) w.cand[(size_t)n * w.capc + k] = Cand{i, j, p, 0};
+            }
+        }
+    }
+}
+
+struct BorderGeom { int h0c, w0c, h1c, w1c, b; };
+
+__device__ __forceinline__ bool off_border(int idx, int h, int wd, int b) {
+    const int y = idx / wd, x = idx - y * wd;
+    return y >= b && y < h - b && x >= b && x < wd - b;
+}
+
+// phase 0: jsel[i] = min j over surviving candidates; phase 1: psel[i] = conf of the selected one
+template <int PHASE>
+__global__ void cm_select_kernel(const CmWs w, int N, int L, int S, BorderGeom bg) {
+    const int n = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nc = min(w.ncand[n], w.capc);
+    if (k >= nc) return;
+    const Cand c = w.cand[(size_t)n * w.capc + k];
+    const unsigned pb = __float_as_uint(c.p);
+    if (pb != w.rowmaxP[(size_t)n * L + c.i] || pb != w.colmaxP[(size_t)n * S + c.j]) return;
+    if (!off_border(c.i, bg.h0c, bg.w0c, bg.b) || !off_border(c.j, bg.h1c, bg.w1c, bg.b)) return;
+    if (PHASE == 0) atomicMin(&w.jsel[(size_t)n * L + c.i], c.j);
+    else if (w.jsel[(size_t)n * L + c.i] == c.j) w.psel[(size_t)n * L + c.i] = c.p;
+}
+
+// one block (1024 threads) per pair: exclusive scan of the match flags over i
+__global__ void __launch_bounds__(1024) cm_scan_kernel(const CmWs w, int L, int* __restrict__ count) {
+    __shared__ int wtot[16];
+    __shared__ int running;
+    const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) running = 0;
+    __syncthreads();
+    for (int base = 0; base < L; base += 1024) {
+        const int i = base + t;
+        const bool f = i < L && w.jsel[(size_t)n * L + i] != INT_MAX;
+        const unsigned long long bal = __ballot(f);
+        const int excl = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wtot[wave] = __popcll(bal);
+        __syncthreads();
+        int off = running;
+        for (int k = 0; k < wave; ++k) off += wtot[k];
+        if (i < L) w.lpos[(size_t)n * L + i] = off + excl;
+        __syncthreads();
+        if (t == 0) {
+            int s = 0;
+            for (int k = 0; k < 16; ++k) s += wtot[k];
+            running += s;
+        }
+        __syncthreads();
+    }
+    if (t == 0) count[1 + n] = running;
+}
+
+struct EmitArgs {
+    int64_t *b_ids, *i_ids, *j_ids;
+    float *mconf, *mk0, *mk1;
+    const float *scale0, *scale1;
+    int* count;
+    int N, L, cap, w0c, w1c;
+    float scale;
+};
+
+__global__ void cm_emit_kernel(const CmWs w, const EmitArgs e) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0) {
+        int s = 0;
+        for (int k = 0; k < e.N; ++k) s += e.count[1 + k];
+        e.count[0] = s;
+    }
+    if (idx >= (size_t)e.N * e.L) return;
+    const int n = (int)(idx / e.L), i = (int)(idx - (size_t)n * e.L);
+    const int j = w.jsel[idx];
+    if (j == INT_MAX) return;
+    int o = w.lpos[idx];
+    for (int k = 0; k < n; ++k) o += e.count[1 + k];
+    if (o >= e.cap) return;
+    e.b_ids[o] = n; e.i_ids[o] = i; e.j_ids[o] = j;
+    e.mconf[o] = w.psel[idx];
+    // mkpts = [idx % w, idx // w] * (scale * scale{0,1}[b])   (coarse_matching.py:237-245)
+    const float s0x = e.scale0 ? e.scale * e.scale0[n * 2 + 0] : e.scale;
+    const float s0y = e.scale0 ? e.scale * e.scale0[n * 2 + 1] : e.scale;
+    const float s1x = e.scale1 ? e.scale * e.scale1[n * 2 + 0] : e.scale;
+    const float s1y = e.scale1 ? e.scale * e.scale1[n * 2 + 1] : e.scale;
+    e.mk0[2 * o + 0] = (float)(i % e.w0c) * s0x;
+    e.mk0[2 * o + 1] = (float)(i / e.w0c) * s0y;
+    e.mk1[2 * o + 0] = (float)(j % e.w1c) * s1x;
+    e.mk1[2 * o + 1] = (float)(j / e.w1c) * s1y;
+}
+
+int validate(const gim_coarse_args& a) {
+    GIM_REQUIRE(a.feat0 && a.feat1 && a.ws && a.count, "coarse_match: NULL pointer");
+    GIM_REQUIRE(a.N > 0 && a.L > 0 && a.S > 0, "coarse_match: bad sizes");
+    GIM_REQUIRE(a.C > 0 && a.C % 32 == 0, "coarse_match: C=%d must be a multiple of 32", a.C);
+    GIM_REQUIRE(a.h0c * a.w0c == a.L && a.h1c * a.w1c == a.S, "coarse_match: hw0_c/hw1_c do not match L/S");
+    GIM_REQUIRE((int64_t)a.L * a.C * 4 < (int64_t)0xFFFFFFF0ll && (int64_t)a.S * a.C * 4 < (int64_t)0xFFFFFFF0ll, "coarse_match: feature map too large");
+    GIM_REQUIRE(a.temperature > 0.f && a.thr > 0.f, "coarse_match: temperature and thr must be positive");
+    return GIM_OK;
+}
+
+template <typename K>
+int set_smem(K kern) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_SMEM);
+    if (e != hipSuccess) { gim_set_error("coarse_match: hipFuncSetAttribute: %s", hipGetErrorString(e)); return GIM_ERR_LAUNCH; }
+    return GIM_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t gim_coarse_match_ws_bytes(int N, int L, int S) {
+    CmWs w;
+    return (int64_t)carve(w, nullptr, N, L, S, 1024) + 256;
+}
+
+static int cm_prepare(const gim_coarse_args& a, CmWs& w, CmGeom& g) {
+    carve(w, (char*)a.ws, a.N, a.L, a.S, a.C);
+    g.feat0 = a.feat0; g.feat1 = a.feat1; g.N = a.N; g.L = a.L; g.S = a.S; g.C = a.C;
+    g.inv_c = 1.0f / (float)a.C; g.temperature = a.temperature; g.thr = a.thr;
+    static bool attr = false;
+    if (!attr) {
+        int rc = set_smem(cm_stats_kernel);
+        if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<0>);
+        if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<1>);
+        if (rc != GIM_OK) return rc;
+        attr = true;
+    }
+    return GIM_OK;
+}
+
+extern "C" int gim_coarse_match(const gim_coarse_args* ap, gim_stream_t stream) {
+    GIM_REQUIRE(ap, "coarse_match: NULL args");
+    const gim_coarse_args& a = *ap;
+    int rc = validate(a);
+    if (rc != GIM_OK) return rc;
+    GIM_REQUIRE(a.b_ids && a.i_ids && a.j_ids && a.mconf && a.mkpts0_c && a.mkpts1_c && a.cap > 0, "coarse_match: NULL output");
+    CmWs w; CmGeom g;
+    rc = cm_prepare(a, w, g);
+    if (rc != GIM_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nmax = (size_t)a.N * (a.L > a.S ? a.L : a.S);
+    hipLaunchKernelGGL(cm_init_kernel, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, s, w, a.N, a.L, a.S);
+    hipLaunchKernelGGL(cm_ktab_kernel, dim3(1), dim3(256), 0, s, w.ktab, a.C);
+    dim3 tgrid((unsigned)(w.ntL * w.ntS), (unsigned)a.N);
+    hipLaunchKernelGGL(cm_stats_kernel, tgrid, dim3(256), TILE_SMEM, s, g, w);
+    hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.L + 255) / 256)), dim3(256), 0, s, w.rowpart, w.rowstat, a.N, a.L, w.ntS);
+    hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.S + 255) / 256)), dim3(256), 0, s, w.colpart, w.colstat, a.N, a.S, w.ntL);
+    hipLaunchKernelGGL(cm_cand_kernel<0>, tgrid, dim3(256), TILE_SMEM, s, g, w, (float*)nullptr);
+    BorderGeom bg{a.h0c, a.w0c, a.h1c, a.w1c, a.border_rm};
+    dim3 cgrid((unsigned)((w.capc + 255) / 256), (unsigned)a.N);
+    hipLaunchKernelGGL(cm_select_kernel<0>, cgrid, dim3(256), 0, s, w, a.N, a.L, a.S, bg);
+    hipLaunchKernelGGL(cm_select_kernel<1>, cgrid, dim3(256), 0, s, w, a.N, a.L, a.S, bg);
+    hipLaunchKernelGGL(cm_scan_kernel, dim3((unsigned)a.N), dim3(1024), 0, s, w, a.L, a.count);
+    EmitArgs e{a.b_ids, a.i_ids, a.j_ids, a.mconf, a.mkpts0_c, a.mkpts1_c, a.scale0, a.scale1, a.count,
+               a.N, a.L, a.cap, a.w0c, a.w1c, a.scale};
+    hipLaunchKernelGGL(cm_emit_kernel, dim3((unsigned)(((size_t)a.N * a.L + 255) / 256)), dim3(256), 0, s, w, e);
+    return gim_check_launch("coarse_match");
+}
+
+extern "C" int gim_coarse_conf_matrix(const gim_coarse_args* ap, float* conf, gim_stream_t stream) {
+    GIM_REQUIRE(ap && conf, "coarse_conf_matrix: NULL args");
+    const gim_coarse_args& a = *ap;
+    int rc = validate(a);
+    if (rc != GIM_OK) return rc;
+    CmWs w; CmGeom g;
+    rc = cm_prepare(a, w, g);
+    if (rc != GIM_OK) return rc;
+    dim3 tgrid((unsigned)(w.ntL * w.ntS), (unsigned)a.N);
+    hipLaunchKernelGGL(cm_cand_kernel<1>, tgrid, dim3(256), TILE_SMEM, (hipStream_t)stream, g, w, conf);
+    return gim_check_launch("coarse_conf_matrix");
+}

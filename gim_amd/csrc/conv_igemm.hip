@@ -1,0 +1,141 @@
+// Implicit-GEMM convolution / linear layer with fused epilogue for gfx950 (MI355X).
+//
+//   y[m, n] = act( sum_k A[m,k] * w[n,k] + bias[n] + res[m, n] )
+//
+// m = output pixel row (b, ho, wo) in NHWC order, n = output channel, k = (dy, dx, c).
+// A is never materialised: each 16-byte K group of each pixel row is fetched straight from the NHWC
+// activation tensor into LDS by `buffer_load_dwordx4 ... lds` (LDS-DMA); spatial zero padding and
+// the K/M tails come for free from the buffer descriptor's bounds check (out-of-range offset -> 0).
+//
+// Tiling (wave64, MFMA 32x32): a 256-thread workgroup owns a BM x BN output tile, K is walked in
+// 128-byte slabs (64 bf16 / 32 fp32 per row), double buffered in LDS.  LDS image per operand is
+// [rows][128 B] with the 16-byte slot index XOR-swizzled by ((row >> 1) & 7): LDS-DMA writes are
+// lane-linear, so the swizzle is applied to the *source* K group each lane fetches and again on the
+// ds_read_b128 side -- conflict-free for the 32x32 fragment pattern (lanes 0-31: rows r..r+31 of one
+// slot, lanes 32-63: next slot).
+//
+// The MFMA computes the transposed tile (weights as the A operand, pixels as B) so that each lane
+// ends up with 4 *consecutive channels* of one pixel per accumulator quad -> 8/16-byte NHWC stores.
+//
+// dtype GIM_BF16: v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  dtype GIM_F32: v_mfma_f32_32x32x2_f32,
+// bit-equivalent to an fp32 fmaf chain -- the exact-parity mode.
+//
+// Replaces (reference file:line): networks/loftr/backbone/resnet.py:109-126,230-233,316-327 and the
+// nn.Linear calls of networks/loftr/submodules/transformer.py:47-55.
+#include "igemm_mainloop.h"
+
+namespace {
+
+using gim::KTB;
+
+template <int BM, int BN, int WM, int WN, bool BF16, bool LDSDMA>
+__global__ void __launch_bounds__(256)
+igemm_kernel(const gim_conv_args a, const int mtiles, const int ntiles, const int M) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ES = BF16 ? 2 : 4;
+    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned tile = xcd_remap(blockIdx.x, (unsigned)(mtiles * ntiles));
+    const int mt = tile / ntiles, nt = tile - mt * ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave - wm * WN;
+
+    gim::MainloopArgs ml;
+    ml.x = a.x; ml.w = a.w; ml.ktab = a.ktab;
+    ml.x_bytes = (unsigned)a.x_bytes;
+    ml.w_bytes = (unsigned)a.npad * (unsigned)a.kpad * ES;
+    ml.H = a.H; ml.W = a.W; ml.Ho = a.Ho; ml.Wo = a.Wo; ml.stride = a.stride; ml.pad = a.pad; ml.ldx = a.ldx;
+    ml.kpad = a.kpad; ml.M = M;
+    f32x16_t acc[TN][TM];
+    gim::igemm_mainloop<BM, BN, WM, WN, BF16, LDSDMA>(ml, smem, m0, n0, acc);
+
+    // ---- epilogue: lane holds, per (tn, tm), 4 quads of 4 consecutive channels of pixel l31 ------
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + wm * WTM + j * 32 + l31;
+        if (m >= M) continue;
+        const size_t yrow = (size_t)m * a.ldy;
+        const size_t rrow = a.res ? (size_t)(a.res_mod > 0 ? m % a.res_mod : m) * a.ldres : 0;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int n = n0 + wn * WTN + i * 32 + rg * 8 + lh * 4;
+                if (n >= a.N) continue;
+                float4 v = make_float4(acc[i][j][rg * 4 + 0], acc[i][j][rg * 4 + 1],
+                                       acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]);
+                if (a.bias) {
+                    const float4 bb = *(const float4*)(a.bias + n);
+                    v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+                }
+                if (a.res) {
+                    const float4 rr = a.res_dtype == GIM_BF16 ? ElemIO<true>::ld4(a.res, rrow + n)
+                                                              : ElemIO<false>::ld4(a.res, rrow + n);
+                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                }
+                if (a.act == GIM_ACT_RELU) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                } else if (a.act == GIM_ACT_LEAKY) {
+                    v.x = v.x > 0.f ? v.x : 0.01f * v.x; v.y = v.y > 0.f ? v.y : 0.01f * v.y;
+                    v.z = v.z > 0.f ? v.z : 0.01f * v.z; v.w = v.w > 0.f ? v.w : 0.01f * v.w;
+                } else if (a.act == GIM_ACT_ELU1) {  // elu(x)+1 exactly as torch: x>0 ? x+1 : (exp(x)-1)+1
+                    v.x = v.x > 0.f ? v.x + 1.f : (expf(v.x) - 1.f) + 1.f;
+                    v.y = v.y > 0.f ? v.y + 1.f : (expf(v.y) - 1.f) + 1.f;
+                    v.z = v.z > 0.f ? v.z + 1.f : (expf(v.z) - 1.f) + 1.f;
+                    v.w = v.w > 0.f ? v.w + 1.f : (expf(v.w) - 1.f) + 1.f;
+                }
+                if (a.out_dtype == GIM_BF16) ElemIO<true>::st4(a.y, yrow + n, v);
+                else ElemIO<false>::st4(a.y, yrow + n, v);
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool BF16, bool LDSDMA>
+int launch_igemm(const gim_conv_args& a, hipStream_t stream) {
+    constexpr int smem = 2 * (BM + BN) * KTB;
+    auto kern = igemm_kernel<BM, BN, WM, WN, BF16, LDSDMA>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) {
+            gim_set_error("hipFuncSetAttribute(%d B LDS): %s", smem, hipGetErrorString(e));
+            return GIM_ERR_LAUNCH;
+        }
+        attr_done = true;
+    }
+    const int M = a.B * a.Ho * a.Wo;
+    const int mtiles = (M + BM - 1) / BM, ntiles = a.npad / BN;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(mtiles * ntiles)), dim3(256), smem, stream, a, mtiles, ntiles, M);
+    return gim_check_launch("igemm_kernel");
+}
+
+template <bool BF16, bool LDSDMA>
+int dispatch_tile(const gim_conv_args& a, hipStream_t s) {
+    if (a.npad % 128 == 0) return launch_igemm<128, 128, 2, 2, BF16, LDSDMA>(a, s);
+    return launch_igemm<256, 64, 4, 1, BF16, LDSDMA>(a, s);
+}
+
+}  // namespace
+
+extern "C" int gim_conv2d_bn_act(const gim_conv_args* ap, gim_stream_t stream) {
+    GIM_REQUIRE(ap, "gim_conv2d_bn_act: NULL args");
+    const gim_conv_args& a = *ap;
+    const int es = a.dtype == GIM_BF16 ? 2 : 4;
+    GIM_REQUIRE(a.dtype == GIM_BF16 || a.dtype == GIM_F32, "conv: bad dtype %d", a.dtype);
+    GIM_REQUIRE(a.x && a.w && a.y && a.ktab, "conv: NULL x/w/y/ktab");
+    GIM_REQUIRE(a.npad > 0 && a.npad % 64 == 0, "conv: npad=%d must be a multiple of 64", a.npad);
+    GIM_REQUIRE(a.kpad > 0 && (a.kpad * es) % KTB == 0, "conv: kpad=%d is not a multiple of the %d-byte K slab", a.kpad, KTB);
+    GIM_REQUIRE(a.N > 0 && a.N % 4 == 0 && a.N <= a.npad, "conv: N=%d must be a multiple of 4 and <= npad=%d", a.N, a.npad);
+    GIM_REQUIRE(a.x_bytes > 0 && a.x_bytes < (int64_t)0xFFFFFFF0ll, "conv: x_bytes=%lld must be < 4 GiB", (long long)a.x_bytes);
+    GIM_REQUIRE(a.ldx % (16 / es) == 0, "conv: ldx=%d breaks 16-byte alignment", a.ldx);
+    GIM_REQUIRE(a.ldy % 4 == 0 && (!a.res || a.ldres % 4 == 0), "conv: ldy/ldres must be multiples of 4");
+    GIM_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.Ho > 0 && a.Wo > 0 && a.stride > 0, "conv: bad geometry");
+    GIM_REQUIRE((int64_t)a.B * a.Ho * a.Wo < (int64_t)0x7fffffff, "conv: too many output rows");
+    hipStream_t s = (hipStream_t)stream;
+    if (a.dtype == GIM_BF16) return a.use_lds_dma ? dispatch_tile<true, true>(a, s) : dispatch_tile<true, false>(a, s);
+    return a.use_lds_dma ? dispatch_tile<false, true>(a, s) : dispatch_tile<false, false>(a, s);
+}

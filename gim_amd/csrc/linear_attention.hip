@@ -1,0 +1,175 @@
+// LinearAttention core (networks/loftr/submodules/attentions.py:20-47) for gfx950.
+//
+//   KV[b,h] = sum_s K[b,s,h,:]^T (V[b,s,h,:] / S)        [D x D]      (attentions.py:42-43)
+//   Ksum[b,h] = sum_s K[b,s,h,:]                         [D]          (attentions.py:44)
+//   out[b,l,h,:] = (Q[b,l,h,:] KV[b,h]) * 1/(Q[b,l,h,:].Ksum[b,h] + eps) * S   (attentions.py:44-45)
+//
+// q/k arrive already mapped through elu(x)+1 (fused into the projection GEMM epilogue).  The whole
+// stage is HBM-bound (reads q,k,v once, writes out once); the D x D state lives in LDS.  Partial
+// sums over S chunks are combined in a fixed order (no float atomics -> run-to-run deterministic).
+#include "gim_common.h"
+
+namespace {
+
+constexpr int CH = 128;  // rows of S per block in the KV reduction
+
+template <int D, bool BF16>
+__global__ void __launch_bounds__(256)
+la_kv_kernel(const void* __restrict__ k, const void* __restrict__ v, float* __restrict__ part, int S, int H,
+             int ldk, int ldv, int nchunk) {
+    __shared__ __attribute__((aligned(16))) float Ks[CH][D];
+    __shared__ __attribute__((aligned(16))) float Vs[CH][D];
+    const int bh = blockIdx.x, chunk = blockIdx.y;
+    const int b = bh / H, h = bh - b * H;
+    const int s0 = chunk * CH;
+    const int t = threadIdx.x;
+    constexpr int Q4 = D / 4;            // float4 per row
+    constexpr int RPP = 256 / Q4;        // rows per pass
+    const float slen = (float)S;
+    for (int r = t / Q4; r < CH; r += RPP) {
+        const int s = s0 + r, c4 = (t % Q4) * 4;
+        float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
+        if (s < S) {
+            kk = ElemIO<BF16>::ld4(k, ((size_t)b * S + s) * ldk + h * D + c4);
+            vv = ElemIO<BF16>::ld4(v, ((size_t)b * S + s) * ldv + h * D + c4);
+            vv.x = vv.x / slen; vv.y = vv.y / slen; vv.z = vv.z / slen; vv.w = vv.w / slen;  // values / v_length
+        }
+        *(float4*)&Ks[r][c4] = kk;
+        *(float4*)&Vs[r][c4] = vv;
+    }
+    __syncthreads();
+    float* out = part + ((size_t)bh * nchunk + chunk) * (D * D + D);
+    const int nrow = min(CH, S - s0);
+    if (t < D * Q4) {
+        const int d = t / Q4, v0 = (t % Q4) * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = 0; r < nrow; ++r) {
+            const float kd = Ks[r][d];
+            const float4 vv = *(const float4*)&Vs[r][v0];
+            acc.x = fmaf(kd, vv.x, acc.x); acc.y = fmaf(kd, vv.y, acc.y);
+            acc.z = fmaf(kd, vv.z, acc.z); acc.w = fmaf(kd, vv.w, acc.w);
+        }
+        *(float4*)(out + d * D + v0) = acc;
+    }
+    if (t < D) {
+        float sk = 0.f;
+        for (int r = 0; r < nrow; ++r) sk += Ks[r][t];
+        out[D * D + t] = sk;
+    }
+}
+
+// final[bh][:] = sum_chunk part[bh][chunk][:] (ascending chunk order)
+__global__ void la_kv_finalize_kernel(const float* __restrict__ part, float* __restrict__ fin, int per, int nchunk,
+                                      size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const size_t bh = idx / per, e = idx - bh * per;
+    float s = 0.f;
+    for (int c = 0; c < nchunk; ++c) s += part[(bh * nchunk + c) * per + e];
+    fin[idx] = s;
+}
+
+template <int D, bool BF16, bool OUT_BF16>
+__global__ void __launch_bounds__(256)
+la_apply_kernel(const void* __restrict__ q, const float* __restrict__ kvfin, void* __restrict__ out, int L, int S,
+                int H, int ldq, int ldo) {
+    extern __shared__ __attribute__((aligned(16))) float kv[];  // [H][D*D + D]
+    const int b = blockIdx.x, l0 = blockIdx.y * 64;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    constexpr int PER = D * D + D;
+    for (int i = t; i < H * PER; i += 256) kv[i] = kvfin[(size_t)b * H * PER + i];
+    __syncthreads();
+    const int l = l0 + lane;
+    if (l >= L) return;
+    const float slen = (float)S;
+    for (int h = wave; h < H; h += 4) {
+        float qv[D];
+#pragma unroll
+        for (int c = 0; c < D; c += 4) {
+            const float4 x = ElemIO<BF16>::ld4(q, ((size_t)b * L + l) * ldq + h * D + c);
+            qv[c] = x.x; qv[c + 1] = x.y; qv[c + 2] = x.z; qv[c + 3] = x.w;
+        }
+        const float* KV = kv + h * PER;
+        float z = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) z = fmaf(qv[d], KV[D * D + d], z);
+        const float Z = 1.0f / (z + 1e-6f);
+#pragma unroll
+        for (int v0 = 0; v0 < D; v0 += 4) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const float4 w = *(const float4*)(KV + d * D + v0);
+                acc.x = fmaf(qv[d], w.x, acc.x); acc.y = fmaf(qv[d], w.y, acc.y);
+                acc.z = fmaf(qv[d], w.z, acc.z); acc.w = fmaf(qv[d], w.w, acc.w);
+            }
+            acc.x = acc.x * Z * slen; acc.y = acc.y * Z * slen; acc.z = acc.z * Z * slen; acc.w = acc.w * Z * slen;
+            ElemIO<OUT_BF16>::st4(out, ((size_t)b * L + l) * ldo + h * D + v0, acc);
+        }
+    }
+}
+
+inline int nchunks(int S) { return (S + CH - 1) / CH; }
+
+}  // namespace
+
+extern "C" int64_t gim_linear_attention_ws_bytes(int nb, int S, int H, int D) {
+    const int64_t per = (int64_t)D * D + D;
+    const int64_t nc = nchunks(S);
+    return (int64_t)nb * H * per * 4 * (nc > 1 ? nc + 1 : 1);
+}
+
+extern "C" int gim_linear_attention_kv(const void* k, const void* v, float* kv_ws, int nb, int S, int H, int D,
+                                       int ldk, int ldv, int dtype, gim_stream_t stream) {
+    GIM_REQUIRE(k && v && kv_ws && nb > 0 && S > 0 && H > 0, "linear_attention_kv: bad args");
+    GIM_REQUIRE(D == 32 || D == 16, "linear_attention_kv: head dim %d unsupported (16 or 32)", D);
+    GIM_REQUIRE(ldk % 4 == 0 && ldv % 4 == 0, "linear_attention_kv: ld alignment");
+    hipStream_t s = (hipStream_t)stream;
+    const int nc = nchunks(S);
+    const int per = D * D + D;
+    float* fin = kv_ws;
+    float* part = nc > 1 ? kv_ws + (size_t)nb * H * per : kv_ws;
+    dim3 grid((unsigned)(nb * H), (unsigned)nc);
+    const bool bf = dtype == GIM_BF16;
+    if (D == 32) {
+        if (bf) hipLaunchKernelGGL((la_kv_kernel<32, true>), grid, dim3(256), 0, s, k, v, part, S, H, ldk, ldv, nc);
+        else hipLaunchKernelGGL((la_kv_kernel<32, false>), grid, dim3(256), 0, s, k, v, part, S, H, ldk, ldv, nc);
+    } else {
+        if (bf) hipLaunchKernelGGL((la_kv_kernel<16, true>), grid, dim3(256), 0, s, k, v, part, S, H, ldk, ldv, nc);
+        else hipLaunchKernelGGL((la_kv_kernel<16, false>), grid, dim3(256), 0, s, k, v, part, S, H, ldk, ldv, nc);
+    }
+    int rc = gim_check_launch("la_kv");
+    if (rc != GIM_OK) return rc;
+    if (nc > 1) {
+        const size_t total = (size_t)nb * H * per;
+        hipLaunchKernelGGL(la_kv_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, part, fin, per, nc, total);
+        rc = gim_check_launch("la_kv_finalize");
+    }
+    return rc;
+}
+
+extern "C" int gim_linear_attention_apply(const void* q, const float* kv_ws, void* out, int nb, int L, int S, int H,
+                                          int D, int ldq, int ldo, int dtype, int out_dtype, gim_stream_t stream) {
+    GIM_REQUIRE(q && kv_ws && out && nb > 0 && L > 0 && S > 0 && H > 0, "linear_attention_apply: bad args");
+    GIM_REQUIRE(D == 32 || D == 16, "linear_attention_apply: head dim %d unsupported (16 or 32)", D);
+    GIM_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0, "linear_attention_apply: ld alignment");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)nb, (unsigned)((L + 63) / 64));
+    const size_t smem = (size_t)H * (D * D + D) * 4;
+    GIM_REQUIRE(smem <= 64 * 1024, "linear_attention_apply: H=%d too large", H);
+    const bool bf = dtype == GIM_BF16, obf = out_dtype == GIM_BF16;
+#define LA_APPLY(DD, A, B) hipLaunchKernelGGL((la_apply_kernel<DD, A, B>), grid, dim3(256), smem, s, q, kv_ws, out, L, S, H, ldq, ldo)
+    if (D == 32) {
+        if (bf && obf) LA_APPLY(32, true, true);
+        else if (bf) LA_APPLY(32, true, false);
+        else if (obf) LA_APPLY(32, false, true);
+        else LA_APPLY(32, false, false);
+    } else {
+        if (bf && obf) LA_APPLY(16, true, true);
+        else if (bf) LA_APPLY(16, true, false);
+        else if (obf) LA_APPLY(16, false, true);
+        else LA_APPLY(16, false, false);
+    }
+#undef LA_APPLY
+    return gim_check_launch("la_apply");
+}

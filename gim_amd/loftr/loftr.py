@@ -1,0 +1,432 @@
+"""gim_loftr on MI355X: the reference's `LoFTR` module surface (`networks/loftr/loftr.py:14-99`) over
+hand-written HIP.
+
+Drop-in contract kept:
+  * `LoFTR(config)` takes the same lower-case dict (`demo.py:333-335`, `trainer/lightning.py:45-46`);
+  * `state_dict()` has the reference's 375 keys / shapes, `load_state_dict` strips the `model.` /
+    `matcher.` prefixes (`loftr.py:93-99`), so reference checkpoints load unchanged;
+  * `model(data)` mutates `data` in place and returns None; keys, dtypes, shapes and insertion order
+    follow SURVEY Appendix A2 (`conf_matrix` is produced lazily, see `LazyConfMatrix`).
+
+What is different underneath: the nn.Module tree below only *holds parameters*.  `forward` never calls a
+torch op on the data path: weights are pre-packed once (BN folded, K-contiguous, padded) and every stage
+is a libgimhip kernel launched through ctypes on torch's current HIP stream.  There is no CPU / eager
+fallback: without the HIP library the import fails, without a GPU tensor the call raises.
+
+Precision modes (`config['precision']`, default env GIM_PRECISION or 'bf16'):
+  'fp32'  fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32 products/accumulate) -- the parity mode;
+  'bf16'  bf16 operands / fp32 accumulate for the backbone and the transformer GEMMs -- the throughput
+          mode.  Coarse matching always runs on fp32 features with fp32 MFMA (index exactness).
+"""
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import ACT_ELU1, ACT_LEAKY, ACT_NONE, ACT_RELU, GIM_BF16, GIM_F32, GimHipError
+from ..packing import cstore, pack_conv, torch_dtype
+
+
+# --------------------------------------------------------------------------------------------------
+# parameter containers with the reference's names (never executed)
+# --------------------------------------------------------------------------------------------------
+def _conv(ci, co, k, stride=1):
+    return nn.Conv2d(ci, co, kernel_size=k, stride=stride, padding=k // 2, bias=False)
+
+
+class _Bottleneck(nn.Module):
+    """parameter layout of resnet.py:71-107 (ResNet v1.5 bottleneck, stride on conv2)"""
+
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = _conv(inplanes, planes, 1)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = _conv(planes, planes, 3, stride)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = _conv(planes, planes * 4, 1)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class _ResNetEncoder(nn.Module):
+    """resnet.py:129-167 with Bottleneck,[3,4,6,3]: conv1/bn1 + layer1..3 (no maxpool, no layer4/fc)"""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        inpl = 64
+        for li, (planes, nblk, stride) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2)), start=1):
+            blocks = []
+            for bi in range(nblk):
+                ds = None
+                if bi == 0:
+                    ds = nn.Sequential(_conv(inpl, planes * 4, 1, stride), nn.BatchNorm2d(planes * 4))
+                blocks.append(_Bottleneck(inpl, planes, stride if bi == 0 else 1, ds))
+                inpl = planes * 4
+            setattr(self, f"layer{li}", nn.Sequential(*blocks))
+
+
+class _ResNetFPN_8_2(nn.Module):
+    """parameter layout of resnet.py:253-297"""
+
+    def __init__(self, config):
+        super().__init__()
+        bd = config["block_dims"]
+        self.encode = _ResNetEncoder()
+        self.layer3_outconv = _conv(bd[5], bd[3], 1)
+        self.layer2_outconv = _conv(bd[4], bd[3], 1)
+        self.layer2_outconv2 = nn.Sequential(_conv(bd[3], bd[3], 3), nn.BatchNorm2d(bd[3]), nn.LeakyReLU(),
+                                             _conv(bd[3], bd[2], 3))
+        self.layer1_outconv = _conv(bd[3], bd[2], 1)
+        self.layer1_outconv2 = nn.Sequential(_conv(bd[2], bd[2], 3), nn.BatchNorm2d(bd[2]), nn.LeakyReLU(),
+                                             _conv(bd[2], bd[1], 3))
+        for m in self.modules():  # resnet.py:291-296
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+
+class _EncoderLayer(nn.Module):
+    """parameter layout of transformer.py:8-33"""
+
+    def __init__(self, d_model, nhead):
+        super().__init__()
+        self.q_proj = nn.Linear(d_model, d_model, bias=False)
+        self.k_proj = nn.Linear(d_model, d_model, bias=False)
+        self.v_proj = nn.Linear(d_model, d_model, bias=False)
+        self.merge = nn.Linear(d_model, d_model, bias=False)
+        self.mlp = nn.Sequential(nn.Linear(d_model * 2, d_model * 2, bias=False), nn.ReLU(True),
+                                 nn.Linear(d_model * 2, d_model, bias=False))
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+
+
+class _LocalFeatureTransformer(nn.Module):
+    """parameter layout of transformer.py:64-78"""
+
+    def __init__(self, config):
+        super().__init__()
+        if config["attention"] != "linear":
+            raise NotImplementedError("gim_loftr uses LinearAttention (config.py:22,41); 'full' is not built")
+        self.d_model, self.nhead = config["d_model"], config["nhead"]
+        self.layer_names = ["self", "cross"] * config["layer_names"]
+        self.layers = nn.ModuleList([_EncoderLayer(self.d_model, self.nhead) for _ in self.layer_names])
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+
+class LazyConfMatrix:
+    """data['conf_matrix'] (coarse_matching.py:144).  Nothing on the inference path reads it (only the
+    training losses do), and at 640x480 batch 8 it is 737 MB, so the engine materialises it on demand:
+    `.get()` / `torch.as_tensor(obj.get())` launches the HIP kernel that writes [N,L,S] fp32."""
+
+    def __init__(self, coarse_result):
+        self._r = coarse_result
+        self._t = None
+
+    def get(self):
+        if self._t is None:
+            self._t = ops.coarse_conf_matrix(self._r)
+        return self._t
+
+    @property
+    def shape(self):
+        a = self._r.args
+        return torch.Size([a.N, a.L, a.S])
+
+
+def _precision_from(config):
+    p = (config.get("precision") or os.environ.get("GIM_PRECISION") or "bf16").lower()
+    if p not in ("bf16", "fp32"):
+        raise ValueError(f"precision must be 'bf16' or 'fp32', got {p!r}")
+    return p
+
+
+class LoFTR(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        if config["backbone_type"] != "ResNetFPN" or tuple(config["resolution"]) != (8, 2):
+            # backbone/__init__.py:4-11: only ResNetFPN (8,2) is constructible in the reference either
+            raise ValueError(f"LOFTR.BACKBONE_TYPE/RESOLUTION {config['backbone_type']} {config['resolution']} not supported.")
+        if config["match_coarse"]["match_type"] != "dual_softmax":
+            raise NotImplementedError("only match_type='dual_softmax' (the gim_loftr setting) is built")
+        if config["fine_concat_coarse_feat"]:
+            raise NotImplementedError("fine_concat_coarse_feat=True is not used by gim_loftr and is not built")
+        self.precision = _precision_from(config)
+        self.backbone = _ResNetFPN_8_2(config["resnetfpn"])
+        self.loftr_coarse = _LocalFeatureTransformer(config["coarse"])
+        self.loftr_fine = _LocalFeatureTransformer(config["fine"])
+        self.W = config["fine_window_size"]
+        self.use_lds_dma = os.environ.get("GIM_LDS_DMA", "1") != "0"
+        self._packed = None
+        self._packed_key = None
+        self._pe_cache = {}
+        self.debug = None  # set to a dict to capture stage outputs (tests): coarse/fine maps, token features
+        if config.get("weight") is not None:
+            self.load_state_dict(torch.load(config["weight"], map_location="cpu"))
+
+    # ---- checkpoint surface (loftr.py:93-99) -----------------------------------------------------
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        for k in list(state_dict.keys()):
+            if k.startswith("model."):
+                state_dict[k.replace("model.", "", 1)] = state_dict.pop(k)
+            if k.startswith("matcher."):
+                state_dict[k.replace("matcher.", "", 1)] = state_dict.pop(k)
+        self._packed = None
+        return super().load_state_dict(state_dict, *args, **kwargs)
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def set_precision(self, precision):
+        assert precision in ("bf16", "fp32")
+        self.precision = precision
+        self._packed = None
+        return self
+
+    # ---- weight pre-pack --------------------------------------------------------------------------
+    @staticmethod
+    def _bn(m):
+        return (m.weight, m.bias, m.running_mean, m.running_var, m.eps)
+
+    def _prepack(self, device):
+        key = (str(device), self.precision)
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        dt = GIM_BF16 if self.precision == "bf16" else GIM_F32
+        P = {}
+        enc = self.backbone.encode
+        P["stem"] = pack_conv(enc.conv1.weight, self._bn(enc.bn1), dt, device, stride=2, pad=3, cin_pad=cstore(3, dt))
+        for li in (1, 2, 3):
+            for bi, blk in enumerate(getattr(enc, f"layer{li}")):
+                p = f"l{li}.{bi}."
+                P[p + "c1"] = pack_conv(blk.conv1.weight, self._bn(blk.bn1), dt, device)
+                P[p + "c2"] = pack_conv(blk.conv2.weight, self._bn(blk.bn2), dt, device, stride=blk.stride, pad=1)
+                P[p + "c3"] = pack_conv(blk.conv3.weight, self._bn(blk.bn3), dt, device)
+                if blk.downsample is not None:
+                    P[p + "ds"] = pack_conv(blk.downsample[0].weight, self._bn(blk.downsample[1]), dt, device,
+                                            stride=blk.stride)
+        bb = self.backbone
+        P["l3o"] = pack_conv(bb.layer3_outconv.weight, None, dt, device)
+        P["l2o"] = pack_conv(bb.layer2_outconv.weight, None, dt, device)
+        P["l2o2a"] = pack_conv(bb.layer2_outconv2[0].weight, self._bn(bb.layer2_outconv2[1]), dt, device, pad=1)
+        P["l2o2b"] = pack_conv(bb.layer2_outconv2[3].weight, None, dt, device, pad=1)
+        P["l1o"] = pack_conv(bb.layer1_outconv.weight, None, dt, device)
+        P["l1o2a"] = pack_conv(bb.layer1_outconv2[0].weight, self._bn(bb.layer1_outconv2[1]), dt, device, pad=1)
+        P["l1o2b"] = pack_conv(bb.layer1_outconv2[3].weight, None, dt, device, pad=1)
+        for name, tf in (("c", self.loftr_coarse), ("f", self.loftr_fine)):
+            for li, layer in enumerate(tf.layers):
+                p = f"{name}{li}."
+                for lin in ("q_proj", "k_proj", "v_proj", "merge"):
+                    P[p + lin] = pack_conv(getattr(layer, lin).weight, None, dt, device)
+                P[p + "mlp0"] = pack_conv(layer.mlp[0].weight, None, dt, device)
+                P[p + "mlp2"] = pack_conv(layer.mlp[2].weight, None, dt, device)
+                for nm in ("norm1", "norm2"):
+                    ln = getattr(layer, nm)
+                    P[p + nm] = (ln.weight.detach().float().to(device).contiguous(),
+                                 ln.bias.detach().float().to(device).contiguous(), ln.eps)
+        self._packed, self._packed_key = P, key
+        return P
+
+    def _pos_encoding(self, d_model, h, w, device):
+        """[h*w, C] fp32 table = pos_encoding buffer (position_encoding.py:22-36, temp_bug_fix=False as in
+        loftr.py:22-24) sliced to (h,w) and laid out 'h w c'.  Constant per shape: built once on the host
+        with the same fp32 ops as the reference, cached on the device."""
+        key = (d_model, h, w, str(device))
+        if key not in self._pe_cache:
+            if h > 256 or w > 256:
+                raise ValueError("coarse map exceeds PositionEncodingSine max_shape (256,256)")
+            y_pos = torch.ones(h, w).cumsum(0).float().unsqueeze(0)
+            x_pos = torch.ones(h, w).cumsum(1).float().unsqueeze(0)
+            div = torch.exp(torch.arange(0, d_model // 2, 2).float() * (-math.log(10000.0) / d_model // 2))
+            div = div[:, None, None]
+            pe = torch.zeros(d_model, h, w)
+            pe[0::4] = torch.sin(x_pos * div)
+            pe[1::4] = torch.cos(x_pos * div)
+            pe[2::4] = torch.sin(y_pos * div)
+            pe[3::4] = torch.cos(y_pos * div)
+            self._pe_cache[key] = pe.permute(1, 2, 0).reshape(h * w, d_model).contiguous().to(device)
+        return self._pe_cache[key]
+
+    # ---- stages -------------------------------------------------------------------------------------
+    def _backbone(self, P, images, dt):
+        """images: list of [n_i,3,H,W] fp32 tensors sharing (H,W).  Returns (x3_out NHWC [B,h8,w8,256],
+        feat_f NHWC [B,h2,w2,128]) in the compute dtype.  (resnet.py:230-235, 306-329)"""
+        dev = images[0].device
+        H, W = images[0].shape[2:]
+        B = sum(im.shape[0] for im in images)
+        tdt = torch_dtype(dt)
+        x = torch.empty(B, H, W, cstore(3, dt), dtype=tdt, device=dev)
+        off = 0
+        for im in images:  # replaces torch.cat([color0, color1]) (loftr.py:60)
+            ops.nchw_to_nhwc(im.contiguous().float(), x, off)
+            off += im.shape[0]
+        dma = self.use_lds_dma
+        x = ops.conv2d(x, P["stem"], ACT_RELU, lds_dma=dma)
+        feats = []
+        for li, nblk in ((1, 3), (2, 4), (3, 6)):
+            for bi in range(nblk):
+                p = f"l{li}.{bi}."
+                o = ops.conv2d(x, P[p + "c1"], ACT_RELU, lds_dma=dma)
+                o = ops.conv2d(o, P[p + "c2"], ACT_RELU, lds_dma=dma)
+                idn = ops.conv2d(x, P[p + "ds"], ACT_NONE, lds_dma=dma) if (p + "ds") in P else x
+                x = ops.conv2d(o, P[p + "c3"], ACT_RELU, res=idn, lds_dma=dma)
+            feats.append(x)
+        x1, x2, x3 = feats
+        x3_out = ops.conv2d(x3, P["l3o"], lds_dma=dma)
+        x2_out = ops.conv2d(x2, P["l2o"], lds_dma=dma)
+        ops.upsample2x_add(x3_out, x2_out)
+        x2_out = ops.conv2d(ops.conv2d(x2_out, P["l2o2a"], ACT_LEAKY, lds_dma=dma), P["l2o2b"], lds_dma=dma)
+        x1_out = ops.conv2d(x1, P["l1o"], lds_dma=dma)
+        ops.upsample2x_add(x2_out, x1_out)
+        x1_out = ops.conv2d(ops.conv2d(x1_out, P["l1o2a"], ACT_LEAKY, lds_dma=dma), P["l1o2b"], lds_dma=dma)
+        return x3_out, x1_out
+
+    class _TfBuffers:
+        """Row buffers of one LocalFeatureTransformer run over R rows of width C."""
+
+        def __init__(self, R, C, tdt, dev):
+            f32 = torch.float32
+            self.X32 = torch.empty(R, C, dtype=f32, device=dev)       # fp32 master of the token features
+            self.CAT = torch.empty(R, 2 * C, dtype=tdt, device=dev)   # [x | norm1(message)] GEMM operand
+            self.Q = torch.empty(R, C, dtype=tdt, device=dev)
+            self.K = torch.empty(R, C, dtype=tdt, device=dev)
+            self.V = torch.empty(R, C, dtype=tdt, device=dev)
+            self.MSG = torch.empty(R, C, dtype=tdt, device=dev)
+            self.MRG = torch.empty(R, C, dtype=f32, device=dev)
+            self.HID = torch.empty(R, 2 * C, dtype=tdt, device=dev)
+            self.MLP = torch.empty(R, C, dtype=f32, device=dev)
+            self.ws = None
+
+    def _encoder_layer(self, P, p, T, xs, ss, nb, L, S, H):
+        """LoFTREncoderLayer.forward (transformer.py:35-58) on row ranges xs (queries) / ss (source)."""
+        C = T.X32.shape[1]
+        dma = self.use_lds_dma
+        x_t, s_t = T.CAT[xs, :C], T.CAT[ss, :C]
+        ops.linear(x_t, P[p + "q_proj"], T.Q[xs], ACT_ELU1, dma)   # elu(q)+1 fused (attentions.py:31)
+        ops.linear(s_t, P[p + "k_proj"], T.K[ss], ACT_ELU1, dma)   # elu(k)+1 fused (attentions.py:32)
+        ops.linear(s_t, P[p + "v_proj"], T.V[ss], ACT_NONE, dma)
+        T.ws = ops.linear_attention(T.Q[xs], T.K[ss], T.V[ss], T.MSG[xs], nb, L, nb, S, H, T.ws)
+        ops.linear(T.MSG[xs], P[p + "merge"], T.MRG[xs], ACT_NONE, dma)
+        g1, b1, e1 = P[p + "norm1"]
+        ops.layernorm_residual(T.MRG[xs], g1, b1, None, None, T.CAT[xs, C:], e1)
+        ops.linear(T.CAT[xs], P[p + "mlp0"], T.HID[xs], ACT_RELU, dma)
+        ops.linear(T.HID[xs], P[p + "mlp2"], T.MLP[xs], ACT_NONE, dma)
+        g2, b2, e2 = P[p + "norm2"]
+        ops.layernorm_residual(T.MLP[xs], g2, b2, T.X32[xs], T.X32[xs], T.CAT[xs, :C], e2)  # x + message
+
+    def _transformer(self, P, name, tf, T, n0, L, n1, S):
+        """LocalFeatureTransformer.forward (transformer.py:80-101).  Rows [0, n0*L) are feat0's tokens,
+        rows [n0*L, n0*L + n1*S) feat1's; n0 == n1 sequences on each side."""
+        r0, r1 = slice(0, n0 * L), slice(n0 * L, n0 * L + n1 * S)
+        rall = slice(0, n0 * L + n1 * S)
+        H = tf.nhead
+        for li, kind in enumerate(tf.layer_names):
+            p = f"{name}{li}."
+            if kind == "self":
+                if L == S:  # one launch set for both sides: same weights, independent sequences
+                    self._encoder_layer(P, p, T, rall, rall, n0 + n1, L, S, H)
+                else:
+                    self._encoder_layer(P, p, T, r0, r0, n0, L, L, H)
+                    self._encoder_layer(P, p, T, r1, r1, n1, S, S, H)
+            else:  # cross: feat0 first, then feat1 against the *updated* feat0 (transformer.py:95-96)
+                self._encoder_layer(P, p, T, r0, r1, n0, L, S, H)
+                self._encoder_layer(P, p, T, r1, r0, n1, S, L, H)
+
+    # ---- forward (loftr.py:43-91) -------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, data):
+        for k in ("image0", "image1", "color0", "color1"):
+            if k not in data:
+                raise KeyError(f"LoFTR.forward needs data[{k!r}] (loftr.py:54-63)")
+        color0, color1 = data["color0"], data["color1"]
+        if not color0.is_cuda:
+            raise GimHipError("gim_amd LoFTR runs on the HIP device only (no CPU fallback): move the inputs "
+                              "and the module to 'cuda'")
+        if "mask0" in data:
+            raise NotImplementedError("padding masks (mask0/mask1, coarse_matching.py:29-44) are not built yet")
+        dev = color0.device
+        dt = GIM_BF16 if self.precision == "bf16" else GIM_F32
+        tdt = torch_dtype(dt)
+        P = self._prepack(dev)
+        cfg = self.config
+
+        data.update({"bs": data["image0"].size(0),
+                     "hw0_i": data["image0"].shape[2:], "hw1_i": data["image1"].shape[2:]})
+        bs = data["bs"]
+        if data["hw0_i"] == data["hw1_i"]:
+            c_all, f_all = self._backbone(P, [color0, color1], dt)
+            c0, c1 = c_all[:bs], c_all[bs:]
+            f_both = f_all
+        else:
+            c0, f0 = self._backbone(P, [color0], dt)
+            c1, f1 = self._backbone(P, [color1], dt)
+            f_both = None
+        if self.debug is not None:
+            self.debug.update({"c0": c0, "c1": c1, "f_all": f_both, "f0": None if f_both is not None else f0,
+                               "f1": None if f_both is not None else f1})
+        hw0_c, hw1_c = c0.shape[1:3], c1.shape[1:3]
+        hw0_f = (f_all.shape[1:3] if f_both is not None else f0.shape[1:3])
+        hw1_f = (f_all.shape[1:3] if f_both is not None else f1.shape[1:3])
+        data.update({"hw0_c": torch.Size(hw0_c), "hw1_c": torch.Size(hw1_c),
+                     "hw0_f": torch.Size(hw0_f), "hw1_f": torch.Size(hw1_f)})
+
+        # 2. coarse transformer on pos-encoded tokens (NHWC rows == 'n (h w) c', loftr.py:74-75)
+        C = cfg["coarse"]["d_model"]
+        L, S = hw0_c[0] * hw0_c[1], hw1_c[0] * hw1_c[1]
+        T = self._TfBuffers(bs * (L + S), C, tdt, dev)
+        r0, r1 = slice(0, bs * L), slice(bs * L, bs * (L + S))
+        ops.posenc_add(c0.reshape(-1, C), self._pos_encoding(C, *hw0_c, dev), T.X32[r0], T.CAT[r0, :C])
+        ops.posenc_add(c1.reshape(-1, C), self._pos_encoding(C, *hw1_c, dev), T.X32[r1], T.CAT[r1, :C])
+        self._transformer(P, "c", self.loftr_coarse, T, bs, L, bs, S)
+
+        if self.debug is not None:
+            self.debug.update({"feat_c0": T.X32[r0].view(bs, L, C), "feat_c1": T.X32[r1].view(bs, S, C)})
+
+        # 3. coarse matching (coarse_matching.py:88-259), fused
+        mc = cfg["match_coarse"]
+        scale = data["hw0_i"][0] / hw0_c[0]
+        cr = ops.coarse_match(T.X32[r0].view(bs, L, C), T.X32[r1].view(bs, S, C), hw0_c, hw1_c, scale,
+                              mc["dsmax_temperature"], mc["thr"], mc["border_rm"],
+                              data.get("scale0"), data.get("scale1"))
+        M = int(cr.count[0].item())  # the one host sync the reference also has (torch.where, :193)
+        b_ids, i_ids, j_ids = cr.b_ids[:M], cr.i_ids[:M], cr.j_ids[:M]
+        mconf = cr.mconf[:M]
+        data.update({"conf_matrix": LazyConfMatrix(cr)})
+        data.update({"b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids,
+                     "gt_mask": torch.zeros(M, dtype=torch.bool, device=dev),  # mconf == 0 never holds (> thr)
+                     "m_bids": b_ids.clone(),
+                     "mkpts0_c": cr.mkpts0_c[:M], "mkpts1_c": cr.mkpts1_c[:M], "mconf": mconf})
+        self._last_coarse = cr
+
+        # 4./5. fine level (fine_preprocess.py:29-47, transformer on [M,25,128], fine_matching.py:15-74)
+        W = self.W
+        data.update({"W": W})
+        WW = W * W
+        Cf = cfg["fine"]["d_model"]
+        if M == 0:
+            data.update({"expec_f": torch.empty(0, 3, device=dev),
+                         "mkpts0_f": data["mkpts0_c"], "mkpts1_f": data["mkpts1_c"]})
+            return
+        if f_both is None:
+            if hw0_f != hw1_f:
+                raise NotImplementedError("different fine-map sizes for image0/image1 are not built yet")
+            f_both = torch.cat([f0, f1], 0)  # plumbing only (device copy), different-shape path
+        stride = hw0_f[0] // hw0_c[0]
+        F = self._TfBuffers(2 * M * WW, Cf, tdt, dev)
+        ops.fine_gather(f_both, b_ids, i_ids, j_ids, M, bs, hw0_c[1], hw1_c[1], stride, W, F.X32, F.CAT[:, :Cf])
+        self._transformer(P, "f", self.loftr_fine, F, M, WW, M, WW)
+        if self.debug is not None:
+            self.debug.update({"fine0": F.X32[:M * WW].view(M, WW, Cf), "fine1": F.X32[M * WW:].view(M, WW, Cf)})
+        fscale = data["hw0_i"][0] / hw0_f[0]
+        has_s0 = "scale0" in data
+        s1 = cr.keep[3] if has_s0 else None
+        expec_f, mkpts1_f = ops.fine_match(F.X32[:M * WW], F.X32[M * WW:], data["mkpts1_c"], b_ids, s1, M, WW,
+                                           fscale, has_s0)
+        data.update({"expec_f": expec_f, "mkpts0_f": data["mkpts0_c"], "mkpts1_f": mkpts1_f})

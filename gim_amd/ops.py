@@ -1,0 +1,237 @@
+"""Thin torch-tensor wrappers over the libgimhip C ABI (device pointers + current stream; torch is only
+the allocator / stream owner).  Every function launches HIP kernels from `gim_amd/csrc`; none of them
+has a torch or CPU fallback."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_ELU1, ACT_LEAKY, ACT_NONE, ACT_RELU, GIM_BF16, GIM_F32, check, lib  # noqa: F401
+from .packing import elem_size, torch_dtype
+
+_DT = {torch.float32: GIM_F32, torch.bfloat16: GIM_BF16}
+
+
+# When set to a list, every gim_conv2d_bn_act launch is bracketed by HIP events recorded on the launch
+# stream and (start, end, algorithmic_flops, label) is appended -- bench.py's live roofline measurement.
+PROFILE = None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _req_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.GimHipError("gim_amd ops need device (cuda/HIP) tensors: the product path has no CPU fallback")
+
+
+def gim_dtype(t):
+    return _DT[t.dtype]
+
+
+def _rows(t):
+    """[..., C] tensor with a uniform row stride -> (rows, ld)"""
+    assert t.stride(-1) == 1
+    if t.dim() == 2:
+        return t.shape[0], t.stride(0)
+    assert t.is_contiguous()
+    return t.numel() // t.shape[-1], t.shape[-1]
+
+
+# ---- layout ------------------------------------------------------------------------------------
+def nchw_to_nhwc(src, dst, b_off=0):
+    """src [B,C,H,W] fp32 -> dst [Btot,H,W,cpad] (fp32/bf16), images b_off.."""
+    _req_cuda(src, dst)
+    assert src.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous()
+    B, C, H, W = src.shape
+    check(lib.gim_nchw_to_nhwc(_p(src), _p(dst), B, C, H, W, dst.shape[-1], dst.shape[-1], b_off,
+                               gim_dtype(dst), _stream()), "gim_nchw_to_nhwc")
+
+
+def nhwc_to_nchw(src, C):
+    """src [B,H,W,cstore] -> new fp32 [B,C,H,W] (reference layout, for tests / lazy outputs)"""
+    _req_cuda(src)
+    B, H, W, ld = src.shape
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device=src.device)
+    check(lib.gim_nhwc_to_nchw(_p(src), _p(out), B, C, H, W, ld, gim_dtype(src), _stream()), "gim_nhwc_to_nchw")
+    return out
+
+
+# ---- conv / linear --------------------------------------------------------------------------------
+def conv_rows(x, pk, geom, y, act=ACT_NONE, res=None, res_mod=0, lds_dma=True):
+    """Generic launch.  x: 2-D row view [rows_in, ldx]; geom = (B, H, W, Ho, Wo); y: 2-D row view."""
+    _req_cuda(x, y, res)
+    B, H, W, Ho, Wo = geom
+    a = _lib.ConvArgs()
+    a.x, a.w, a.ktab = x.data_ptr(), pk.w.data_ptr(), pk.ktab.data_ptr()
+    a.bias = pk.bias.data_ptr() if pk.bias is not None else None
+    a.res = res.data_ptr() if res is not None else None
+    a.y = y.data_ptr()
+    es = elem_size(pk.dtype)
+    assert x.dtype == torch_dtype(pk.dtype), (x.dtype, pk.dtype)
+    a.x_bytes = ((B * H * W - 1) * x.stride(0) + pk.cin_pad) * es
+    a.B, a.H, a.W, a.Ho, a.Wo = B, H, W, Ho, Wo
+    a.stride, a.pad = pk.stride, pk.pad
+    a.ldx, a.ldy = x.stride(0), y.stride(0)
+    a.ldres = res.stride(0) if res is not None else 0
+    a.N, a.npad, a.kpad = pk.n_store, pk.npad, pk.kpad
+    a.act, a.res_mod = act, res_mod
+    a.dtype, a.out_dtype = pk.dtype, gim_dtype(y)
+    a.res_dtype = gim_dtype(res) if res is not None else GIM_F32
+    a.use_lds_dma = 1 if lds_dma else 0
+    assert y.shape[0] >= B * Ho * Wo and y.shape[1] >= pk.n_store
+    if PROFILE is None:
+        check(lib.gim_conv2d_bn_act(ctypes.byref(a), _stream()), "gim_conv2d_bn_act")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib.gim_conv2d_bn_act(ctypes.byref(a), _stream()), "gim_conv2d_bn_act")
+    e1.record()
+    flops = 2.0 * B * Ho * Wo * pk.cout * pk.cin * pk.kh * pk.kw  # algorithmic: real channels, no padding
+    PROFILE.append((e0, e1, flops, f"{pk.cin}->{pk.cout} k{pk.kh}s{pk.stride} M={B * Ho * Wo}"))
+
+
+def conv2d(x, pk, act=ACT_NONE, res=None, out_dtype=None, lds_dma=True):
+    """x [B,H,W,cin_pad] NHWC -> new [B,Ho,Wo,n_store]"""
+    B, H, W, cs = x.shape
+    assert cs == pk.cin_pad, (cs, pk)
+    Ho = (H + 2 * pk.pad - pk.kh) // pk.stride + 1
+    Wo = (W + 2 * pk.pad - pk.kw) // pk.stride + 1
+    y = torch.empty(B, Ho, Wo, pk.n_store, dtype=out_dtype or x.dtype, device=x.device)
+    r = res.view(-1, res.shape[-1]) if res is not None else None
+    conv_rows(x.view(-1, cs), pk, (B, H, W, Ho, Wo), y.view(-1, pk.n_store), act, r, 0, lds_dma)
+    return y
+
+
+def linear(x, pk, y, act=ACT_NONE, lds_dma=True):
+    """x: row view [rows, >=K] (row stride may exceed K), y: row view [rows, >=N].  y = act(x @ W^T)."""
+    rows = x.shape[0]
+    conv_rows(x, pk, (1, 1, rows, 1, rows), y, act, None, 0, lds_dma)
+
+
+# ---- elementwise ------------------------------------------------------------------------------------
+def upsample2x_add(x, y):
+    """y [B,2h,2w,C] += bilinear2x(x [B,h,w,C]) (align_corners=True), in place"""
+    _req_cuda(x, y)
+    B, h, w, C = x.shape
+    assert y.shape == (B, 2 * h, 2 * w, C) and x.dtype == y.dtype
+    check(lib.gim_upsample2x_add(_p(x), _p(y), B, h, w, C, C, C, gim_dtype(x), _stream()), "gim_upsample2x_add")
+
+
+def posenc_add(x, pe, out_f32, out_t):
+    """x rows [R, C] (dtype T); pe [hw, C] fp32; out_f32 row view and/or out_t row view"""
+    _req_cuda(x, pe, out_f32, out_t)
+    R, C = x.shape
+    check(lib.gim_posenc_add(_p(x), _p(pe), _p(out_f32), _p(out_t), R, pe.shape[0], C, x.stride(0),
+                             out_f32.stride(0) if out_f32 is not None else 4,
+                             out_t.stride(0) if out_t is not None else 4, gim_dtype(x), _stream()), "gim_posenc_add")
+
+
+def layernorm_residual(x, gamma, beta, res, out_f32, out_t, eps=1e-5):
+    """x fp32 row view [R, C]; out_f32 / out_t row views (either may be None)"""
+    _req_cuda(x, gamma, beta, res, out_f32, out_t)
+    R, C = x.shape
+    dt = gim_dtype(out_t) if out_t is not None else GIM_F32
+    check(lib.gim_layernorm_residual(_p(x), _p(gamma), _p(beta), _p(res), _p(out_f32), _p(out_t), R, C,
+                                     x.stride(0), res.stride(0) if res is not None else 4,
+                                     out_f32.stride(0) if out_f32 is not None else 4,
+                                     out_t.stride(0) if out_t is not None else 4, dt, eps, _stream()),
+          "gim_layernorm_residual")
+
+
+# ---- linear attention ---------------------------------------------------------------------------------
+def linear_attention(q, k, v, out, nb_q, L, nb_kv, S, H, ws=None):
+    """q row view [nb_q*L, C]; k,v row views [nb_kv*S, C]; nb_q == nb_kv.  out row view [nb_q*L, C]."""
+    _req_cuda(q, k, v, out)
+    assert nb_q == nb_kv
+    C = H * (q.shape[1] // H)
+    D = q.shape[1] // H
+    need = lib.gim_linear_attention_ws_bytes(nb_kv, S, H, D)
+    if ws is None or ws.numel() * ws.element_size() < need:
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=q.device)
+    check(lib.gim_linear_attention_kv(_p(k), _p(v), _p(ws), nb_kv, S, H, D, k.stride(0), v.stride(0),
+                                      gim_dtype(k), _stream()), "gim_linear_attention_kv")
+    check(lib.gim_linear_attention_apply(_p(q), _p(ws), _p(out), nb_q, L, S, H, D, q.stride(0), out.stride(0),
+                                         gim_dtype(q), gim_dtype(out), _stream()), "gim_linear_attention_apply")
+    return ws
+
+
+# ---- coarse matching -----------------------------------------------------------------------------------
+class CoarseResult:
+    __slots__ = ("args", "ws", "count", "b_ids", "i_ids", "j_ids", "mconf", "mkpts0_c", "mkpts1_c", "keep")
+
+
+def coarse_match(feat0, feat1, hw0_c, hw1_c, scale, temperature=0.1, thr=0.2, border_rm=2,
+                 scale0=None, scale1=None):
+    """feat0 [N,L,C], feat1 [N,S,C] fp32 contiguous.  Returns CoarseResult with cap-sized device buffers;
+    count[0] (device int32) is the number of valid leading entries."""
+    _req_cuda(feat0, feat1, scale0, scale1)
+    assert feat0.dtype == torch.float32 and feat0.is_contiguous() and feat1.is_contiguous()
+    N, L, C = feat0.shape
+    S = feat1.shape[1]
+    dev = feat0.device
+    cap = N * min(L, S)
+    r = CoarseResult()
+    r.ws = torch.empty(lib.gim_coarse_match_ws_bytes(N, L, S), dtype=torch.uint8, device=dev)
+    r.count = torch.empty(1 + N, dtype=torch.int32, device=dev)
+    r.b_ids = torch.empty(cap, dtype=torch.int64, device=dev)
+    r.i_ids = torch.empty(cap, dtype=torch.int64, device=dev)
+    r.j_ids = torch.empty(cap, dtype=torch.int64, device=dev)
+    r.mconf = torch.empty(cap, dtype=torch.float32, device=dev)
+    r.mkpts0_c = torch.empty(cap, 2, dtype=torch.float32, device=dev)
+    r.mkpts1_c = torch.empty(cap, 2, dtype=torch.float32, device=dev)
+    if scale0 is not None:
+        scale0 = scale0.to(device=dev, dtype=torch.float32).contiguous()
+        scale1 = scale1.to(device=dev, dtype=torch.float32).contiguous()
+    r.keep = (feat0, feat1, scale0, scale1)
+    a = _lib.CoarseArgs()
+    a.feat0, a.feat1 = feat0.data_ptr(), feat1.data_ptr()
+    a.scale0 = scale0.data_ptr() if scale0 is not None else None
+    a.scale1 = scale1.data_ptr() if scale1 is not None else None
+    a.ws, a.count = r.ws.data_ptr(), r.count.data_ptr()
+    a.b_ids, a.i_ids, a.j_ids = r.b_ids.data_ptr(), r.i_ids.data_ptr(), r.j_ids.data_ptr()
+    a.mconf, a.mkpts0_c, a.mkpts1_c = r.mconf.data_ptr(), r.mkpts0_c.data_ptr(), r.mkpts1_c.data_ptr()
+    a.N, a.L, a.S, a.C = N, L, S, C
+    a.h0c, a.w0c, a.h1c, a.w1c = hw0_c[0], hw0_c[1], hw1_c[0], hw1_c[1]
+    a.cap, a.temperature, a.thr, a.border_rm, a.scale = cap, temperature, thr, border_rm, scale
+    r.args = a
+    check(lib.gim_coarse_match(ctypes.byref(a), _stream()), "gim_coarse_match")
+    return r
+
+
+def coarse_conf_matrix(r):
+    """Materialise conf_matrix [N,L,S] from the statistics of a previous coarse_match call."""
+    a = r.args
+    conf = torch.empty(a.N, a.L, a.S, dtype=torch.float32, device=r.count.device)
+    check(lib.gim_coarse_conf_matrix(ctypes.byref(a), _p(conf), _stream()), "gim_coarse_conf_matrix")
+    return conf
+
+
+# ---- fine level ---------------------------------------------------------------------------------------
+def fine_gather(feat_f, b_ids, i_ids, j_ids, M, bs, w0c, w1c, stride, W, out_f32, out_t):
+    """feat_f [2*bs, hf, wf, C] NHWC; out_* row views [2*M*W*W, >=C]"""
+    _req_cuda(feat_f, b_ids, out_f32, out_t)
+    _, hf, wf, C = feat_f.shape
+    check(lib.gim_fine_gather(_p(feat_f), _p(b_ids), _p(i_ids), _p(j_ids), _p(out_f32), _p(out_t), M, bs, hf, wf,
+                              C, C, w0c, w1c, stride, W, out_f32.stride(0) if out_f32 is not None else 4,
+                              out_t.stride(0) if out_t is not None else 4, gim_dtype(feat_f), _stream()),
+          "gim_fine_gather")
+
+
+def fine_match(f0, f1, mkpts1_c, b_ids, scale1, M, WW, scale, has_scale0):
+    """f0/f1 fp32 row views [M*WW, C].  Returns (expec_f [M,3], mkpts1_f [M,2])."""
+    _req_cuda(f0, f1, mkpts1_c)
+    dev = f0.device
+    expec = torch.empty(M, 3, dtype=torch.float32, device=dev)
+    mk1 = torch.empty(M, 2, dtype=torch.float32, device=dev)
+    if M > 0:
+        check(lib.gim_fine_match(_p(f0), _p(f1), _p(mkpts1_c), _p(b_ids), _p(scale1), _p(expec), _p(mk1), M, WW,
+                                 f0.shape[1], f0.stride(0), scale, 1 if has_scale0 else 0, _stream()),
+              "gim_fine_match")
+    return expec, mk1

@@ -1,0 +1,106 @@
+"""Host-side weight pre-packing for libgimhip (runs once per checkpoint / device / precision).
+
+  * eval-mode BatchNorm is folded into the preceding bias-free conv: w' = w * g/sqrt(var+eps),
+    b' = beta - mean * g/sqrt(var+eps)   (reference layers: networks/loftr/backbone/resnet.py:90-126,277-289);
+  * weights go to the kernel's [npad][kpad] K-contiguous layout with K ordered (ky, kx, c) and channels
+    padded to the activation's stored channel count (196 -> 200 for bf16: 16-byte groups);
+  * `ktab` maps every 16-byte K group to (dy, dx, c) for the implicit-GEMM gather, plus two trailing
+    slabs of "invalid" entries (the kernel prefetches the table one slab ahead).
+
+This is layout plumbing in torch on the host; no matching arithmetic happens here.
+"""
+import torch
+
+from . import _lib
+
+KTILE_BYTES = _lib.lib.gim_ktile_bytes()
+NPAD = _lib.lib.gim_npad_granule()
+
+
+def torch_dtype(dt):
+    return torch.bfloat16 if dt == _lib.GIM_BF16 else torch.float32
+
+
+def elem_size(dt):
+    return 2 if dt == _lib.GIM_BF16 else 4
+
+
+def group_elems(dt):
+    """elements per 16-byte K group"""
+    return 16 // elem_size(dt)
+
+
+def cstore(c, dt):
+    """channels actually stored for a c-channel activation (padded to a 16-byte group)"""
+    g = group_elems(dt)
+    return (c + g - 1) // g * g
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class PackedConv:
+    """One conv / linear layer in kernel layout."""
+    __slots__ = ("w", "bias", "ktab", "kh", "kw", "stride", "pad", "cin", "cin_pad", "cout", "n_store",
+                 "npad", "kpad", "dtype")
+
+    def __repr__(self):
+        return (f"PackedConv({self.cin}->{self.cout} k{self.kh} s{self.stride} cin_pad={self.cin_pad} "
+                f"n_store={self.n_store} npad={self.npad} kpad={self.kpad} dt={self.dtype})")
+
+
+def fold_bn(weight, bn):
+    """bn = (gamma, beta, running_mean, running_var, eps) or None -> (weight', bias' or None), fp32."""
+    w = weight.detach().float()
+    if bn is None:
+        return w, None
+    gamma, beta, mean, var, eps = bn
+    s = gamma.detach().float() / torch.sqrt(var.detach().float() + eps)
+    return w * s.view(-1, 1, 1, 1), beta.detach().float() - mean.detach().float() * s
+
+
+def pack_conv(weight, bn, dtype, device, stride=1, pad=0, cin_pad=None, bias=None):
+    """weight [Cout, Cin, kh, kw] (or [out, in] for a Linear).  Returns PackedConv on `device`."""
+    if weight.dim() == 2:
+        weight = weight[:, :, None, None]
+    w, b = fold_bn(weight, bn)
+    if bias is not None:
+        b = bias.detach().float() if b is None else b + bias.detach().float()
+    cout, cin, kh, kw = w.shape
+    g = group_elems(dtype)
+    es = elem_size(dtype)
+    cin_pad = cstore(cin, dtype) if cin_pad is None else cin_pad
+    assert cin_pad >= cin and cin_pad % g == 0
+    kslab = KTILE_BYTES // es
+    k = kh * kw * cin_pad
+    kpad = _round_up(k, kslab)
+    npad = _round_up(cout, NPAD)
+    wp = torch.zeros(npad, kh, kw, cin_pad, dtype=torch.float32)
+    wp[:cout, :, :, :cin] = w.permute(0, 2, 3, 1).cpu()
+    wk = torch.zeros(npad, kpad, dtype=torch.float32)
+    wk[:, :k] = wp.reshape(npad, k)
+    nkt = kpad // kslab
+    ngrp = (nkt + 2) * 8
+    gidx = torch.arange(ngrp, dtype=torch.int64) * g
+    tap = gidx // cin_pad
+    c = gidx % cin_pad
+    dy, dx = tap // kw, tap % kw
+    ent = c | (dx << 16) | (dy << 24)
+    ent = torch.where(tap < kh * kw, ent, torch.full_like(ent, 0xFF000000))
+    ent = torch.where(ent >= 2 ** 31, ent - 2 ** 32, ent).to(torch.int32)
+
+    p = PackedConv()
+    p.w = wk.to(torch_dtype(dtype)).to(device).contiguous()
+    if b is not None:
+        bp = torch.zeros(npad, dtype=torch.float32)
+        bp[:cout] = b.cpu()
+        p.bias = bp.to(device)
+    else:
+        p.bias = None
+    p.ktab = ent.to(device)
+    p.kh, p.kw, p.stride, p.pad = kh, kw, stride, pad
+    p.cin, p.cin_pad, p.cout = cin, cin_pad, cout
+    p.n_store = cstore(cout, dtype)
+    p.npad, p.kpad, p.dtype = npad, kpad, dtype
+    return p

@@ -58,7 +58,7 @@ PROTOTYPES = {
     "gim_coarse_match_ws_bytes": (c_int64, [c_int] * 3),
     "gim_coarse_match": (c_int, [ctypes.POINTER(CoarseArgs), c_void_p]),
     "gim_coarse_conf_matrix": (c_int, [ctypes.POINTER(CoarseArgs), c_void_p, c_void_p]),
-    "gim_fine_gather": (c_int, [c_void_p] * 6 + [c_int] * 13 + [c_void_p]),
+    "gim_fine_gather": (c_int, [c_void_p] * 7 + [c_int] * 14 + [c_void_p]),
     "gim_fine_match": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_float, c_int, c_void_p]),
 }
 

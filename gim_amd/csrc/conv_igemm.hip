@@ -28,6 +28,58 @@ namespace {
 
 using gim::KTB;
 
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == GIM_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == GIM_ACT_LEAKY) return v > 0.f ? v : 0.01f * v;
+    if (act == GIM_ACT_ELU1) return v > 0.f ? v + 1.f : (expf(v) - 1.f) + 1.f;  // elu(x)+1 exactly as torch
+    return v;
+}
+
+template <int BM, int BN, bool OUT_BF16>
+__device__ __forceinline__ void epilogue_rows(const gim_conv_args& a, const float* Ct, int m0, int n0, int M) {
+    constexpr int CLD = BN + 4;
+    constexpr int G = OUT_BF16 ? 8 : 4;   // channels per 16-byte store
+    constexpr int LPR = BN / G;           // lanes per pixel row
+    constexpr int RPP = 256 / LPR;        // pixel rows per pass
+    const int t = threadIdx.x;
+    const int cg = (t % LPR) * G, n = n0 + cg;
+    if (n >= a.N) return;
+    float bias[G];
+#pragma unroll
+    for (int e = 0; e < G; ++e) bias[e] = a.bias ? a.bias[n + e] : 0.f;
+    for (int r = t / LPR; r < BM; r += RPP) {
+        const int m = m0 + r;
+        if (m >= M) break;
+        float v[G];
+#pragma unroll
+        for (int e = 0; e < G; e += 4) {
+            const float4 c = *(const float4*)(Ct + r * CLD + cg + e);
+            v[e] = c.x + bias[e]; v[e + 1] = c.y + bias[e + 1]; v[e + 2] = c.z + bias[e + 2]; v[e + 3] = c.w + bias[e + 3];
+        }
+        if (a.res) {
+            const size_t ro = (size_t)(a.res_mod > 0 ? m % a.res_mod : m) * a.ldres + n;
+#pragma unroll
+            for (int e = 0; e < G; e += 4) {
+                const float4 rr = a.res_dtype == GIM_BF16 ? ElemIO<true>::ld4(a.res, ro + e) : ElemIO<false>::ld4(a.res, ro + e);
+                v[e] += rr.x; v[e + 1] += rr.y; v[e + 2] += rr.z; v[e + 3] += rr.w;
+            }
+        }
+        if (a.act != GIM_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < G; ++e) v[e] = apply_act(v[e], a.act);
+        }
+        const size_t yo = (size_t)m * a.ldy + n;
+        if constexpr (OUT_BF16) {
+            uint4 o;
+            o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+            o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+            *(uint4*)((unsigned short*)a.y + yo) = o;
+        } else {
+            *(float4*)((float*)a.y + yo) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, bool BF16, bool LDSDMA>
 __global__ void __launch_bounds__(256)
 igemm_kernel(const gim_conv_args a, const int mtiles, const int ntiles, const int M) {
@@ -52,51 +104,34 @@ igemm_kernel(const gim_conv_args a, const int mtiles, const int ntiles, const in
     f32x16_t acc[TN][TM];
     gim::igemm_mainloop<BM, BN, WM, WN, BF16, LDSDMA>(ml, smem, m0, n0, acc);
 
-    // ---- epilogue: lane holds, per (tn, tm), 4 quads of 4 consecutive channels of pixel l31 ------
+    // ---- epilogue, phase 1: accumulators -> fp32 tile Ct[pixel][channel] in LDS (stage buffers are free:
+    // the main loop ends with a barrier).  Row stride BN+4 floats keeps the 8-lane ds_write_b128 groups
+    // (8 consecutive pixels, same channel quad) on distinct banks.
+    float* Ct = (float*)smem;
+    constexpr int CLD = BN + 4;
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-        const int m = m0 + wm * WTM + j * 32 + l31;
-        if (m >= M) continue;
-        const size_t yrow = (size_t)m * a.ldy;
-        const size_t rrow = a.res ? (size_t)(a.res_mod > 0 ? m % a.res_mod : m) * a.ldres : 0;
+        const int px = wm * WTM + j * 32 + l31;
 #pragma unroll
-        for (int i = 0; i < TN; ++i) {
+        for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const int n = n0 + wn * WTN + i * 32 + rg * 8 + lh * 4;
-                if (n >= a.N) continue;
-                float4 v = make_float4(acc[i][j][rg * 4 + 0], acc[i][j][rg * 4 + 1],
-                                       acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]);
-                if (a.bias) {
-                    const float4 bb = *(const float4*)(a.bias + n);
-                    v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-                }
-                if (a.res) {
-                    const float4 rr = a.res_dtype == GIM_BF16 ? ElemIO<true>::ld4(a.res, rrow + n)
-                                                              : ElemIO<false>::ld4(a.res, rrow + n);
-                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-                }
-                if (a.act == GIM_ACT_RELU) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                } else if (a.act == GIM_ACT_LEAKY) {
-                    v.x = v.x > 0.f ? v.x : 0.01f * v.x; v.y = v.y > 0.f ? v.y : 0.01f * v.y;
-                    v.z = v.z > 0.f ? v.z : 0.01f * v.z; v.w = v.w > 0.f ? v.w : 0.01f * v.w;
-                } else if (a.act == GIM_ACT_ELU1) {  // elu(x)+1 exactly as torch: x>0 ? x+1 : (exp(x)-1)+1
-                    v.x = v.x > 0.f ? v.x + 1.f : (expf(v.x) - 1.f) + 1.f;
-                    v.y = v.y > 0.f ? v.y + 1.f : (expf(v.y) - 1.f) + 1.f;
-                    v.z = v.z > 0.f ? v.z + 1.f : (expf(v.z) - 1.f) + 1.f;
-                    v.w = v.w > 0.f ? v.w + 1.f : (expf(v.w) - 1.f) + 1.f;
-                }
-                if (a.out_dtype == GIM_BF16) ElemIO<true>::st4(a.y, yrow + n, v);
-                else ElemIO<false>::st4(a.y, yrow + n, v);
+                const int ch = wn * WTN + i * 32 + rg * 8 + lh * 4;
+                *(float4*)(Ct + px * CLD + ch) = make_float4(acc[i][j][rg * 4 + 0], acc[i][j][rg * 4 + 1],
+                                                             acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]);
             }
-        }
     }
+    __syncthreads();
+    // ---- phase 2: each lane owns one 16-byte channel group of a pixel row -> bias, residual, activation,
+    // fully coalesced NHWC stores (a 256-byte bf16 row is written by 16 adjacent lanes).
+    if (a.out_dtype == GIM_BF16) epilogue_rows<BM, BN, true>(a, Ct, m0, n0, M);
+    else epilogue_rows<BM, BN, false>(a, Ct, m0, n0, M);
 }
 
 template <int BM, int BN, int WM, int WN, bool BF16, bool LDSDMA>
 int launch_igemm(const gim_conv_args& a, hipStream_t stream) {
-    constexpr int smem = 2 * (BM + BN) * KTB;
+    constexpr int stage = 2 * (BM + BN) * KTB, ctile = BM * (BN + 4) * 4;
+    constexpr int smem = stage > ctile ? stage : ctile;
     auto kern = igemm_kernel<BM, BN, WM, WN, BF16, LDSDMA>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -133,6 +168,7 @@ extern "C" int gim_conv2d_bn_act(const gim_conv_args* ap, gim_stream_t stream) {
     GIM_REQUIRE(a.x_bytes > 0 && a.x_bytes < (int64_t)0xFFFFFFF0ll, "conv: x_bytes=%lld must be < 4 GiB", (long long)a.x_bytes);
     GIM_REQUIRE(a.ldx % (16 / es) == 0, "conv: ldx=%d breaks 16-byte alignment", a.ldx);
     GIM_REQUIRE(a.ldy % 4 == 0 && (!a.res || a.ldres % 4 == 0), "conv: ldy/ldres must be multiples of 4");
+    GIM_REQUIRE(a.out_dtype != GIM_BF16 || (a.N % 8 == 0 && a.ldy % 8 == 0), "conv: bf16 output needs N and ldy multiples of 8 (16-byte row stores)");
     GIM_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.Ho > 0 && a.Wo > 0 && a.stride > 0, "conv: bad geometry");
     GIM_REQUIRE((int64_t)a.B * a.Ho * a.Wo < (int64_t)0x7fffffff, "conv: too many output rows");
     hipStream_t s = (hipStream_t)stream;

@@ -11,11 +11,11 @@
 namespace {
 
 template <bool BF16>
-__global__ void fine_gather_kernel(const void* __restrict__ feat, const int64_t* __restrict__ b_ids,
-                                   const int64_t* __restrict__ i_ids, const int64_t* __restrict__ j_ids,
-                                   float* __restrict__ out_f32, void* __restrict__ out_t, int M, int bs, int hf,
-                                   int wf, int C4, int ldf, int w0c, int w1c, int stride, int W, int ld_f32,
-                                   int ld_t) {
+__global__ void fine_gather_kernel(const void* __restrict__ feat0, const void* __restrict__ feat1,
+                                   const int64_t* __restrict__ b_ids, const int64_t* __restrict__ i_ids,
+                                   const int64_t* __restrict__ j_ids, float* __restrict__ out_f32,
+                                   void* __restrict__ out_t, int M, int hf0, int wf0, int hf1, int wf1, int C4,
+                                   int ldf, int w0c, int w1c, int stride, int W, int ld_f32, int ld_t) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int WW = W * W;
     const size_t total = (size_t)2 * M * WW * C4;
@@ -32,10 +32,9 @@ __global__ void fine_gather_kernel(const void* __restrict__ feat, const int64_t*
     const int cy = cell / wc, cx = cell - cy * wc;
     const int y = cy * stride - W / 2 + ww / W, x = cx * stride - W / 2 + ww % W;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (y >= 0 && y < hf && x >= 0 && x < wf) {
-        const size_t img = (size_t)(side ? bs + b : b);
-        v = ElemIO<BF16>::ld4(feat, ((img * hf + y) * wf + x) * ldf + cq * 4);
-    }
+    const int hf = side ? hf1 : hf0, wf = side ? wf1 : wf0;
+    if (y >= 0 && y < hf && x >= 0 && x < wf)
+        v = ElemIO<BF16>::ld4(side ? feat1 : feat0, (((size_t)b * hf + y) * wf + x) * ldf + cq * 4);
     if (out_f32) *(float4*)(out_f32 + row * ld_f32 + cq * 4) = v;
     if (out_t) ElemIO<BF16>::st4(out_t, row * ld_t + cq * 4, v);
 }
@@ -86,20 +85,21 @@ fine_match_kernel(const float* __restrict__ f0, const float* __restrict__ f1, co
 
 }  // namespace
 
-extern "C" int gim_fine_gather(const void* feat_f, const int64_t* b_ids, const int64_t* i_ids, const int64_t* j_ids,
-                               float* out_f32, void* out_t, int M, int bs, int hf, int wf, int C, int ldf, int w0c,
-                               int w1c, int stride, int W, int ld_f32, int ld_t, int dtype, gim_stream_t stream) {
+extern "C" int gim_fine_gather(const void* feat_f0, const void* feat_f1, const int64_t* b_ids, const int64_t* i_ids,
+                               const int64_t* j_ids, float* out_f32, void* out_t, int M, int hf0, int wf0, int hf1,
+                               int wf1, int C, int ldf, int w0c, int w1c, int stride, int W, int ld_f32, int ld_t,
+                               int dtype, gim_stream_t stream) {
     if (M == 0) return GIM_OK;
-    GIM_REQUIRE(feat_f && b_ids && i_ids && j_ids && (out_f32 || out_t), "fine_gather: NULL pointer");
-    GIM_REQUIRE(M > 0 && bs > 0 && hf > 0 && wf > 0 && C > 0 && C % 4 == 0 && W > 0 && (W & 1) && stride > 0, "fine_gather: bad sizes");
+    GIM_REQUIRE(feat_f0 && feat_f1 && b_ids && i_ids && j_ids && (out_f32 || out_t), "fine_gather: NULL pointer");
+    GIM_REQUIRE(M > 0 && hf0 > 0 && wf0 > 0 && hf1 > 0 && wf1 > 0 && C > 0 && C % 4 == 0 && W > 0 && (W & 1) && stride > 0, "fine_gather: bad sizes");
     GIM_REQUIRE(ldf % 4 == 0 && ld_f32 % 4 == 0 && ld_t % 4 == 0, "fine_gather: ld alignment");
     const size_t total = (size_t)2 * M * W * W * (C / 4);
     const unsigned grid = (unsigned)((total + 255) / 256);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == GIM_BF16)
-        hipLaunchKernelGGL(fine_gather_kernel<true>, dim3(grid), dim3(256), 0, s, feat_f, b_ids, i_ids, j_ids, out_f32, out_t, M, bs, hf, wf, C / 4, ldf, w0c, w1c, stride, W, ld_f32, ld_t);
+        hipLaunchKernelGGL(fine_gather_kernel<true>, dim3(grid), dim3(256), 0, s, feat_f0, feat_f1, b_ids, i_ids, j_ids, out_f32, out_t, M, hf0, wf0, hf1, wf1, C / 4, ldf, w0c, w1c, stride, W, ld_f32, ld_t);
     else
-        hipLaunchKernelGGL(fine_gather_kernel<false>, dim3(grid), dim3(256), 0, s, feat_f, b_ids, i_ids, j_ids, out_f32, out_t, M, bs, hf, wf, C / 4, ldf, w0c, w1c, stride, W, ld_f32, ld_t);
+        hipLaunchKernelGGL(fine_gather_kernel<false>, dim3(grid), dim3(256), 0, s, feat_f0, feat_f1, b_ids, i_ids, j_ids, out_f32, out_t, M, hf0, wf0, hf1, wf1, C / 4, ldf, w0c, w1c, stride, W, ld_f32, ld_t);
     return gim_check_launch("fine_gather");
 }
 

@@ -363,17 +363,14 @@ class LoFTR(nn.Module):
         if data["hw0_i"] == data["hw1_i"]:
             c_all, f_all = self._backbone(P, [color0, color1], dt)
             c0, c1 = c_all[:bs], c_all[bs:]
-            f_both = f_all
-        else:
+            f0, f1 = f_all[:bs], f_all[bs:]
+        else:  # different input shapes (loftr.py:62-63)
             c0, f0 = self._backbone(P, [color0], dt)
             c1, f1 = self._backbone(P, [color1], dt)
-            f_both = None
         if self.debug is not None:
-            self.debug.update({"c0": c0, "c1": c1, "f_all": f_both, "f0": None if f_both is not None else f0,
-                               "f1": None if f_both is not None else f1})
+            self.debug.update({"c0": c0, "c1": c1, "f0": f0, "f1": f1})
         hw0_c, hw1_c = c0.shape[1:3], c1.shape[1:3]
-        hw0_f = (f_all.shape[1:3] if f_both is not None else f0.shape[1:3])
-        hw1_f = (f_all.shape[1:3] if f_both is not None else f1.shape[1:3])
+        hw0_f, hw1_f = f0.shape[1:3], f1.shape[1:3]
         data.update({"hw0_c": torch.Size(hw0_c), "hw1_c": torch.Size(hw1_c),
                      "hw0_f": torch.Size(hw0_f), "hw1_f": torch.Size(hw1_f)})
 
@@ -414,13 +411,9 @@ class LoFTR(nn.Module):
             data.update({"expec_f": torch.empty(0, 3, device=dev),
                          "mkpts0_f": data["mkpts0_c"], "mkpts1_f": data["mkpts1_c"]})
             return
-        if f_both is None:
-            if hw0_f != hw1_f:
-                raise NotImplementedError("different fine-map sizes for image0/image1 are not built yet")
-            f_both = torch.cat([f0, f1], 0)  # plumbing only (device copy), different-shape path
         stride = hw0_f[0] // hw0_c[0]
         F = self._TfBuffers(2 * M * WW, Cf, tdt, dev)
-        ops.fine_gather(f_both, b_ids, i_ids, j_ids, M, bs, hw0_c[1], hw1_c[1], stride, W, F.X32, F.CAT[:, :Cf])
+        ops.fine_gather(f0, f1, b_ids, i_ids, j_ids, M, hw0_c[1], hw1_c[1], stride, W, F.X32, F.CAT[:, :Cf])
         self._transformer(P, "f", self.loftr_fine, F, M, WW, M, WW)
         if self.debug is not None:
             self.debug.update({"fine0": F.X32[:M * WW].view(M, WW, Cf), "fine1": F.X32[M * WW:].view(M, WW, Cf)})

@@ -214,13 +214,16 @@ def coarse_conf_matrix(r):
 
 
 # ---- fine level ---------------------------------------------------------------------------------------
-def fine_gather(feat_f, b_ids, i_ids, j_ids, M, bs, w0c, w1c, stride, W, out_f32, out_t):
-    """feat_f [2*bs, hf, wf, C] NHWC; out_* row views [2*M*W*W, >=C]"""
-    _req_cuda(feat_f, b_ids, out_f32, out_t)
-    _, hf, wf, C = feat_f.shape
-    check(lib.gim_fine_gather(_p(feat_f), _p(b_ids), _p(i_ids), _p(j_ids), _p(out_f32), _p(out_t), M, bs, hf, wf,
-                              C, C, w0c, w1c, stride, W, out_f32.stride(0) if out_f32 is not None else 4,
-                              out_t.stride(0) if out_t is not None else 4, gim_dtype(feat_f), _stream()),
+def fine_gather(feat_f0, feat_f1, b_ids, i_ids, j_ids, M, w0c, w1c, stride, W, out_f32, out_t):
+    """feat_f0 [bs,hf0,wf0,C], feat_f1 [bs,hf1,wf1,C] NHWC; out_* row views [2*M*W*W, >=C]"""
+    _req_cuda(feat_f0, feat_f1, b_ids, out_f32, out_t)
+    _, hf0, wf0, C = feat_f0.shape
+    _, hf1, wf1, _ = feat_f1.shape
+    assert feat_f0.is_contiguous() and feat_f1.is_contiguous() and feat_f1.shape[3] == C
+    check(lib.gim_fine_gather(_p(feat_f0), _p(feat_f1), _p(b_ids), _p(i_ids), _p(j_ids), _p(out_f32), _p(out_t),
+                              M, hf0, wf0, hf1, wf1, C, C, w0c, w1c, stride, W,
+                              out_f32.stride(0) if out_f32 is not None else 4,
+                              out_t.stride(0) if out_t is not None else 4, gim_dtype(feat_f0), _stream()),
           "gim_fine_gather")
 
 

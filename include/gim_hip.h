@@ -141,12 +141,12 @@ int gim_coarse_conf_matrix(const gim_coarse_args* a, float* conf, gim_stream_t s
 /* --------------------------------------------------------------------------------------------
  * Fine level.  gim_fine_gather = F.unfold(k=W,stride,pad=W/2) + [b_ids,i_ids] pick
  * (submodules/fine_preprocess.py:40-47) without materialising the unfold: windows of image0 go to
- * rows [0, M*WW), windows of image1 (feature rows of image bs+b) to rows [M*WW, 2*M*WW).
- * feat_f: [2*bs, hf, wf, C] rows (ldf) in `dtype`. */
-int gim_fine_gather(const void* feat_f, const int64_t* b_ids, const int64_t* i_ids,
-                    const int64_t* j_ids, float* out_f32, void* out_t, int M, int bs, int hf, int wf,
-                    int C, int ldf, int w0c, int w1c, int stride, int W, int ld_f32, int ld_t,
-                    int dtype, gim_stream_t stream);
+ * rows [0, M*WW), windows of image1 to rows [M*WW, 2*M*WW).
+ * feat_f0: [bs, hf0, wf0, C] rows, feat_f1: [bs, hf1, wf1, C] rows (row stride ldf) in `dtype`. */
+int gim_fine_gather(const void* feat_f0, const void* feat_f1, const int64_t* b_ids,
+                    const int64_t* i_ids, const int64_t* j_ids, float* out_f32, void* out_t, int M,
+                    int hf0, int wf0, int hf1, int wf1, int C, int ldf, int w0c, int w1c, int stride,
+                    int W, int ld_f32, int ld_t, int dtype, gim_stream_t stream);
 /* FineMatching.forward + get_fine_match (utils/fine_matching.py:43-74): centre-row correlation,
  * softmax over WW, DSNT expectation + std, final coordinates.
  * f0/f1: fp32 [M*WW, C] rows.  scale1: NULL or fp32 [bs,2] (applied iff has_scale0, line 68). */

@@ -301,10 +301,10 @@ def test_fine_gather_and_match(dt):
     j_ids = torch.randint(0, hc * wc, (M,), generator=g)
     i_ids[:4] = torch.tensor([0, wc - 1, wc * (hc - 1), hc * wc - 1])  # corners -> zero padding
     u0, u1 = O.fine_preprocess(_rnd(ff0, dt), _rnd(ff1, dt), b_ids, i_ids, j_ids, (hc, wc), (hf, wf), W)
-    fd = _to_nhwc(torch.cat([ff0, ff1], 0), C, dt, dev)
+    fd0, fd1 = _to_nhwc(ff0, C, dt, dev), _to_nhwc(ff1, C, dt, dev)
     o32 = torch.empty(2 * M * W * W, C, device=dev)
     ot = torch.empty(2 * M * W * W, 2 * C, dtype=_tdt(dt), device=dev)
-    ops.fine_gather(fd, b_ids.to(dev), i_ids.to(dev), j_ids.to(dev), M, bs, wc, wc, stride, W, o32, ot[:, :C])
+    ops.fine_gather(fd0, fd1, b_ids.to(dev), i_ids.to(dev), j_ids.to(dev), M, wc, wc, stride, W, o32, ot[:, :C])
     torch.cuda.synchronize()
     ref = torch.cat([u0, u1], 0).reshape(-1, C)
     _assert_close(o32, ref, 0.0, "fine gather f32")

@@ -54,7 +54,7 @@ def test_fp32_end_to_end_matches_oracle(oracle_sd, hw):
         rc, rf = O.backbone(oracle_sd, torch.cat([c0, c1], 0))
     dbg = m.debug
     gc = torch.cat([_nchw(dbg["c0"], 256), _nchw(dbg["c1"], 256)], 0)
-    gf = _nchw(dbg["f_all"], 128)
+    gf = torch.cat([_nchw(dbg["f0"], 128), _nchw(dbg["f1"], 128)], 0)
     assert _rel(gc, rc)[1] < 1e-4, ("coarse map", _rel(gc, rc))
     assert _rel(gf, rf)[1] < 1e-4, ("fine map", _rel(gf, rf))
     conf = d["conf_matrix"].get().cpu()
@@ -120,7 +120,7 @@ def test_bf16_end_to_end_close_to_oracle(oracle_sd, hw):
     with torch.no_grad():
         rc, rf = O.backbone(oracle_sd, torch.cat([c0, c1], 0))
     gc = torch.cat([_nchw(m.debug["c0"], 256), _nchw(m.debug["c1"], 256)], 0)
-    gf = _nchw(m.debug["f_all"], 128)
+    gf = torch.cat([_nchw(m.debug["f0"], 128), _nchw(m.debug["f1"], 128)], 0)
     ec, ef = _rel(gc, rc), _rel(gf, rf)
     print("bf16 backbone rel err (fro, max): coarse", ec, "fine", ef)
     assert ec[0] < 3e-2 and ef[0] < 3e-2, (ec, ef)

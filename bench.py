@@ -100,11 +100,14 @@ def main():
     # ---- live roofline of the dominant kernel (instrumented steps outside the timed region) --------
     roof = None
     if rank == 0:
+        graph_was, model.use_graph = model.use_graph, False  # events need eager launches
+        step()
         ops.PROFILE = []
         for _ in range(2):
             step()
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
+        model.use_graph = graph_was
         tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in prof)
         tot_fl = sum(f for _, _, f, _ in prof)
         nlaunch = len(prof)
@@ -150,7 +153,8 @@ def main():
             "config": {"workload": f"gim_loftr {W}x{H}, batch {nb} pairs per GPU per step, random-init weights, "
                                    f"uniform-noise images (device resident), outputs incl. match count read back",
                        "pairs_per_step": world * nb, "matches_per_pair": round(n_matches / max(1, pairs), 2),
-                       "parallelism": f"pairs sharded over {world} GPU(s), no collective per step"},
+                       "parallelism": f"pairs sharded over {world} GPU(s), no collective per step",
+                       "hip_graph": bool(model.use_graph)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -128,6 +128,243 @@ igemm_kernel(const gim_conv_args a, const int mtiles, const int ntiles, const in
     else epilogue_rows<BM, BN, false>(a, Ct, m0, n0, M);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent, cross-tile software-pipelined variant (the default, LDS-DMA staging).
+//
+// Each workgroup walks a list of output tiles; K slabs of consecutive tiles form ONE flattened stream:
+// while slab s is on the MFMAs, the LDS-DMA of slab s+1 (possibly the first slab of the *next* tile) and
+// the residual rows of the current tile are already in flight, and the stores of the previous tile's
+// epilogue drain in the background.  Tiles are handed out in XCD-contiguous chunks (block b runs on XCD
+// b % 8), so tiles sharing an activation panel are in flight on the same L2 at the same time.
+//
+// Epilogue (measured: 8-byte per-lane stores at pixel stride cost 4x the TCP->TCC requests of full
+// lines and bound the half-resolution 1x1 layers): every wave transposes its 64 px x 64 ch sub-tile
+// through the stage buffer the tile just finished with (XOR-swizzled 16-byte slots, no extra LDS), so
+// that residual loads and output stores are 16 bytes per lane with a whole 128/256-byte row segment per
+// 8/16 adjacent lanes.  Bias enters as the accumulator's initial value; activation kind, bounds and
+// dtypes are tile-uniform branches; bf16 rounding is one v_cvt_pk_bf16_f32 per pair.
+// HAS_RES: residual of the same dtype as the output, prefetched into registers before the last slab.
+template <int BM, int BN, int WM, int WN, bool BF16, bool OUT_BF16, bool HAS_RES>
+__global__ void __launch_bounds__(256, 2)  // 2 waves per SIMD = 2 workgroups per CU (the LDS budget)
+igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntiles, const int M) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef gim::Igemm<BM, BN, WM, WN, BF16, true> G;
+    constexpr int TM = G::TM, TN = G::TN, WTM = G::WTM, WTN = G::WTN;
+    static_assert(WTM == 64 && WTN == 64, "epilogue transposition assumes 64x64 wave tiles");
+    constexpr int OES = OUT_BF16 ? 2 : 4;       // output element size
+    constexpr int RB = 64 * OES;                // bytes of one pixel row of the wave sub-tile
+    constexpr int LPR = RB / 16;                // lanes per row in row layout (8 / 16)
+    constexpr int RPI = 64 / LPR;               // rows per wave instruction (8 / 4)
+    constexpr int NI = 32 / RPI;                // row-layout instructions per 32-pixel pass (4 / 8)
+    static_assert(4 * 32 * RB <= G::STAGE, "transposition tile must fit in one stage buffer");
+
+    // ---- tile list of this block: first, first + step, ... < end ---------------------------------
+    const unsigned T = (unsigned)(mtiles * ntiles), nb = gridDim.x, b = blockIdx.x;
+    unsigned first, step, end;
+    if (nb >= 8 && T >= 16) {
+        const unsigned xcd = b & 7u, slot = b >> 3;
+        const unsigned q = T >> 3, r = T & 7u;
+        const unsigned cstart = xcd * q + (xcd < r ? xcd : r);
+        end = cstart + q + (xcd < r ? 1u : 0u);
+        step = (nb >> 3) + (xcd < (nb & 7u) ? 1u : 0u);
+        first = cstart + slot;
+    } else {
+        first = b; step = nb; end = T;
+    }
+    if (first >= end) return;
+
+    gim::MainloopArgs ml;
+    ml.x = a.x; ml.w = a.w; ml.ktab = a.ktab;
+    ml.x_bytes = (unsigned)a.x_bytes;
+    ml.w_bytes = (unsigned)a.npad * (unsigned)a.kpad * G::ES;
+    ml.H = a.H; ml.W = a.W; ml.Ho = a.Ho; ml.Wo = a.Wo; ml.stride = a.stride; ml.pad = a.pad; ml.ldx = a.ldx;
+    ml.kpad = a.kpad; ml.M = M;
+    const int nkt = a.kpad * G::ES / KTB;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int rrow = lane / LPR, rslot = lane % LPR;  // row-layout role of this lane
+
+    // acc := bias (the MFMAs accumulate on top of it)
+    auto init_acc = [&](typename G::Acc& acc, int n0_) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.bias) bb = *(const float4*)(a.bias + n0_ + wn * WTN + i * 32 + rg * 8 + lh * 4);  // bias is padded to npad
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    acc[i][j][rg * 4 + 0] = bb.x; acc[i][j][rg * 4 + 1] = bb.y;
+                    acc[i][j][rg * 4 + 2] = bb.z; acc[i][j][rg * 4 + 3] = bb.w;
+                }
+            }
+    };
+
+    G g, gn;  // staging coordinates of the current / the next tile
+    typename G::Acc acc;
+    int buf = 0;
+    int m0 = (int)(first / ntiles) * BM, n0 = (int)(first % ntiles) * BN;
+    init_acc(acc, n0);
+    g.decode(ml, m0, n0);
+    g.stage_issue(ml, smem, 0, 0, a.ktab[G::ktab_index(0)]);
+    int e_nxt = a.ktab[G::ktab_index(nkt > 1 ? 1 : 0)];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    uint4 rres[HAS_RES ? TM : 1][HAS_RES ? NI : 1];  // residual rows of this tile, row layout
+
+    for (unsigned tile = first; tile < end; tile += step) {
+        const unsigned tile_n = tile + step;
+        const bool has_next = tile_n < end;
+        const int m0n = (int)(tile_n / ntiles) * BM, n0n = (int)(tile_n % ntiles) * BN;
+        if (has_next) gn.decode(ml, m0n, n0n);
+        const bool full = (m0 + BM <= M) && (n0 + BN <= a.N);
+        // row-layout coordinates of this lane in the wave's 64 x 64 sub-tile
+        const int ncol = n0 + wn * WTN + rslot * (16 / OES);
+        const bool ncol_ok = full || ncol < a.N;
+        // ---- K loop: only MFMAs touch the accumulators in here (they stay in AGPRs) --------------------
+        for (int kt = 0; kt < nkt; ++kt) {
+            const bool last = kt + 1 == nkt;
+            int k2 = kt + 2;
+            if (k2 >= nkt) k2 -= nkt;
+            if (k2 >= nkt) k2 = 0;  // nkt == 1
+            const int e_n2 = a.ktab[G::ktab_index(k2)];
+            if (!last) g.stage_issue(ml, smem, buf ^ 1, kt + 1, e_nxt);
+            else if (has_next) gn.stage_issue(ml, smem, buf ^ 1, 0, e_nxt);  // first slab of the next tile
+            if (HAS_RES && last) {  // coalesced residual rows -> registers, in flight during the MFMAs
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+#pragma unroll
+                    for (int k = 0; k < NI; ++k) {
+                        const int m = m0 + wm * WTM + j * 32 + k * RPI + rrow;
+                        const bool ok = ncol_ok && (full || m < M);
+                        const size_t ro = (size_t)(a.res_mod > 0 ? m % a.res_mod : m) * a.ldres + ncol;
+                        rres[j][k] = ok ? *(const uint4*)((const char*)a.res + ro * OES) : make_uint4(0u, 0u, 0u, 0u);
+                    }
+            }
+            G::compute(smem, buf, acc);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            buf ^= 1;
+            e_nxt = e_n2;
+        }
+        // ---- epilogue: residual + activation in accumulator layout, transposition through the freed stage
+        // buffer (buf ^ 1 after the flip above), coalesced stores that drain during the next tile -------------
+        char* wl = smem + (buf ^ 1) * G::STAGE + wave * (32 * RB);  // this wave's transposition tile [32 px][RB]
+        const bool obf = OUT_BF16;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            if constexpr (HAS_RES) {
+#pragma unroll
+                for (int k = 0; k < NI; ++k) {
+                    const int row = k * RPI + rrow;
+                    *(uint4*)(wl + row * RB + ((rslot ^ (row & 7)) << 4)) = rres[j][k];
+                }
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        if constexpr (OUT_BF16) {
+                            const uint2 u = *(const uint2*)(wl + l31 * RB + (((i * 4 + rg) ^ (l31 & 7)) << 4) + lh * 8);
+                            acc[i][j][rg * 4 + 0] += __uint_as_float(u.x << 16);
+                            acc[i][j][rg * 4 + 1] += __uint_as_float(u.x & 0xffff0000u);
+                            acc[i][j][rg * 4 + 2] += __uint_as_float(u.y << 16);
+                            acc[i][j][rg * 4 + 3] += __uint_as_float(u.y & 0xffff0000u);
+                        } else {
+                            const float4 rr = *(const float4*)(wl + l31 * RB + (((i * 8 + rg * 2 + lh) ^ (l31 & 7)) << 4));
+                            acc[i][j][rg * 4 + 0] += rr.x; acc[i][j][rg * 4 + 1] += rr.y;
+                            acc[i][j][rg * 4 + 2] += rr.z; acc[i][j][rg * 4 + 3] += rr.w;
+                        }
+                    }
+            }
+            if (a.act == GIM_ACT_RELU) {
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f);
+            } else if (a.act == GIM_ACT_LEAKY) {
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f) + 0.01f * fminf(acc[i][j][r], 0.f);
+            } else if (a.act == GIM_ACT_ELU1) {
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = apply_act(acc[i][j][r], GIM_ACT_ELU1);
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    if constexpr (OUT_BF16) {
+                        *(uint2*)(wl + l31 * RB + (((i * 4 + rg) ^ (l31 & 7)) << 4) + lh * 8) =
+                            make_uint2(cvt_pk_bf16(acc[i][j][rg * 4 + 0], acc[i][j][rg * 4 + 1]),
+                                       cvt_pk_bf16(acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]));
+                    } else {
+                        *(float4*)(wl + l31 * RB + (((i * 8 + rg * 2 + lh) ^ (l31 & 7)) << 4)) =
+                            make_float4(acc[i][j][rg * 4 + 0], acc[i][j][rg * 4 + 1], acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]);
+                    }
+                }
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int row = k * RPI + rrow;
+                const int m = m0 + wm * WTM + j * 32 + row;
+                const uint4 o = *(const uint4*)(wl + row * RB + ((rslot ^ (row & 7)) << 4));
+                if (ncol_ok && (full || m < M)) *(uint4*)((char*)a.y + ((size_t)m * a.ldy + ncol) * OES) = o;
+            }
+        }
+        (void)obf;
+        init_acc(acc, n0n < a.npad ? n0n : 0);
+        g = gn;
+        m0 = m0n; n0 = n0n;
+        __syncthreads();  // the transposition tile lives in a stage buffer the next slab's DMA will overwrite
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool BF16, bool OUT_BF16, bool HAS_RES>
+int launch_persistent(const gim_conv_args& a, hipStream_t stream) {
+    constexpr int smem = 2 * (BM + BN) * KTB;
+    auto kern = igemm_persistent_kernel<BM, BN, WM, WN, BF16, OUT_BF16, HAS_RES>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) {
+            gim_set_error("hipFuncSetAttribute(%d B LDS): %s", smem, hipGetErrorString(e));
+            return GIM_ERR_LAUNCH;
+        }
+        attr_done = true;
+    }
+    const int M = a.B * a.Ho * a.Wo;
+    const int mtiles = (M + BM - 1) / BM, ntiles = a.npad / BN;
+    const int T = mtiles * ntiles;
+    constexpr int RESIDENT = 2 * 256;  // 2 workgroups per CU (LDS bound) x 256 CUs
+    const int rounds = (T + RESIDENT - 1) / RESIDENT;
+    const int grid = (T + rounds - 1) / rounds;  // balanced: every block gets `rounds` (or rounds-1) tiles
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, stream, a, mtiles, ntiles, M);
+    return gim_check_launch("igemm_persistent_kernel");
+}
+
+template <int BM, int BN, int WM, int WN, bool BF16>
+int dispatch_res(const gim_conv_args& a, hipStream_t s) {
+    const bool obf = a.out_dtype == GIM_BF16;
+    if (a.res) {
+        if (obf) return launch_persistent<BM, BN, WM, WN, BF16, true, true>(a, s);
+        return launch_persistent<BM, BN, WM, WN, BF16, false, true>(a, s);
+    }
+    if (obf) return launch_persistent<BM, BN, WM, WN, BF16, true, false>(a, s);
+    return launch_persistent<BM, BN, WM, WN, BF16, false, false>(a, s);
+}
+
+template <bool BF16>
+int dispatch_persistent(const gim_conv_args& a, hipStream_t s) {
+    if (a.npad % 128 == 0) return dispatch_res<128, 128, 2, 2, BF16>(a, s);
+    return dispatch_res<256, 64, 4, 1, BF16>(a, s);
+}
+
 template <int BM, int BN, int WM, int WN, bool BF16, bool LDSDMA>
 int launch_igemm(const gim_conv_args& a, hipStream_t stream) {
     constexpr int stage = 2 * (BM + BN) * KTB, ctile = BM * (BN + 4) * 4;
@@ -169,9 +406,10 @@ extern "C" int gim_conv2d_bn_act(const gim_conv_args* ap, gim_stream_t stream) {
     GIM_REQUIRE(a.ldx % (16 / es) == 0, "conv: ldx=%d breaks 16-byte alignment", a.ldx);
     GIM_REQUIRE(a.ldy % 4 == 0 && (!a.res || a.ldres % 4 == 0), "conv: ldy/ldres must be multiples of 4");
     GIM_REQUIRE(a.out_dtype != GIM_BF16 || (a.N % 8 == 0 && a.ldy % 8 == 0), "conv: bf16 output needs N and ldy multiples of 8 (16-byte row stores)");
+    GIM_REQUIRE(!a.res || (a.res_dtype == a.out_dtype && (a.res_dtype != GIM_BF16 || a.ldres % 8 == 0)), "conv: residual must have the output dtype (and ldres %% 8 == 0 for bf16)");
     GIM_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.Ho > 0 && a.Wo > 0 && a.stride > 0, "conv: bad geometry");
     GIM_REQUIRE((int64_t)a.B * a.Ho * a.Wo < (int64_t)0x7fffffff, "conv: too many output rows");
     hipStream_t s = (hipStream_t)stream;
-    if (a.dtype == GIM_BF16) return a.use_lds_dma ? dispatch_tile<true, true>(a, s) : dispatch_tile<true, false>(a, s);
-    return a.use_lds_dma ? dispatch_tile<false, true>(a, s) : dispatch_tile<false, false>(a, s);
+    if (a.dtype == GIM_BF16) return a.use_lds_dma ? dispatch_persistent<true>(a, s) : dispatch_tile<true, false>(a, s);
+    return a.use_lds_dma ? dispatch_persistent<false>(a, s) : dispatch_tile<false, false>(a, s);
 }

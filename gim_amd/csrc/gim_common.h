@@ -31,9 +31,13 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
 }
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+// two fp32 -> packed bf16x2 (lo in bits 0-15), round to nearest even: one gfx950 instruction
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
 }
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return cvt_pk_bf16(lo, hi); }
 
 // generic typed element access used by the small memory-bound kernels
 template <bool BF16> struct ElemIO;

@@ -1,16 +1,16 @@
-// Shared MFMA main loop of the implicit-GEMM kernels (conv / linear / coarse-matching similarity).
+// Shared MFMA building blocks of the implicit-GEMM kernels (conv / linear / coarse-matching similarity).
 // See conv_igemm.hip for the design notes (LDS image, swizzle, LDS-DMA staging, transposed MFMA tile).
 #pragma once
 #include "gim_common.h"
 
 namespace gim {
 
-constexpr int KTB = 128;  // bytes of K per row per LDS stage
+constexpr int KTB = 128;  // bytes of K per row per LDS stage ("slab")
 
 struct MainloopArgs {
     const void* x;      // pixel rows (NHWC), dtype T
     const void* w;      // [npad][kpad] rows, dtype T
-    const int* ktab;    // [(nkt + 2) * 8]
+    const int* ktab;    // [(nkt + 2) * 8]: K group -> c | dx<<16 | dy<<24 (dy = 255: padding)
     unsigned x_bytes;   // buffer bound of x (offsets >= bound read 0)
     unsigned w_bytes;   // buffer bound of w
     int H, W, Ho, Wo, stride, pad, ldx;
@@ -21,66 +21,74 @@ struct MainloopArgs {
 template <int BM, int BN>
 constexpr int mainloop_smem_bytes() { return 2 * (BM + BN) * KTB; }
 
-// Accumulates the BM x BN tile at (m0, n0) into acc[TN][TM] (transposed fragments: acc[i][j][rg*4+e] is
-// output channel n0 + wn*WTN + i*32 + rg*8 + (lane>>5)*4 + e of pixel m0 + wm*WTM + j*32 + (lane&31)).
-// On return all waves have passed a barrier and the LDS stage buffers are free for reuse.
+// Per-thread state + steps of one BM x BN tile pipeline.  256 threads = 4 waves (WM x WN).
+//   staging role : thread t fetches LDS slot (t & 7) of row (t >> 3) of every 32-row pass; the K group it
+//                  fetches into that slot is slot ^ ((row >> 1) & 7)  (source-side swizzle, LDS-DMA is
+//                  lane-linear);
+//   compute role : wave (wm, wn) owns a (BM/WM) x (BN/WN) sub-tile as TM x TN 32x32 MFMA fragments,
+//                  computed transposed: acc[i][j][rg*4+e] = channel n0 + wn*WTN + i*32 + rg*8 + (lane>>5)*4 + e
+//                  of pixel m0 + wm*WTM + j*32 + (lane & 31).
 template <int BM, int BN, int WM, int WN, bool BF16, bool LDSDMA>
-__device__ __forceinline__ void igemm_mainloop(const MainloopArgs& a, char* smem, const int m0, const int n0,
-                                               f32x16_t (&acc)[BN / WN / 32][BM / WM / 32]) {
-    constexpr int ES = BF16 ? 2 : 4;
-    constexpr int A_BYTES = BM * KTB, B_BYTES = BN * KTB, STAGE = A_BYTES + B_BYTES;
-    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
-    constexpr int PA = BM / 32, PB = BN / 32;
+struct Igemm {
+    static constexpr int ES = BF16 ? 2 : 4;
+    static constexpr int A_BYTES = BM * KTB, B_BYTES = BN * KTB, STAGE = A_BYTES + B_BYTES;
+    static constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    static constexpr int PA = BM / 32, PB = BN / 32;
     static_assert(WM * WN == 4, "4 waves");
-    const int M = a.M;
-
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    // ---- staging role of this thread: row (t>>3) of each 32-row pass, LDS slot (t&7) -----------
-    const int srow = t >> 3, sslot = t & 7;
-    const int sgrp = sslot ^ ((srow >> 1) & 7);  // K group (16 B) within the slab fetched into that slot
+    typedef f32x16_t Acc[TN][TM];
 
     int iy0[PA], ix0[PA];
-    unsigned pix0[PA];
-    {
+    unsigned rowoff[PA];  // byte offset of pixel (b, iy0, ix0), channel 0 (mod 2^32; only used when valid)
+    unsigned wrow;
+    uint4 ra[LDSDMA ? 1 : PA], rb[LDSDMA ? 1 : PB];
+
+    // pixel coordinates of this thread's staging rows for the tile at (m0, n0)
+    __device__ __forceinline__ void decode(const MainloopArgs& a, int m0, int n0) {
+        const int t = threadIdx.x, srow = t >> 3, sslot = t & 7;
+        const int sgrp = sslot ^ ((srow >> 1) & 7);
+        const bool flat = (a.Ho == 1) && (a.H == 1) && (a.stride == 1) && (a.pad == 0);  // pixel index == row index
         const int HoWo = a.Ho * a.Wo;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int m = m0 + i * 32 + srow;
-            if (m < M) {
+            int y = 0, x = m;
+            unsigned pix = 0;
+            if (!flat) {
                 const int b = m / HoWo, r = m - b * HoWo;
                 const int ho = r / a.Wo, wo = r - ho * a.Wo;
-                iy0[i] = ho * a.stride - a.pad;
-                ix0[i] = wo * a.stride - a.pad;
-                pix0[i] = (unsigned)b * (unsigned)(a.H * a.W);
-            } else {
-                iy0[i] = -(1 << 24);
-                ix0[i] = 0;
-                pix0[i] = 0;
+                y = ho * a.stride - a.pad;
+                x = wo * a.stride - a.pad;
+                pix = (unsigned)b * (unsigned)(a.H * a.W);
             }
+            iy0[i] = m < a.M ? y : -(1 << 24);
+            ix0[i] = x;
+            rowoff[i] = (pix + (unsigned)(y * a.W + x)) * (unsigned)a.ldx * ES;
         }
+        wrow = (unsigned)(n0 + srow) * (unsigned)a.kpad * ES + sgrp * 16;
     }
-    const unsigned oobx = a.x_bytes;
-    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)oobx, 0x00020000);
-    const unsigned wbytes = a.w_bytes;
-    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)wbytes, 0x00020000);
-    const unsigned wrow = (unsigned)(n0 + srow) * (unsigned)a.kpad * ES + sgrp * 16;
 
-    uint4 ra[LDSDMA ? 1 : PA], rb[LDSDMA ? 1 : PB];
+    static __device__ __forceinline__ int ktab_index(int kt) {
+        const int t = threadIdx.x;
+        return kt * 8 + ((t & 7) ^ (((t >> 3) >> 1) & 7));
+    }
 
-    // `e` = ktab entry of this lane's K group for slab kt; it is fetched one slab ahead (below) so that
-    // no dependent global load sits in front of the LDS-DMA issue.  The host pads ktab with two slabs
-    // of "invalid" entries, so the look-ahead never needs a bounds check.
-    auto stage_issue = [&](int buf, int kt, int e) {
-        const int c = e & 0xffff, dx = (e >> 16) & 0xff, dy = (e >> 24) & 0xff;
+    // issue the loads of slab kt into LDS stage `buf`.  `e` = ktab[ktab_index(kt)], fetched by the caller
+    // one slab ahead so that no dependent global load sits in front of the DMA issue.
+    __device__ __forceinline__ void stage_issue(const MainloopArgs& a, char* smem, int buf, int kt, int e) {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+        const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.w_bytes, 0x00020000);
+        const int c = e & 0xffff, dx = (e >> 16) & 0xff;
+        int dy = (e >> 24) & 0xff;
+        dy = dy == 255 ? (1 << 28) : dy;  // K padding group: pushes iy out of range for every row
+        // tap offset is common to all rows of this thread
+        const unsigned tapoff = ((unsigned)(dy * a.W + dx) * (unsigned)a.ldx + (unsigned)c) * ES;
         char* sA = smem + buf * STAGE;
         char* sB = sA + A_BYTES;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            const int iy = iy0[i] + dy, ix = ix0[i] + dx;
-            const bool ok = (dy != 255) && ((unsigned)iy < (unsigned)a.H) && ((unsigned)ix < (unsigned)a.W);
-            const unsigned off = ((pix0[i] + (unsigned)(iy * a.W + ix)) * (unsigned)a.ldx + (unsigned)c) * ES;
-            const unsigned voff = ok ? off : oobx;
+            const bool ok = ((unsigned)(iy0[i] + dy) < (unsigned)a.H) & ((unsigned)(ix0[i] + dx) < (unsigned)a.W);
+            const unsigned voff = ok ? rowoff[i] + tapoff : a.x_bytes;
             if constexpr (LDSDMA) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(sA + (i * 32 + wave * 8) * KTB), 16, voff, 0, 0, 0);
             } else {
@@ -96,9 +104,12 @@ __device__ __forceinline__ void igemm_mainloop(const MainloopArgs& a, char* smem
                 rb[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, voff, 0, 0));
             }
         }
-    };
-    auto stage_write = [&](int buf) {
+    }
+
+    // register-staging path only: write the fetched slab into LDS stage `buf`
+    __device__ __forceinline__ void stage_write(char* smem, int buf) {
         if constexpr (!LDSDMA) {
+            const int t = threadIdx.x, srow = t >> 3, sslot = t & 7;
             char* sA = smem + buf * STAGE;
             char* sB = sA + A_BYTES;
 #pragma unroll
@@ -106,43 +117,26 @@ __device__ __forceinline__ void igemm_mainloop(const MainloopArgs& a, char* smem
 #pragma unroll
             for (int i = 0; i < PB; ++i) *(uint4*)(sB + (i * 32 + srow) * KTB + sslot * 16) = rb[i];
         }
-    };
+    }
 
-    // ---- compute role --------------------------------------------------------------------------
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int wm = wave / WN, wn = wave - wm * WN;
-    const int lswz = (l31 >> 1) & 7;
-    const int arow0 = (wm * WTM + l31) * KTB, brow0 = (wn * WTN + l31) * KTB;
-
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nkt = a.kpad * ES / KTB;
-    int e_nxt = a.ktab[8 + sgrp];
-    stage_issue(0, 0, a.ktab[sgrp]);
-    stage_write(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        const int e_n2 = a.ktab[(kt + 2) * 8 + sgrp];
-        if (kt + 1 < nkt) stage_issue(cur ^ 1, kt + 1, e_nxt);
-        const char* sA = smem + cur * STAGE;
-        const char* sB = sA + A_BYTES;
+    // acc += slab in LDS stage `buf`
+    static __device__ __forceinline__ void compute(const char* smem, int buf, Acc& acc) {
+        const int lane = threadIdx.x & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int l31 = lane & 31, lh = lane >> 5;
+        const int wm = wave / WN, wn = wave - wm * WN;
+        const int lswz = (l31 >> 1) & 7;
+        const char* sA = smem + buf * STAGE + (wm * WTM + l31) * KTB;
+        const char* sB = smem + buf * STAGE + A_BYTES + (wn * WTN + l31) * KTB;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int so = ((2 * ks + lh) ^ lswz) << 4;
             if constexpr (BF16) {
                 bf16x8_t fa[TM], fb[TN];
 #pragma unroll
-                for (int j = 0; j < TM; ++j) fa[j] = *(const bf16x8_t*)(sA + arow0 + j * 32 * KTB + so);
+                for (int j = 0; j < TM; ++j) fa[j] = *(const bf16x8_t*)(sA + j * 32 * KTB + so);
 #pragma unroll
-                for (int i = 0; i < TN; ++i) fb[i] = *(const bf16x8_t*)(sB + brow0 + i * 32 * KTB + so);
+                for (int i = 0; i < TN; ++i) fb[i] = *(const bf16x8_t*)(sB + i * 32 * KTB + so);
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -151,9 +145,9 @@ __device__ __forceinline__ void igemm_mainloop(const MainloopArgs& a, char* smem
             } else {
                 f32x4_t fa[TM], fb[TN];
 #pragma unroll
-                for (int j = 0; j < TM; ++j) fa[j] = *(const f32x4_t*)(sA + arow0 + j * 32 * KTB + so);
+                for (int j = 0; j < TM; ++j) fa[j] = *(const f32x4_t*)(sA + j * 32 * KTB + so);
 #pragma unroll
-                for (int i = 0; i < TN; ++i) fb[i] = *(const f32x4_t*)(sB + brow0 + i * 32 * KTB + so);
+                for (int i = 0; i < TN; ++i) fb[i] = *(const f32x4_t*)(sB + i * 32 * KTB + so);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -163,12 +157,43 @@ __device__ __forceinline__ void igemm_mainloop(const MainloopArgs& a, char* smem
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[i][q], fa[j][q], acc[i][j], 0, 0, 0);
             }
         }
-        if (kt + 1 < nkt) stage_write(cur ^ 1);
+    }
+
+    static __device__ __forceinline__ void zero(Acc& acc) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+};
+
+// One whole tile, double-buffered over K (non-persistent use: coarse matching, register-staging fallback).
+// On return all waves have passed a barrier and the LDS stage buffers are free for reuse.
+template <int BM, int BN, int WM, int WN, bool BF16, bool LDSDMA>
+__device__ __forceinline__ void igemm_mainloop(const MainloopArgs& a, char* smem, const int m0, const int n0,
+                                               f32x16_t (&acc)[BN / WN / 32][BM / WM / 32]) {
+    typedef Igemm<BM, BN, WM, WN, BF16, LDSDMA> G;
+    G g;
+    g.decode(a, m0, n0);
+    G::zero(acc);
+    const int nkt = a.kpad * G::ES / KTB;
+    int e_nxt = a.ktab[G::ktab_index(1)];
+    g.stage_issue(a, smem, 0, 0, a.ktab[G::ktab_index(0)]);
+    g.stage_write(smem, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const int e_n2 = a.ktab[G::ktab_index(kt + 2)];
+        if (kt + 1 < nkt) g.stage_issue(a, smem, cur ^ 1, kt + 1, e_nxt);
+        G::compute(smem, cur, acc);
+        if (kt + 1 < nkt) g.stage_write(smem, cur ^ 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         e_nxt = e_n2;
     }
-
 }
 
 }  // namespace gim

@@ -124,12 +124,17 @@ class LazyConfMatrix:
     training losses do), and at 640x480 batch 8 it is 737 MB, so the engine materialises it on demand:
     `.get()` / `torch.as_tensor(obj.get())` launches the HIP kernel that writes [N,L,S] fp32."""
 
-    def __init__(self, coarse_result):
+    def __init__(self, coarse_result, owner=None, generation=None):
         self._r = coarse_result
         self._t = None
+        self._owner, self._gen = owner, generation
 
     def get(self):
         if self._t is None:
+            if self._gen is not None and self._owner._generation != self._gen:
+                raise RuntimeError("conf_matrix of an earlier forward: with HIP-graph replay the softmax "
+                                   "statistics are overwritten by the next call; call .get() before it "
+                                   "(or set GIM_GRAPH=0)")
             self._t = ops.coarse_conf_matrix(self._r)
         return self._t
 
@@ -167,6 +172,10 @@ class LoFTR(nn.Module):
         self._packed_key = None
         self._pe_cache = {}
         self.debug = None  # set to a dict to capture stage outputs (tests): coarse/fine maps, token features
+        # HIP-graph replay of the shape-static part of the forward (env GIM_GRAPH=0 disables)
+        self.use_graph = os.environ.get("GIM_GRAPH", "1") != "0"
+        self._graphs = {}
+        self._generation = 0
         if config.get("weight") is not None:
             self.load_state_dict(torch.load(config["weight"], map_location="cpu"))
 
@@ -178,16 +187,20 @@ class LoFTR(nn.Module):
             if k.startswith("matcher."):
                 state_dict[k.replace("matcher.", "", 1)] = state_dict.pop(k)
         self._packed = None
+        self._graphs.clear()
         return super().load_state_dict(state_dict, *args, **kwargs)
 
     def _apply(self, fn, *a, **k):
         self._packed = None
+        if hasattr(self, "_graphs"):
+            self._graphs.clear()
         return super()._apply(fn, *a, **k)
 
     def set_precision(self, precision):
         assert precision in ("bf16", "fp32")
         self.precision = precision
         self._packed = None
+        self._graphs.clear()
         return self
 
     # ---- weight pre-pack --------------------------------------------------------------------------
@@ -340,6 +353,67 @@ class LoFTR(nn.Module):
                 self._encoder_layer(P, p, T, r1, r0, n1, S, L, H)
 
     # ---- forward (loftr.py:43-91) -------------------------------------------------------------------
+    def _coarse_stage(self, color0, color1, scale0, scale1):
+        """Everything up to and including coarse matching: a fixed launch sequence with no host sync and
+        no data-dependent shape, so it can be captured once per input shape into a HIP graph and replayed.
+        Returns a dict of device tensors (graph-owned when captured)."""
+        dev = color0.device
+        dt = GIM_BF16 if self.precision == "bf16" else GIM_F32
+        tdt = torch_dtype(dt)
+        P = self._prepack(dev)
+        cfg = self.config
+        bs = color0.shape[0]
+        if color0.shape[2:] == color1.shape[2:]:
+            c_all, f_all = self._backbone(P, [color0, color1], dt)
+            c0, c1 = c_all[:bs], c_all[bs:]
+            f0, f1 = f_all[:bs], f_all[bs:]
+        else:  # different input shapes (loftr.py:62-63)
+            c0, f0 = self._backbone(P, [color0], dt)
+            c1, f1 = self._backbone(P, [color1], dt)
+        hw0_c, hw1_c = c0.shape[1:3], c1.shape[1:3]
+        # 2. coarse transformer on pos-encoded tokens (NHWC rows == 'n (h w) c', loftr.py:74-75)
+        C = cfg["coarse"]["d_model"]
+        L, S = hw0_c[0] * hw0_c[1], hw1_c[0] * hw1_c[1]
+        T = self._TfBuffers(bs * (L + S), C, tdt, dev)
+        r0, r1 = slice(0, bs * L), slice(bs * L, bs * (L + S))
+        ops.posenc_add(c0.reshape(-1, C), self._pos_encoding(C, *hw0_c, dev), T.X32[r0], T.CAT[r0, :C])
+        ops.posenc_add(c1.reshape(-1, C), self._pos_encoding(C, *hw1_c, dev), T.X32[r1], T.CAT[r1, :C])
+        self._transformer(P, "c", self.loftr_coarse, T, bs, L, bs, S)
+        # 3. coarse matching (coarse_matching.py:88-259), fused
+        mc = cfg["match_coarse"]
+        scale = color0.shape[2] / hw0_c[0]
+        cr = ops.coarse_match(T.X32[r0].view(bs, L, C), T.X32[r1].view(bs, S, C), hw0_c, hw1_c, scale,
+                              mc["dsmax_temperature"], mc["thr"], mc["border_rm"], scale0, scale1)
+        return {"c0": c0, "c1": c1, "f0": f0, "f1": f1, "cr": cr,
+                "feat_c0": T.X32[r0].view(bs, L, C), "feat_c1": T.X32[r1].view(bs, S, C)}
+
+    def _coarse_stage_graphed(self, color0, color1, scale0, scale1):
+        """HIP-graph replay of `_coarse_stage` (one graph per input shape / precision).  ~300 kernel launches
+        collapse into one graph launch; inputs are copied into the graph's static buffers."""
+        key = (tuple(color0.shape), tuple(color1.shape), scale0 is not None, self.precision, str(color0.device))
+        ent = self._graphs.get(key)
+        if ent is None:
+            self._prepack(color0.device)
+            for hw in (color0.shape[2:], color1.shape[2:]):
+                self._pos_encoding(self.config["coarse"]["d_model"], hw[0] // 8, hw[1] // 8, color0.device)
+            sin = [color0.clone(), color1.clone(),
+                   scale0.clone().float() if scale0 is not None else None,
+                   scale1.clone().float() if scale1 is not None else None]
+            self._coarse_stage(*sin)  # warm-up: one-time hipFuncSetAttribute calls, allocator pools
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._coarse_stage(*sin)
+            ent = self._graphs[key] = (graph, sin, out)
+        graph, sin, out = ent
+        sin[0].copy_(color0)
+        sin[1].copy_(color1)
+        if scale0 is not None:
+            sin[2].copy_(scale0)
+            sin[3].copy_(scale1)
+        graph.replay()
+        return out
+
     @torch.no_grad()
     def forward(self, data):
         for k in ("image0", "image1", "color0", "color1"):
@@ -354,53 +428,47 @@ class LoFTR(nn.Module):
         dev = color0.device
         dt = GIM_BF16 if self.precision == "bf16" else GIM_F32
         tdt = torch_dtype(dt)
-        P = self._prepack(dev)
         cfg = self.config
+        color0 = color0.contiguous().float()
+        color1 = color1.contiguous().float()
+        scale0, scale1 = data.get("scale0"), data.get("scale1")
+        if scale0 is not None:
+            scale0 = scale0.to(device=dev, dtype=torch.float32).contiguous()
+            scale1 = scale1.to(device=dev, dtype=torch.float32).contiguous()
 
         data.update({"bs": data["image0"].size(0),
                      "hw0_i": data["image0"].shape[2:], "hw1_i": data["image1"].shape[2:]})
         bs = data["bs"]
-        if data["hw0_i"] == data["hw1_i"]:
-            c_all, f_all = self._backbone(P, [color0, color1], dt)
-            c0, c1 = c_all[:bs], c_all[bs:]
-            f0, f1 = f_all[:bs], f_all[bs:]
-        else:  # different input shapes (loftr.py:62-63)
-            c0, f0 = self._backbone(P, [color0], dt)
-            c1, f1 = self._backbone(P, [color1], dt)
+        graphed = self.use_graph and self.debug is None
+        if graphed:
+            try:
+                st = self._coarse_stage_graphed(color0, color1, scale0, scale1)
+            except Exception as e:  # capture unsupported in this environment: same kernels, eager launches
+                import warnings
+                warnings.warn(f"gim_amd: HIP graph capture failed ({e!r}); falling back to eager kernel launches")
+                self.use_graph = graphed = False
+                self._graphs.clear()
+        if not graphed:
+            st = self._coarse_stage(color0, color1, scale0, scale1)
+        c0, c1, f0, f1, cr = st["c0"], st["c1"], st["f0"], st["f1"], st["cr"]
         if self.debug is not None:
-            self.debug.update({"c0": c0, "c1": c1, "f0": f0, "f1": f1})
+            self.debug.update({k: st[k] for k in ("c0", "c1", "f0", "f1", "feat_c0", "feat_c1")})
         hw0_c, hw1_c = c0.shape[1:3], c1.shape[1:3]
         hw0_f, hw1_f = f0.shape[1:3], f1.shape[1:3]
         data.update({"hw0_c": torch.Size(hw0_c), "hw1_c": torch.Size(hw1_c),
                      "hw0_f": torch.Size(hw0_f), "hw1_f": torch.Size(hw1_f)})
 
-        # 2. coarse transformer on pos-encoded tokens (NHWC rows == 'n (h w) c', loftr.py:74-75)
-        C = cfg["coarse"]["d_model"]
-        L, S = hw0_c[0] * hw0_c[1], hw1_c[0] * hw1_c[1]
-        T = self._TfBuffers(bs * (L + S), C, tdt, dev)
-        r0, r1 = slice(0, bs * L), slice(bs * L, bs * (L + S))
-        ops.posenc_add(c0.reshape(-1, C), self._pos_encoding(C, *hw0_c, dev), T.X32[r0], T.CAT[r0, :C])
-        ops.posenc_add(c1.reshape(-1, C), self._pos_encoding(C, *hw1_c, dev), T.X32[r1], T.CAT[r1, :C])
-        self._transformer(P, "c", self.loftr_coarse, T, bs, L, bs, S)
-
-        if self.debug is not None:
-            self.debug.update({"feat_c0": T.X32[r0].view(bs, L, C), "feat_c1": T.X32[r1].view(bs, S, C)})
-
-        # 3. coarse matching (coarse_matching.py:88-259), fused
-        mc = cfg["match_coarse"]
-        scale = data["hw0_i"][0] / hw0_c[0]
-        cr = ops.coarse_match(T.X32[r0].view(bs, L, C), T.X32[r1].view(bs, S, C), hw0_c, hw1_c, scale,
-                              mc["dsmax_temperature"], mc["thr"], mc["border_rm"],
-                              data.get("scale0"), data.get("scale1"))
         M = int(cr.count[0].item())  # the one host sync the reference also has (torch.where, :193)
-        b_ids, i_ids, j_ids = cr.b_ids[:M], cr.i_ids[:M], cr.j_ids[:M]
-        mconf = cr.mconf[:M]
-        data.update({"conf_matrix": LazyConfMatrix(cr)})
+        self._generation += 1
+        # graph replays reuse their output buffers: hand out private copies of the (small) match lists
+        own = (lambda t: t.clone()) if graphed else (lambda t: t)
+        b_ids, i_ids, j_ids = own(cr.b_ids[:M]), own(cr.i_ids[:M]), own(cr.j_ids[:M])
+        mkpts0_c, mkpts1_c, mconf = own(cr.mkpts0_c[:M]), own(cr.mkpts1_c[:M]), own(cr.mconf[:M])
+        data.update({"conf_matrix": LazyConfMatrix(cr, self, self._generation if graphed else None)})
         data.update({"b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids,
                      "gt_mask": torch.zeros(M, dtype=torch.bool, device=dev),  # mconf == 0 never holds (> thr)
                      "m_bids": b_ids.clone(),
-                     "mkpts0_c": cr.mkpts0_c[:M], "mkpts1_c": cr.mkpts1_c[:M], "mconf": mconf})
-        self._last_coarse = cr
+                     "mkpts0_c": mkpts0_c, "mkpts1_c": mkpts1_c, "mconf": mconf})
 
         # 4./5. fine level (fine_preprocess.py:29-47, transformer on [M,25,128], fine_matching.py:15-74)
         W = self.W
@@ -411,6 +479,7 @@ class LoFTR(nn.Module):
             data.update({"expec_f": torch.empty(0, 3, device=dev),
                          "mkpts0_f": data["mkpts0_c"], "mkpts1_f": data["mkpts1_c"]})
             return
+        P = self._prepack(dev)
         stride = hw0_f[0] // hw0_c[0]
         F = self._TfBuffers(2 * M * WW, Cf, tdt, dev)
         ops.fine_gather(f0, f1, b_ids, i_ids, j_ids, M, hw0_c[1], hw1_c[1], stride, W, F.X32, F.CAT[:, :Cf])
@@ -419,7 +488,6 @@ class LoFTR(nn.Module):
             self.debug.update({"fine0": F.X32[:M * WW].view(M, WW, Cf), "fine1": F.X32[M * WW:].view(M, WW, Cf)})
         fscale = data["hw0_i"][0] / hw0_f[0]
         has_s0 = "scale0" in data
-        s1 = cr.keep[3] if has_s0 else None
-        expec_f, mkpts1_f = ops.fine_match(F.X32[:M * WW], F.X32[M * WW:], data["mkpts1_c"], b_ids, s1, M, WW,
-                                           fscale, has_s0)
+        expec_f, mkpts1_f = ops.fine_match(F.X32[:M * WW], F.X32[M * WW:], mkpts1_c, b_ids,
+                                           scale1 if has_s0 else None, M, WW, fscale, has_s0)
         data.update({"expec_f": expec_f, "mkpts0_f": data["mkpts0_c"], "mkpts1_f": mkpts1_f})

@@ -105,7 +105,10 @@ def conv2d(x, pk, act=ACT_NONE, res=None, out_dtype=None, lds_dma=True):
     Wo = (W + 2 * pk.pad - pk.kw) // pk.stride + 1
     y = torch.empty(B, Ho, Wo, pk.n_store, dtype=out_dtype or x.dtype, device=x.device)
     r = res.view(-1, res.shape[-1]) if res is not None else None
-    conv_rows(x.view(-1, cs), pk, (B, H, W, Ho, Wo), y.view(-1, pk.n_store), act, r, 0, lds_dma)
+    geom = (B, H, W, Ho, Wo)
+    if pk.kh == 1 and pk.kw == 1 and pk.stride == 1 and pk.pad == 0:
+        geom = (1, 1, B * H * W, 1, B * H * W)  # pixel index == row index: the kernel skips the coordinate decode
+    conv_rows(x.view(-1, cs), pk, geom, y.view(-1, pk.n_store), act, r, 0, lds_dma)
     return y
 
 

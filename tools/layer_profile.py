@@ -35,11 +35,14 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
+print("hip graph:", m.use_graph)
 t0 = time.perf_counter()
 for _ in range(10):
     step()
 torch.cuda.synchronize()
 print(f"forward: {(time.perf_counter() - t0) * 100:.3f} ms/step  (dma={args.dma} {args.precision})")
+m.use_graph = False
+step()
 ops.PROFILE = []
 for _ in range(3):
     step()

@@ -80,14 +80,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for w_ in range(args.warmup):  # the COMPLETE step, incl. match packing (torch loads its kernels lazily)
+        pack_matches(step(), list(range(nb)))
+    all_gather_matches(torch.zeros(1, 6, device=dev))
     sync_all()
     t0 = time.perf_counter()
     rows = []
+    tstep = []
     for s in range(args.steps):
         d = step()
         rows.append(pack_matches(d, [(s * world + rank) * nb + b for b in range(nb)]))
+        tstep.append(time.perf_counter())
     allrows = all_gather_matches(torch.cat(rows))  # the one collective: matches, for reporting
     n_matches = int(allrows.shape[0])
     sync_all()
@@ -143,6 +146,8 @@ def main():
                "sample": f"{n} pair(s) 640x480 fp32, one un-warmed forward of oracle/loftr_oracle.py "
                          f"(torch CPU, {ncore} threads), {tc:.1f} s"}
 
+    if rank == 0 and os.environ.get("GIM_BENCH_DEBUG"):
+        print("per-step ms:", [round(1e3 * (b - a), 2) for a, b in zip([t0] + tstep[:-1], tstep)], file=sys.stderr)
     if rank == 0:
         pairs = world * nb * args.steps
         out = {

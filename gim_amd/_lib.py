@@ -22,7 +22,7 @@ class ConvArgs(ctypes.Structure):
         ("y", c_void_p), ("x_bytes", c_int64),
         ("B", c_int), ("H", c_int), ("W", c_int), ("Ho", c_int), ("Wo", c_int),
         ("stride", c_int), ("pad", c_int), ("ldx", c_int), ("ldy", c_int), ("ldres", c_int),
-        ("N", c_int), ("npad", c_int), ("kpad", c_int), ("act", c_int), ("res_mod", c_int),
+        ("N", c_int), ("npad", c_int), ("kpad", c_int), ("act", c_int), ("act_cols", c_int), ("res_mod", c_int),
         ("dtype", c_int), ("out_dtype", c_int), ("res_dtype", c_int), ("use_lds_dma", c_int),
     ]
 

@@ -11,15 +11,23 @@
 //          bit-exact indices against a CPU fp32 oracle, which bf16 operands cannot give -- SURVEY 7),
 //          tile staged in LDS, per-tile row/column (max, sum-exp) partials.
 // combine: partials -> per-row / per-column softmax statistics.
-// Pass B  (cm_cand):   tiles recomputed; conf evaluated only where the row factor alone already exceeds
-//          thr; elements with conf > thr become candidates (<= 4 per row, since sum_j softmax_j <= 1):
-//          atomicMax of conf into rowmax/colmax (positive floats order like their bit patterns).
-//          Restricting the maxima to candidates is exact: if conf[i,j] > thr and some conf[i,j'] >=
-//          conf[i,j], then (i,j') is a candidate too.
+//          Pass A also emits *pre-candidates*: the softmax over a tile's 128 columns (rows) bounds the
+//          true row (column) softmax from above, so only elements whose tile-local row factor, column
+//          factor and product all exceed thr can end up with conf > thr (<= 4 per row per tile); they are
+//          stored as (i, j, sim).  Exact, and it removes the second similarity pass.
+// Pass B  (cm_precand): every pre-candidate is evaluated with the final statistics; conf > thr makes
+//          it a candidate (<= 4 per row, since sum_j softmax_j <= 1): atomicMax of conf into
+//          rowmax/colmax (positive floats order like their bit patterns).  Restricting the maxima to
+//          candidates is exact: if conf[i,j] > thr and some conf[i,j'] >= conf[i,j], then (i,j') is a
+//          candidate too.  If the pre-candidate buffer overflows (cannot happen for thr >= 0.2 with the
+//          default capacity unless more than 16 entries per row survive on average) the device-side flag
+//          makes cm_cand recompute the tiles instead (the original two-pass scheme); it exits at once
+//          otherwise.
 // select:  candidate survives iff it equals both maxima and is off the border; ties -> smallest j
 //          (mask.max(dim=2) returns the first True).  compact: block scan per pair, ascending i.
 #include "igemm_mainloop.h"
 #include <limits.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -29,6 +37,7 @@ constexpr int TILE_SMEM = BM * TLD * 4 + (4 * 128 + 4 * 128) * 4;  // tile + red
 static_assert(TILE_SMEM >= gim::mainloop_smem_bytes<BM, BN>(), "stage buffers must fit in the tile allocation");
 
 struct Cand { int i, j; float p; int pad; };
+struct PreCand { int i, j; float s; };
 
 struct CmWs {  // device pointers carved out of the caller's workspace
     float2* rowpart;   // [N][ntS][L]
@@ -42,8 +51,10 @@ struct CmWs {  // device pointers carved out of the caller's workspace
     int* lpos;         // [N][L]
     int* ncand;        // [N]
     Cand* cand;        // [N][capc]
+    int* npre;         // [N] pre-candidate counters, npre[N] = overflow flag
+    PreCand* pre;      // [N][capp]
     int* ktab;         // dense K table for the mainloop
-    int ntL, ntS, capc;
+    int ntL, ntS, capc, capp;
 };
 
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -52,6 +63,10 @@ size_t carve(CmWs& w, char* base, int N, int L, int S, int C) {
     w.ntL = (L + BM - 1) / BM;
     w.ntS = (S + BN - 1) / BN;
     w.capc = 4 * L + 64;
+    // pre-candidate capacity; GIM_CM_PRECAND_PER_ROW (default 16) exists so that tests can force the
+    // overflow -> recompute fallback
+    static const int per_row = [] { const char* e = getenv("GIM_CM_PRECAND_PER_ROW"); int v = e ? atoi(e) : 16; return v < 0 ? 0 : v; }();
+    w.capp = per_row * L + 1024;
     size_t o = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + o : nullptr; o += al(bytes); return p; };
     w.rowpart = (float2*)take((size_t)N * w.ntS * L * 8);
@@ -65,6 +80,8 @@ size_t carve(CmWs& w, char* base, int N, int L, int S, int C) {
     w.lpos = (int*)take((size_t)N * L * 4);
     w.ncand = (int*)take((size_t)N * 4);
     w.cand = (Cand*)take((size_t)N * w.capc * sizeof(Cand));
+    w.npre = (int*)take((size_t)(N + 1) * 4);
+    w.pre = (PreCand*)take((size_t)N * w.capp * sizeof(PreCand));
     w.ktab = (int*)take((size_t)(C / 32 + 2) * 8 * 4);
     return o;
 }
@@ -112,6 +129,11 @@ __device__ __forceinline__ void sim_tile_to_lds(const CmGeom& g, const int* ktab
     __syncthreads();
 }
 
+// exp for the softmax *statistics* (sums of up to S terms): v_exp_f32 on x*log2(e).  Relative error
+// <= ~|x| * 6e-8 -- 1e-6 for every term that contributes more than e^-15 of a sum -- while each of the few
+// final confidences is evaluated with the accurate expf (cm_precand / cm_cand).
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+
 __global__ void __launch_bounds__(256) cm_stats_kernel(const CmGeom g, const CmWs w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = blockIdx.y;
@@ -119,7 +141,11 @@ __global__ void __launch_bounds__(256) cm_stats_kernel(const CmGeom g, const CmW
     const int m0 = mt * BM, n0 = nt * BN;
     sim_tile_to_lds<0>(g, w.ktab, n, m0, n0, smem);
     const float* St = (const float*)smem;
-    float* red = (float*)(smem + BM * TLD * 4);  // [4][128]: rowmax halves, rowsum halves
+    float* red = (float*)(smem + BM * TLD * 4);  // [4][128] reduction scratch
+    float* rowm = red + 512;                     // tile-local row max / sum, column max / sum
+    float* rowz = red + 640;
+    float* colm = red + 768;
+    float* colz = red + 896;
     const int t = threadIdx.x, idx = t & 127, half = t >> 7;
     const float NEG = -INFINITY;
     // ---- rows: thread (row idx, column half) ----
@@ -140,15 +166,18 @@ __global__ void __launch_bounds__(256) cm_stats_kernel(const CmGeom g, const CmW
         for (int jj = 0; jj < 64; jj += 4) {
             const int j = half * 64 + jj;
             const float4 v = *(const float4*)(St + idx * TLD + j);
-            if (n0 + j + 0 < g.S) z += expf(v.x - m);
-            if (n0 + j + 1 < g.S) z += expf(v.y - m);
-            if (n0 + j + 2 < g.S) z += expf(v.z - m);
-            if (n0 + j + 3 < g.S) z += expf(v.w - m);
+            if (n0 + j + 0 < g.S) z += fast_exp(v.x - m);
+            if (n0 + j + 1 < g.S) z += fast_exp(v.y - m);
+            if (n0 + j + 2 < g.S) z += fast_exp(v.z - m);
+            if (n0 + j + 3 < g.S) z += fast_exp(v.w - m);
         }
         red[256 + half * 128 + idx] = z;
         __syncthreads();
-        if (half == 0 && m0 + idx < g.L)
-            w.rowpart[((size_t)n * w.ntS + nt) * g.L + m0 + idx] = make_float2(m, red[256 + idx] + red[384 + idx]);
+        if (half == 0) {
+            const float zz = red[256 + idx] + red[384 + idx];
+            rowm[idx] = m; rowz[idx] = zz;
+            if (m0 + idx < g.L) w.rowpart[((size_t)n * w.ntS + nt) * g.L + m0 + idx] = make_float2(m, zz);
+        }
         __syncthreads();
     }
     // ---- columns: thread (column idx, row half) ----
@@ -161,11 +190,61 @@ __global__ void __launch_bounds__(256) cm_stats_kernel(const CmGeom g, const CmW
         const float m = fmaxf(red[idx], red[128 + idx]);
         float z = 0.f;
         for (int r = half * 64; r < half * 64 + 64; ++r)
-            if (m0 + r < g.L) z += expf(St[r * TLD + idx] - m);
+            if (m0 + r < g.L) z += fast_exp(St[r * TLD + idx] - m);
         red[256 + half * 128 + idx] = z;
         __syncthreads();
-        if (half == 0 && n0 + idx < g.S)
-            w.colpart[((size_t)n * w.ntL + mt) * g.S + n0 + idx] = make_float2(m, red[256 + idx] + red[384 + idx]);
+        if (half == 0) {
+            const float zz = red[256 + idx] + red[384 + idx];
+            colm[idx] = m; colz[idx] = zz;
+            if (n0 + idx < g.S) w.colpart[((size_t)n * w.ntL + mt) * g.S + n0 + idx] = make_float2(m, zz);
+        }
+        __syncthreads();
+    }
+    // ---- pre-candidates.  softmax over the tile's columns (rows) >= the true row (column) softmax, so
+    // conf > thr needs: tile-local row factor > thr, column factor > thr (cheap tests  s > m + log(thr z))
+    // and their product > thr (evaluated only for the few survivors).
+    {
+        const float thr_pre = g.thr * (1.0f - 1e-4f);  // slack: rounding must never drop a true candidate
+        if (half == 0) red[idx] = rowm[idx] + logf(thr_pre * rowz[idx]);
+        else red[128 + idx] = colm[idx] + logf(thr_pre * colz[idx]);
+        __syncthreads();
+        const int i = m0 + idx;
+        if (i >= g.L) return;
+        const float trow = red[idx], rm = rowm[idx], rz = rowz[idx];
+        for (int jj = 0; jj < 64; ++jj) {
+            const int jl = half * 64 + jj, j = n0 + jl;
+            if (j >= g.S) break;
+            const float sv = St[idx * TLD + jl];
+            if (sv > trow && sv > red[128 + jl]) {
+                const float pr = expf(sv - rm) / rz;
+                const float pc = expf(sv - colm[jl]) / colz[jl];
+                if (pr * pc > thr_pre) {
+                    const int k = atomicAdd(&w.npre[n], 1);
+                    if (k < w.capp) w.pre[(size_t)n * w.capp + k] = PreCand{i, j, sv};
+                    else w.npre[g.N] = 1;  // overflow: cm_cand_kernel<0> recomputes
+                }
+            }
+        }
+    }
+}
+
+// Pass B on the pre-candidate list: final statistics -> conf; candidates + row/column maxima
+__global__ void cm_precand_kernel(const CmGeom g, const CmWs w) {
+    const int n = blockIdx.y;
+    if (w.npre[g.N]) return;  // overflowed: cm_cand_kernel<0> recomputes everything
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= min(w.npre[n], w.capp)) return;
+    const PreCand c = w.pre[(size_t)n * w.capp + k];
+    const float2 r = w.rowstat[(size_t)n * g.L + c.i], cs = w.colstat[(size_t)n * g.S + c.j];
+    const float pr = expf(c.s - r.x) / r.y;    // softmax over j (dim=2)
+    const float pc = expf(c.s - cs.x) / cs.y;  // softmax over i (dim=1)
+    const float p = pc * pr;
+    if (p > g.thr) {
+        const unsigned pb = __float_as_uint(p);
+        atomicMax(&w.rowmaxP[(size_t)n * g.L + c.i], pb);
+        atomicMax(&w.colmaxP[(size_t)n * g.S + c.j], pb);
+        const int q = atomicAdd(&w.ncand[n], 1);
+        if (q < w.capc) w.cand[(size_t)n * w.capc + q] = Cand{c.i, c.j, p, 0};
     }
 }
 
@@ -189,6 +268,7 @@ __global__ void cm_init_kernel(const CmWs w, int N, int L, int S) {
     if (idx < (size_t)N * L) { w.rowmaxP[idx] = 0u; w.jsel[idx] = INT_MAX; w.psel[idx] = 0.f; }
     if (idx < (size_t)N * S) w.colmaxP[idx] = 0u;
     if (idx < (size_t)N) w.ncand[idx] = 0;
+    if (idx <= (size_t)N) w.npre[idx] = 0;
 }
 
 __global__ void cm_ktab_kernel(int* ktab, int C) {  // dense table: K group g -> channel 4g; 2 padding slabs
@@ -201,6 +281,7 @@ __global__ void cm_ktab_kernel(int* ktab, int C) {  // dense table: K group g ->
 template <int MODE>
 __global__ void __launch_bounds__(256) cm_cand_kernel(const CmGeom g, const CmWs w, float* __restrict__ conf) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (MODE == 0 && !w.npre[g.N]) return;  // fallback only: the pre-candidate path did the work
     const int n = blockIdx.y;
     const int mt = blockIdx.x / w.ntS, nt = blockIdx.x - mt * w.ntS;
     const int m0 = mt * BM, n0 = nt * BN;
@@ -380,6 +461,7 @@ extern "C" int gim_coarse_match(const gim_coarse_args* ap, gim_stream_t stream) 
     hipLaunchKernelGGL(cm_stats_kernel, tgrid, dim3(256), TILE_SMEM, s, g, w);
     hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.L + 255) / 256)), dim3(256), 0, s, w.rowpart, w.rowstat, a.N, a.L, w.ntS);
     hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.S + 255) / 256)), dim3(256), 0, s, w.colpart, w.colstat, a.N, a.S, w.ntL);
+    hipLaunchKernelGGL(cm_precand_kernel, dim3((unsigned)((w.capp + 255) / 256), (unsigned)a.N), dim3(256), 0, s, g, w);
     hipLaunchKernelGGL(cm_cand_kernel<0>, tgrid, dim3(256), TILE_SMEM, s, g, w, (float*)nullptr);
     BorderGeom bg{a.h0c, a.w0c, a.h1c, a.w1c, a.border_rm};
     dim3 cgrid((unsigned)((w.capc + 255) / 256), (unsigned)a.N);

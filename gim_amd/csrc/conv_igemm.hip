@@ -44,6 +44,7 @@ __device__ __forceinline__ void epilogue_rows(const gim_conv_args& a, const floa
     const int t = threadIdx.x;
     const int cg = (t % LPR) * G, n = n0 + cg;
     if (n >= a.N) return;
+    const int act = (a.act_cols > 0 && n0 >= a.act_cols) ? GIM_ACT_NONE : a.act;
     float bias[G];
 #pragma unroll
     for (int e = 0; e < G; ++e) bias[e] = a.bias ? a.bias[n + e] : 0.f;
@@ -64,9 +65,9 @@ __device__ __forceinline__ void epilogue_rows(const gim_conv_args& a, const floa
                 v[e] += rr.x; v[e + 1] += rr.y; v[e + 2] += rr.z; v[e + 3] += rr.w;
             }
         }
-        if (a.act != GIM_ACT_NONE) {
+        if (act != GIM_ACT_NONE) {
 #pragma unroll
-            for (int e = 0; e < G; ++e) v[e] = apply_act(v[e], a.act);
+            for (int e = 0; e < G; ++e) v[e] = apply_act(v[e], act);
         }
         const size_t yo = (size_t)m * a.ldy + n;
         if constexpr (OUT_BF16) {
@@ -255,6 +256,7 @@ igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntile
         // buffer (buf ^ 1 after the flip above), coalesced stores that drain during the next tile -------------
         char* wl = smem + (buf ^ 1) * G::STAGE + wave * (32 * RB);  // this wave's transposition tile [32 px][RB]
         const bool obf = OUT_BF16;
+        const int act = (a.act_cols > 0 && n0 >= a.act_cols) ? GIM_ACT_NONE : a.act;  // tile-uniform
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
             if constexpr (HAS_RES) {
@@ -280,17 +282,17 @@ igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntile
                         }
                     }
             }
-            if (a.act == GIM_ACT_RELU) {
+            if (act == GIM_ACT_RELU) {
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f);
-            } else if (a.act == GIM_ACT_LEAKY) {
+            } else if (act == GIM_ACT_LEAKY) {
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f) + 0.01f * fminf(acc[i][j][r], 0.f);
-            } else if (a.act == GIM_ACT_ELU1) {
+            } else if (act == GIM_ACT_ELU1) {
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -407,6 +409,7 @@ extern "C" int gim_conv2d_bn_act(const gim_conv_args* ap, gim_stream_t stream) {
     GIM_REQUIRE(a.ldy % 4 == 0 && (!a.res || a.ldres % 4 == 0), "conv: ldy/ldres must be multiples of 4");
     GIM_REQUIRE(a.out_dtype != GIM_BF16 || (a.N % 8 == 0 && a.ldy % 8 == 0), "conv: bf16 output needs N and ldy multiples of 8 (16-byte row stores)");
     GIM_REQUIRE(!a.res || (a.res_dtype == a.out_dtype && (a.res_dtype != GIM_BF16 || a.ldres % 8 == 0)), "conv: residual must have the output dtype (and ldres %% 8 == 0 for bf16)");
+    GIM_REQUIRE(a.act_cols >= 0 && a.act_cols % 128 == 0, "conv: act_cols=%d must be a multiple of 128", a.act_cols);
     GIM_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.Ho > 0 && a.Wo > 0 && a.stride > 0, "conv: bad geometry");
     GIM_REQUIRE((int64_t)a.B * a.Ho * a.Wo < (int64_t)0x7fffffff, "conv: too many output rows");
     hipStream_t s = (hipStream_t)stream;

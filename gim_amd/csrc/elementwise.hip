@@ -39,15 +39,17 @@ __global__ void nhwc_to_nchw_kernel(const void* __restrict__ src, float* __restr
 
 // y[b, Y, X, :] += bilinear(x)[b, Y, X, :], scale 2, align_corners=True.
 // Weights exactly as ATen's area_pixel_compute_source_index(align_corners=true): src = dst*(in-1)/(out-1).
+// One thread = one 16-byte channel group (8 bf16 / 4 fp32) of one output pixel.
 template <bool BF16>
 __global__ void upsample2x_add_kernel(const void* __restrict__ x, void* __restrict__ y, int B, int h, int w,
-                                      int C4, int ldx, int ldy) {
+                                      int CG, int ldx, int ldy) {
+    constexpr int G = BF16 ? 8 : 4;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int H2 = 2 * h, W2 = 2 * w;
-    const size_t total = (size_t)B * H2 * W2 * C4;
+    const size_t total = (size_t)B * H2 * W2 * CG;
     if (idx >= total) return;
-    const int cq = (int)(idx % C4);
-    const size_t pix = idx / C4;
+    const int cg = (int)(idx % CG);
+    const size_t pix = idx / CG;
     const int X = (int)(pix % W2);
     const int Y = (int)((pix / W2) % H2);
     const int b = (int)(pix / ((size_t)W2 * H2));
@@ -58,17 +60,20 @@ __global__ void upsample2x_add_kernel(const void* __restrict__ x, void* __restri
     const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
     const float ly1 = fy - y0, ly0 = 1.f - ly1, lx1 = fx - x0, lx0 = 1.f - lx1;
     const size_t base = (size_t)b * h * w;
-    const float4 a = ElemIO<BF16>::ld4(x, (base + (size_t)y0 * w + x0) * ldx + cq * 4);
-    const float4 bq = ElemIO<BF16>::ld4(x, (base + (size_t)y0 * w + x1) * ldx + cq * 4);
-    const float4 c = ElemIO<BF16>::ld4(x, (base + (size_t)y1 * w + x0) * ldx + cq * 4);
-    const float4 d = ElemIO<BF16>::ld4(x, (base + (size_t)y1 * w + x1) * ldx + cq * 4);
-    const size_t yo = pix * ldy + cq * 4;
-    float4 o = ElemIO<BF16>::ld4(y, yo);
-    o.x += ly0 * (lx0 * a.x + lx1 * bq.x) + ly1 * (lx0 * c.x + lx1 * d.x);
-    o.y += ly0 * (lx0 * a.y + lx1 * bq.y) + ly1 * (lx0 * c.y + lx1 * d.y);
-    o.z += ly0 * (lx0 * a.z + lx1 * bq.z) + ly1 * (lx0 * c.z + lx1 * d.z);
-    o.w += ly0 * (lx0 * a.w + lx1 * bq.w) + ly1 * (lx0 * c.w + lx1 * d.w);
-    ElemIO<BF16>::st4(y, yo, o);
+    const size_t o00 = (base + (size_t)y0 * w + x0) * ldx + cg * G, o01 = (base + (size_t)y0 * w + x1) * ldx + cg * G;
+    const size_t o10 = (base + (size_t)y1 * w + x0) * ldx + cg * G, o11 = (base + (size_t)y1 * w + x1) * ldx + cg * G;
+    const size_t yo = pix * ldy + cg * G;
+#pragma unroll
+    for (int e = 0; e < G; e += 4) {
+        const float4 a = ElemIO<BF16>::ld4(x, o00 + e), bq = ElemIO<BF16>::ld4(x, o01 + e);
+        const float4 c = ElemIO<BF16>::ld4(x, o10 + e), d = ElemIO<BF16>::ld4(x, o11 + e);
+        float4 o = ElemIO<BF16>::ld4(y, yo + e);
+        o.x += ly0 * (lx0 * a.x + lx1 * bq.x) + ly1 * (lx0 * c.x + lx1 * d.x);
+        o.y += ly0 * (lx0 * a.y + lx1 * bq.y) + ly1 * (lx0 * c.y + lx1 * d.y);
+        o.z += ly0 * (lx0 * a.z + lx1 * bq.z) + ly1 * (lx0 * c.z + lx1 * d.z);
+        o.w += ly0 * (lx0 * a.w + lx1 * bq.w) + ly1 * (lx0 * c.w + lx1 * d.w);
+        ElemIO<BF16>::st4(y, yo + e, o);
+    }
 }
 
 template <bool BF16>
@@ -165,12 +170,14 @@ extern "C" int gim_upsample2x_add(const void* x, void* y, int B, int h, int w, i
                                   gim_stream_t stream) {
     GIM_REQUIRE(x && y && B > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0, "upsample2x_add: bad args (C=%d)", C);
     GIM_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "upsample2x_add: ld must be a multiple of 4");
-    const size_t n = (size_t)B * 2 * h * 2 * w * (C / 4);
+    const int G = dtype == GIM_BF16 ? 8 : 4;
+    GIM_REQUIRE(C % G == 0, "upsample2x_add: C=%d must be a multiple of %d (16-byte groups)", C, G);
+    const size_t n = (size_t)B * 2 * h * 2 * w * (C / G);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == GIM_BF16)
-        hipLaunchKernelGGL(upsample2x_add_kernel<true>, dim3(nblocks(n, 256)), dim3(256), 0, s, x, y, B, h, w, C / 4, ldx, ldy);
+        hipLaunchKernelGGL(upsample2x_add_kernel<true>, dim3(nblocks(n, 256)), dim3(256), 0, s, x, y, B, h, w, C / G, ldx, ldy);
     else
-        hipLaunchKernelGGL(upsample2x_add_kernel<false>, dim3(nblocks(n, 256)), dim3(256), 0, s, x, y, B, h, w, C / 4, ldx, ldy);
+        hipLaunchKernelGGL(upsample2x_add_kernel<false>, dim3(nblocks(n, 256)), dim3(256), 0, s, x, y, B, h, w, C / G, ldx, ldy);
     return gim_check_launch("upsample2x_add");
 }
 

@@ -236,8 +236,12 @@ class LoFTR(nn.Module):
         for name, tf in (("c", self.loftr_coarse), ("f", self.loftr_fine)):
             for li, layer in enumerate(tf.layers):
                 p = f"{name}{li}."
-                for lin in ("q_proj", "k_proj", "v_proj", "merge"):
-                    P[p + lin] = pack_conv(getattr(layer, lin).weight, None, dt, device)
+                P[p + "merge"] = pack_conv(layer.merge.weight, None, dt, device)
+                P[p + "q_proj"] = pack_conv(layer.q_proj.weight, None, dt, device)
+                # fused projections (one GEMM instead of three / two): self layers [q|k|v], cross layers [k|v]
+                P[p + "qkv"] = pack_conv(torch.cat([layer.q_proj.weight, layer.k_proj.weight, layer.v_proj.weight], 0),
+                                         None, dt, device)
+                P[p + "kv"] = pack_conv(torch.cat([layer.k_proj.weight, layer.v_proj.weight], 0), None, dt, device)
                 P[p + "mlp0"] = pack_conv(layer.mlp[0].weight, None, dt, device)
                 P[p + "mlp2"] = pack_conv(layer.mlp[2].weight, None, dt, device)
                 for nm in ("norm1", "norm2"):
@@ -308,9 +312,7 @@ class LoFTR(nn.Module):
             f32 = torch.float32
             self.X32 = torch.empty(R, C, dtype=f32, device=dev)       # fp32 master of the token features
             self.CAT = torch.empty(R, 2 * C, dtype=tdt, device=dev)   # [x | norm1(message)] GEMM operand
-            self.Q = torch.empty(R, C, dtype=tdt, device=dev)
-            self.K = torch.empty(R, C, dtype=tdt, device=dev)
-            self.V = torch.empty(R, C, dtype=tdt, device=dev)
+            self.QKV = torch.empty(R, 3 * C, dtype=tdt, device=dev)   # [elu(q)+1 | elu(k)+1 | v] row buffers
             self.MSG = torch.empty(R, C, dtype=tdt, device=dev)
             self.MRG = torch.empty(R, C, dtype=f32, device=dev)
             self.HID = torch.empty(R, 2 * C, dtype=tdt, device=dev)
@@ -322,10 +324,13 @@ class LoFTR(nn.Module):
         C = T.X32.shape[1]
         dma = self.use_lds_dma
         x_t, s_t = T.CAT[xs, :C], T.CAT[ss, :C]
-        ops.linear(x_t, P[p + "q_proj"], T.Q[xs], ACT_ELU1, dma)   # elu(q)+1 fused (attentions.py:31)
-        ops.linear(s_t, P[p + "k_proj"], T.K[ss], ACT_ELU1, dma)   # elu(k)+1 fused (attentions.py:32)
-        ops.linear(s_t, P[p + "v_proj"], T.V[ss], ACT_NONE, dma)
-        T.ws = ops.linear_attention(T.Q[xs], T.K[ss], T.V[ss], T.MSG[xs], nb, L, nb, S, H, T.ws)
+        # q/k/v projections with elu(.)+1 (attentions.py:31-32) fused into the epilogue of the q and k columns
+        if xs == ss:
+            ops.linear(x_t, P[p + "qkv"], T.QKV[xs], ACT_ELU1, dma, act_cols=2 * C)
+        else:
+            ops.linear(x_t, P[p + "q_proj"], T.QKV[xs, :C], ACT_ELU1, dma)
+            ops.linear(s_t, P[p + "kv"], T.QKV[ss, C:], ACT_ELU1, dma, act_cols=C)
+        T.ws = ops.linear_attention(T.QKV[xs, :C], T.QKV[ss, C:2 * C], T.QKV[ss, 2 * C:], T.MSG[xs], nb, L, nb, S, H, T.ws)
         ops.linear(T.MSG[xs], P[p + "merge"], T.MRG[xs], ACT_NONE, dma)
         g1, b1, e1 = P[p + "norm1"]
         ops.layernorm_residual(T.MRG[xs], g1, b1, None, None, T.CAT[xs, C:], e1)

@@ -64,7 +64,7 @@ def nhwc_to_nchw(src, C):
 
 
 # ---- conv / linear --------------------------------------------------------------------------------
-def conv_rows(x, pk, geom, y, act=ACT_NONE, res=None, res_mod=0, lds_dma=True):
+def conv_rows(x, pk, geom, y, act=ACT_NONE, res=None, res_mod=0, lds_dma=True, act_cols=0):
     """Generic launch.  x: 2-D row view [rows_in, ldx]; geom = (B, H, W, Ho, Wo); y: 2-D row view."""
     _req_cuda(x, y, res)
     B, H, W, Ho, Wo = geom
@@ -81,7 +81,7 @@ def conv_rows(x, pk, geom, y, act=ACT_NONE, res=None, res_mod=0, lds_dma=True):
     a.ldx, a.ldy = x.stride(0), y.stride(0)
     a.ldres = res.stride(0) if res is not None else 0
     a.N, a.npad, a.kpad = pk.n_store, pk.npad, pk.kpad
-    a.act, a.res_mod = act, res_mod
+    a.act, a.res_mod, a.act_cols = act, res_mod, act_cols
     a.dtype, a.out_dtype = pk.dtype, gim_dtype(y)
     a.res_dtype = gim_dtype(res) if res is not None else GIM_F32
     a.use_lds_dma = 1 if lds_dma else 0
@@ -112,10 +112,11 @@ def conv2d(x, pk, act=ACT_NONE, res=None, out_dtype=None, lds_dma=True):
     return y
 
 
-def linear(x, pk, y, act=ACT_NONE, lds_dma=True):
-    """x: row view [rows, >=K] (row stride may exceed K), y: row view [rows, >=N].  y = act(x @ W^T)."""
+def linear(x, pk, y, act=ACT_NONE, lds_dma=True, act_cols=0):
+    """x: row view [rows, >=K] (row stride may exceed K), y: row view [rows, >=N].  y = act(x @ W^T);
+    act_cols > 0 restricts the activation to output columns < act_cols."""
     rows = x.shape[0]
-    conv_rows(x, pk, (1, 1, rows, 1, rows), y, act, None, 0, lds_dma)
+    conv_rows(x, pk, (1, 1, rows, 1, rows), y, act, None, 0, lds_dma, act_cols)
 
 
 # ---- elementwise ------------------------------------------------------------------------------------

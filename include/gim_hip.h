@@ -68,6 +68,8 @@ typedef struct gim_conv_args {
     int N;              /* valid output channels stored (multiple of 4, <= npad) */
     int npad, kpad;
     int act;            /* GIM_ACT_* */
+    int act_cols;       /* 0: activation on every column; >0 (multiple of 128): only on columns < act_cols
+                           (fused [q|k|v] projection: elu+1 on q,k but not on v) */
     int res_mod;        /* 0: res row = m;  >0: res row = m % res_mod (broadcast over images) */
     int dtype;          /* dtype of x and w */
     int out_dtype;      /* dtype of y */

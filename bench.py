@@ -121,8 +121,14 @@ def main():
             ms, fl = by.get(lab, (0.0, 0.0))
             by[lab] = (ms + e0.elapsed_time(e1), fl + f)
         top = sorted(by.items(), key=lambda kv: -kv[1][0])[:8]
+        # HBM bytes per launch from the TCC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected in
+        # separate rocprofv3 --pmc passes of the same workload by tools/pmc_traffic.sh and committed under profiles/
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if args.precision == "bf16" and nb == 8 and os.path.exists(tj):
+            traffic = round(json.load(open(tj))["traffic_bytes_per_launch"])
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": None,
+                "frac": round(achieved / peak, 4), "traffic": traffic,
                 "kernel": "igemm_kernel (gim_conv2d_bn_act)", "launches_per_step": nlaunch // 2,
                 "avg_launch_us": round(1e3 * tot_ms / nlaunch, 2),
                 "gflop_per_launch": round(tot_fl / nlaunch / 1e9, 3),

@@ -31,7 +31,7 @@ class CoarseArgs(ctypes.Structure):
     """struct gim_coarse_args (include/gim_hip.h)."""
     _fields_ = [
         ("feat0", c_void_p), ("feat1", c_void_p), ("scale0", c_void_p), ("scale1", c_void_p),
-        ("ws", c_void_p), ("b_ids", c_void_p), ("i_ids", c_void_p), ("j_ids", c_void_p),
+        ("mask0", c_void_p), ("mask1", c_void_p), ("ws", c_void_p), ("b_ids", c_void_p), ("i_ids", c_void_p), ("j_ids", c_void_p),
         ("mconf", c_void_p), ("mkpts0_c", c_void_p), ("mkpts1_c", c_void_p), ("count", c_void_p),
         ("N", c_int), ("L", c_int), ("S", c_int), ("C", c_int),
         ("h0c", c_int), ("w0c", c_int), ("h1c", c_int), ("w1c", c_int),
@@ -52,8 +52,8 @@ PROTOTYPES = {
     "gim_upsample2x_add": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "gim_posenc_add": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
     "gim_linear_attention_ws_bytes": (c_int64, [c_int] * 4),
-    "gim_linear_attention_kv": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),
-    "gim_linear_attention_apply": (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p]),
+    "gim_linear_attention_kv": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
+    "gim_linear_attention_apply": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
     "gim_layernorm_residual": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_float, c_void_p]),
     "gim_coarse_match_ws_bytes": (c_int64, [c_int] * 3),
     "gim_coarse_match": (c_int, [ctypes.POINTER(CoarseArgs), c_void_p]),

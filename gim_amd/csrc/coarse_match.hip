@@ -51,6 +51,7 @@ struct CmWs {  // device pointers carved out of the caller's workspace
     int* lpos;         // [N][L]
     int* ncand;        // [N]
     Cand* cand;        // [N][capc]
+    int* ext;          // [N][4] valid extents of the padding masks
     int* npre;         // [N] pre-candidate counters, npre[N] = overflow flag
     PreCand* pre;      // [N][capp]
     int* ktab;         // dense K table for the mainloop
@@ -80,6 +81,7 @@ size_t carve(CmWs& w, char* base, int N, int L, int S, int C) {
     w.lpos = (int*)take((size_t)N * L * 4);
     w.ncand = (int*)take((size_t)N * 4);
     w.cand = (Cand*)take((size_t)N * w.capc * sizeof(Cand));
+    w.ext = (int*)take((size_t)N * 16);
     w.npre = (int*)take((size_t)(N + 1) * 4);
     w.pre = (PreCand*)take((size_t)N * w.capp * sizeof(PreCand));
     w.ktab = (int*)take((size_t)(C / 32 + 2) * 8 * 4);
@@ -89,6 +91,8 @@ size_t carve(CmWs& w, char* base, int N, int L, int S, int C) {
 struct CmGeom {
     const float* feat0;
     const float* feat1;
+    const uint8_t* mask0;  // [N][L] or NULL
+    const uint8_t* mask1;  // [N][S] or NULL
     int N, L, S, C;
     float inv_c, temperature, thr;
 };
@@ -110,9 +114,13 @@ __device__ __forceinline__ void sim_tile_to_lds(const CmGeom& g, const int* ktab
     float* St = (float*)smem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, lh = lane >> 5, wm = wave / WN, wn = wave - wm * WN;
+    const bool masked = g.mask0 != nullptr;
+    const float NEG_INF = -1e9f;  // INF = 1e9 (coarse_matching.py:6): sim.masked_fill_(~(mask0 x mask1), -INF)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int i_loc = wm * 64 + j * 32 + l31;
+        const int gi = m0 + i_loc;
+        const bool vi = !masked || (gi < g.L && g.mask0[(size_t)n * g.L + gi]);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -123,6 +131,14 @@ __device__ __forceinline__ void sim_tile_to_lds(const CmGeom& g, const int* ktab
                 v.y = (acc[i][j][rg * 4 + 1] * g.inv_c) / g.temperature;
                 v.z = (acc[i][j][rg * 4 + 2] * g.inv_c) / g.temperature;
                 v.w = (acc[i][j][rg * 4 + 3] * g.inv_c) / g.temperature;
+                if (masked) {
+                    const int gj = n0 + j_loc;
+                    const uint8_t* m1 = g.mask1 + (size_t)n * g.S;
+                    if (!vi || gj + 0 >= g.S || !m1[gj + 0]) v.x = NEG_INF;
+                    if (!vi || gj + 1 >= g.S || !m1[gj + 1]) v.y = NEG_INF;
+                    if (!vi || gj + 2 >= g.S || !m1[gj + 2]) v.z = NEG_INF;
+                    if (!vi || gj + 3 >= g.S || !m1[gj + 3]) v.w = NEG_INF;
+                }
                 *(float4*)(St + i_loc * TLD + j_loc) = v;
             }
     }
@@ -319,11 +335,38 @@ __global__ void __launch_bounds__(256) cm_cand_kernel(const CmGeom g, const CmWs
     }
 }
 
-struct BorderGeom { int h0c, w0c, h1c, w1c, b; };
+struct BorderGeom { int h0c, w0c, h1c, w1c, b; const int* ext; };  // ext: NULL or [N][4] = valid (h0, w0, h1, w1)
 
-__device__ __forceinline__ bool off_border(int idx, int h, int wd, int b) {
+// cell idx of a map of row length `wd`; valid extent (h, w): off the border iff b <= y < h-b and b <= x < w-b
+__device__ __forceinline__ bool off_border2(int idx, int wd, int h, int w, int b) {
     const int y = idx / wd, x = idx - y * wd;
-    return y >= b && y < h - b && x >= b && x < wd - b;
+    return y >= b && y < h - b && x >= b && x < w - b;
+}
+
+// valid extent of the padding masks, as the reference computes it: h = max over columns of the per-column
+// count of valid cells (p_m.sum(1).max(-1)), w = max over rows of the per-row count (p_m.sum(-1).max(-1)).
+__global__ void cm_mask_extent_kernel(const uint8_t* __restrict__ m0, const uint8_t* __restrict__ m1, int* __restrict__ ext,
+                                      int h0c, int w0c, int h1c, int w1c) {
+    __shared__ int best[4];
+    const int n = blockIdx.x, t = threadIdx.x;
+    if (t < 4) best[t] = 0;
+    __syncthreads();
+    for (int which = 0; which < 2; ++which) {
+        const uint8_t* m = which ? m1 + (size_t)n * h1c * w1c : m0 + (size_t)n * h0c * w0c;
+        const int h = which ? h1c : h0c, w = which ? w1c : w0c;
+        for (int x = t; x < w; x += blockDim.x) {  // column sums -> valid height
+            int c = 0;
+            for (int y = 0; y < h; ++y) c += m[y * w + x] ? 1 : 0;
+            atomicMax(&best[which * 2 + 0], c);
+        }
+        for (int y = t; y < h; y += blockDim.x) {  // row sums -> valid width
+            int c = 0;
+            for (int x = 0; x < w; ++x) c += m[y * w + x] ? 1 : 0;
+            atomicMax(&best[which * 2 + 1], c);
+        }
+    }
+    __syncthreads();
+    if (t < 4) ext[n * 4 + t] = best[t];
 }
 
 // phase 0: jsel[i] = min j over surviving candidates; phase 1: psel[i] = conf of the selected one
@@ -336,7 +379,11 @@ __global__ void cm_select_kernel(const CmWs w, int N, int L, int S, BorderGeom b
     const Cand c = w.cand[(size_t)n * w.capc + k];
     const unsigned pb = __float_as_uint(c.p);
     if (pb != w.rowmaxP[(size_t)n * L + c.i] || pb != w.colmaxP[(size_t)n * S + c.j]) return;
-    if (!off_border(c.i, bg.h0c, bg.w0c, bg.b) || !off_border(c.j, bg.h1c, bg.w1c, bg.b)) return;
+    // mask_border (coarse_matching.py:9-26) or, with padding masks, mask_border_with_padding (:29-44):
+    // the far borders are measured from the valid extent of each image
+    const int h0 = bg.ext ? bg.ext[n * 4 + 0] : bg.h0c, w0 = bg.ext ? bg.ext[n * 4 + 1] : bg.w0c;
+    const int h1 = bg.ext ? bg.ext[n * 4 + 2] : bg.h1c, w1 = bg.ext ? bg.ext[n * 4 + 3] : bg.w1c;
+    if (!off_border2(c.i, bg.w0c, h0, w0, bg.b) || !off_border2(c.j, bg.w1c, h1, w1, bg.b)) return;
     if (PHASE == 0) atomicMin(&w.jsel[(size_t)n * L + c.i], c.j);
     else if (w.jsel[(size_t)n * L + c.i] == c.j) w.psel[(size_t)n * L + c.i] = c.p;
 }
@@ -412,6 +459,7 @@ int validate(const gim_coarse_args& a) {
     GIM_REQUIRE(a.h0c * a.w0c == a.L && a.h1c * a.w1c == a.S, "coarse_match: hw0_c/hw1_c do not match L/S");
     GIM_REQUIRE((int64_t)a.L * a.C * 4 < (int64_t)0xFFFFFFF0ll && (int64_t)a.S * a.C * 4 < (int64_t)0xFFFFFFF0ll, "coarse_match: feature map too large");
     GIM_REQUIRE(a.temperature > 0.f && a.thr > 0.f, "coarse_match: temperature and thr must be positive");
+    GIM_REQUIRE((a.mask0 == nullptr) == (a.mask1 == nullptr), "coarse_match: mask0 and mask1 must be given together");
     return GIM_OK;
 }
 
@@ -431,7 +479,7 @@ extern "C" int64_t gim_coarse_match_ws_bytes(int N, int L, int S) {
 
 static int cm_prepare(const gim_coarse_args& a, CmWs& w, CmGeom& g) {
     carve(w, (char*)a.ws, a.N, a.L, a.S, a.C);
-    g.feat0 = a.feat0; g.feat1 = a.feat1; g.N = a.N; g.L = a.L; g.S = a.S; g.C = a.C;
+    g.feat0 = a.feat0; g.feat1 = a.feat1; g.mask0 = a.mask0; g.mask1 = a.mask1; g.N = a.N; g.L = a.L; g.S = a.S; g.C = a.C;
     g.inv_c = 1.0f / (float)a.C; g.temperature = a.temperature; g.thr = a.thr;
     static bool attr = false;
     if (!attr) {
@@ -463,7 +511,8 @@ extern "C" int gim_coarse_match(const gim_coarse_args* ap, gim_stream_t stream) 
     hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.S + 255) / 256)), dim3(256), 0, s, w.colpart, w.colstat, a.N, a.S, w.ntL);
     hipLaunchKernelGGL(cm_precand_kernel, dim3((unsigned)((w.capp + 255) / 256), (unsigned)a.N), dim3(256), 0, s, g, w);
     hipLaunchKernelGGL(cm_cand_kernel<0>, tgrid, dim3(256), TILE_SMEM, s, g, w, (float*)nullptr);
-    BorderGeom bg{a.h0c, a.w0c, a.h1c, a.w1c, a.border_rm};
+    if (a.mask0) hipLaunchKernelGGL(cm_mask_extent_kernel, dim3((unsigned)a.N), dim3(256), 0, s, a.mask0, a.mask1, w.ext, a.h0c, a.w0c, a.h1c, a.w1c);
+    BorderGeom bg{a.h0c, a.w0c, a.h1c, a.w1c, a.border_rm, a.mask0 ? w.ext : nullptr};
     dim3 cgrid((unsigned)((w.capc + 255) / 256), (unsigned)a.N);
     hipLaunchKernelGGL(cm_select_kernel<0>, cgrid, dim3(256), 0, s, w, a.N, a.L, a.S, bg);
     hipLaunchKernelGGL(cm_select_kernel<1>, cgrid, dim3(256), 0, s, w, a.N, a.L, a.S, bg);

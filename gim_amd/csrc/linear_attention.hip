@@ -15,8 +15,8 @@ constexpr int CH = 128;  // rows of S per block in the KV reduction
 
 template <int D, bool BF16>
 __global__ void __launch_bounds__(256)
-la_kv_kernel(const void* __restrict__ k, const void* __restrict__ v, float* __restrict__ part, int S, int H,
-             int ldk, int ldv, int nchunk) {
+la_kv_kernel(const void* __restrict__ k, const void* __restrict__ v, const uint8_t* __restrict__ kv_mask,
+             float* __restrict__ part, int S, int H, int ldk, int ldv, int nchunk) {
     __shared__ __attribute__((aligned(16))) float Ks[CH][D];
     __shared__ __attribute__((aligned(16))) float Vs[CH][D];
     const int bh = blockIdx.x, chunk = blockIdx.y;
@@ -29,7 +29,7 @@ la_kv_kernel(const void* __restrict__ k, const void* __restrict__ v, float* __re
     for (int r = t / Q4; r < CH; r += RPP) {
         const int s = s0 + r, c4 = (t % Q4) * 4;
         float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
-        if (s < S) {
+        if (s < S && (!kv_mask || kv_mask[(size_t)b * S + s])) {  // K * kv_mask, values * kv_mask (attentions.py:38-39)
             kk = ElemIO<BF16>::ld4(k, ((size_t)b * S + s) * ldk + h * D + c4);
             vv = ElemIO<BF16>::ld4(v, ((size_t)b * S + s) * ldv + h * D + c4);
             vv.x = vv.x / slen; vv.y = vv.y / slen; vv.z = vv.z / slen; vv.w = vv.w / slen;  // values / v_length
@@ -71,8 +71,8 @@ __global__ void la_kv_finalize_kernel(const float* __restrict__ part, float* __r
 
 template <int D, bool BF16, bool OUT_BF16>
 __global__ void __launch_bounds__(256)
-la_apply_kernel(const void* __restrict__ q, const float* __restrict__ kvfin, void* __restrict__ out, int L, int S,
-                int H, int ldq, int ldo) {
+la_apply_kernel(const void* __restrict__ q, const uint8_t* __restrict__ q_mask, const float* __restrict__ kvfin,
+                void* __restrict__ out, int L, int S, int H, int ldq, int ldo) {
     extern __shared__ __attribute__((aligned(16))) float kv[];  // [H][D*D + D]
     const int b = blockIdx.x, l0 = blockIdx.y * 64;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -82,11 +82,13 @@ la_apply_kernel(const void* __restrict__ q, const float* __restrict__ kvfin, voi
     const int l = l0 + lane;
     if (l >= L) return;
     const float slen = (float)S;
+    const bool qvalid = !q_mask || q_mask[(size_t)b * L + l];  // Q * q_mask (attentions.py:36): masked row -> Q = 0
     for (int h = wave; h < H; h += 4) {
         float qv[D];
 #pragma unroll
         for (int c = 0; c < D; c += 4) {
-            const float4 x = ElemIO<BF16>::ld4(q, ((size_t)b * L + l) * ldq + h * D + c);
+            float4 x = ElemIO<BF16>::ld4(q, ((size_t)b * L + l) * ldq + h * D + c);
+            if (!qvalid) x = make_float4(0.f, 0.f, 0.f, 0.f);
             qv[c] = x.x; qv[c + 1] = x.y; qv[c + 2] = x.z; qv[c + 3] = x.w;
         }
         const float* KV = kv + h * PER;
@@ -119,8 +121,8 @@ extern "C" int64_t gim_linear_attention_ws_bytes(int nb, int S, int H, int D) {
     return (int64_t)nb * H * per * 4 * (nc > 1 ? nc + 1 : 1);
 }
 
-extern "C" int gim_linear_attention_kv(const void* k, const void* v, float* kv_ws, int nb, int S, int H, int D,
-                                       int ldk, int ldv, int dtype, gim_stream_t stream) {
+extern "C" int gim_linear_attention_kv(const void* k, const void* v, const uint8_t* kv_mask, float* kv_ws, int nb,
+                                       int S, int H, int D, int ldk, int ldv, int dtype, gim_stream_t stream) {
     GIM_REQUIRE(k && v && kv_ws && nb > 0 && S > 0 && H > 0, "linear_attention_kv: bad args");
     GIM_REQUIRE(D == 32 || D == 16, "linear_attention_kv: head dim %d unsupported (16 or 32)", D);
     GIM_REQUIRE(ldk % 4 == 0 && ldv % 4 == 0, "linear_attention_kv: ld alignment");
@@ -132,11 +134,11 @@ extern "C" int gim_linear_attention_kv(const void* k, const void* v, float* kv_w
     dim3 grid((unsigned)(nb * H), (unsigned)nc);
     const bool bf = dtype == GIM_BF16;
     if (D == 32) {
-        if (bf) hipLaunchKernelGGL((la_kv_kernel<32, true>), grid, dim3(256), 0, s, k, v, part, S, H, ldk, ldv, nc);
-        else hipLaunchKernelGGL((la_kv_kernel<32, false>), grid, dim3(256), 0, s, k, v, part, S, H, ldk, ldv, nc);
+        if (bf) hipLaunchKernelGGL((la_kv_kernel<32, true>), grid, dim3(256), 0, s, k, v, kv_mask, part, S, H, ldk, ldv, nc);
+        else hipLaunchKernelGGL((la_kv_kernel<32, false>), grid, dim3(256), 0, s, k, v, kv_mask, part, S, H, ldk, ldv, nc);
     } else {
-        if (bf) hipLaunchKernelGGL((la_kv_kernel<16, true>), grid, dim3(256), 0, s, k, v, part, S, H, ldk, ldv, nc);
-        else hipLaunchKernelGGL((la_kv_kernel<16, false>), grid, dim3(256), 0, s, k, v, part, S, H, ldk, ldv, nc);
+        if (bf) hipLaunchKernelGGL((la_kv_kernel<16, true>), grid, dim3(256), 0, s, k, v, kv_mask, part, S, H, ldk, ldv, nc);
+        else hipLaunchKernelGGL((la_kv_kernel<16, false>), grid, dim3(256), 0, s, k, v, kv_mask, part, S, H, ldk, ldv, nc);
     }
     int rc = gim_check_launch("la_kv");
     if (rc != GIM_OK) return rc;
@@ -148,8 +150,9 @@ extern "C" int gim_linear_attention_kv(const void* k, const void* v, float* kv_w
     return rc;
 }
 
-extern "C" int gim_linear_attention_apply(const void* q, const float* kv_ws, void* out, int nb, int L, int S, int H,
-                                          int D, int ldq, int ldo, int dtype, int out_dtype, gim_stream_t stream) {
+extern "C" int gim_linear_attention_apply(const void* q, const uint8_t* q_mask, const float* kv_ws, void* out, int nb,
+                                          int L, int S, int H, int D, int ldq, int ldo, int dtype, int out_dtype,
+                                          gim_stream_t stream) {
     GIM_REQUIRE(q && kv_ws && out && nb > 0 && L > 0 && S > 0 && H > 0, "linear_attention_apply: bad args");
     GIM_REQUIRE(D == 32 || D == 16, "linear_attention_apply: head dim %d unsupported (16 or 32)", D);
     GIM_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0, "linear_attention_apply: ld alignment");
@@ -158,7 +161,7 @@ extern "C" int gim_linear_attention_apply(const void* q, const float* kv_ws, voi
     const size_t smem = (size_t)H * (D * D + D) * 4;
     GIM_REQUIRE(smem <= 64 * 1024, "linear_attention_apply: H=%d too large", H);
     const bool bf = dtype == GIM_BF16, obf = out_dtype == GIM_BF16;
-#define LA_APPLY(DD, A, B) hipLaunchKernelGGL((la_apply_kernel<DD, A, B>), grid, dim3(256), smem, s, q, kv_ws, out, L, S, H, ldq, ldo)
+#define LA_APPLY(DD, A, B) hipLaunchKernelGGL((la_apply_kernel<DD, A, B>), grid, dim3(256), smem, s, q, q_mask, kv_ws, out, L, S, H, ldq, ldo)
     if (D == 32) {
         if (bf && obf) LA_APPLY(32, true, true);
         else if (bf) LA_APPLY(32, true, false);

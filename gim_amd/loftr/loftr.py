@@ -318,6 +318,7 @@ class LoFTR(nn.Module):
             self.HID = torch.empty(R, 2 * C, dtype=tdt, device=dev)
             self.MLP = torch.empty(R, C, dtype=f32, device=dev)
             self.ws = None
+            self.MASK = None  # optional uint8 [R] padding mask aligned with the rows (coarse level only)
 
     def _encoder_layer(self, P, p, T, xs, ss, nb, L, S, H):
         """LoFTREncoderLayer.forward (transformer.py:35-58) on row ranges xs (queries) / ss (source)."""
@@ -330,7 +331,10 @@ class LoFTR(nn.Module):
         else:
             ops.linear(x_t, P[p + "q_proj"], T.QKV[xs, :C], ACT_ELU1, dma)
             ops.linear(s_t, P[p + "kv"], T.QKV[ss, C:], ACT_ELU1, dma, act_cols=C)
-        T.ws = ops.linear_attention(T.QKV[xs, :C], T.QKV[ss, C:2 * C], T.QKV[ss, 2 * C:], T.MSG[xs], nb, L, nb, S, H, T.ws)
+        qm = T.MASK[xs] if T.MASK is not None else None  # x_mask / source_mask (transformer.py:50, attentions.py:35-39)
+        km = T.MASK[ss] if T.MASK is not None else None
+        T.ws = ops.linear_attention(T.QKV[xs, :C], T.QKV[ss, C:2 * C], T.QKV[ss, 2 * C:], T.MSG[xs], nb, L, nb, S, H,
+                                    T.ws, qm, km)
         ops.linear(T.MSG[xs], P[p + "merge"], T.MRG[xs], ACT_NONE, dma)
         g1, b1, e1 = P[p + "norm1"]
         ops.layernorm_residual(T.MRG[xs], g1, b1, None, None, T.CAT[xs, C:], e1)
@@ -358,7 +362,7 @@ class LoFTR(nn.Module):
                 self._encoder_layer(P, p, T, r1, r0, n1, S, L, H)
 
     # ---- forward (loftr.py:43-91) -------------------------------------------------------------------
-    def _coarse_stage(self, color0, color1, scale0, scale1):
+    def _coarse_stage(self, color0, color1, scale0, scale1, mask0=None, mask1=None):
         """Everything up to and including coarse matching: a fixed launch sequence with no host sync and
         no data-dependent shape, so it can be captured once per input shape into a HIP graph and replayed.
         Returns a dict of device tensors (graph-owned when captured)."""
@@ -381,6 +385,10 @@ class LoFTR(nn.Module):
         L, S = hw0_c[0] * hw0_c[1], hw1_c[0] * hw1_c[1]
         T = self._TfBuffers(bs * (L + S), C, tdt, dev)
         r0, r1 = slice(0, bs * L), slice(bs * L, bs * (L + S))
+        if mask0 is not None:  # mask_c0 = mask0.flatten(-2) (loftr.py:78-79); row-aligned with the token buffers
+            T.MASK = torch.empty(bs * (L + S), dtype=torch.uint8, device=dev)
+            T.MASK[r0].copy_(mask0.reshape(-1))
+            T.MASK[r1].copy_(mask1.reshape(-1))
         ops.posenc_add(c0.reshape(-1, C), self._pos_encoding(C, *hw0_c, dev), T.X32[r0], T.CAT[r0, :C])
         ops.posenc_add(c1.reshape(-1, C), self._pos_encoding(C, *hw1_c, dev), T.X32[r1], T.CAT[r1, :C])
         self._transformer(P, "c", self.loftr_coarse, T, bs, L, bs, S)
@@ -388,14 +396,16 @@ class LoFTR(nn.Module):
         mc = cfg["match_coarse"]
         scale = color0.shape[2] / hw0_c[0]
         cr = ops.coarse_match(T.X32[r0].view(bs, L, C), T.X32[r1].view(bs, S, C), hw0_c, hw1_c, scale,
-                              mc["dsmax_temperature"], mc["thr"], mc["border_rm"], scale0, scale1)
+                              mc["dsmax_temperature"], mc["thr"], mc["border_rm"], scale0, scale1,
+                              T.MASK[r0] if mask0 is not None else None, T.MASK[r1] if mask0 is not None else None)
         return {"c0": c0, "c1": c1, "f0": f0, "f1": f1, "cr": cr,
                 "feat_c0": T.X32[r0].view(bs, L, C), "feat_c1": T.X32[r1].view(bs, S, C)}
 
-    def _coarse_stage_graphed(self, color0, color1, scale0, scale1):
+    def _coarse_stage_graphed(self, color0, color1, scale0, scale1, mask0=None, mask1=None):
         """HIP-graph replay of `_coarse_stage` (one graph per input shape / precision).  ~300 kernel launches
         collapse into one graph launch; inputs are copied into the graph's static buffers."""
-        key = (tuple(color0.shape), tuple(color1.shape), scale0 is not None, self.precision, str(color0.device))
+        key = (tuple(color0.shape), tuple(color1.shape), scale0 is not None, mask0 is not None, self.precision,
+               str(color0.device))
         ent = self._graphs.get(key)
         if ent is None:
             self._prepack(color0.device)
@@ -403,7 +413,8 @@ class LoFTR(nn.Module):
                 self._pos_encoding(self.config["coarse"]["d_model"], hw[0] // 8, hw[1] // 8, color0.device)
             sin = [color0.clone(), color1.clone(),
                    scale0.clone().float() if scale0 is not None else None,
-                   scale1.clone().float() if scale1 is not None else None]
+                   scale1.clone().float() if scale1 is not None else None,
+                   mask0.clone() if mask0 is not None else None, mask1.clone() if mask1 is not None else None]
             self._coarse_stage(*sin)  # warm-up: one-time hipFuncSetAttribute calls, allocator pools
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
@@ -416,6 +427,9 @@ class LoFTR(nn.Module):
         if scale0 is not None:
             sin[2].copy_(scale0)
             sin[3].copy_(scale1)
+        if mask0 is not None:
+            sin[4].copy_(mask0)
+            sin[5].copy_(mask1)
         graph.replay()
         return out
 
@@ -428,8 +442,6 @@ class LoFTR(nn.Module):
         if not color0.is_cuda:
             raise GimHipError("gim_amd LoFTR runs on the HIP device only (no CPU fallback): move the inputs "
                               "and the module to 'cuda'")
-        if "mask0" in data:
-            raise NotImplementedError("padding masks (mask0/mask1, coarse_matching.py:29-44) are not built yet")
         dev = color0.device
         dt = GIM_BF16 if self.precision == "bf16" else GIM_F32
         tdt = torch_dtype(dt)
@@ -441,20 +453,29 @@ class LoFTR(nn.Module):
             scale0 = scale0.to(device=dev, dtype=torch.float32).contiguous()
             scale1 = scale1.to(device=dev, dtype=torch.float32).contiguous()
 
+        mask0 = mask1 = None
+        if "mask0" in data:  # [N, h/8, w/8] padding masks, '0' = padded (loftr.py:49-50, 77-79)
+            mask0 = data["mask0"].to(device=dev).ne(0).to(torch.uint8).contiguous()
+            mask1 = data["mask1"].to(device=dev).ne(0).to(torch.uint8).contiguous()
+            exp0 = (color0.shape[0], color0.shape[2] // 8, color0.shape[3] // 8)
+            exp1 = (color1.shape[0], color1.shape[2] // 8, color1.shape[3] // 8)
+            if tuple(mask0.shape) != exp0 or tuple(mask1.shape) != exp1:
+                raise ValueError(f"mask0/mask1 must be [N, H/8, W/8]: got {tuple(mask0.shape)}, {tuple(mask1.shape)}")
+
         data.update({"bs": data["image0"].size(0),
                      "hw0_i": data["image0"].shape[2:], "hw1_i": data["image1"].shape[2:]})
         bs = data["bs"]
         graphed = self.use_graph and self.debug is None
         if graphed:
             try:
-                st = self._coarse_stage_graphed(color0, color1, scale0, scale1)
+                st = self._coarse_stage_graphed(color0, color1, scale0, scale1, mask0, mask1)
             except Exception as e:  # capture unsupported in this environment: same kernels, eager launches
                 import warnings
                 warnings.warn(f"gim_amd: HIP graph capture failed ({e!r}); falling back to eager kernel launches")
                 self.use_graph = graphed = False
                 self._graphs.clear()
         if not graphed:
-            st = self._coarse_stage(color0, color1, scale0, scale1)
+            st = self._coarse_stage(color0, color1, scale0, scale1, mask0, mask1)
         c0, c1, f0, f1, cr = st["c0"], st["c1"], st["f0"], st["f1"], st["cr"]
         if self.debug is not None:
             self.debug.update({k: st[k] for k in ("c0", "c1", "f0", "f1", "feat_c0", "feat_c1")})

@@ -150,18 +150,19 @@ def layernorm_residual(x, gamma, beta, res, out_f32, out_t, eps=1e-5):
 
 
 # ---- linear attention ---------------------------------------------------------------------------------
-def linear_attention(q, k, v, out, nb_q, L, nb_kv, S, H, ws=None):
-    """q row view [nb_q*L, C]; k,v row views [nb_kv*S, C]; nb_q == nb_kv.  out row view [nb_q*L, C]."""
-    _req_cuda(q, k, v, out)
+def linear_attention(q, k, v, out, nb_q, L, nb_kv, S, H, ws=None, q_mask=None, kv_mask=None):
+    """q row view [nb_q*L, C]; k,v row views [nb_kv*S, C]; nb_q == nb_kv.  out row view [nb_q*L, C].
+    q_mask [nb_q*L] / kv_mask [nb_kv*S]: uint8 padding masks or None."""
+    _req_cuda(q, k, v, out, q_mask, kv_mask)
     assert nb_q == nb_kv
     C = H * (q.shape[1] // H)
     D = q.shape[1] // H
     need = lib.gim_linear_attention_ws_bytes(nb_kv, S, H, D)
     if ws is None or ws.numel() * ws.element_size() < need:
         ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=q.device)
-    check(lib.gim_linear_attention_kv(_p(k), _p(v), _p(ws), nb_kv, S, H, D, k.stride(0), v.stride(0),
+    check(lib.gim_linear_attention_kv(_p(k), _p(v), _p(kv_mask), _p(ws), nb_kv, S, H, D, k.stride(0), v.stride(0),
                                       gim_dtype(k), _stream()), "gim_linear_attention_kv")
-    check(lib.gim_linear_attention_apply(_p(q), _p(ws), _p(out), nb_q, L, S, H, D, q.stride(0), out.stride(0),
+    check(lib.gim_linear_attention_apply(_p(q), _p(q_mask), _p(ws), _p(out), nb_q, L, S, H, D, q.stride(0), out.stride(0),
                                          gim_dtype(q), gim_dtype(out), _stream()), "gim_linear_attention_apply")
     return ws
 
@@ -172,7 +173,7 @@ class CoarseResult:
 
 
 def coarse_match(feat0, feat1, hw0_c, hw1_c, scale, temperature=0.1, thr=0.2, border_rm=2,
-                 scale0=None, scale1=None):
+                 scale0=None, scale1=None, mask0=None, mask1=None):
     """feat0 [N,L,C], feat1 [N,S,C] fp32 contiguous.  Returns CoarseResult with cap-sized device buffers;
     count[0] (device int32) is the number of valid leading entries."""
     _req_cuda(feat0, feat1, scale0, scale1)
@@ -193,11 +194,16 @@ def coarse_match(feat0, feat1, hw0_c, hw1_c, scale, temperature=0.1, thr=0.2, bo
     if scale0 is not None:
         scale0 = scale0.to(device=dev, dtype=torch.float32).contiguous()
         scale1 = scale1.to(device=dev, dtype=torch.float32).contiguous()
-    r.keep = (feat0, feat1, scale0, scale1)
+    if mask0 is not None:
+        assert mask0.dtype == torch.uint8 and mask1.dtype == torch.uint8 and mask0.is_contiguous() and mask1.is_contiguous()
+        assert mask0.numel() == N * L and mask1.numel() == N * S
+    r.keep = (feat0, feat1, scale0, scale1, mask0, mask1)
     a = _lib.CoarseArgs()
     a.feat0, a.feat1 = feat0.data_ptr(), feat1.data_ptr()
     a.scale0 = scale0.data_ptr() if scale0 is not None else None
     a.scale1 = scale1.data_ptr() if scale1 is not None else None
+    a.mask0 = mask0.data_ptr() if mask0 is not None else None
+    a.mask1 = mask1.data_ptr() if mask1 is not None else None
     a.ws, a.count = r.ws.data_ptr(), r.count.data_ptr()
     a.b_ids, a.i_ids, a.j_ids = r.b_ids.data_ptr(), r.i_ids.data_ptr(), r.j_ids.data_ptr()
     a.mconf, a.mkpts0_c, a.mkpts1_c = r.mconf.data_ptr(), r.mkpts0_c.data_ptr(), r.mkpts1_c.data_ptr()

@@ -92,13 +92,15 @@ int gim_posenc_add(const void* x, const float* pe, float* out_f32, void* out_t, 
  * LinearAttention (submodules/attentions.py:20-47), q/k already elu+1'd by the projection epilogue.
  *   step 1  gim_linear_attention_kv:  KV[b,h,:,:] = sum_s K[b,s,h,:]^T (V[b,s,h,:]/S),  Ksum[b,h,:]
  *   step 2  gim_linear_attention_apply: out[b,l,h,:] = (Q KV) / (Q.Ksum + eps) * S
- * k,v: [nb*S, ld] rows, q: [nb*L, ld] rows; `kv_ws` >= gim_linear_attention_ws_bytes(...) bytes. */
+ * k,v: [nb*S, ld] rows, q: [nb*L, ld] rows; `kv_ws` >= gim_linear_attention_ws_bytes(...) bytes.
+ * kv_mask [nb*S] / q_mask [nb*L] (uint8, NULL = no mask): padded positions, attentions.py:35-39
+ * (K, V rows with mask 0 do not contribute; Q rows with mask 0 give a zero message). */
 int64_t gim_linear_attention_ws_bytes(int nb, int S, int H, int D);
-int gim_linear_attention_kv(const void* k, const void* v, float* kv_ws, int nb, int S, int H, int D,
-                            int ldk, int ldv, int dtype, gim_stream_t stream);
-int gim_linear_attention_apply(const void* q, const float* kv_ws, void* out, int nb, int L, int S,
-                               int H, int D, int ldq, int ldo, int dtype, int out_dtype,
-                               gim_stream_t stream);
+int gim_linear_attention_kv(const void* k, const void* v, const uint8_t* kv_mask, float* kv_ws, int nb,
+                            int S, int H, int D, int ldk, int ldv, int dtype, gim_stream_t stream);
+int gim_linear_attention_apply(const void* q, const uint8_t* q_mask, const float* kv_ws, void* out,
+                               int nb, int L, int S, int H, int D, int ldq, int ldo, int dtype,
+                               int out_dtype, gim_stream_t stream);
 
 /* LayerNorm (+ optional residual):  v = LN(x[m,:]) * gamma + beta ; if res: v += res[m,:]
  * (transformer.py:52,56,58).  Writes fp32 (out_f32, may be NULL) and/or `dtype` copy (out_t). */
@@ -118,6 +120,8 @@ typedef struct gim_coarse_args {
     const float* feat1;
     const float* scale0;
     const float* scale1;
+    const uint8_t* mask0; /* NULL or [N, L] padding mask of image0's coarse cells (coarse_matching.py:116-117) */
+    const uint8_t* mask1; /* NULL or [N, S]; with masks the border rule is mask_border_with_padding (:29-44) */
     void* ws;             /* >= gim_coarse_match_ws_bytes() */
     int64_t* b_ids;
     int64_t* i_ids;

@@ -141,6 +141,33 @@ def main():
                  unfold0_first=u0[:4].numpy(), expec_f=data["expec_f"].numpy(),
                  mkpts0_f=data["mkpts0_f"].numpy(), mkpts1_f=data["mkpts1_f"].numpy())
 
+        # ---- padding masks: masked coarse transformer + masked coarse matching (mask_border_with_padding) ----
+        def pad_mask(n, h, w, valid):  # bottom/right padding like datasets/utils.py pad_bottom_right
+            m = torch.zeros(n, h, w, dtype=torch.bool)
+            for b, (vh, vw) in enumerate(valid):
+                m[b, :vh, :vw] = True
+            return m
+        m0 = pad_mask(2, *hw_c, [(12, 13), (9, 16)])
+        m1 = pad_mask(2, *hw_c, [(10, 16), (12, 11)])
+        g = torch.Generator().manual_seed(61)
+        tf0, tf1 = torch.randn(2, 192, 256, generator=g), torch.randn(2, 192, 256, generator=g)
+        rm0, rm1 = ref.loftr_coarse(tf0, tf1, m0.flatten(-2), m1.flatten(-2))
+        om0, om1 = O.local_feature_transformer(sd, "loftr_coarse", tf0, tf1, 8, 4, m0.flatten(-2), m1.flatten(-2))
+        report["masked_tf"] = max(close(om0, rm0, 1e-5, "mtf0"), close(om1, rm1, 1e-5, "mtf1"))
+        data = {"hw0_i": torch.Size(hw_i), "hw1_i": torch.Size(hw_i), "hw0_c": torch.Size(hw_c),
+                "hw1_c": torch.Size(hw_c), "mask0": m0, "mask1": m1}
+        ref.coarse_matching(pf0, pf1, data, mask_c0=m0.flatten(-2), mask_c1=m1.flatten(-2))
+        confm = O.conf_matrix_dual_softmax(pf0, pf1, 0.1, m0.flatten(-2), m1.flatten(-2))
+        close(confm, data["conf_matrix"], 1e-6, "masked conf")
+        omm = O.get_coarse_match(confm, hw_i, hw_i, hw_c, hw_c, 0.2, 2, None, None, m0, m1)
+        for k in ("b_ids", "i_ids", "j_ids", "mkpts0_c", "mkpts1_c", "mconf"):
+            close(omm[k], data[k], 1e-6, "masked cm " + k)
+        report["masked_coarse_M"] = int(data["b_ids"].numel())
+        np.savez(os.path.join(GOLDEN, "masked.npz"), seed_tf=61, seed_cm=31, hw_c=hw_c, hw_i=hw_i,
+                 valid0=np.array([(12, 13), (9, 16)]), valid1=np.array([(10, 16), (12, 11)]),
+                 tf_out0_sub=rm0[:, ::4].numpy(), tf_out1_sub=rm1[:, ::4].numpy(),
+                 **{k: data[k].numpy() for k in ("b_ids", "i_ids", "j_ids", "mkpts0_c", "mkpts1_c", "mconf")})
+
         # ---- end to end (plumbing: keys, dtypes, shapes, few matches with random weights) ----
         for tag, (h, w) in (("e2e_64x96", (64, 96)), ("e2e_96x128", (96, 128))):
             c0, c1 = O.seeded_images(2, h, w, seed=51)
@@ -158,6 +185,25 @@ def main():
                      conf_rowmax=cm.max(dim=2)[0].numpy(), conf_colmax=cm.max(dim=1)[0].numpy(),
                      key_order=np.array([k for k in d_ref.keys()]),
                      **{k: d_ref[k].numpy() for k in keys})
+
+        # ---- end to end with padding masks ------------------------------------------------------------
+        c0, c1 = O.seeded_images(2, 64, 96, seed=71)
+        mm0, mm1 = pad_mask(2, 8, 12, [(8, 9), (6, 12)]), pad_mask(2, 8, 12, [(7, 12), (8, 10)])
+        c0 = c0 * torch.nn.functional.interpolate(mm0[:, None].float(), scale_factor=8)   # zero-padded pixels
+        c1 = c1 * torch.nn.functional.interpolate(mm1[:, None].float(), scale_factor=8)
+        d_ref = {"image0": c0[:, :1], "image1": c1[:, :1], "color0": c0, "color1": c1, "mask0": mm0, "mask1": mm1}
+        ref(d_ref)
+        d_or = O.loftr_forward(sd, {"image0": c0[:, :1], "image1": c1[:, :1], "color0": c0, "color1": c1,
+                                    "mask0": mm0, "mask1": mm1})
+        for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts0_f", "mkpts1_f"):
+            close(d_or[k], d_ref[k], 1e-5, "e2e masked " + k)
+        close(d_or["conf_matrix"], d_ref["conf_matrix"], 1e-5, "e2e masked conf")
+        report["e2e_masked_M"] = int(d_ref["b_ids"].numel())
+        cmm = d_ref["conf_matrix"]
+        np.savez(os.path.join(GOLDEN, "e2e_masked.npz"), seed=71, hw=(64, 96),
+                 valid0=np.array([(8, 9), (6, 12)]), valid1=np.array([(7, 12), (8, 10)]),
+                 conf_rowmax=cmm.max(dim=2)[0].numpy(), conf_colmax=cmm.max(dim=1)[0].numpy(),
+                 **{k: d_ref[k].numpy() for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts0_f", "mkpts1_f")})
 
     for k, v in report.items():
         print(f"{k:28s} {v}")

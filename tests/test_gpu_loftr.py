@@ -174,3 +174,68 @@ def test_full_size_properties_bf16(oracle_sd):
     m(d3)
     sel = b == 3
     assert torch.equal(d3["i_ids"].cpu(), i[sel]) and torch.equal(d3["j_ids"].cpu(), j[sel])
+
+
+def _pad_mask(n, h, w, valid):
+    m = torch.zeros(n, h, w, dtype=torch.bool)
+    for b, (vh, vw) in enumerate(valid):
+        m[b, :vh, :vw] = True
+    return m
+
+
+def test_fp32_masked_stages_match_oracle(oracle_sd):
+    """padding masks through the HIP path: masked coarse transformer and masked coarse matching"""
+    from gim_amd import ops
+    dev = torch.device("cuda:0")
+    m = _model("fp32", oracle_sd)
+    P = m._prepack(dev)
+    hw_c = (12, 16)
+    m0, m1 = _pad_mask(2, *hw_c, [(12, 13), (9, 16)]), _pad_mask(2, *hw_c, [(10, 16), (12, 11)])
+    g = torch.Generator().manual_seed(61)
+    bs, L, C = 2, 192, 256
+    f0, f1 = torch.randn(bs, L, C, generator=g), torch.randn(bs, L, C, generator=g)
+    T = m._TfBuffers(2 * bs * L, C, torch.float32, dev)
+    T.X32.copy_(torch.cat([f0, f1], 0).reshape(-1, C))
+    T.CAT[:, :C].copy_(T.X32)
+    T.MASK = torch.cat([m0.reshape(-1), m1.reshape(-1)]).to(torch.uint8).to(dev)
+    m._transformer(P, "c", m.loftr_coarse, T, bs, L, bs, L)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        r0, r1 = O.local_feature_transformer(oracle_sd, "loftr_coarse", f0, f1, 8, 4, m0.flatten(-2), m1.flatten(-2))
+    got = T.X32.cpu().view(2 * bs, L, C)
+    assert _rel(got[:bs], r0)[1] < 1e-4 and _rel(got[bs:], r1)[1] < 1e-4, (_rel(got[:bs], r0), _rel(got[bs:], r1))
+    # masked coarse matching on planted features
+    pf0, pf1, _ = O.planted_coarse_features(2, hw_c, sigma=1.0, eps=0.5, seed=31)
+    conf = O.conf_matrix_dual_softmax(pf0, pf1, 0.1, m0.flatten(-2), m1.flatten(-2))
+    ref = O.get_coarse_match(conf, (96, 128), (96, 128), hw_c, hw_c, 0.2, 2, None, None, m0, m1)
+    r = ops.coarse_match(pf0.to(dev), pf1.to(dev), hw_c, hw_c, 8.0, 0.1, 0.2, 2, None, None,
+                         m0.reshape(2, -1).to(torch.uint8).to(dev).contiguous(),
+                         m1.reshape(2, -1).to(torch.uint8).to(dev).contiguous())
+    M = int(r.count[0])
+    assert M == ref["b_ids"].numel() == 45
+    for k in ("b_ids", "i_ids", "j_ids"):
+        assert torch.equal(getattr(r, k)[:M].cpu(), ref[k]), k
+    assert (r.mconf[:M].cpu() - ref["mconf"]).abs().max() < 1e-5
+    cm = ops.coarse_conf_matrix(r).cpu()
+    assert (cm - conf).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_fp32_end_to_end_masked(oracle_sd, graph):
+    m = _model("fp32", oracle_sd)
+    m.use_graph = graph
+    c0, c1 = O.seeded_images(2, 64, 96, seed=71)
+    m0, m1 = _pad_mask(2, 8, 12, [(8, 9), (6, 12)]), _pad_mask(2, 8, 12, [(7, 12), (8, 10)])
+    c0 = c0 * torch.nn.functional.interpolate(m0[:, None].float(), scale_factor=8)
+    c1 = c1 * torch.nn.functional.interpolate(m1[:, None].float(), scale_factor=8)
+    d = _data(c0, c1, "cuda:0", mask0=m0, mask1=m1)
+    m(d)
+    with torch.no_grad():
+        ref = O.loftr_forward(oracle_sd, _data(c0, c1, mask0=m0, mask1=m1))
+    for k in ("b_ids", "i_ids", "j_ids"):
+        assert torch.equal(d[k].cpu(), ref[k]), k
+    conf = d["conf_matrix"].get().cpu()
+    assert _rel(conf, ref["conf_matrix"])[1] < 1e-3
+    for k in ("mconf", "mkpts0_f", "mkpts1_f"):
+        if ref[k].numel():
+            assert (d[k].cpu() - ref[k]).abs().max() <= 1e-4 * max(1.0, ref[k].abs().max().item()), k

@@ -122,3 +122,46 @@ def test_empty_match_case(oracle_sd):
                                out["b_ids"], out["i_ids"], out["j_ids"], (6, 8), (24, 32))
     fm = O.fine_matching(u0, u1, out["mkpts0_c"], out["mkpts1_c"], out["b_ids"], 0, (48, 64), (24, 32))
     assert fm["expec_f"].shape == (0, 3) and fm["mkpts1_f"].shape == (0, 2)
+
+
+def _pad_mask(n, h, w, valid):
+    m = torch.zeros(n, h, w, dtype=torch.bool)
+    for b, (vh, vw) in enumerate(valid):
+        m[b, :int(vh), :int(vw)] = True
+    return m
+
+
+def test_masked_golden(oracle_sd, golden_dir):
+    """padding masks: LinearAttention q/kv masks (attentions.py:35-39), masked_fill(-INF)
+    (coarse_matching.py:116-117) and mask_border_with_padding (:29-44)"""
+    g = np.load(os.path.join(golden_dir, "masked.npz"))
+    hw_c, hw_i = tuple(g["hw_c"]), tuple(g["hw_i"])
+    m0, m1 = _pad_mask(2, *hw_c, g["valid0"]), _pad_mask(2, *hw_c, g["valid1"])
+    gen = torch.Generator().manual_seed(int(g["seed_tf"]))
+    tf0, tf1 = torch.randn(2, 192, 256, generator=gen), torch.randn(2, 192, 256, generator=gen)
+    with torch.no_grad():
+        o0, o1 = O.local_feature_transformer(oracle_sd, "loftr_coarse", tf0, tf1, 8, 4, m0.flatten(-2), m1.flatten(-2))
+    _close(o0[:, ::4], g["tf_out0_sub"])
+    _close(o1[:, ::4], g["tf_out1_sub"])
+    f0, f1, _ = O.planted_coarse_features(2, hw_c, sigma=1.0, eps=0.5, seed=int(g["seed_cm"]))
+    conf = O.conf_matrix_dual_softmax(f0, f1, 0.1, m0.flatten(-2), m1.flatten(-2))
+    out = O.get_coarse_match(conf, hw_i, hw_i, hw_c, hw_c, 0.2, 2, None, None, m0, m1)
+    assert out["b_ids"].numel() == 45
+    for k in ("b_ids", "i_ids", "j_ids"):
+        _close(out[k], g[k])
+    for k in ("mkpts0_c", "mkpts1_c", "mconf"):
+        _close(out[k], g[k], 1e-6)
+
+
+def test_end_to_end_masked_golden(oracle_sd, golden_dir):
+    g = np.load(os.path.join(golden_dir, "e2e_masked.npz"))
+    c0, c1 = O.seeded_images(2, *g["hw"], seed=int(g["seed"]))
+    m0, m1 = _pad_mask(2, 8, 12, g["valid0"]), _pad_mask(2, 8, 12, g["valid1"])
+    c0 = c0 * torch.nn.functional.interpolate(m0[:, None].float(), scale_factor=8)
+    c1 = c1 * torch.nn.functional.interpolate(m1[:, None].float(), scale_factor=8)
+    with torch.no_grad():
+        d = O.loftr_forward(oracle_sd, {"image0": c0[:, :1], "image1": c1[:, :1], "color0": c0, "color1": c1,
+                                        "mask0": m0, "mask1": m1})
+    for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts0_f", "mkpts1_f"):
+        _close(d[k], g[k], 1e-5)
+    _close(d["conf_matrix"].max(dim=2)[0], g["conf_rowmax"], 1e-5)

@@ -1,0 +1,141 @@
+"""ZEB scoring and dump I/O (host side, numpy) -- the "pose-AUC@5/10/20" half of the headline metric.
+
+Restates, without Lightning:
+  * `analysis.py:34-53` `error_auc` (pose AUC of max(R_err, t_err), nan/inf -> 180 deg) and the per-scene
+    read / de-duplicate / score loop of `analysis.py:84-103`;
+  * the dump format written by `trainer/lightning.py:258-275`
+    ("identifiers covisible0 covisible1 R_errs t_errs t_errs2 Bef.Prec Bef.Num Aft.Prec Aft.Num",
+    file name "[T] <weight> <scene:>15> <version>.txt"), so `check.py` / `analysis.py` of the reference keep
+    working on dumps produced by this engine;
+  * `tools/metrics.py:28-53,107-168` relative pose error and the RANSAC call -- RANSAC stays on the host with
+    OpenCV as north_star prescribes (imported lazily; not available in the build container).
+Pinned by `tests/test_zeb_cpu.py` against AUC values computed by the reference's own `analysis.py` on a
+sample of its shipped dumps (`oracle/make_golden_zeb.py`).
+"""
+import os
+
+import numpy as np
+
+DATASETS = ["GL3D", "BlendedMVS", "ETH3DI", "ETH3DO", "KITTI", "RobotcarWeather", "RobotcarSeason",
+            "RobotcarNight", "Multi-FoV", "SceneNetRGBD", "ICL-NUIM", "GTA-SfM"]  # analysis.py:18-31
+HEADER = "identifiers covisible0 covisible1 R_errs t_errs t_errs2 Bef.Prec Bef.Num Aft.Prec Aft.Num"
+
+
+def error_auc(errs0, errs1, thresholds=(5.0, 10.0, 20.0)):
+    """analysis.py:34-53 with numeric thresholds (degrees).  Returns {thr: auc in [0,1]}."""
+    errs0 = np.array(errs0, dtype=np.float64)
+    errs1 = np.array(errs1, dtype=np.float64)
+    for e in (errs0, errs1):
+        e[np.isnan(e)] = 180
+        e[np.isinf(e)] = 180
+    errors = np.max(np.stack([errs0, errs1]), axis=0)
+    errors = [0] + sorted(list(errors))
+    recall = list(np.linspace(0, 1, len(errors)))
+    out = {}
+    for thr in thresholds:
+        thr = float(thr)
+        last_index = np.searchsorted(errors, thr)
+        y = recall[:last_index] + [recall[last_index - 1]]
+        x = errors[:last_index] + [thr]
+        out[thr] = float(np.trapz(y, x) / thr)
+    return out
+
+
+def dump_path(directory, weight, scene, version):
+    return os.path.join(directory, f"[T] {weight} {scene:>15} {version}.txt")  # lightning.py:273
+
+
+def format_row(identifier, covisible0, covisible1, R_err, t_err, t_err2, epi_errs, inliers, epi_thr=5e-4):
+    """One dump line (lightning.py:261-270).  epi_errs: float array [M]; inliers: bool array [M]."""
+    epi = np.asarray(epi_errs)
+    inl = np.asarray(inliers, dtype=bool) if len(epi) else np.zeros(0, dtype=bool)
+    bef = epi < epi_thr
+    aft = epi[inl] < epi_thr if len(epi) else np.zeros(0, dtype=bool)
+    mean = lambda x: sum(x) / max(len(x), 1)  # noqa: E731
+    return (f"{identifier} {covisible0} {covisible1} {R_err} {t_err} {t_err2} "
+            f"{mean(bef)} {sum(bef)} {mean(aft)} {sum(aft)}")
+
+
+def write_dump(path, rows):
+    """rows: iterable of already formatted lines; written sorted by identifier, duplicates removed
+    (lightning.py:253-255)."""
+    uniq = {}
+    for r in rows:
+        uniq.setdefault(r.split()[0], r)
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    with open(path, "w") as f:
+        f.write(HEADER + "\n")
+        for k in sorted(uniq):
+            f.write(uniq[k] + "\n")
+
+
+def read_dump(path):
+    """-> dict of column -> list (first occurrence of each identifier only, analysis.py:95-101)."""
+    with open(path) as f:
+        lines = f.readlines()
+    head = lines[0].split()
+    cols = {k: [] for k in head}
+    seen = set()
+    for ln in lines[1:]:
+        x = ln.split()
+        if not x or x[0] in seen:
+            continue
+        seen.add(x[0])
+        for k, v in zip(head, x):
+            cols[k].append(v)
+    return cols
+
+
+def score_dir(directory, weight, version, thresholds=(5.0, 10.0, 20.0)):
+    """AUC per scene and mean over the scenes present, in percent.  -> ({scene: {thr: auc%}}, {thr: mean%})"""
+    files = {}
+    for d in os.listdir(directory):
+        stem = d.rpartition(".txt")[0].split()
+        if len(stem) >= 4 and stem[1] == weight and stem[-1] == version:
+            files[stem[2]] = d
+    per = {}
+    for scene in DATASETS:
+        if scene not in files:
+            continue
+        c = read_dump(os.path.join(directory, files[scene]))
+        auc = error_auc([float(v) for v in c["R_errs"]], [float(v) for v in c["t_errs"]], thresholds)
+        per[scene] = {t: 100.0 * a for t, a in auc.items()}
+    mean = {t: float(np.mean([per[s][t] for s in per])) for t in thresholds} if per else {}
+    return per, mean
+
+
+# ---- host-side pose metrics (tools/metrics.py) ---------------------------------------------------
+def relative_pose_error(T_0to1, R, t, ignore_gt_t_thr=0.0):
+    """tools/metrics.py:28-53: angular errors (deg) of the estimated rotation / translation direction."""
+    t_gt = T_0to1[:3, 3]
+    n = np.linalg.norm(t) * np.linalg.norm(t_gt)
+    t_err = np.rad2deg(np.arccos(np.clip(np.dot(t, t_gt) / n, -1.0, 1.0)))
+    t_err = np.minimum(t_err, 180 - t_err)
+    if np.linalg.norm(t_gt) < ignore_gt_t_thr:
+        t_err = 0
+    R_gt = T_0to1[:3, :3]
+    cos = np.clip((np.trace(np.dot(R.T, R_gt)) - 1) / 2, -1.0, 1.0)
+    return t_err, np.rad2deg(np.abs(np.arccos(cos)))
+
+
+def estimate_pose(kpts0, kpts1, K0, K1, thresh=0.5, conf=0.99999):
+    """tools/metrics.py:77-103 (cv2.findEssentialMat RANSAC + recoverPose).  Host only; needs OpenCV."""
+    try:
+        import cv2
+    except ImportError as e:  # pragma: no cover
+        raise ImportError("ZEB pose estimation runs cv2 RANSAC on the host (tools/metrics.py:88-98); "
+                          "install opencv-python on the evaluation machine") from e
+    if len(kpts0) < 5:
+        return None
+    kpts0 = (kpts0 - K0[[0, 1], [2, 2]][None]) / K0[[0, 1], [0, 1]][None]
+    kpts1 = (kpts1 - K1[[0, 1], [2, 2]][None]) / K1[[0, 1], [0, 1]][None]
+    ransac_thr = thresh / np.mean([K0[0, 0], K1[1, 1], K0[0, 0], K1[1, 1]])
+    E, mask = cv2.findEssentialMat(kpts0, kpts1, np.eye(3), threshold=ransac_thr, prob=conf, method=cv2.RANSAC)
+    if E is None:
+        return None
+    best, ret = 0, None
+    for _E in np.split(E, len(E) / 3):
+        n, R, t, _ = cv2.recoverPose(_E, kpts0, kpts1, np.eye(3), 1e9, mask=mask)
+        if n > best:
+            ret, best = (R, t[:, 0], mask.ravel() > 0), n
+    return ret

@@ -23,6 +23,7 @@
 // Replaces (reference file:line): networks/loftr/backbone/resnet.py:109-126,230-233,316-327 and the
 // nn.Linear calls of networks/loftr/submodules/transformer.py:47-55.
 #include "igemm_mainloop.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -130,38 +131,152 @@ igemm_kernel(const gim_conv_args a, const int mtiles, const int ntiles, const in
 }
 
 // ------------------------------------------------------------------------------------------------
-// Persistent, cross-tile software-pipelined variant (the default, LDS-DMA staging).
-//
-// Each workgroup walks a list of output tiles; K slabs of consecutive tiles form ONE flattened stream:
-// while slab s is on the MFMAs, the LDS-DMA of slab s+1 (possibly the first slab of the *next* tile) and
-// the residual rows of the current tile are already in flight, and the stores of the previous tile's
-// epilogue drain in the background.  Tiles are handed out in XCD-contiguous chunks (block b runs on XCD
-// b % 8), so tiles sharing an activation panel are in flight on the same L2 at the same time.
-//
-// Epilogue (measured: 8-byte per-lane stores at pixel stride cost 4x the TCP->TCC requests of full
-// lines and bound the half-resolution 1x1 layers): every wave transposes its 64 px x 64 ch sub-tile
-// through the stage buffer the tile just finished with (XOR-swizzled 16-byte slots, no extra LDS), so
-// that residual loads and output stores are 16 bytes per lane with a whole 128/256-byte row segment per
-// 8/16 adjacent lanes.  Bias enters as the accumulator's initial value; activation kind, bounds and
-// dtypes are tile-uniform branches; bf16 rounding is one v_cvt_pk_bf16_f32 per pair.
-// HAS_RES: residual of the same dtype as the output, prefetched into registers before the last slab.
-template <int BM, int BN, int WM, int WN, bool BF16, bool OUT_BF16, bool HAS_RES>
-__global__ void __launch_bounds__(256, 2)  // 2 waves per SIMD = 2 workgroups per CU (the LDS budget)
-igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntiles, const int M) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef gim::Igemm<BM, BN, WM, WN, BF16, true> G;
-    constexpr int TM = G::TM, TN = G::TN, WTM = G::WTM, WTN = G::WTN;
-    static_assert(WTM == 64 && WTN == 64, "epilogue transposition assumes 64x64 wave tiles");
-    constexpr int OES = OUT_BF16 ? 2 : 4;       // output element size
-    constexpr int RB = 64 * OES;                // bytes of one pixel row of the wave sub-tile
-    constexpr int LPR = RB / 16;                // lanes per row in row layout (8 / 16)
-    constexpr int RPI = 64 / LPR;               // rows per wave instruction (8 / 4)
-    constexpr int NI = 32 / RPI;                // row-layout instructions per 32-pixel pass (4 / 8)
-    static_assert(4 * 32 * RB <= G::STAGE, "transposition tile must fit in one stage buffer");
+// Shared epilogue of the persistent kernels (measured: 8-byte per-lane stores at pixel stride cost 4x the
+// TCP->TCC requests of full lines and bound the half-resolution 1x1 layers): every wave transposes its
+// 64 px x 64 ch sub-tile through a stage buffer the tile has finished with (XOR-swizzled 16-byte slots, no
+// extra LDS), so that residual loads and output stores are 16 bytes per lane with a whole 128/256-byte row
+// segment per 8/16 adjacent lanes.  Bias enters as the accumulator's initial value; activation kind,
+// bounds and dtypes are tile-uniform branches; bf16 rounding is one v_cvt_pk_bf16_f32 per pair.
+template <typename G, bool OUT_BF16, bool HAS_RES>
+struct Epilogue {
+    static constexpr int TM = G::TM, TN = G::TN, WTM = G::WTM, WTN = G::WTN, WN = G::WTN == 0 ? 1 : (G::B_BYTES / KTB) / G::WTN;
+    static_assert(WTM == 64 && WTN % 64 == 0, "epilogue transposition works on 32 px x 64 ch passes of a 64 x (64*NH) wave tile");
+    static constexpr int NH = WTN / 64;            // 64-channel halves of the wave tile
+    static_assert(!HAS_RES || NH == 1, "residual prefetch is only built for 64-channel wave tiles");
+    static constexpr int OES = OUT_BF16 ? 2 : 4;   // output element size
+    static constexpr int RB = 64 * OES;            // bytes of one pixel row of the wave sub-tile
+    static constexpr int LPR = RB / 16;            // lanes per row in row layout (8 / 16)
+    static constexpr int RPI = 64 / LPR;           // rows per wave instruction (8 / 4)
+    static constexpr int NI = 32 / RPI;            // row-layout instructions per 32-pixel pass (4 / 8)
+    static constexpr int WAVE_BYTES = 32 * RB;     // transposition tile of one wave
+    static_assert(G::NW * WAVE_BYTES <= G::STAGE, "transposition tiles must fit in one stage buffer");
+    typedef uint4 Res[HAS_RES ? TM : 1][HAS_RES ? NI : 1];
 
-    // ---- tile list of this block: first, first + step, ... < end ---------------------------------
-    const unsigned T = (unsigned)(mtiles * ntiles), nb = gridDim.x, b = blockIdx.x;
-    unsigned first, step, end;
+    int wm, wn, l31, lh, rrow, rslot, wave;
+    __device__ __forceinline__ Epilogue() {
+        const int lane = threadIdx.x & 63;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        l31 = lane & 31; lh = lane >> 5;
+        wm = wave / WN; wn = wave - wm * WN;
+        rrow = lane / LPR; rslot = lane % LPR;
+    }
+
+    // acc := bias (the MFMAs accumulate on top of it)
+    __device__ __forceinline__ void init_acc(const gim_conv_args& a, typename G::Acc& acc, int n0) const {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.bias) bb = *(const float4*)(a.bias + n0 + wn * WTN + i * 32 + rg * 8 + lh * 4);  // bias is padded to npad
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    acc[i][j][rg * 4 + 0] = bb.x; acc[i][j][rg * 4 + 1] = bb.y;
+                    acc[i][j][rg * 4 + 2] = bb.z; acc[i][j][rg * 4 + 3] = bb.w;
+                }
+            }
+    }
+
+    // coalesced residual rows of the tile -> registers (issued before the tile's last slab is computed)
+    __device__ __forceinline__ void prefetch_res(const gim_conv_args& a, Res& rres, int m0, int n0, int M) const {
+        if constexpr (HAS_RES) {
+            const bool full = (m0 + G::A_BYTES / KTB <= M) && (n0 + G::B_BYTES / KTB <= a.N);
+            const int ncol = n0 + wn * WTN + rslot * (16 / OES);
+            const bool ncol_ok = full || ncol < a.N;
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int k = 0; k < NI; ++k) {
+                    const int m = m0 + wm * WTM + j * 32 + k * RPI + rrow;
+                    const bool ok = ncol_ok && (full || m < M);
+                    const size_t ro = (size_t)(a.res_mod > 0 ? m % a.res_mod : m) * a.ldres + ncol;
+                    rres[j][k] = ok ? *(const uint4*)((const char*)a.res + ro * OES) : make_uint4(0u, 0u, 0u, 0u);
+                }
+        }
+    }
+
+    // residual + activation in accumulator layout, transposition through `stage` (a stage buffer no wave reads
+    // any more), coalesced stores.  The caller must barrier before the stage is overwritten again.
+    __device__ __forceinline__ void run(const gim_conv_args& a, typename G::Acc& acc, const Res& rres, char* stage,
+                                        int m0, int n0, int M) const {
+        char* wl = stage + wave * WAVE_BYTES;  // this wave's transposition tile [32 px][RB]
+        const bool full = (m0 + G::A_BYTES / KTB <= M) && (n0 + G::B_BYTES / KTB <= a.N);
+        const int act = (a.act_cols > 0 && n0 >= a.act_cols) ? GIM_ACT_NONE : a.act;  // tile-uniform
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+#pragma unroll
+            for (int nh = 0; nh < NH; ++nh) {  // one 32 px x 64 ch pass
+                const int ncol = n0 + wn * WTN + nh * 64 + rslot * (16 / OES);
+                const bool ncol_ok = full || ncol < a.N;
+                if constexpr (HAS_RES) {
+#pragma unroll
+                    for (int k = 0; k < NI; ++k) {
+                        const int row = k * RPI + rrow;
+                        *(uint4*)(wl + row * RB + ((rslot ^ (row & 7)) << 4)) = rres[j][k];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            if constexpr (OUT_BF16) {
+                                const uint2 u = *(const uint2*)(wl + l31 * RB + (((i * 4 + rg) ^ (l31 & 7)) << 4) + lh * 8);
+                                acc[i][j][rg * 4 + 0] += __uint_as_float(u.x << 16);
+                                acc[i][j][rg * 4 + 1] += __uint_as_float(u.x & 0xffff0000u);
+                                acc[i][j][rg * 4 + 2] += __uint_as_float(u.y << 16);
+                                acc[i][j][rg * 4 + 3] += __uint_as_float(u.y & 0xffff0000u);
+                            } else {
+                                const float4 rr = *(const float4*)(wl + l31 * RB + (((i * 8 + rg * 2 + lh) ^ (l31 & 7)) << 4));
+                                acc[i][j][rg * 4 + 0] += rr.x; acc[i][j][rg * 4 + 1] += rr.y;
+                                acc[i][j][rg * 4 + 2] += rr.z; acc[i][j][rg * 4 + 3] += rr.w;
+                            }
+                        }
+                }
+                if (act == GIM_ACT_RELU) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[nh * 2 + i][j][r] = fmaxf(acc[nh * 2 + i][j][r], 0.f);
+                } else if (act == GIM_ACT_LEAKY) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            acc[nh * 2 + i][j][r] = fmaxf(acc[nh * 2 + i][j][r], 0.f) + 0.01f * fminf(acc[nh * 2 + i][j][r], 0.f);
+                } else if (act == GIM_ACT_ELU1) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[nh * 2 + i][j][r] = apply_act(acc[nh * 2 + i][j][r], GIM_ACT_ELU1);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const f32x16_t& v = acc[nh * 2 + i][j];
+                        if constexpr (OUT_BF16) {
+                            *(uint2*)(wl + l31 * RB + (((i * 4 + rg) ^ (l31 & 7)) << 4) + lh * 8) =
+                                make_uint2(cvt_pk_bf16(v[rg * 4 + 0], v[rg * 4 + 1]), cvt_pk_bf16(v[rg * 4 + 2], v[rg * 4 + 3]));
+                        } else {
+                            *(float4*)(wl + l31 * RB + (((i * 8 + rg * 2 + lh) ^ (l31 & 7)) << 4)) =
+                                make_float4(v[rg * 4 + 0], v[rg * 4 + 1], v[rg * 4 + 2], v[rg * 4 + 3]);
+                        }
+                    }
+#pragma unroll
+                for (int k = 0; k < NI; ++k) {
+                    const int row = k * RPI + rrow;
+                    const int m = m0 + wm * WTM + j * 32 + row;
+                    const uint4 o = *(const uint4*)(wl + row * RB + ((rslot ^ (row & 7)) << 4));
+                    if (ncol_ok && (full || m < M)) *(uint4*)((char*)a.y + ((size_t)m * a.ldy + ncol) * OES) = o;
+                }
+            }
+        }
+    }
+};
+
+// tile list of a persistent block: first, first + step, ... < end, handed out in XCD-contiguous chunks
+// (block b runs on XCD b % 8) so that tiles sharing an activation panel are in flight on the same L2.
+__device__ __forceinline__ void tile_list(unsigned T, unsigned& first, unsigned& step, unsigned& end) {
+    const unsigned nb = gridDim.x, b = blockIdx.x;
     if (nb >= 8 && T >= 16) {
         const unsigned xcd = b & 7u, slot = b >> 3;
         const unsigned q = T >> 3, r = T & 7u;
@@ -172,61 +287,57 @@ igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntile
     } else {
         first = b; step = nb; end = T;
     }
-    if (first >= end) return;
+}
 
+__device__ __forceinline__ gim::MainloopArgs mainloop_args(const gim_conv_args& a, int M, int ES) {
     gim::MainloopArgs ml;
     ml.x = a.x; ml.w = a.w; ml.ktab = a.ktab;
     ml.x_bytes = (unsigned)a.x_bytes;
-    ml.w_bytes = (unsigned)a.npad * (unsigned)a.kpad * G::ES;
+    ml.w_bytes = (unsigned)a.npad * (unsigned)a.kpad * ES;
     ml.H = a.H; ml.W = a.W; ml.Ho = a.Ho; ml.Wo = a.Wo; ml.stride = a.stride; ml.pad = a.pad; ml.ldx = a.ldx;
     ml.kpad = a.kpad; ml.M = M;
+    return ml;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent, cross-tile software-pipelined variant, 4 waves, 2 LDS stages (2 workgroups per CU).
+//
+// Each workgroup walks a list of output tiles; K slabs of consecutive tiles form ONE flattened stream:
+// while slab s is on the MFMAs, the LDS-DMA of slab s+1 (possibly the first slab of the *next* tile) and
+// the residual rows of the current tile are already in flight, and the stores of the previous tile's
+// epilogue drain in the background.
+template <int BM, int BN, int WM, int WN, bool BF16, bool OUT_BF16, bool HAS_RES>
+__global__ void __launch_bounds__(WM * WN * 64, 2)  // 2 waves per SIMD: 2 x 4-wave or 1 x 8-wave workgroup per CU
+igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntiles, const int M) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef gim::Igemm<BM, BN, WM, WN, BF16, true> G;
+    typedef Epilogue<G, OUT_BF16, HAS_RES> E;
+
+    unsigned first, step, end;
+    tile_list((unsigned)(mtiles * ntiles), first, step, end);
+    if (first >= end) return;
+    const gim::MainloopArgs ml = mainloop_args(a, M, G::ES);
     const int nkt = a.kpad * G::ES / KTB;
 
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int wm = wave / WN, wn = wave - wm * WN;
-    const int rrow = lane / LPR, rslot = lane % LPR;  // row-layout role of this lane
-
-    // acc := bias (the MFMAs accumulate on top of it)
-    auto init_acc = [&](typename G::Acc& acc, int n0_) {
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a.bias) bb = *(const float4*)(a.bias + n0_ + wn * WTN + i * 32 + rg * 8 + lh * 4);  // bias is padded to npad
-#pragma unroll
-                for (int j = 0; j < TM; ++j) {
-                    acc[i][j][rg * 4 + 0] = bb.x; acc[i][j][rg * 4 + 1] = bb.y;
-                    acc[i][j][rg * 4 + 2] = bb.z; acc[i][j][rg * 4 + 3] = bb.w;
-                }
-            }
-    };
-
+    E epi;
     G g, gn;  // staging coordinates of the current / the next tile
     typename G::Acc acc;
+    typename E::Res rres;
     int buf = 0;
     int m0 = (int)(first / ntiles) * BM, n0 = (int)(first % ntiles) * BN;
-    init_acc(acc, n0);
+    epi.init_acc(a, acc, n0);
     g.decode(ml, m0, n0);
     g.stage_issue(ml, smem, 0, 0, a.ktab[G::ktab_index(0)]);
     int e_nxt = a.ktab[G::ktab_index(nkt > 1 ? 1 : 0)];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    uint4 rres[HAS_RES ? TM : 1][HAS_RES ? NI : 1];  // residual rows of this tile, row layout
-
     for (unsigned tile = first; tile < end; tile += step) {
         const unsigned tile_n = tile + step;
         const bool has_next = tile_n < end;
         const int m0n = (int)(tile_n / ntiles) * BM, n0n = (int)(tile_n % ntiles) * BN;
         if (has_next) gn.decode(ml, m0n, n0n);
-        const bool full = (m0 + BM <= M) && (n0 + BN <= a.N);
-        // row-layout coordinates of this lane in the wave's 64 x 64 sub-tile
-        const int ncol = n0 + wn * WTN + rslot * (16 / OES);
-        const bool ncol_ok = full || ncol < a.N;
-        // ---- K loop: only MFMAs touch the accumulators in here (they stay in AGPRs) --------------------
+        // ---- K loop: only MFMAs touch the accumulators in here ------------------------------------------
         for (int kt = 0; kt < nkt; ++kt) {
             const bool last = kt + 1 == nkt;
             int k2 = kt + 2;
@@ -235,95 +346,99 @@ igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntile
             const int e_n2 = a.ktab[G::ktab_index(k2)];
             if (!last) g.stage_issue(ml, smem, buf ^ 1, kt + 1, e_nxt);
             else if (has_next) gn.stage_issue(ml, smem, buf ^ 1, 0, e_nxt);  // first slab of the next tile
-            if (HAS_RES && last) {  // coalesced residual rows -> registers, in flight during the MFMAs
-#pragma unroll
-                for (int j = 0; j < TM; ++j)
-#pragma unroll
-                    for (int k = 0; k < NI; ++k) {
-                        const int m = m0 + wm * WTM + j * 32 + k * RPI + rrow;
-                        const bool ok = ncol_ok && (full || m < M);
-                        const size_t ro = (size_t)(a.res_mod > 0 ? m % a.res_mod : m) * a.ldres + ncol;
-                        rres[j][k] = ok ? *(const uint4*)((const char*)a.res + ro * OES) : make_uint4(0u, 0u, 0u, 0u);
-                    }
-            }
+            if (last) epi.prefetch_res(a, rres, m0, n0, M);
             G::compute(smem, buf, acc);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             buf ^= 1;
             e_nxt = e_n2;
         }
-        // ---- epilogue: residual + activation in accumulator layout, transposition through the freed stage
-        // buffer (buf ^ 1 after the flip above), coalesced stores that drain during the next tile -------------
-        char* wl = smem + (buf ^ 1) * G::STAGE + wave * (32 * RB);  // this wave's transposition tile [32 px][RB]
-        const bool obf = OUT_BF16;
-        const int act = (a.act_cols > 0 && n0 >= a.act_cols) ? GIM_ACT_NONE : a.act;  // tile-uniform
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            if constexpr (HAS_RES) {
-#pragma unroll
-                for (int k = 0; k < NI; ++k) {
-                    const int row = k * RPI + rrow;
-                    *(uint4*)(wl + row * RB + ((rslot ^ (row & 7)) << 4)) = rres[j][k];
-                }
-#pragma unroll
-                for (int i = 0; i < TN; ++i)
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        if constexpr (OUT_BF16) {
-                            const uint2 u = *(const uint2*)(wl + l31 * RB + (((i * 4 + rg) ^ (l31 & 7)) << 4) + lh * 8);
-                            acc[i][j][rg * 4 + 0] += __uint_as_float(u.x << 16);
-                            acc[i][j][rg * 4 + 1] += __uint_as_float(u.x & 0xffff0000u);
-                            acc[i][j][rg * 4 + 2] += __uint_as_float(u.y << 16);
-                            acc[i][j][rg * 4 + 3] += __uint_as_float(u.y & 0xffff0000u);
-                        } else {
-                            const float4 rr = *(const float4*)(wl + l31 * RB + (((i * 8 + rg * 2 + lh) ^ (l31 & 7)) << 4));
-                            acc[i][j][rg * 4 + 0] += rr.x; acc[i][j][rg * 4 + 1] += rr.y;
-                            acc[i][j][rg * 4 + 2] += rr.z; acc[i][j][rg * 4 + 3] += rr.w;
-                        }
-                    }
-            }
-            if (act == GIM_ACT_RELU) {
-#pragma unroll
-                for (int i = 0; i < TN; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f);
-            } else if (act == GIM_ACT_LEAKY) {
-#pragma unroll
-                for (int i = 0; i < TN; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f) + 0.01f * fminf(acc[i][j][r], 0.f);
-            } else if (act == GIM_ACT_ELU1) {
-#pragma unroll
-                for (int i = 0; i < TN; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = apply_act(acc[i][j][r], GIM_ACT_ELU1);
-            }
-#pragma unroll
-            for (int i = 0; i < TN; ++i)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    if constexpr (OUT_BF16) {
-                        *(uint2*)(wl + l31 * RB + (((i * 4 + rg) ^ (l31 & 7)) << 4) + lh * 8) =
-                            make_uint2(cvt_pk_bf16(acc[i][j][rg * 4 + 0], acc[i][j][rg * 4 + 1]),
-                                       cvt_pk_bf16(acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]));
-                    } else {
-                        *(float4*)(wl + l31 * RB + (((i * 8 + rg * 2 + lh) ^ (l31 & 7)) << 4)) =
-                            make_float4(acc[i][j][rg * 4 + 0], acc[i][j][rg * 4 + 1], acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]);
-                    }
-                }
-#pragma unroll
-            for (int k = 0; k < NI; ++k) {
-                const int row = k * RPI + rrow;
-                const int m = m0 + wm * WTM + j * 32 + row;
-                const uint4 o = *(const uint4*)(wl + row * RB + ((rslot ^ (row & 7)) << 4));
-                if (ncol_ok && (full || m < M)) *(uint4*)((char*)a.y + ((size_t)m * a.ldy + ncol) * OES) = o;
-            }
-        }
-        (void)obf;
-        init_acc(acc, n0n < a.npad ? n0n : 0);
+        epi.run(a, acc, rres, smem + (buf ^ 1) * G::STAGE, m0, n0, M);  // buf ^ 1: the stage just consumed
+        epi.init_acc(a, acc, n0n < a.npad ? n0n : 0);
         g = gn;
         m0 = m0n; n0 = n0n;
         __syncthreads();  // the transposition tile lives in a stage buffer the next slab's DMA will overwrite
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Deep-prefetch variant for the MFMA-bound layers: 8 waves (4 x 2), 256 x 128 tile, THREE LDS stages of
+// 48 KiB (one workgroup per CU).  With two stages the DMA of slab s+1 has only one compute phase (~1000
+// cycles) to land -- less than the loaded L2/HBM latency -- and both resident workgroups stall together
+// (measured: MFMA pipe 43 % busy).  Here slab s+2 is issued right after the barrier that opens slab s, i.e.
+// two full phases ahead; the wave waits with a COUNTED vmcnt (only the newest slab may be outstanding) and a
+// raw s_barrier, so loads stay in flight across barriers.  There is no ordinary global load in the K loop
+// (the K-group table is copied to LDS once): hipcc drains vmcnt to 0 in front of any use of one.
+template <bool BF16, bool HAS_RES>
+__global__ void __launch_bounds__(512, 2)
+igemm_ring3_kernel(const gim_conv_args a, const int mtiles, const int ntiles, const int M) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 256, BN = 128;
+    typedef gim::Igemm<BM, BN, 4, 2, BF16, true> G;
+    typedef Epilogue<G, true, HAS_RES> E;
+    static_assert(G::PA + G::PB == 6, "counted vmcnt below assumes 6 DMA instructions per slab");
+    int* ktl = (int*)(smem + 3 * G::STAGE);
+
+    unsigned first, step, end;
+    tile_list((unsigned)(mtiles * ntiles), first, step, end);
+    if (first >= end) return;
+    const gim::MainloopArgs ml = mainloop_args(a, M, G::ES);
+    const int nkt = a.kpad * G::ES / KTB;
+    for (int i = threadIdx.x; i < (nkt + 2) * 8; i += 512) ktl[i] = a.ktab[i];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int ntl = (int)((end - first + step - 1) / step);
+    const int nslab = ntl * nkt;
+
+    // issue cursor (runs two slabs ahead of the compute cursor)
+    G gi;
+    unsigned it_tile = first;
+    int it_k = 0, issued = 0, istage = 0;
+    gi.decode(ml, (int)(it_tile / ntiles) * BM, (int)(it_tile % ntiles) * BN);
+    auto issue_next = [&]() {
+        gi.stage_issue(ml, smem, istage, it_k, ktl[G::ktab_index(it_k)]);
+        istage = istage == 2 ? 0 : istage + 1;
+        ++issued;
+        if (++it_k == nkt) {
+            it_k = 0;
+            it_tile += step;
+            if (it_tile < end) gi.decode(ml, (int)(it_tile / ntiles) * BM, (int)(it_tile % ntiles) * BN);
+        }
+    };
+    issue_next();
+    if (nslab > 1) issue_next();
+
+    E epi;
+    typename G::Acc acc;
+    typename E::Res rres;
+    unsigned ct = first;
+    int ck = 0, cstage = 0;
+    int m0 = (int)(ct / ntiles) * BM, n0 = (int)(ct % ntiles) * BN;
+    epi.init_acc(a, acc, n0);
+
+    for (int c = 0; c < nslab; ++c) {
+        // slab c must have landed; only the newest issued slab (c+1) may still be in flight
+        if (issued > c + 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // slab c visible to all waves; all waves are done with slab c-1's stage
+        if (issued < nslab) issue_next();  // slab c+2 -> the stage slab c-1 occupied
+        const bool last = ck + 1 == nkt;
+        if (last) epi.prefetch_res(a, rres, m0, n0, M);
+        G::compute(smem, cstage, acc);
+        if (last) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // every wave has finished reading stage `cstage`
+            epi.run(a, acc, rres, smem + cstage * G::STAGE, m0, n0, M);
+            ck = 0;
+            ct += step;
+            m0 = (int)(ct / ntiles) * BM;
+            n0 = (int)(ct % ntiles) * BN;
+            epi.init_acc(a, acc, n0 < a.npad ? n0 : 0);
+        } else {
+            ++ck;
+        }
+        cstage = cstage == 2 ? 0 : cstage + 1;
     }
 }
 
@@ -343,12 +458,52 @@ int launch_persistent(const gim_conv_args& a, hipStream_t stream) {
     const int M = a.B * a.Ho * a.Wo;
     const int mtiles = (M + BM - 1) / BM, ntiles = a.npad / BN;
     const int T = mtiles * ntiles;
-    constexpr int RESIDENT = 2 * 256;  // 2 workgroups per CU (LDS bound) x 256 CUs
+    constexpr int NT = WM * WN * 64;
+    constexpr int RESIDENT = (NT == 256 ? 2 : 1) * 256;  // workgroups per CU (LDS bound) x 256 CUs
     const int rounds = (T + RESIDENT - 1) / RESIDENT;
     const int grid = (T + rounds - 1) / rounds;  // balanced: every block gets `rounds` (or rounds-1) tiles
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, stream, a, mtiles, ntiles, M);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), smem, stream, a, mtiles, ntiles, M);
     return gim_check_launch("igemm_persistent_kernel");
 }
+
+template <bool BF16, bool HAS_RES>
+int launch_ring3(const gim_conv_args& a, hipStream_t stream) {
+    const int es = BF16 ? 2 : 4;
+    const int nkt = a.kpad * es / KTB;
+    const int smem = 3 * (256 + 128) * KTB + (nkt + 2) * 8 * 4;
+    auto kern = igemm_ring3_kernel<BF16, HAS_RES>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            gim_set_error("hipFuncSetAttribute(160 KiB LDS): %s", hipGetErrorString(e));
+            return GIM_ERR_LAUNCH;
+        }
+        attr_done = true;
+    }
+    const int M = a.B * a.Ho * a.Wo;
+    const int mtiles = (M + 255) / 256, ntiles = a.npad / 128;
+    const int T = mtiles * ntiles;
+    constexpr int RESIDENT = 256;  // one workgroup per CU
+    const int rounds = (T + RESIDENT - 1) / RESIDENT;
+    const int grid = (T + rounds - 1) / rounds;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, a, mtiles, ntiles, M);
+    return gim_check_launch("igemm_ring3_kernel");
+}
+
+// GIM_IGEMM_RING3: 0 = never (default: measured no faster than the 2-stage kernels), 1 = heuristic,
+// 2 = whenever the shape allows (tests).  GIM_IGEMM_BIG: same for the 256x256 / 8-wave tile.
+static int ring3_mode() {
+    static const int mode = [] { const char* e = getenv("GIM_IGEMM_RING3"); return e ? atoi(e) : 0; }();
+    return mode;
+}
+static int big_mode() {
+    static const int mode = [] { const char* e = getenv("GIM_IGEMM_BIG"); return e ? atoi(e) : 1; }();
+    return mode;
+}
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static int big_min_tiles() { static const int v = env_int("GIM_IGEMM_BIG_MIN_TILES", 512); return v; }
+static int big_min_nkt() { static const int v = env_int("GIM_IGEMM_BIG_MIN_NKT", 4); return v; }
 
 template <int BM, int BN, int WM, int WN, bool BF16>
 int dispatch_res(const gim_conv_args& a, hipStream_t s) {
@@ -363,7 +518,25 @@ int dispatch_res(const gim_conv_args& a, hipStream_t s) {
 
 template <bool BF16>
 int dispatch_persistent(const gim_conv_args& a, hipStream_t s) {
-    if (a.npad % 128 == 0) return dispatch_res<128, 128, 2, 2, BF16>(a, s);
+    if (a.npad % 128 == 0) {
+        // deep-prefetch 256x128 kernel: bf16 output, enough K per tile to be MFMA-bound and enough tiles to fill
+        // 256 one-per-CU workgroups a few times over
+        const int es = BF16 ? 2 : 4;
+        const int nkt = a.kpad * es / KTB;
+        const long long M = (long long)a.B * a.Ho * a.Wo;
+        const long long T = ((M + 255) / 256) * (a.npad / 128);
+        // 256 x 256 tile, 8 waves, 64 x 128 wave tile: twice the MFMAs per wave and slab against nearly the same
+        // staging / addressing overhead -- for the MFMA-bound layers (no residual, bf16 out, N % 256 == 0)
+        const int bmode = big_mode();
+        if (a.npad % 256 == 0 && a.out_dtype == GIM_BF16 && !a.res &&
+            (bmode == 2 || (bmode == 1 && nkt >= big_min_nkt() && ((M + 255) / 256) * (a.npad / 256) >= big_min_tiles())))
+            return launch_persistent<256, 256, 4, 2, BF16, true, false>(a, s);
+        const int mode = ring3_mode();
+        const bool can = a.out_dtype == GIM_BF16 && nkt <= 72;
+        if (can && (mode == 2 || (mode == 1 && nkt >= 8 && T >= 4 * 256)))
+            return a.res ? launch_ring3<BF16, true>(a, s) : launch_ring3<BF16, false>(a, s);
+        return dispatch_res<128, 128, 2, 2, BF16>(a, s);
+    }
     return dispatch_res<256, 64, 4, 1, BF16>(a, s);
 }
 

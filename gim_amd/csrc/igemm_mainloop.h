@@ -33,8 +33,11 @@ struct Igemm {
     static constexpr int ES = BF16 ? 2 : 4;
     static constexpr int A_BYTES = BM * KTB, B_BYTES = BN * KTB, STAGE = A_BYTES + B_BYTES;
     static constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
-    static constexpr int PA = BM / 32, PB = BN / 32;
-    static_assert(WM * WN == 4, "4 waves");
+    static constexpr int NW = WM * WN;            // waves per workgroup (4 or 8)
+    static constexpr int RPP = 8 * NW;            // rows staged per pass (one 16-byte slot per thread)
+    static constexpr int PA = BM / RPP, PB = BN / RPP;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
     typedef f32x16_t Acc[TN][TM];
 
     int iy0[PA], ix0[PA];
@@ -50,7 +53,7 @@ struct Igemm {
         const int HoWo = a.Ho * a.Wo;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            const int m = m0 + i * 32 + srow;
+            const int m = m0 + i * RPP + srow;
             int y = 0, x = m;
             unsigned pix = 0;
             if (!flat) {
@@ -75,6 +78,7 @@ struct Igemm {
     // issue the loads of slab kt into LDS stage `buf`.  `e` = ktab[ktab_index(kt)], fetched by the caller
     // one slab ahead so that no dependent global load sits in front of the DMA issue.
     __device__ __forceinline__ void stage_issue(const MainloopArgs& a, char* smem, int buf, int kt, int e) {
+        // `buf` selects the stage at smem + buf * STAGE (2-stage double buffer or a deeper ring)
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
         const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.w_bytes, 0x00020000);
@@ -90,16 +94,16 @@ struct Igemm {
             const bool ok = ((unsigned)(iy0[i] + dy) < (unsigned)a.H) & ((unsigned)(ix0[i] + dx) < (unsigned)a.W);
             const unsigned voff = ok ? rowoff[i] + tapoff : a.x_bytes;
             if constexpr (LDSDMA) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(sA + (i * 32 + wave * 8) * KTB), 16, voff, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(sA + (i * RPP + wave * 8) * KTB), 16, voff, 0, 0, 0);
             } else {
                 ra[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, 0, 0));
             }
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            const unsigned voff = wrow + (unsigned)(i * 32) * (unsigned)a.kpad * ES + (unsigned)kt * KTB;
+            const unsigned voff = wrow + (unsigned)(i * RPP) * (unsigned)a.kpad * ES + (unsigned)kt * KTB;
             if constexpr (LDSDMA) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(sB + (i * 32 + wave * 8) * KTB), 16, voff, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(sB + (i * RPP + wave * 8) * KTB), 16, voff, 0, 0, 0);
             } else {
                 rb[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, voff, 0, 0));
             }
@@ -113,9 +117,9 @@ struct Igemm {
             char* sA = smem + buf * STAGE;
             char* sB = sA + A_BYTES;
 #pragma unroll
-            for (int i = 0; i < PA; ++i) *(uint4*)(sA + (i * 32 + srow) * KTB + sslot * 16) = ra[i];
+            for (int i = 0; i < PA; ++i) *(uint4*)(sA + (i * RPP + srow) * KTB + sslot * 16) = ra[i];
 #pragma unroll
-            for (int i = 0; i < PB; ++i) *(uint4*)(sB + (i * 32 + srow) * KTB + sslot * 16) = rb[i];
+            for (int i = 0; i < PB; ++i) *(uint4*)(sB + (i * RPP + srow) * KTB + sslot * 16) = rb[i];
         }
     }
 

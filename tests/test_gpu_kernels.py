@@ -347,3 +347,18 @@ print('OK', M)
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True,
                          env={**os.environ, "GIM_CM_PRECAND_PER_ROW": "0"}, timeout=300)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("env", [{"GIM_IGEMM_BIG": "2"}, {"GIM_IGEMM_RING3": "2", "GIM_IGEMM_BIG": "0"}],
+                         ids=["big256x256", "ring3"])
+def test_conv_kernel_variants_forced(env):
+    """the 256x256 / 8-wave tile and the 3-stage ring variant are normally picked by shape heuristics; force each
+    of them onto every eligible conv / linear case (the choice is read once per process -> subprocess)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_kernels.py", "-m", "gpu", "-q", "-x",
+                          "-k", "conv2d_bn_act or linear_strided", "-p", "no:cacheprovider"],
+                         cwd=root, capture_output=True, text=True, env={**os.environ, **env}, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]

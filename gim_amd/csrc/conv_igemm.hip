@@ -140,7 +140,7 @@ igemm_kernel(const gim_conv_args a, const int mtiles, const int ntiles, const in
 template <typename G, bool OUT_BF16, bool HAS_RES>
 struct Epilogue {
     static constexpr int TM = G::TM, TN = G::TN, WTM = G::WTM, WTN = G::WTN, WN = G::WTN == 0 ? 1 : (G::B_BYTES / KTB) / G::WTN;
-    static_assert(WTM == 64 && WTN % 64 == 0, "epilogue transposition works on 32 px x 64 ch passes of a 64 x (64*NH) wave tile");
+    static_assert(WTM % 32 == 0 && WTN % 64 == 0, "epilogue transposition works on 32 px x 64 ch passes of the wave tile");
     static constexpr int NH = WTN / 64;            // 64-channel halves of the wave tile
     static_assert(!HAS_RES || NH == 1, "residual prefetch is only built for 64-channel wave tiles");
     static constexpr int OES = OUT_BF16 ? 2 : 4;   // output element size
@@ -531,6 +531,8 @@ int dispatch_persistent(const gim_conv_args& a, hipStream_t s) {
         if (a.npad % 256 == 0 && a.out_dtype == GIM_BF16 && !a.res &&
             (bmode == 2 || (bmode == 1 && nkt >= big_min_nkt() && ((M + 255) / 256) * (a.npad / 256) >= big_min_tiles())))
             return launch_persistent<256, 256, 4, 2, BF16, true, false>(a, s);
+        // (a 512 x 128 tile with 128 x 64 wave tiles for the N = 128 layers measured slower than 128 x 128: 875 vs 716 us
+        //  on 196->128 3x3 -- not built)
         const int mode = ring3_mode();
         const bool can = a.out_dtype == GIM_BF16 && nkt <= 72;
         if (can && (mode == 2 || (mode == 1 && nkt >= 8 && T >= 4 * 256)))

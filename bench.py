@@ -161,7 +161,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"gim_loftr {W}x{H}, batch {nb} pairs per GPU per step, random-init weights, "
+            "config": {"fine_stage_note": "random-init weights give ~1 match/pair, so the fine level is nearly idle here; "
+                                          "measured separately with synthetic matches (tools/bench_fine.py, "
+                                          "profiles/r01_fine_stage.txt): +1.2 / +3.1 / +7.9 ms per batch at 500 / "
+                                          "1500 / 4000 matches per pair",
+                       "workload": f"gim_loftr {W}x{H}, batch {nb} pairs per GPU per step, random-init weights, "
                                    f"uniform-noise images (device resident), outputs incl. match count read back",
                        "pairs_per_step": world * nb, "matches_per_pair": round(n_matches / max(1, pairs), 2),
                        "parallelism": f"pairs sharded over {world} GPU(s), no collective per step",

@@ -418,7 +418,8 @@ class LoFTR(nn.Module):
             self._coarse_stage(*sin)  # warm-up: one-time hipFuncSetAttribute calls, allocator pools
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: other threads (e.g. RCCL's watchdog in multi-GPU runs) may issue HIP calls meanwhile
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 out = self._coarse_stage(*sin)
             ent = self._graphs[key] = (graph, sin, out)
         graph, sin, out = ent

@@ -111,6 +111,93 @@ la_apply_kernel(const void* __restrict__ q, const uint8_t* __restrict__ q_mask, 
     }
 }
 
+// Short sequences (the fine level: 25-token windows, tens of thousands of sequences): one wave per sequence does
+// the whole LinearAttention -- KV/Ksum reduction and the apply step -- with the D x D state exchanged through a
+// private LDS slice; no workspace, no second launch.  Lane = (head h = lane/8, j = lane%8): in the reduction it
+// owns rows d = j*D/8 .. of KV_h, in the apply step columns v = j*D/8 .. of the output.  H must be 8.
+template <int D, bool BF16, bool OUT_BF16>
+__global__ void __launch_bounds__(256)
+la_short_kernel(const void* __restrict__ q, const void* __restrict__ k, const void* __restrict__ v,
+                const uint8_t* __restrict__ q_mask, const uint8_t* __restrict__ kv_mask, void* __restrict__ out,
+                int nb, int L, int S, int ldq, int ldk, int ldv, int ldo) {
+    constexpr int H = 8, PL = D / 8, PER = D * D + D;  // PL: KV rows (reduction) / output columns (apply) per lane
+    __shared__ __attribute__((aligned(16))) float kvs[4][H][PER];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= nb) return;
+    const int h = lane >> 3, j = lane & 7;
+    const float slen = (float)S;
+    // ---- KV_h[d][:] = sum_s K[s,h,d] * V[s,h,:]/S ,  Ksum_h[d] = sum_s K[s,h,d]     (attentions.py:41-44) ----
+    float acc[PL][D], ks[PL];
+#pragma unroll
+    for (int x = 0; x < PL; ++x) {
+        ks[x] = 0.f;
+#pragma unroll
+        for (int y = 0; y < D; ++y) acc[x][y] = 0.f;
+    }
+    for (int s = 0; s < S; ++s) {
+        if (kv_mask && !kv_mask[(size_t)b * S + s]) continue;
+        const size_t kr = ((size_t)b * S + s) * ldk + h * D, vr = ((size_t)b * S + s) * ldv + h * D;
+        float kk[PL], vv[D];
+#pragma unroll
+        for (int x = 0; x < PL; ++x) kk[x] = ElemIO<BF16>::ld(k, kr + j * PL + x);
+#pragma unroll
+        for (int y = 0; y < D; y += 4) {
+            const float4 t = ElemIO<BF16>::ld4(v, vr + y);
+            vv[y] = t.x / slen; vv[y + 1] = t.y / slen; vv[y + 2] = t.z / slen; vv[y + 3] = t.w / slen;
+        }
+#pragma unroll
+        for (int x = 0; x < PL; ++x) {
+            ks[x] += kk[x];
+#pragma unroll
+            for (int y = 0; y < D; ++y) acc[x][y] = fmaf(kk[x], vv[y], acc[x][y]);
+        }
+    }
+    float* KV = &kvs[wave][h][0];
+#pragma unroll
+    for (int x = 0; x < PL; ++x) {
+        KV[D * D + j * PL + x] = ks[x];
+#pragma unroll
+        for (int y = 0; y < D; y += 4)
+            *(float4*)(KV + (j * PL + x) * D + y) = make_float4(acc[x][y], acc[x][y + 1], acc[x][y + 2], acc[x][y + 3]);
+    }
+    // LDS operations of one wave execute in order: the reads below see the writes above (all lanes of this head's
+    // 8-lane group belong to this wave); only the data dependency needs a wait.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float kvc[D][PL], ksum[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        ksum[d] = KV[D * D + d];
+#pragma unroll
+        for (int e = 0; e < PL; ++e) kvc[d][e] = KV[d * D + j * PL + e];
+    }
+    // ---- out[l,h,:] = (Q[l,h,:] KV_h) / (Q[l,h,:].Ksum_h + eps) * S                  (attentions.py:44-45) ----
+    for (int l = 0; l < L; ++l) {
+        const bool qvalid = !q_mask || q_mask[(size_t)b * L + l];
+        const size_t qr = ((size_t)b * L + l) * ldq + h * D;
+        float qv[D];
+#pragma unroll
+        for (int d = 0; d < D; d += 4) {
+            float4 t = ElemIO<BF16>::ld4(q, qr + d);
+            if (!qvalid) t = make_float4(0.f, 0.f, 0.f, 0.f);
+            qv[d] = t.x; qv[d + 1] = t.y; qv[d + 2] = t.z; qv[d + 3] = t.w;
+        }
+        float z = 0.f, o[PL];
+#pragma unroll
+        for (int e = 0; e < PL; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            z = fmaf(qv[d], ksum[d], z);
+#pragma unroll
+            for (int e = 0; e < PL; ++e) o[e] = fmaf(qv[d], kvc[d][e], o[e]);
+        }
+        const float Z = 1.0f / (z + 1e-6f);
+        const size_t oo = ((size_t)b * L + l) * ldo + h * D + j * PL;
+#pragma unroll
+        for (int e = 0; e < PL; ++e) ElemIO<OUT_BF16>::st(out, oo + e, o[e] * Z * slen);
+    }
+}
+
 inline int nchunks(int S) { return (S + CH - 1) / CH; }
 
 }  // namespace
@@ -175,4 +262,30 @@ extern "C" int gim_linear_attention_apply(const void* q, const uint8_t* q_mask, 
     }
 #undef LA_APPLY
     return gim_check_launch("la_apply");
+}
+
+extern "C" int gim_linear_attention_short(const void* q, const void* k, const void* v, const uint8_t* q_mask,
+                                          const uint8_t* kv_mask, void* out, int nb, int L, int S, int H, int D,
+                                          int ldq, int ldk, int ldv, int ldo, int dtype, int out_dtype,
+                                          gim_stream_t stream) {
+    GIM_REQUIRE(q && k && v && out && nb > 0 && L > 0 && S > 0, "linear_attention_short: bad args");
+    GIM_REQUIRE(H == 8 && (D == 16 || D == 32), "linear_attention_short: needs H == 8 and D in {16, 32} (got H=%d D=%d)", H, D);
+    GIM_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0, "linear_attention_short: ld alignment");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((nb + 3) / 4));
+    const bool bf = dtype == GIM_BF16, obf = out_dtype == GIM_BF16;
+#define LA_SHORT(DD, A, B) hipLaunchKernelGGL((la_short_kernel<DD, A, B>), grid, dim3(256), 0, s, q, k, v, q_mask, kv_mask, out, nb, L, S, ldq, ldk, ldv, ldo)
+    if (D == 16) {
+        if (bf && obf) LA_SHORT(16, true, true);
+        else if (bf) LA_SHORT(16, true, false);
+        else if (obf) LA_SHORT(16, false, true);
+        else LA_SHORT(16, false, false);
+    } else {
+        if (bf && obf) LA_SHORT(32, true, true);
+        else if (bf) LA_SHORT(32, true, false);
+        else if (obf) LA_SHORT(32, false, true);
+        else LA_SHORT(32, false, false);
+    }
+#undef LA_SHORT
+    return gim_check_launch("la_short");
 }

@@ -172,6 +172,10 @@ class LoFTR(nn.Module):
         self._packed_key = None
         self._pe_cache = {}
         self.debug = None  # set to a dict to capture stage outputs (tests): coarse/fine maps, token features
+        # bench-only hook: (feat_c0, feat_c1) fp32 [N,L,C] device tensors that REPLACE the transformer output in
+        # front of coarse matching, to load the fine level with a realistic number of matches when the weights
+        # are random (bench.py "realistic_fine").  Never set by product code.
+        self.bench_override_coarse = None
         # HIP-graph replay of the shape-static part of the forward (env GIM_GRAPH=0 disables)
         self.use_graph = os.environ.get("GIM_GRAPH", "1") != "0"
         self._graphs = {}
@@ -395,6 +399,9 @@ class LoFTR(nn.Module):
         # 3. coarse matching (coarse_matching.py:88-259), fused
         mc = cfg["match_coarse"]
         scale = color0.shape[2] / hw0_c[0]
+        if self.bench_override_coarse is not None:
+            T.X32[r0].copy_(self.bench_override_coarse[0].reshape(-1, C))
+            T.X32[r1].copy_(self.bench_override_coarse[1].reshape(-1, C))
         cr = ops.coarse_match(T.X32[r0].view(bs, L, C), T.X32[r1].view(bs, S, C), hw0_c, hw1_c, scale,
                               mc["dsmax_temperature"], mc["thr"], mc["border_rm"], scale0, scale1,
                               T.MASK[r0] if mask0 is not None else None, T.MASK[r1] if mask0 is not None else None)

@@ -157,6 +157,11 @@ def linear_attention(q, k, v, out, nb_q, L, nb_kv, S, H, ws=None, q_mask=None, k
     assert nb_q == nb_kv
     C = H * (q.shape[1] // H)
     D = q.shape[1] // H
+    if H == 8 and D in (16, 32) and L <= 64 and S <= 64:  # short sequences: fused single-launch kernel
+        check(lib.gim_linear_attention_short(_p(q), _p(k), _p(v), _p(q_mask), _p(kv_mask), _p(out), nb_q, L, S, H, D,
+                                             q.stride(0), k.stride(0), v.stride(0), out.stride(0), gim_dtype(q),
+                                             gim_dtype(out), _stream()), "gim_linear_attention_short")
+        return ws
     need = lib.gim_linear_attention_ws_bytes(nb_kv, S, H, D)
     if ws is None or ws.numel() * ws.element_size() < need:
         ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=q.device)

@@ -102,6 +102,13 @@ int gim_linear_attention_apply(const void* q, const uint8_t* q_mask, const float
                                int nb, int L, int S, int H, int D, int ldq, int ldo, int dtype,
                                int out_dtype, gim_stream_t stream);
 
+/* Same LinearAttention for SHORT sequences (the fine level's 25-token windows, transformer on [M,25,128],
+ * loftr.py:88): one wave per sequence fuses both steps, no workspace.  Requires H == 8, D in {16, 32}. */
+int gim_linear_attention_short(const void* q, const void* k, const void* v, const uint8_t* q_mask,
+                               const uint8_t* kv_mask, void* out, int nb, int L, int S, int H, int D,
+                               int ldq, int ldk, int ldv, int ldo, int dtype, int out_dtype,
+                               gim_stream_t stream);
+
 /* LayerNorm (+ optional residual):  v = LN(x[m,:]) * gamma + beta ; if res: v += res[m,:]
  * (transformer.py:52,56,58).  Writes fp32 (out_f32, may be NULL) and/or `dtype` copy (out_t). */
 int gim_layernorm_residual(const float* x, const float* gamma, const float* beta, const float* res,

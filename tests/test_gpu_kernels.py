@@ -193,7 +193,8 @@ def test_layernorm_residual(dt, C):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("shape", [(3, 300, 300, 8, 32), (2, 77, 150, 8, 32), (5, 25, 25, 8, 16)],
+@pytest.mark.parametrize("shape", [(3, 300, 300, 8, 32), (2, 77, 150, 8, 32), (5, 25, 25, 8, 16), (6, 40, 33, 8, 32),
+                                   (9, 25, 25, 8, 16)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_linear_attention(dt, shape):
     """against oracle linear_attention (attentions.py:20-47); q/k pre-mapped by elu+1 like the GEMM epilogue"""
@@ -362,3 +363,23 @@ def test_conv_kernel_variants_forced(env):
                           "-k", "conv2d_bn_act or linear_strided", "-p", "no:cacheprovider"],
                          cwd=root, capture_output=True, text=True, env={**os.environ, **env}, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("shape", [(4, 25, 25, 8, 16), (2, 200, 140, 8, 32)], ids=["short", "long"])
+def test_linear_attention_masks(shape):
+    """q_mask / kv_mask (attentions.py:35-39) on both the fused short-sequence kernel and the chunked one"""
+    from gim_amd import ops
+    dev = _dev()
+    nb, L, S, H, D = shape
+    g = torch.Generator().manual_seed(17)
+    q, k, v = (torch.randn(nb, n, H, D, generator=g) for n in (L, S, S))
+    qm = torch.rand(nb, L, generator=g) > 0.3
+    km = torch.rand(nb, S, generator=g) > 0.3
+    ref = O.linear_attention(q, k, v, qm, km)
+    C = H * D
+    Qe, Ke = F.elu(q) + 1, F.elu(k) + 1
+    out = torch.empty(nb * L, C, device=dev)
+    ops.linear_attention(Qe.reshape(nb * L, C).to(dev), Ke.reshape(nb * S, C).to(dev), v.reshape(nb * S, C).to(dev), out,
+                         nb, L, nb, S, H, None, qm.reshape(-1).to(torch.uint8).to(dev), km.reshape(-1).to(torch.uint8).to(dev))
+    torch.cuda.synchronize()
+    _assert_close(out.view(nb, L, H, D), ref, 1e-5, f"masked linear attention {shape}")

@@ -33,7 +33,8 @@ namespace {
 
 constexpr int BM = 128, BN = 128, WM = 2, WN = 2;
 constexpr int TLD = BN + 4;  // LDS similarity tile row stride in floats
-constexpr int TILE_SMEM = BM * TLD * 4 + (4 * 128 + 4 * 128) * 4;  // tile + reduction scratch
+constexpr int PLIST = 512;  // per-tile pre-candidate list in LDS (4 per row can pass the tile-local test)
+constexpr int TILE_SMEM = BM * TLD * 4 + (4 * 128 + 4 * 128) * 4 + PLIST * 12 + 16;  // tile + scratch + list
 static_assert(TILE_SMEM >= gim::mainloop_smem_bytes<BM, BN>(), "stage buffers must fit in the tile allocation");
 
 struct Cand { int i, j; float p; int pad; };
@@ -218,29 +219,49 @@ __global__ void __launch_bounds__(256) cm_stats_kernel(const CmGeom g, const CmW
     }
     // ---- pre-candidates.  softmax over the tile's columns (rows) >= the true row (column) softmax, so
     // conf > thr needs: tile-local row factor > thr, column factor > thr (cheap tests  s > m + log(thr z))
-    // and their product > thr (evaluated only for the few survivors).
+    // and their product > thr (evaluated only for the few survivors).  Survivors are collected in an LDS
+    // list (LDS atomics) and the tile reserves its global range with ONE atomic: a returning global atomic
+    // per survivor stalled the waves for microseconds each (measured 2.8x on wide-spread similarities).
     {
+        PreCand* plist = (PreCand*)(smem + BM * TLD * 4 + 4096);
+        int* pcnt = (int*)(plist + PLIST);  // [0] = local count, [1] = global base
         const float thr_pre = g.thr * (1.0f - 1e-4f);  // slack: rounding must never drop a true candidate
         if (half == 0) red[idx] = rowm[idx] + logf(thr_pre * rowz[idx]);
         else red[128 + idx] = colm[idx] + logf(thr_pre * colz[idx]);
+        if (t == 0) pcnt[0] = 0;
         __syncthreads();
         const int i = m0 + idx;
-        if (i >= g.L) return;
-        const float trow = red[idx], rm = rowm[idx], rz = rowz[idx];
-        for (int jj = 0; jj < 64; ++jj) {
-            const int jl = half * 64 + jj, j = n0 + jl;
-            if (j >= g.S) break;
-            const float sv = St[idx * TLD + jl];
-            if (sv > trow && sv > red[128 + jl]) {
-                const float pr = expf(sv - rm) / rz;
-                const float pc = expf(sv - colm[jl]) / colz[jl];
-                if (pr * pc > thr_pre) {
-                    const int k = atomicAdd(&w.npre[n], 1);
-                    if (k < w.capp) w.pre[(size_t)n * w.capp + k] = PreCand{i, j, sv};
-                    else w.npre[g.N] = 1;  // overflow: cm_cand_kernel<0> recomputes
+        if (i < g.L) {
+            const float trow = red[idx], rm = rowm[idx], rz = rowz[idx];
+            for (int jj = 0; jj < 64; ++jj) {
+                const int jl = half * 64 + jj, j = n0 + jl;
+                if (j >= g.S) break;
+                const float sv = St[idx * TLD + jl];
+                if (sv > trow && sv > red[128 + jl]) {
+                    const float pr = expf(sv - rm) / rz;
+                    const float pc = expf(sv - colm[jl]) / colz[jl];
+                    if (pr * pc > thr_pre) {
+                        const int k = atomicAdd(&pcnt[0], 1);
+                        if (k < PLIST) plist[k] = PreCand{i, j, sv};
+                    }
                 }
             }
         }
+        __syncthreads();
+        const int cnt = pcnt[0];
+        if (cnt == 0) return;
+        if (cnt > PLIST) {  // cannot happen for thr >= 4/128-ish tiles, but stay exact: recompute path
+            if (t == 0) w.npre[g.N] = 1;
+            return;
+        }
+        if (t == 0) pcnt[1] = atomicAdd(&w.npre[n], cnt);
+        __syncthreads();
+        const int base = pcnt[1];
+        if (base + cnt > w.capp) {
+            if (t == 0) w.npre[g.N] = 1;  // overflow: cm_cand_kernel<0> recomputes
+            return;
+        }
+        for (int k = t; k < cnt; k += 256) w.pre[(size_t)n * w.capp + base + k] = plist[k];
     }
 }
 

@@ -6,7 +6,7 @@ pmc=()
 while [[ $1 != "--" ]]; do pmc+=("$1"); shift; done; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 rm -rf $out; mkdir -p $out
-( cd /tmp && TMPDIR=/tmp timeout 150 rocprofv3 --kernel-trace --pmc "${pmc[@]}" --output-format csv -d $out -o p -- python $GRAFT_REPO_ROOT/tools/microbench_conv.py "$@" ) > $out/log.txt 2>&1
+( cd /tmp && TMPDIR=/tmp timeout 150 rocprofv3 --kernel-trace --pmc "${pmc[@]}" --output-format csv -d $out -o p -- python $GRAFT_REPO_ROOT/${PMC_SCRIPT:-tools/microbench_conv.py} "$@" ) > $out/log.txt 2>&1
 python - "$out" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
@@ -17,7 +17,7 @@ for r in csv.DictReader(open(f[0])):
     k = r['Kernel_Name'][:60]
     acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in acc.items():
-    if 'igemm' not in k: continue
+    if not any(t in k for t in ("igemm", "cm_stats")): continue
     print(k)
     for c, v in d.items(): print(f"   {c:28s} avg {sum(v)/len(v):14.1f}  (n={len(v)})")
 PY

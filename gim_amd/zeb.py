@@ -106,16 +106,18 @@ def score_dir(directory, weight, version, thresholds=(5.0, 10.0, 20.0)):
 
 # ---- host-side pose metrics (tools/metrics.py) ---------------------------------------------------
 def relative_pose_error(T_0to1, R, t, ignore_gt_t_thr=0.0):
-    """tools/metrics.py:28-53: angular errors (deg) of the estimated rotation / translation direction."""
+    """tools/metrics.py:10-29: (t_err deg, R_err deg, t_err2) of an estimated pose against T_0to1."""
     t_gt = T_0to1[:3, 3]
     n = np.linalg.norm(t) * np.linalg.norm(t_gt)
     t_err = np.rad2deg(np.arccos(np.clip(np.dot(t, t_gt) / n, -1.0, 1.0)))
     t_err = np.minimum(t_err, 180 - t_err)
     if np.linalg.norm(t_gt) < ignore_gt_t_thr:
         t_err = 0
+    r = np.linalg.norm(t_gt) / np.linalg.norm(t)
+    t_err2 = np.linalg.norm((t * r - t_gt))
     R_gt = T_0to1[:3, :3]
     cos = np.clip((np.trace(np.dot(R.T, R_gt)) - 1) / 2, -1.0, 1.0)
-    return t_err, np.rad2deg(np.abs(np.arccos(cos)))
+    return t_err, np.rad2deg(np.abs(np.arccos(cos))), t_err2
 
 
 def estimate_pose(kpts0, kpts1, K0, K1, thresh=0.5, conf=0.99999):
@@ -139,3 +141,71 @@ def estimate_pose(kpts0, kpts1, K0, K1, thresh=0.5, conf=0.99999):
         if n > best:
             ret, best = (R, t[:, 0], mask.ravel() > 0), n
     return ret
+
+
+def symmetric_epipolar_distance(pts0, pts1, E, K0, K1):
+    """tools/metrics.py:32-52 (squared symmetric epipolar distance in normalised coordinates), numpy."""
+    pts0 = (pts0 - K0[[0, 1], [2, 2]][None]) / K0[[0, 1], [0, 1]][None]
+    pts1 = (pts1 - K1[[0, 1], [2, 2]][None]) / K1[[0, 1], [0, 1]][None]
+    pts0 = np.concatenate([pts0, np.ones_like(pts0[:, :1])], 1)
+    pts1 = np.concatenate([pts1, np.ones_like(pts1[:, :1])], 1)
+    Ep0 = pts0 @ E.T
+    p1Ep0 = np.sum(pts1 * Ep0, -1)
+    Etp1 = pts1 @ E
+    return p1Ep0 ** 2 * (1.0 / (Ep0[:, 0] ** 2 + Ep0[:, 1] ** 2) + 1.0 / (Etp1[:, 0] ** 2 + Etp1[:, 1] ** 2))
+
+
+def _np(x):
+    return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+
+
+def evaluate_batch(batch, estimate=None):
+    """Per-pair dump rows of one matched batch = `Trainer.compute_metrics` (lightning.py:101-122) +
+    `compute_symmetrical_epipolar_errors` / `compute_pose_errors` (tools/metrics.py:56-74,107-168).
+    `batch` needs mkpts0_f, mkpts1_f, m_bids (the matcher's outputs) and K0, K1, T_0to1, scene_id, pair_names,
+    covisible0, covisible1 (the ZEB loaders' fields).  `estimate(kpts0, kpts1, K0, K1)` defaults to the cv2
+    RANSAC of the reference (thresh 0.5, conf 0.99999 -- the values tools/metrics.py:139 hard-codes)."""
+    estimate = estimate or (lambda a, b, k0, k1: estimate_pose(a, b, k0, k1, 0.5, 0.99999))
+    m_bids = _np(batch["m_bids"])
+    pts0, pts1 = _np(batch["mkpts0_f"]).astype(np.float64), _np(batch["mkpts1_f"]).astype(np.float64)
+    K0, K1, T = _np(batch["K0"]).astype(np.float64), _np(batch["K1"]).astype(np.float64), _np(batch["T_0to1"]).astype(np.float64)
+    names = list(zip(batch["scene_id"], *batch["pair_names"]))
+    rows = []
+    for b in range(K0.shape[0]):
+        sel = m_bids == b
+        p0, p1 = pts0[sel], pts1[sel]
+        t = T[b, :3, 3]
+        Tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        epi = symmetric_epipolar_distance(p0, p1, Tx @ T[b, :3, :3], K0[b], K1[b]) if len(p0) else np.zeros(0)
+        ret = estimate(p0, p1, K0[b], K1[b])
+        if ret is None:
+            R_err = t_err = t_err2 = np.inf
+            inl = np.array([]).astype(bool)
+        else:
+            R, tt, inl = ret
+            t_err, R_err, t_err2 = relative_pose_error(T[b], R, tt, ignore_gt_t_thr=0.0)
+        rows.append(format_row("#".join(names[b]), _np(batch["covisible0"])[b], _np(batch["covisible1"])[b],
+                               R_err, t_err, t_err2, epi, inl))
+    return rows
+
+
+def run_scene(matcher, batches, out_path, rank=0, world=1, estimate=None, skip_existing=True):
+    """The ZEB test loop of `test.py:188-231` + `trainer/lightning.py:243-275` without Lightning.
+    Every rank runs `matcher(batch)` (mutates the batch like LoFTR.forward) over ITS batches -- shard with
+    `gim_amd.runner.shard_pairs` or a DistributedSampler -- and scores them on the host; the per-pair rows
+    (~100 B each) are gathered once at the end and rank 0 writes the dump in the reference's format.
+    Restartable like the reference: an existing dump is kept (`test.py:226-228`)."""
+    if skip_existing and os.path.exists(out_path):
+        return None
+    rows = []
+    for batch in batches:
+        matcher(batch)
+        rows.extend(evaluate_batch(batch, estimate))
+    if world > 1:
+        import torch.distributed as dist
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rows)
+        rows = [r for part in gathered for r in part]
+    if rank == 0:
+        write_dump(out_path, rows)
+    return rows

@@ -47,5 +47,69 @@ def test_relative_pose_error():
     T[:3, 3] = [1.0, 0, 0]
     c, s = np.cos(np.deg2rad(10)), np.sin(np.deg2rad(10))
     R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
-    t_err, R_err = zeb.relative_pose_error(T, R, np.array([-1.0, 0, 0]))
-    assert abs(R_err - 10) < 1e-6 and abs(t_err) < 1e-6  # sign-ambiguous translation (min(e, 180-e))
+    t_err, R_err, t_err2 = zeb.relative_pose_error(T, R, np.array([-1.0, 0, 0]))
+    assert abs(R_err - 10) < 1e-6 and abs(t_err) < 1e-6 and abs(t_err2 - 2.0) < 1e-9  # sign-ambiguous translation (min(e, 180-e))
+
+
+# ---- the sharded evaluation loop (test.py + lightning.test_epoch_end), CPU, world_size 2 over gloo ----
+def _synthetic_batches(pairs):
+    """two cameras with a known relative pose looking at random 3-D points; `matcher` returns their projections"""
+    import torch
+    out = []
+    for p in pairs:
+        g = np.random.default_rng(p)
+        K = np.array([[500.0, 0, 320], [0, 500.0, 240], [0, 0, 1]])
+        a = 0.1 + 0.01 * p
+        R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        t = np.array([0.5, 0.05 * p, 0.1])
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+        X = np.concatenate([g.uniform(-1, 1, (60, 2)), g.uniform(4, 8, (60, 1))], 1)
+        x0 = (K @ X.T).T; x0 = x0[:, :2] / x0[:, 2:]
+        X1 = (R @ X.T).T + t
+        x1 = (K @ X1.T).T; x1 = x1[:, :2] / x1[:, 2:]
+        out.append({"scene_id": ["s"], "pair_names": (["%04d" % p], ["%04d" % (p + 1)]), "K0": torch.tensor(K)[None],
+                    "K1": torch.tensor(K)[None], "T_0to1": torch.tensor(T)[None], "covisible0": torch.tensor([0.5]),
+                    "covisible1": torch.tensor([0.25]), "_x0": x0, "_x1": x1, "_T": T})
+    return out
+
+
+def _matcher(batch):
+    import torch
+    batch.update({"mkpts0_f": torch.tensor(batch["_x0"]), "mkpts1_f": torch.tensor(batch["_x1"]),
+                  "m_bids": torch.zeros(len(batch["_x0"]), dtype=torch.int64)})
+
+
+def _oracle_pose(batch_holder):
+    def est(p0, p1, K0, K1):  # stands in for cv2 RANSAC (not installed here): returns the ground-truth pose
+        T = batch_holder["T"]
+        return T[:3, :3], T[:3, 3] * 3.0, np.ones(len(p0), dtype=bool)
+    return est
+
+
+def _zeb_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gim_amd.runner import shard_pairs
+    mine = shard_pairs(5, rank, world)
+    batches = _synthetic_batches(mine)
+    holder = {}
+
+    def matcher(b):
+        _matcher(b); holder["T"] = b["_T"]
+    rows = zeb.run_scene(matcher, batches, out, rank, world, estimate=_oracle_pose(holder))
+    assert len(rows) == 5
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_run_scene_world2(tmp_path):
+    import torch.multiprocessing as mp
+    out = zeb.dump_path(str(tmp_path), "gim_loftr", "GL3D", "test")
+    mp.spawn(_zeb_worker, args=(2, 29900 + os.getpid() % 1000, out), nprocs=2, join=True)
+    cols = zeb.read_dump(out)
+    assert cols["identifiers"] == ["s#%04d#%04d" % (p, p + 1) for p in range(5)]      # sorted, no duplicates
+    assert all(float(r) < 1e-4 for r in cols["R_errs"]) and all(float(t) < 1e-4 for t in cols["t_errs"])
+    assert all(float(x) == 1.0 for x in cols["Bef.Prec"]) and cols["Bef.Num"] == ["60"] * 5  # exact projections: epi err ~ 0
+    per, mean = zeb.score_dir(str(tmp_path), "gim_loftr", "test")
+    assert per["GL3D"][5.0] > 99.9
+    assert zeb.run_scene(None, [], out) is None  # restartable: an existing dump is kept

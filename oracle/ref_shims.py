@@ -8,6 +8,9 @@ path that are not installed here and cannot be installed (no network):
         kornia.utils.grid.create_meshgrid                    (line 50)
   * yacs           -- `networks/loftr/config.py:1` (`CfgNode`)
 
+  * omegaconf      -- `networks/lightglue/models/base_model.py:8-9`, `models/matchers/lightglue.py:8`
+                      (gim_lightglue path; `install_omegaconf()`)
+
 `install()` registers minimal modules under those names in `sys.modules` (restating the published
 behaviour of the two kornia functions and a dict-backed CfgNode) and puts `/root/reference` on
 `sys.path`, so `oracle/make_golden.py` can run the reference's own modules to pin `oracle/loftr_oracle.py`.
@@ -102,6 +105,73 @@ def install():
         y.config = yc
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
+
+
+class DictConfig(dict):
+    """Stand-in for omegaconf.DictConfig: a dict with attribute access (nested dicts converted)."""
+
+    def __init__(self, d=None):
+        super().__init__()
+        for k, v in (d or {}).items():
+            self[k] = DictConfig(v) if isinstance(v, dict) else v
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+class _OmegaConf:
+    @staticmethod
+    def create(d=None):
+        return DictConfig(d or {})
+
+    @staticmethod
+    def merge(*cfgs):
+        out = DictConfig()
+        for c in cfgs:
+            for k, v in dict(c).items():
+                if isinstance(v, dict) and isinstance(out.get(k), dict):
+                    out[k] = _OmegaConf.merge(out[k], v)
+                else:
+                    out[k] = DictConfig(v) if isinstance(v, dict) else v
+        return out
+
+    @staticmethod
+    def set_struct(conf, flag):
+        pass
+
+    @staticmethod
+    def set_readonly(conf, flag):
+        pass
+
+
+def install_omegaconf():
+    """Registers the omegaconf stand-in so `networks.lightglue.*` imports."""
+    import contextlib
+    install()
+    if "omegaconf" not in sys.modules:
+        m = types.ModuleType("omegaconf")
+        m.OmegaConf = _OmegaConf
+        m.DictConfig = DictConfig
+        m.read_write = lambda conf: contextlib.nullcontext()
+        m.open_dict = lambda conf: contextlib.nullcontext()
+        sys.modules["omegaconf"] = m
+
+
+def reference_lightglue_models():
+    """(SuperPoint, LightGlue) built exactly as `trainer/lightning.py:49-60` / `demo.py:338-349` build them."""
+    install_omegaconf()
+    from networks.lightglue.superpoint import SuperPoint
+    from networks.lightglue.models.matchers.lightglue import LightGlue
+    detector = SuperPoint({"max_num_keypoints": 2048, "force_num_keypoints": True, "detection_threshold": 0.0,
+                           "nms_radius": 3, "trainable": False})
+    model = LightGlue({"filter_threshold": 0.1, "flash": False, "checkpointed": True})
+    return detector.eval(), model.eval()
 
 
 def reference_loftr_config():

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgimhip.so")
 
 GIM_F32, GIM_BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU1 = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU1, ACT_GELU = 0, 1, 2, 3, 4
 
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
@@ -40,6 +40,16 @@ class CoarseArgs(ctypes.Structure):
     ]
 
 
+class LgAssignArgs(ctypes.Structure):
+    """struct gim_lg_assign_args (include/gim_hip.h)."""
+    _fields_ = [
+        ("desc0", c_void_p), ("desc1", c_void_p), ("md0", c_void_p), ("md1", c_void_p), ("match_w", c_void_p),
+        ("match_b", c_void_p), ("ws", c_void_p), ("matches0", c_void_p), ("matches1", c_void_p),
+        ("mscores0", c_void_p), ("mscores1", c_void_p), ("pos", c_void_p), ("count", c_void_p),
+        ("B", c_int), ("M", c_int), ("N", c_int), ("C", c_int), ("ld_desc", c_int), ("threshold", c_float),
+    ]
+
+
 # name -> (restype, argtypes); every symbol declared in include/gim_hip.h
 PROTOTYPES = {
     "gim_version": (c_int, []),
@@ -61,6 +71,24 @@ PROTOTYPES = {
     "gim_coarse_conf_matrix": (c_int, [ctypes.POINTER(CoarseArgs), c_void_p, c_void_p]),
     "gim_fine_gather": (c_int, [c_void_p] * 7 + [c_int] * 14 + [c_void_p]),
     "gim_fine_match": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_float, c_int, c_void_p]),
+    # gim_lightglue path
+    "gim_maxpool2x2": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "gim_sp_scores": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "gim_sp_nms_ws_bytes": (c_int64, [c_int] * 3),
+    "gim_sp_nms": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
+    "gim_sp_topk_ws_bytes": (c_int64, [c_int] * 3),
+    "gim_sp_topk": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_float, c_void_p]),
+    "gim_sp_sample_desc": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
+    "gim_lg_posenc": (c_int, [c_void_p] * 4 + [c_int] * 2 + [c_void_p]),
+    "gim_lg_rotary": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
+    "gim_lg_transpose": (c_int, [c_void_p] * 2 + [c_int] * 6 + [c_void_p]),
+    "gim_sdpa": (c_int, [c_void_p] * 4 + [c_int] * 12 + [c_void_p]),
+    "gim_layernorm_act": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_float, c_void_p]),
+    "gim_cast_rows": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
+    "gim_lg_assign_ws_bytes": (c_int64, [c_int] * 4),
+    "gim_lg_assign": (c_int, [ctypes.POINTER(LgAssignArgs), c_void_p]),
+    "gim_lg_log_assignment": (c_int, [ctypes.POINTER(LgAssignArgs), c_void_p, c_void_p]),
+    "gim_lg_emit_matches": (c_int, [c_void_p] * 13 + [c_int] * 3 + [c_void_p]),
 }
 
 

@@ -6,7 +6,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ACT_ELU1, ACT_LEAKY, ACT_NONE, ACT_RELU, GIM_BF16, GIM_F32, check, lib  # noqa: F401
+from ._lib import ACT_ELU1, ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, GIM_BF16, GIM_F32, check, lib  # noqa: F401
 from .packing import elem_size, torch_dtype
 
 _DT = {torch.float32: GIM_F32, torch.bfloat16: GIM_BF16}
@@ -253,3 +253,160 @@ def fine_match(f0, f1, mkpts1_c, b_ids, scale1, M, WW, scale, has_scale0):
                                  f0.shape[1], f0.stride(0), scale, 1 if has_scale0 else 0, _stream()),
               "gim_fine_match")
     return expec, mk1
+
+
+# ---- gim_lightglue: SuperPoint glue -----------------------------------------------------------------------
+def maxpool2x2(x):
+    """x [B,H,W,C] NHWC -> new [B,H/2,W/2,C]"""
+    _req_cuda(x)
+    B, H, W, C = x.shape
+    y = torch.empty(B, H // 2, W // 2, C, dtype=x.dtype, device=x.device)
+    check(lib.gim_maxpool2x2(_p(x), _p(y), B, H, W, C, C, C, gim_dtype(x), _stream()), "gim_maxpool2x2")
+    return y
+
+
+def sp_scores(logits, B, h, w):
+    """logits rows [B*h*w, >=65] -> scores [B, 8h, 8w] fp32"""
+    _req_cuda(logits)
+    out = torch.empty(B, 8 * h, 8 * w, dtype=torch.float32, device=logits.device)
+    check(lib.gim_sp_scores(_p(logits), _p(out), B, h, w, logits.stride(0), gim_dtype(logits), _stream()), "gim_sp_scores")
+    return out
+
+
+def sp_nms(scores, radius, border):
+    """scores [B,H,W] fp32 -> new [B,H,W]: kept maxima keep their score, others 0, border -1"""
+    _req_cuda(scores)
+    assert scores.dtype == torch.float32 and scores.is_contiguous()
+    B, H, W = scores.shape
+    ws = torch.empty(lib.gim_sp_nms_ws_bytes(B, H, W), dtype=torch.uint8, device=scores.device)
+    out = torch.empty_like(scores)
+    check(lib.gim_sp_nms(_p(scores), _p(out), _p(ws), B, H, W, radius, border, _stream()), "gim_sp_nms")
+    return out
+
+
+def sp_topk(nms_scores, k, thr):
+    """-> (kpts [B,k,2] (x,y) fp32, kscores [B,k], nvalid [B] int32 device)"""
+    _req_cuda(nms_scores)
+    B, H, W = nms_scores.shape
+    dev = nms_scores.device
+    ws = torch.empty(lib.gim_sp_topk_ws_bytes(B, H, W), dtype=torch.uint8, device=dev)
+    kpts = torch.empty(B, k, 2, dtype=torch.float32, device=dev)
+    ksc = torch.empty(B, k, dtype=torch.float32, device=dev)
+    nv = torch.empty(B, dtype=torch.int32, device=dev)
+    check(lib.gim_sp_topk(_p(nms_scores), _p(ws), _p(kpts), _p(ksc), _p(nv), B, H, W, k, thr, _stream()), "gim_sp_topk")
+    return kpts, ksc, nv
+
+
+def sp_sample_desc(dense, kpts, h, w, out_f32, out_t, cell=8):
+    """dense rows [B*h*w, >=256]; kpts [B,K,2]; out_f32 / out_t row views [B*K, >=256] (either may be None)"""
+    _req_cuda(dense, kpts, out_f32, out_t)
+    B, K, _ = kpts.shape
+    check(lib.gim_sp_sample_desc(_p(dense), _p(kpts), _p(out_f32), _p(out_t), B, K, h, w, 256, dense.stride(0),
+                                 out_f32.stride(0) if out_f32 is not None else 4,
+                                 out_t.stride(0) if out_t is not None else 4, cell, gim_dtype(dense), _stream()),
+          "gim_sp_sample_desc")
+
+
+# ---- gim_lightglue: matcher -------------------------------------------------------------------------------
+def lg_posenc(kpts, size_wh, Wr):
+    """kpts [B,K,2], size_wh [B,2] fp32 device, Wr [32,2] -> enc [B*K, 64] (cos | sin)"""
+    _req_cuda(kpts, size_wh, Wr)
+    B, K, _ = kpts.shape
+    enc = torch.empty(B * K, 64, dtype=torch.float32, device=kpts.device)
+    check(lib.gim_lg_posenc(_p(kpts), _p(size_wh), _p(Wr), _p(enc), B, K, _stream()), "gim_lg_posenc")
+    return enc
+
+
+def lg_rotary(x, enc, ncols):
+    """in place on columns [0, ncols) of the row view x"""
+    _req_cuda(x, enc)
+    check(lib.gim_lg_rotary(_p(x), _p(enc), x.shape[0], ncols, x.stride(0), gim_dtype(x), _stream()), "gim_lg_rotary")
+
+
+def lg_transpose(src, dst, nb, S, Sp, C):
+    """src row view [nb*S, >=C] -> dst [nb, C, Sp] (same dtype)"""
+    _req_cuda(src, dst)
+    check(lib.gim_lg_transpose(_p(src), _p(dst), nb, S, Sp, C, src.stride(0), gim_dtype(src), _stream()), "gim_lg_transpose")
+
+
+def sdpa(q, k, vt, out, nb, H, L, S, Sp, kv_shift=0):
+    """q row view [nb*L, ..], k row view [nb*S, ..], vt [nb, H*64, Sp], out row view [nb*L, ..]"""
+    _req_cuda(q, k, vt, out)
+    assert q.dtype == k.dtype == vt.dtype
+    check(lib.gim_sdpa(_p(q), _p(k), _p(vt), _p(out), nb, H, L, S, Sp, 64, q.stride(0), k.stride(0), out.stride(0),
+                       kv_shift, gim_dtype(q), gim_dtype(out), _stream()), "gim_sdpa")
+
+
+def layernorm_act(x, gamma, beta, out, act=ACT_NONE, eps=1e-5):
+    """x fp32 row view [R, C] -> out row view (fp32 / bf16)"""
+    _req_cuda(x, gamma, beta, out)
+    R, C = x.shape
+    check(lib.gim_layernorm_act(_p(x), _p(gamma), _p(beta), _p(out), R, C, x.stride(0), out.stride(0), act,
+                                gim_dtype(out), eps, _stream()), "gim_layernorm_act")
+
+
+def cast_rows(src, dst):
+    """fp32 row view -> dst row view of the same shape (fp32 / bf16)"""
+    _req_cuda(src, dst)
+    R, C = src.shape
+    check(lib.gim_cast_rows(_p(src), _p(dst), R, C, src.stride(0), dst.stride(0), gim_dtype(dst), _stream()), "gim_cast_rows")
+
+
+class AssignResult:
+    __slots__ = ("args", "ws", "matches0", "matches1", "mscores0", "mscores1", "pos", "count", "keep")
+
+
+def lg_assign(desc0, desc1, md0, md1, match_w, match_b, threshold):
+    """desc0 [B,M,256] / desc1 [B,N,256] fp32 (row stride 256), md0/md1 = final_proj outputs (contiguous)."""
+    _req_cuda(desc0, desc1, md0, md1, match_w, match_b)
+    B, M, C = md0.shape
+    N = md1.shape[1]
+    dev = md0.device
+    assert md0.is_contiguous() and md1.is_contiguous() and md0.dtype == torch.float32
+    assert desc0.dtype == torch.float32 and desc0.stride(-1) == 1 and desc0.stride(-2) == desc1.stride(-2)
+    r = AssignResult()
+    r.ws = torch.empty(lib.gim_lg_assign_ws_bytes(B, M, N, C), dtype=torch.uint8, device=dev)
+    r.matches0 = torch.empty(B, M, dtype=torch.int64, device=dev)
+    r.matches1 = torch.empty(B, N, dtype=torch.int64, device=dev)
+    r.mscores0 = torch.empty(B, M, dtype=torch.float32, device=dev)
+    r.mscores1 = torch.empty(B, N, dtype=torch.float32, device=dev)
+    r.pos = torch.empty(B, M, dtype=torch.int32, device=dev)
+    r.count = torch.empty(B, dtype=torch.int32, device=dev)
+    r.keep = (desc0, desc1, md0, md1, match_w, match_b)
+    a = _lib.LgAssignArgs()
+    a.desc0, a.desc1, a.md0, a.md1 = desc0.data_ptr(), desc1.data_ptr(), md0.data_ptr(), md1.data_ptr()
+    a.match_w, a.match_b, a.ws = match_w.data_ptr(), match_b.data_ptr(), r.ws.data_ptr()
+    a.matches0, a.matches1 = r.matches0.data_ptr(), r.matches1.data_ptr()
+    a.mscores0, a.mscores1 = r.mscores0.data_ptr(), r.mscores1.data_ptr()
+    a.pos, a.count = r.pos.data_ptr(), r.count.data_ptr()
+    a.B, a.M, a.N, a.C, a.ld_desc, a.threshold = B, M, N, C, desc0.stride(-2), threshold
+    r.args = a
+    check(lib.gim_lg_assign(ctypes.byref(a), _stream()), "gim_lg_assign")
+    return r
+
+
+def lg_log_assignment(r):
+    """Materialise log_assignment [B, M+1, N+1] from a previous lg_assign call's inputs."""
+    a = r.args
+    out = torch.empty(a.B, a.M + 1, a.N + 1, dtype=torch.float32, device=r.count.device)
+    check(lib.gim_lg_log_assignment(ctypes.byref(a), _p(out), _stream()), "gim_lg_log_assignment")
+    return out
+
+
+def lg_emit_matches(r, total, kpts0=None, kpts1=None, scale0=None, scale1=None):
+    """Packs the match lists of all pairs (torch.where order).  Returns (matches [total,2] int64, scores [total],
+    mkpts0 [total,2] | None, mkpts1, m_bids)."""
+    a = r.args
+    dev = r.count.device
+    matches = torch.empty(total, 2, dtype=torch.int64, device=dev)
+    scores = torch.empty(total, dtype=torch.float32, device=dev)
+    adapter = kpts0 is not None
+    mk0 = torch.empty(total, 2, dtype=torch.float32, device=dev) if adapter else None
+    mk1 = torch.empty(total, 2, dtype=torch.float32, device=dev) if adapter else None
+    bids = torch.empty(total, dtype=torch.int64, device=dev) if adapter else None
+    if total > 0:
+        _req_cuda(kpts0, kpts1, scale0, scale1)
+        check(lib.gim_lg_emit_matches(_p(r.matches0), _p(r.mscores0), _p(r.pos), _p(r.count), _p(kpts0), _p(kpts1),
+                                      _p(scale0), _p(scale1), _p(matches), _p(scores), _p(mk0), _p(mk1), _p(bids),
+                                      a.B, a.M, a.N, _stream()), "gim_lg_emit_matches")
+    return matches, scores, mk0, mk1, bids

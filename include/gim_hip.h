@@ -25,7 +25,7 @@ extern "C" {
 typedef void* gim_stream_t; /* hipStream_t */
 
 enum { GIM_F32 = 0, GIM_BF16 = 1 };
-enum { GIM_ACT_NONE = 0, GIM_ACT_RELU = 1, GIM_ACT_LEAKY = 2, GIM_ACT_ELU1 = 3 /* elu(x)+1 */ };
+enum { GIM_ACT_NONE = 0, GIM_ACT_RELU = 1, GIM_ACT_LEAKY = 2, GIM_ACT_ELU1 = 3 /* elu(x)+1 */, GIM_ACT_GELU = 4 /* exact erf GELU, gim_layernorm_act only */ };
 enum { GIM_OK = 0, GIM_ERR_INVALID = -1, GIM_ERR_LAUNCH = -2, GIM_ERR_UNSUPPORTED = -3 };
 
 int gim_version(void);
@@ -166,6 +166,105 @@ int gim_fine_gather(const void* feat_f0, const void* feat_f1, const int64_t* b_i
 int gim_fine_match(const float* f0, const float* f1, const float* mkpts1_c, const int64_t* b_ids,
                    const float* scale1, float* expec_f, float* mkpts1_f, int M, int WW, int C, int ld,
                    float scale, int has_scale0, gim_stream_t stream);
+
+
+/* ======================================================================================================
+ * gim_lightglue path: SuperPoint detector glue + LightGlue matcher.
+ * The convolutions and Linear layers of both networks run on gim_conv2d_bn_act above.
+ * ====================================================================================================== */
+
+/* nn.MaxPool2d(2, 2) on NHWC rows -- replaces superpoint.py:216,219,222 (`self.pool`). */
+int gim_maxpool2x2(const void* x, void* y, int B, int H, int W, int C, int ldx, int ldy, int dtype,
+                   gim_stream_t stream);
+
+/* Detector head tail -- replaces superpoint.py:231-236: softmax over the 65 logits of each 8x8 cell
+ * (rows [B*h*w][ld], ld >= 65), dustbin dropped, depth-to-space -> scores [B, 8h, 8w] fp32. */
+int gim_sp_scores(const void* logits, float* scores, int B, int h, int w, int ld, int dtype,
+                  gim_stream_t stream);
+
+/* simple_nms + border removal -- replaces superpoint.py:61-80 (radius, 2 refinement rounds) and :247-258
+ * (scores within `border` px of the canvas edge = -1; the reference always uses the canvas size, :207).
+ * out [B,H,W] fp32: score at kept maxima, 0 elsewhere, -1 on the border. */
+int64_t gim_sp_nms_ws_bytes(int B, int H, int W);
+int gim_sp_nms(const float* scores, float* out, void* ws, int B, int H, int W, int radius, int border,
+               gim_stream_t stream);
+
+/* Keypoint extraction -- replaces superpoint.py:260-300,308: candidates `score > thr`, top-k by score in
+ * descending order (`torch.topk(sorted=True)`; fewer than k candidates: all of them in torch.where order),
+ * kpts [B,k,2] = (x, y) as float (without the +0.5 of :346), kscores [B,k], nvalid [B] = min(#candidates, k)
+ * (entries >= nvalid are zero; the caller pads them like pad_and_stack).  B <= 64, k <= 4096, thr >= 0. */
+int64_t gim_sp_topk_ws_bytes(int B, int H, int W);
+int gim_sp_topk(const float* nms_scores, void* ws, float* kpts, float* kscores, int32_t* nvalid, int B,
+                int H, int W, int k, float thr, gim_stream_t stream);
+
+/* Descriptor sampling -- replaces superpoint.py:241 (per-pixel F.normalize of the dense map, fused),
+ * :120-137 (legacy_sampling: bilinear grid_sample, align_corners=True) and the final F.normalize.
+ * dense rows [B*h*w][ld] (raw convDb output), kpts [B,K,2]; out_f32 / out_t rows [B*K][C], C = 256. */
+int gim_sp_sample_desc(const void* dense, const float* kpts, float* out_f32, void* out_t, int B, int K,
+                       int h, int w, int C, int ld, int ld_f32, int ld_t, int cell, int dtype,
+                       gim_stream_t stream);
+
+/* normalize_keypoints + LearnableFourierPositionalEncoding -- replaces lightglue.py:21-33,47-61.
+ * kpts [B,K,2], size_wh [B,2] = (w, h), Wr [32,2]; enc [B*K][64] = cos(proj)[32] | sin(proj)[32]
+ * (the reference's [2,B,1,K,64] tensor is this table with every entry repeated twice). */
+int gim_lg_posenc(const float* kpts, const float* size_wh, const float* Wr, float* enc, int B, int K,
+                  gim_stream_t stream);
+
+/* apply_cached_rotary_emb -- replaces lightglue.py:36-44,150-151: in place on columns [0, ncols) of x
+ * (ncols % 64 == 0; heads of 64, the same table for every head). */
+int gim_lg_rotary(void* x, const float* enc, int rows, int ncols, int ld, int dtype, gim_stream_t stream);
+
+/* V -> V^T per sequence for gim_sdpa: dst[nb][C][Sp], key index contiguous, zero for key >= S (Sp = S
+ * rounded up to a multiple of 64). */
+int gim_lg_transpose(const void* src, void* dst, int nb, int S, int Sp, int C, int ld, int dtype,
+                     gim_stream_t stream);
+
+/* softmax(q k^T / sqrt(D)) v -- replaces Attention.forward (lightglue.py:104-118) and the bidirectional
+ * cross attention of CrossBlock.forward (:196-207; the two directions are two calls).
+ * q rows [nb*L][ldq], k rows [nb*S][ldk] (head h at columns h*D), vt from gim_lg_transpose, out rows
+ * [nb*L][ldo].  Sequence s attends to the keys/values of sequence (s + kv_shift) % nb (self: 0;
+ * cross with image0/image1 stacked as [2B]: kv_shift = B).  D = 64.  dtype f32: exact-fp32 MFMA. */
+int gim_sdpa(const void* q, const void* k, const void* vt, void* out, int nb, int H, int L, int S, int Sp,
+             int D, int ldq, int ldk, int ldo, int kv_shift, int dtype, int out_dtype, gim_stream_t stream);
+
+/* LayerNorm (+ GELU) -- replaces ffn[1], ffn[2] of SelfBlock / CrossBlock (lightglue.py:135-139). */
+int gim_layernorm_act(const float* x, const float* gamma, const float* beta, void* out, int rows, int C,
+                      int ldx, int ldo, int act, int out_dtype, float eps, gim_stream_t stream);
+
+/* fp32 rows -> dtype rows (residual stream -> GEMM operand copy). */
+int gim_cast_rows(const float* src, void* dst, int rows, int C, int ld_src, int ld_dst, int dtype,
+                  gim_stream_t stream);
+
+/* MatchAssignment + sigmoid_log_double_softmax + filter_matches, fused -- replaces lightglue.py:226-300. */
+typedef struct gim_lg_assign_args {
+    const float* desc0;   /* [B*M][ld_desc] final descriptors (matchability input) */
+    const float* desc1;   /* [B*N][ld_desc] */
+    const float* md0;     /* [B][M][C] final_proj(desc0), unscaled */
+    const float* md1;     /* [B][N][C] */
+    const float* match_w; /* matchability.weight [C] */
+    const float* match_b; /* matchability.bias [1] */
+    void* ws;             /* >= gim_lg_assign_ws_bytes() */
+    int64_t* matches0;    /* [B][M], -1 = unmatched */
+    int64_t* matches1;    /* [B][N] */
+    float* mscores0;      /* [B][M] */
+    float* mscores1;      /* [B][N] */
+    int32_t* pos;         /* [B][M] position of row i in its pair's match list, -1 = unmatched */
+    int32_t* count;       /* [B] matches per pair */
+    int B, M, N, C;
+    int ld_desc;
+    float threshold;      /* filter_threshold (0.1) */
+} gim_lg_assign_args;
+int64_t gim_lg_assign_ws_bytes(int B, int M, int N, int C);
+int gim_lg_assign(const gim_lg_assign_args* a, gim_stream_t stream);
+/* `pred["log_assignment"]` [B][M+1][N+1] on demand (lightglue.py:226-238). */
+int gim_lg_log_assignment(const gim_lg_assign_args* a, float* out, gim_stream_t stream);
+/* `matches` / `scores` lists (lightglue.py:497-506) packed over the batch in torch.where order, and the
+ * caller-side adapter of trainer/lightning.py:176-183 / demo.py:503-510 (mkpts = keypoints * scale,
+ * m_bids); mkpts0 == NULL skips the adapter outputs. */
+int gim_lg_emit_matches(const int64_t* matches0, const float* mscores0, const int32_t* pos,
+                        const int32_t* count, const float* kpts0, const float* kpts1, const float* scale0,
+                        const float* scale1, int64_t* matches, float* scores, float* mkpts0, float* mkpts1,
+                        int64_t* m_bids, int B, int M, int N, gim_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -118,3 +118,32 @@ def test_packing_and_ktab_against_conv2d(case, dt):
     assert (got[..., :cout] - ref).abs().max() <= tol * ref.abs().max()
     assert (got[..., cout:] == 0).all()
     assert pk.npad % 64 == 0 and pk.n_store % 4 == 0 and pk.n_store >= cout
+
+
+# ---- gim_lightglue host logic ---------------------------------------------------------------------------------
+def test_lightglue_state_dict_surface_and_qkv_permutation():
+    """reference parameter names/shapes (24 + 251 tensors) and the Wqkv row permutation that turns the
+    reference's interleaved (head, dim, {q,k,v}) output features (lightglue.py:147-148) into [q | k | v]"""
+    import lightglue_oracle as LO
+    from gim_amd.lightglue import LightGlue, SuperPoint
+    sp_sd, lg_sd = LO.make_state_dicts(0)
+    det = SuperPoint({"max_num_keypoints": 2048, "force_num_keypoints": True, "detection_threshold": 0.0, "nms_radius": 3,
+                      "trainable": False})
+    lg = LightGlue({"filter_threshold": 0.1, "flash": False, "checkpointed": True})
+    assert {k: tuple(v.shape) for k, v in det.state_dict().items()} == {k: tuple(v.shape) for k, v in sp_sd.items()}
+    assert {k: tuple(v.shape) for k, v in lg.state_dict().items()} == {k: tuple(v.shape) for k, v in lg_sd.items()}
+    lg.load_state_dict(lg_sd)
+    H, dh, d = 4, 64, 256
+    perm = torch.empty(3 * d, dtype=torch.long)
+    for s in range(3):
+        for h in range(H):
+            for j in range(dh):
+                perm[s * d + h * dh + j] = h * 3 * dh + j * 3 + s
+    x = torch.randn(5, d)
+    w, b = lg_sd["transformers.0.self_attn.Wqkv.weight"], lg_sd["transformers.0.self_attn.Wqkv.bias"]
+    ref = torch.nn.functional.linear(x, w, b).unflatten(-1, (H, -1, 3))            # [5, H, dh, 3]
+    got = torch.nn.functional.linear(x, w[perm], b[perm])
+    for s in range(3):
+        assert torch.equal(got[:, s * d:(s + 1) * d].reshape(5, H, dh), ref[..., s])
+    with pytest.raises(NotImplementedError):
+        LightGlue({"depth_confidence": 0.95})

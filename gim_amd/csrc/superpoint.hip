@@ -58,52 +58,96 @@ __global__ void __launch_bounds__(256) sp_scores_kernel(const void* __restrict__
 }
 
 // ---- simple_nms ---------------------------------------------------------------------------------------------
-// F.max_pool2d pads with -inf, i.e. the window is clipped to the image.
-__device__ __forceinline__ float window_max(const float* __restrict__ s, int H, int W, int y, int x, int r) {
-    float m = -INFINITY;
-    const int y0 = max(y - r, 0), y1 = min(y + r, H - 1), x0 = max(x - r, 0), x1 = min(x + r, W - 1);
-    for (int yy = y0; yy <= y1; ++yy)
-        for (int xx = x0; xx <= x1; ++xx) m = fmaxf(m, s[(size_t)yy * W + xx]);
-    return m;
+// F.max_pool2d pads with -inf, i.e. the window is clipped to the image.  Every pass is a (2r+1)^2 window max
+// over a map; done separably per 64x16 output tile: halo tile -> LDS, row max into LDS, column max from LDS
+// (2(2r+1) LDS reads per pixel instead of (2r+1)^2 global reads).
+constexpr int NT_W = 64, NT_H = 16, NR_MAX = 8;
+constexpr int NT_LW = NT_W + 2 * NR_MAX, NT_LH = NT_H + 2 * NR_MAX;
+
+// window max of v around every pixel of the tile; returns it for this thread's pixels via `out[4]`
+template <typename F>
+__device__ __forceinline__ void tile_window_max(F load, int H, int W, int r, int x0, int y0, float* t0, float* t1, float out[4]) {
+    const int lw = NT_W + 2 * r, lh = NT_H + 2 * r;
+    for (int i = threadIdx.x; i < lw * lh; i += 256) {
+        const int ly = i / lw, lx = i - ly * lw;
+        const int y = y0 + ly - r, x = x0 + lx - r;
+        t0[ly * NT_LW + lx] = (y >= 0 && y < H && x >= 0 && x < W) ? load(y, x) : -INFINITY;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NT_W * lh; i += 256) {   // horizontal max
+        const int ly = i / NT_W, lx = i - ly * NT_W;
+        float m = -INFINITY;
+        for (int d = 0; d <= 2 * r; ++d) m = fmaxf(m, t0[ly * NT_LW + lx + d]);
+        t1[ly * NT_W + lx] = m;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                           // vertical max: rows ty + 4k
+        const int ly = ty + 4 * k;
+        float m = -INFINITY;
+        for (int d = 0; d <= 2 * r; ++d) m = fmaxf(m, t1[(ly + d) * NT_W + tx]);
+        out[k] = m;
+    }
+    __syncthreads();
 }
-__device__ __forceinline__ bool window_any(const uint8_t* __restrict__ k, int H, int W, int y, int x, int r) {
-    const int y0 = max(y - r, 0), y1 = min(y + r, H - 1), x0 = max(x - r, 0), x1 = min(x + r, W - 1);
-    bool a = false;
-    for (int yy = y0; yy <= y1; ++yy)
-        for (int xx = x0; xx <= x1; ++xx) a |= k[(size_t)yy * W + xx] != 0;
-    return a;
-}
+
 // keep = scores == max_pool(scores)
-__global__ void nms_init_kernel(const float* __restrict__ s, uint8_t* __restrict__ keep, int H, int W, int r) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
-    if (x >= W || y >= H) return;
+__global__ void __launch_bounds__(256) nms_init_kernel(const float* __restrict__ s, uint8_t* __restrict__ keep, int H, int W, int r) {
+    __shared__ float t0[NT_LH * NT_LW], t1[NT_LH * NT_W];
+    const int x0 = blockIdx.x * NT_W, y0 = blockIdx.y * NT_H, b = blockIdx.z;
     const float* sb = s + (size_t)b * H * W;
-    keep[((size_t)b * H + y) * W + x] = sb[(size_t)y * W + x] == window_max(sb, H, W, y, x, r);
+    float wm[4];
+    tile_window_max([&](int y, int x) { return sb[(size_t)y * W + x]; }, H, W, r, x0, y0, t0, t1, wm);
+    const int x = x0 + (threadIdx.x & 63);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int y = y0 + (threadIdx.x >> 6) + 4 * k;
+        if (x < W && y < H) keep[((size_t)b * H + y) * W + x] = sb[(size_t)y * W + x] == wm[k];
+    }
 }
 // supp = max_pool(keep) > 0 ; s2 = supp ? 0 : s
-__global__ void nms_supp_kernel(const float* __restrict__ s, const uint8_t* __restrict__ keep, uint8_t* __restrict__ supp,
-                                float* __restrict__ s2, int H, int W, int r) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
-    if (x >= W || y >= H) return;
-    const size_t o = ((size_t)b * H + y) * W + x;
-    const bool sp = window_any(keep + (size_t)b * H * W, H, W, y, x, r);
-    supp[o] = sp;
-    s2[o] = sp ? 0.f : s[o];
+__global__ void __launch_bounds__(256) nms_supp_kernel(const float* __restrict__ s, const uint8_t* __restrict__ keep,
+                                                       uint8_t* __restrict__ supp, float* __restrict__ s2, int H, int W, int r) {
+    __shared__ float t0[NT_LH * NT_LW], t1[NT_LH * NT_W];
+    const int x0 = blockIdx.x * NT_W, y0 = blockIdx.y * NT_H, b = blockIdx.z;
+    const uint8_t* kb = keep + (size_t)b * H * W;
+    float wm[4];
+    tile_window_max([&](int y, int x) { return kb[(size_t)y * W + x] ? 1.f : 0.f; }, H, W, r, x0, y0, t0, t1, wm);
+    const int x = x0 + (threadIdx.x & 63);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int y = y0 + (threadIdx.x >> 6) + 4 * k;
+        if (x < W && y < H) {
+            const size_t o = ((size_t)b * H + y) * W + x;
+            const bool sp = wm[k] > 0.f;
+            supp[o] = sp;
+            s2[o] = sp ? 0.f : s[o];
+        }
+    }
 }
 // keep |= (s2 == max_pool(s2)) & ~supp ; on the last round also writes the masked score map
-__global__ void nms_update_kernel(const float* __restrict__ s, const float* __restrict__ s2, const uint8_t* __restrict__ supp,
-                                  uint8_t* __restrict__ keep, float* __restrict__ out, int H, int W, int r, int border,
-                                  int last) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
-    if (x >= W || y >= H) return;
-    const size_t o = ((size_t)b * H + y) * W + x;
-    const bool nm = (s2[o] == window_max(s2 + (size_t)b * H * W, H, W, y, x, r)) && !supp[o];
-    const bool k = keep[o] || nm;
-    // in-place update of keep is safe: this kernel reads keep only at its own pixel
-    keep[o] = k;
-    if (last) {
-        const bool edge = border > 0 && (x < border || y < border || x >= W - border || y >= H - border);
-        out[o] = edge ? -1.f : (k ? s[o] : 0.f);
+__global__ void __launch_bounds__(256) nms_update_kernel(const float* __restrict__ s, const float* __restrict__ s2,
+                                                         const uint8_t* __restrict__ supp, uint8_t* __restrict__ keep,
+                                                         float* __restrict__ out, int H, int W, int r, int border, int last) {
+    __shared__ float t0[NT_LH * NT_LW], t1[NT_LH * NT_W];
+    const int x0 = blockIdx.x * NT_W, y0 = blockIdx.y * NT_H, b = blockIdx.z;
+    const float* s2b = s2 + (size_t)b * H * W;
+    float wm[4];
+    tile_window_max([&](int y, int x) { return s2b[(size_t)y * W + x]; }, H, W, r, x0, y0, t0, t1, wm);
+    const int x = x0 + (threadIdx.x & 63);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int y = y0 + (threadIdx.x >> 6) + 4 * k;
+        if (x >= W || y >= H) continue;
+        const size_t o = ((size_t)b * H + y) * W + x;
+        const bool nm = (s2[o] == wm[k]) && !supp[o];
+        const bool kp = keep[o] || nm;   // keep is only read at the thread's own pixel: in-place update is safe
+        keep[o] = kp;
+        if (last) {
+            const bool edge = border > 0 && (x < border || y < border || x >= W - border || y >= H - border);
+            out[o] = edge ? -1.f : (kp ? s[o] : 0.f);
+        }
     }
 }
 
@@ -111,14 +155,27 @@ __global__ void nms_update_kernel(const float* __restrict__ s, const float* __re
 // candidate (unordered) list per image: 64-bit keys, unique, "larger is better":
 //   normal      : score bits << 32 | ~index     (score > thr >= 0 => bit pattern orders like the value; ties -> lower index)
 //   few (<= k)  : re-keyed as ~index << 32 so that the descending sort restores torch.where order
-__global__ void sp_candidates_kernel(const float* __restrict__ s, unsigned long long* __restrict__ cand, int* __restrict__ count,
-                                     int HW, float thr) {
+__global__ void __launch_bounds__(256) sp_candidates_kernel(const float* __restrict__ s, unsigned long long* __restrict__ cand,
+                                                            int* __restrict__ count, int HW, float thr) {
+    // one global atomic per workgroup (a returning atomic per candidate serialised the whole map: 445 us -> ~10)
+    __shared__ int wave_cnt[4];
+    __shared__ int s_base;
     const int b = blockIdx.y;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= HW) return;
-    const float v = s[(size_t)b * HW + p];
-    if (v > thr) {
-        const int pos = atomicAdd(count + b, 1);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float v = p < HW ? s[(size_t)b * HW + p] : -1.f;
+    const bool is = v > thr;
+    const unsigned long long bal = __ballot(is);
+    if (lane == 0) wave_cnt[wv] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        s_base = tot ? atomicAdd(count + b, tot) : 0;
+    }
+    __syncthreads();
+    if (is) {
+        int pos = s_base + __popcll(bal & ((1ull << lane) - 1ull));
+        for (int q = 0; q < wv; ++q) pos += wave_cnt[q];
         cand[(size_t)b * HW + pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(~(unsigned)p);
     }
 }
@@ -278,12 +335,13 @@ extern "C" int64_t gim_sp_nms_ws_bytes(int B, int H, int W) {
 extern "C" int gim_sp_nms(const float* scores, float* out, void* ws, int B, int H, int W, int radius, int border,
                           gim_stream_t stream) {
     GIM_REQUIRE(scores && out && ws && B > 0 && H > 0 && W > 0 && radius >= 0 && border >= 0, "sp_nms: bad args");
+    GIM_REQUIRE(radius <= NR_MAX, "sp_nms: radius %d > %d", radius, NR_MAX);
     const size_t n = (size_t)B * H * W, na = (n + 255) & ~(size_t)255;
     uint8_t* keep = (uint8_t*)ws;
     uint8_t* supp = keep + na;
     float* s2 = (float*)(supp + na);
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((W + 63) / 64, (H + 3) / 4, B), blk(256);
+    const dim3 grid((W + NT_W - 1) / NT_W, (H + NT_H - 1) / NT_H, B), blk(256);
     hipLaunchKernelGGL(nms_init_kernel, grid, blk, 0, s, scores, keep, H, W, radius);
     for (int it = 0; it < 2; ++it) {
         hipLaunchKernelGGL(nms_supp_kernel, grid, blk, 0, s, scores, keep, supp, s2, H, W, radius);

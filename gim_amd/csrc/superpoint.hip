@@ -155,29 +155,29 @@ __global__ void __launch_bounds__(256) nms_update_kernel(const float* __restrict
 // candidate (unordered) list per image: 64-bit keys, unique, "larger is better":
 //   normal      : score bits << 32 | ~index     (score > thr >= 0 => bit pattern orders like the value; ties -> lower index)
 //   few (<= k)  : re-keyed as ~index << 32 so that the descending sort restores torch.where order
+constexpr int CAND_PPB = 4096;  // pixels per workgroup of sp_candidates_kernel
 __global__ void __launch_bounds__(256) sp_candidates_kernel(const float* __restrict__ s, unsigned long long* __restrict__ cand,
                                                             int* __restrict__ count, int HW, float thr) {
-    // one global atomic per workgroup (a returning atomic per candidate serialised the whole map: 445 us -> ~10)
-    __shared__ int wave_cnt[4];
-    __shared__ int s_base;
+    // candidates of 4096 pixels are collected in LDS (LDS atomics), then the workgroup reserves its range of the
+    // image's list with ONE global atomic (a returning global atomic per candidate, or even per 256 pixels,
+    // serialises on the 16 per-image counters: 445 / 141 us for 16 maps of 640x480)
+    __shared__ unsigned long long list[CAND_PPB];
+    __shared__ int s_n, s_base;
     const int b = blockIdx.y;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const float v = p < HW ? s[(size_t)b * HW + p] : -1.f;
-    const bool is = v > thr;
-    const unsigned long long bal = __ballot(is);
-    if (lane == 0) wave_cnt[wv] = __popcll(bal);
+    if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        s_base = tot ? atomicAdd(count + b, tot) : 0;
+    const int p0 = blockIdx.x * CAND_PPB;
+#pragma unroll 4
+    for (int k = 0; k < CAND_PPB / 256; ++k) {
+        const int p = p0 + k * 256 + threadIdx.x;
+        const float v = p < HW ? s[(size_t)b * HW + p] : -1.f;
+        if (v > thr) list[atomicAdd(&s_n, 1)] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(~(unsigned)p);
     }
     __syncthreads();
-    if (is) {
-        int pos = s_base + __popcll(bal & ((1ull << lane) - 1ull));
-        for (int q = 0; q < wv; ++q) pos += wave_cnt[q];
-        cand[(size_t)b * HW + pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(~(unsigned)p);
-    }
+    const int n = s_n;
+    if (threadIdx.x == 0) s_base = n ? atomicAdd(count + b, n) : 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) cand[(size_t)b * HW + s_base + i] = list[i];
 }
 
 constexpr int TOPK_MAX = 4096;
@@ -363,7 +363,7 @@ extern "C" int gim_sp_topk(const float* nms_scores, void* ws, float* kpts, float
     unsigned long long* cand = (unsigned long long*)((char*)ws + 256);
     GIM_REQUIRE(B * 4 <= 256, "sp_topk: at most 64 images per call");
     if (hipMemsetAsync(count, 0, 256, s) != hipSuccess) return gim_check_launch("sp_topk memset");
-    hipLaunchKernelGGL(sp_candidates_kernel, dim3(nblocks(HW, 256), B), dim3(256), 0, s, nms_scores, cand, count, HW, thr);
+    hipLaunchKernelGGL(sp_candidates_kernel, dim3(nblocks(HW, CAND_PPB), B), dim3(256), 0, s, nms_scores, cand, count, HW, thr);
     int kp2 = 1;
     while (kp2 < k) kp2 <<= 1;
     hipLaunchKernelGGL(sp_topk_kernel, dim3(B), dim3(1024), 0, s, cand, count, kpts, kscores, nvalid, HW, W, k, kp2);

@@ -138,12 +138,17 @@ template <bool BF16> struct SdpaCfg;
 template <> struct SdpaCfg<true> { static constexpr int ES = 2, ROWB = 128; };   // bytes per LDS row (64 elements)
 template <> struct SdpaCfg<false> { static constexpr int ES = 4, ROWB = 256; };
 
+// raw v_exp_f32 (exp2f() wraps it in a 6-instruction denormal-range fix-up; arguments here are <= 0 and a
+// flushed denormal probability is exactly what the softmax wants)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 template <bool BF16, bool OUT_BF16>
-__global__ void __launch_bounds__(256) sdpa_kernel(const SdpaArgs a) {
+__global__ void __launch_bounds__(256, 2) sdpa_kernel(const SdpaArgs a) {
     constexpr int ES = SdpaCfg<BF16>::ES, ROWB = SdpaCfg<BF16>::ROWB;
     constexpr int NSLOT = ROWB / 16;               // 16-byte slots per LDS row: 8 (bf16) / 16 (f32)
-    __shared__ __attribute__((aligned(16))) char sK[64 * ROWB];
-    __shared__ __attribute__((aligned(16))) char sV[64 * ROWB];
+    // K / V^T tiles, double-buffered: tile t lives in buffer t & 1
+    __shared__ __attribute__((aligned(16))) char sKb[2][64 * ROWB];
+    __shared__ __attribute__((aligned(16))) char sVb[2][64 * ROWB];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, lh = lane >> 5;
     const int seq = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
     const int kvseq = (seq + a.kv_shift) % a.nb;
@@ -184,7 +189,9 @@ __global__ void __launch_bounds__(256) sdpa_kernel(const SdpaArgs a) {
             rv[p] = *(const uint4*)(vbase + ((size_t)row * a.Sp + key0) * ES);
         }
     };
-    auto stash = [&]() {
+    auto stash = [&](int buf) {
+        char* sK = sKb[buf];
+        char* sV = sVb[buf];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int row = p * RPP + srow;
@@ -200,24 +207,16 @@ __global__ void __launch_bounds__(256) sdpa_kernel(const SdpaArgs a) {
             }
         }
     };
-
-    const int ntiles = (a.S + 63) / 64;
-    fetch(0);
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const int key0 = kt * 64;
-        __syncthreads();  // previous tile fully consumed
-        stash();
-        __syncthreads();
-        if (kt + 1 < ntiles) fetch(key0 + 64);
-        // ---- S^T = K Q^T : accS[kb][r] = key kb*32 + (r/4)*8 + lh*4 + r%4, query l31 ----------------------
-        f32x16_t accS[2];
+    // S^T = K Q^T of the tile in buffer `buf`: accS[kb][r] = key kb*32 + (r/4)*8 + lh*4 + r%4, query l31
+    auto scores = [&](int buf, f32x16_t (&accS)[2]) {
+        const char* sK = sKb[buf];
+        const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accS[kb][r] = 0.f;
+            accS[kb] = zero16;  // folded into the first MFMA's inline-constant C operand
             const int krow = kb * 32 + l31;
+            const char* rp = sK + krow * ROWB;
             if constexpr (BF16) {
-                const char* rp = sK + krow * ROWB;
                 const int sw = (krow >> 1) & 7;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
@@ -225,7 +224,6 @@ __global__ void __launch_bounds__(256) sdpa_kernel(const SdpaArgs a) {
                     accS[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, qb[ks], accS[kb], 0, 0, 0);
                 }
             } else {
-                const char* rp = sK + krow * ROWB;
                 const int sw = krow & 15;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -236,7 +234,10 @@ __global__ void __launch_bounds__(256) sdpa_kernel(const SdpaArgs a) {
                 }
             }
         }
-        // ---- online softmax over this tile's 64 keys (32 in this lane, 32 in lane ^ 32) --------------------
+    };
+    // online softmax of tile kt (scores in accS) and O^T += V^T P^T with the V^T tile in buffer `buf`
+    auto softmax_pv = [&](int buf, int key0, f32x16_t (&accS)[2]) {
+        const char* sV = sVb[buf];
         if (key0 + 64 > a.S) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -253,24 +254,28 @@ __global__ void __launch_bounds__(256) sdpa_kernel(const SdpaArgs a) {
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, accS[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f((m_run - m_new) * a.scale_log2e);
         const float mb = m_new * a.scale_log2e;
         float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(accS[kb][r] * a.scale_log2e - mb);
+                const float p = fast_exp2(accS[kb][r] * a.scale_log2e - mb);
                 accS[kb][r] = p;
                 psum += p;
             }
-        l_run = l_run * alpha + psum;  // per-half partial sums share alpha; the halves are added at the end
+        // rescale only when some query of the wave saw a new maximum (rare after the first tiles; wave-uniform
+        // branch).  Per-half partial sums share alpha; the halves are added at the end.
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run)) {
+            const float alpha = fast_exp2((m_run - m_new) * a.scale_log2e);
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accO[d][r] *= alpha;
+        }
+        l_run += psum;
         m_run = m_new;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accO[d][r] *= alpha;
-        // ---- O^T += V^T P^T ---------------------------------------------------------------------------------
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             if constexpr (BF16) {
@@ -305,6 +310,25 @@ __global__ void __launch_bounds__(256) sdpa_kernel(const SdpaArgs a) {
                 }
             }
         }
+    };
+    // Double-buffered tiles, ONE barrier per tile: while tile kt (buffer kt & 1) is consumed, tile kt+1 -- fetched
+    // into registers one step earlier -- is written to the other buffer, which every wave left at the previous
+    // barrier.  (Issuing the next tile's score MFMAs ahead of this tile's softmax inside one wave was measured
+    // slower, 69 vs 64 us: in-order issue stalls the VALU behind the dependent MFMA chain, and the second wave
+    // on the SIMD already fills those gaps.)
+    const int ntiles = (a.S + 63) / 64;
+    f32x16_t accS[2];
+    fetch(0);
+    stash(0);
+    if (ntiles > 1) fetch(64);
+    __syncthreads();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int b = kt & 1;
+        scores(b, accS);
+        softmax_pv(b, kt * 64, accS);
+        if (kt + 1 < ntiles) stash(b ^ 1);
+        if (kt + 2 < ntiles) fetch((kt + 2) * 64);
+        __syncthreads();
     }
     // ---- normalise and store: lane holds query l31, d = db*32 + (r/4)*8 + lh*4 + r%4 ---------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

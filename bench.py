@@ -167,6 +167,41 @@ def main():
         model._graphs.clear()
         model.use_graph = graph_was
 
+    # ---- secondary workload (reported, not the metric): gim_lightglue at the same resolution / batch ---------
+    lightglue = None
+    if rank == 0 and world == 1 and not os.environ.get("GIM_BENCH_SKIP_LIGHTGLUE"):
+        from gim_amd.lightglue import LightGlue, SuperPoint, gim_lightglue_inference
+        torch.manual_seed(0)  # random-init weights of the reference architecture (no checkpoint in the container)
+        det = SuperPoint({"max_num_keypoints": 2048, "force_num_keypoints": True, "detection_threshold": 0.0,
+                          "nms_radius": 3, "trainable": False, "precision": args.precision}).eval()
+        lgm = LightGlue({"filter_threshold": 0.1, "flash": False, "checkpointed": True, "precision": args.precision}).eval()
+        gg = torch.Generator().manual_seed(1)
+        g0 = torch.nn.functional.interpolate(torch.rand(nb, 1, H // 4, W // 4, generator=gg), size=(H, W), mode="bilinear")
+        g0 = (0.7 * g0 + 0.3 * torch.rand(nb, 1, H, W, generator=gg)).contiguous().to(dev)  # textured synthetic images
+        g1 = torch.roll(g0, shifts=(16, 24), dims=(2, 3)).contiguous()
+        rs = torch.tensor([[H, W]] * nb, device=dev)
+        one = torch.ones(nb, 2, device=dev)
+
+        def lg_step():
+            dd = {"image0": g0, "image1": g1, "resize0": rs, "resize1": rs, "scale0": one, "scale1": one}
+            gim_lightglue_inference(det, lgm, dd)
+            return dd["mconf"].shape[0]
+
+        for _ in range(2):
+            lg_step()
+        torch.cuda.synchronize()
+        tl = time.perf_counter()
+        for _ in range(10):
+            lg_step()
+        torch.cuda.synchronize()
+        tl = (time.perf_counter() - tl) / 10
+        lightglue = {"workload": f"gim_lightglue {W}x{H}, batch {nb} pairs, SuperPoint (2048 keypoints) x2 + LightGlue "
+                                 "(9 layers) + adapter, random-init weights", "pairs_per_s": round(nb / tl, 2),
+                     "ms_per_step": round(1e3 * tl, 3), "dtype": args.precision,
+                     "achieved_tflops": round(nb / tl * 334e9 / 1e12, 1),
+                     "note": "algorithmic 334 GFLOP/pair (SURVEY 8d); kernel split in profiles/r01_lightglue_*"}
+        del det, lgm
+
     # ---- CPU baseline: the oracle on this host's cores, bounded sample ------------------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -203,6 +238,7 @@ def main():
                        "parallelism": f"pairs sharded over {world} GPU(s), no collective per step",
                        "hip_graph": bool(model.use_graph)},
             "roofline": roof, "cpu_baseline": cpu, "realistic_fine": realistic,
+            "secondary_workloads": {"gim_lightglue": lightglue},
         }
         print(json.dumps(out), flush=True)
     if world > 1:

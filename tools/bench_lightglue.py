@@ -11,7 +11,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
 def main():
@@ -22,17 +21,16 @@ def main():
     ap.add_argument("--kpts", type=int, default=2048)
     ap.add_argument("--precision", default="bf16")
     a = ap.parse_args()
-    import lightglue_oracle as O  # seeded weights / images only (test infrastructure, not on the measured path)
     from gim_amd.lightglue import LightGlue, SuperPoint, gim_lightglue_inference
     dev = torch.device("cuda:0")
-    sp_sd, lg_sd = O.make_state_dicts(0)
+    torch.manual_seed(0)  # random-init weights of the reference architecture
     det = SuperPoint({"max_num_keypoints": a.kpts, "force_num_keypoints": True, "detection_threshold": 0.0, "nms_radius": 3,
                       "trainable": False, "precision": a.precision}).eval()
     lg = LightGlue({"filter_threshold": 0.1, "flash": False, "checkpointed": True, "precision": a.precision}).eval()
-    det.load_state_dict(sp_sd)
-    lg.load_state_dict(lg_sd)
     B = a.pairs
-    img0 = O.seeded_gray(B, 480, 640, 1).to(dev)
+    gg = torch.Generator().manual_seed(1)
+    img0 = torch.nn.functional.interpolate(torch.rand(B, 1, 120, 160, generator=gg), size=(480, 640), mode="bilinear")
+    img0 = (0.7 * img0 + 0.3 * torch.rand(B, 1, 480, 640, generator=gg)).contiguous().to(dev)
     img1 = torch.roll(img0, shifts=(16, 24), dims=(2, 3)).contiguous()
     rs = torch.tensor([[480, 640]] * B, device=dev)
     sc = torch.ones(B, 2, device=dev)

@@ -65,7 +65,7 @@ PROTOTYPES = {
     "gim_linear_attention_kv": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
     "gim_linear_attention_apply": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
     "gim_linear_attention_short": (c_int, [c_void_p] * 6 + [c_int] * 11 + [c_void_p]),
-    "gim_layernorm_residual": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_float, c_void_p]),
+    "gim_layernorm_residual": (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_float, c_void_p]),
     "gim_coarse_match_ws_bytes": (c_int64, [c_int] * 3),
     "gim_coarse_match": (c_int, [ctypes.POINTER(CoarseArgs), c_void_p]),
     "gim_coarse_conf_matrix": (c_int, [ctypes.POINTER(CoarseArgs), c_void_p, c_void_p]),

@@ -91,9 +91,9 @@ __global__ void posenc_add_kernel(const void* __restrict__ x, const float* __res
 }
 
 // One wave per row, C <= 512, C % 4 == 0.
-template <bool BF16>
+template <bool BF16, bool XBF16>
 __global__ void __launch_bounds__(256)
-layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+layernorm_kernel(const void* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                  const float* __restrict__ res, float* __restrict__ out_f32, void* __restrict__ out_t, int rows,
                  int C, int ldx, int ldres, int ld_f32, int ld_t, float eps) {
     const int lane = threadIdx.x & 63;
@@ -104,7 +104,7 @@ layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, c
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int c = lane * 4 + k * 256;
-        v[k] = c < C ? *(const float4*)(x + (size_t)row * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[k] = c < C ? ElemIO<XBF16>::ld4(x, (size_t)row * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
     }
     const float mean = wave_sum(s) / (float)C;
@@ -194,17 +194,18 @@ extern "C" int gim_posenc_add(const void* x, const float* pe, float* out_f32, vo
     return gim_check_launch("posenc_add");
 }
 
-extern "C" int gim_layernorm_residual(const float* x, const float* gamma, const float* beta, const float* res,
+extern "C" int gim_layernorm_residual(const void* x, const float* gamma, const float* beta, const float* res,
                                       float* out_f32, void* out_t, int rows, int C, int ldx, int ldres, int ld_f32,
-                                      int ld_t, int dtype, float eps, gim_stream_t stream) {
+                                      int ld_t, int x_dtype, int dtype, float eps, gim_stream_t stream) {
     GIM_REQUIRE(x && gamma && beta && (out_f32 || out_t) && rows > 0, "layernorm: bad args");
     GIM_REQUIRE(C > 0 && C % 4 == 0 && C <= 512, "layernorm: C=%d unsupported (multiple of 4, <= 512)", C);
     GIM_REQUIRE(ldx % 4 == 0 && ld_f32 % 4 == 0 && ld_t % 4 == 0 && (!res || ldres % 4 == 0), "layernorm: ld alignment");
     hipStream_t s = (hipStream_t)stream;
     const unsigned g = (unsigned)((rows + 3) / 4);
-    if (dtype == GIM_BF16)
-        hipLaunchKernelGGL(layernorm_kernel<true>, dim3(g), dim3(256), 0, s, x, gamma, beta, res, out_f32, out_t, rows, C, ldx, ldres, ld_f32, ld_t, eps);
-    else
-        hipLaunchKernelGGL(layernorm_kernel<false>, dim3(g), dim3(256), 0, s, x, gamma, beta, res, out_f32, out_t, rows, C, ldx, ldres, ld_f32, ld_t, eps);
+    const bool ob = dtype == GIM_BF16, xb = x_dtype == GIM_BF16;
+    if (ob && xb) hipLaunchKernelGGL((layernorm_kernel<true, true>), dim3(g), dim3(256), 0, s, x, gamma, beta, res, out_f32, out_t, rows, C, ldx, ldres, ld_f32, ld_t, eps);
+    else if (ob) hipLaunchKernelGGL((layernorm_kernel<true, false>), dim3(g), dim3(256), 0, s, x, gamma, beta, res, out_f32, out_t, rows, C, ldx, ldres, ld_f32, ld_t, eps);
+    else if (xb) hipLaunchKernelGGL((layernorm_kernel<false, true>), dim3(g), dim3(256), 0, s, x, gamma, beta, res, out_f32, out_t, rows, C, ldx, ldres, ld_f32, ld_t, eps);
+    else hipLaunchKernelGGL((layernorm_kernel<false, false>), dim3(g), dim3(256), 0, s, x, gamma, beta, res, out_f32, out_t, rows, C, ldx, ldres, ld_f32, ld_t, eps);
     return gim_check_launch("layernorm");
 }

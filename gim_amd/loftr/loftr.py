@@ -318,9 +318,10 @@ class LoFTR(nn.Module):
             self.CAT = torch.empty(R, 2 * C, dtype=tdt, device=dev)   # [x | norm1(message)] GEMM operand
             self.QKV = torch.empty(R, 3 * C, dtype=tdt, device=dev)   # [elu(q)+1 | elu(k)+1 | v] row buffers
             self.MSG = torch.empty(R, C, dtype=tdt, device=dev)
-            self.MRG = torch.empty(R, C, dtype=f32, device=dev)
+            # pre-LayerNorm activations in the operand dtype (A/B on one box: 14.16-14.26 vs 14.38-14.48 ms with fp32)
+            self.MRG = torch.empty(R, C, dtype=tdt, device=dev)
             self.HID = torch.empty(R, 2 * C, dtype=tdt, device=dev)
-            self.MLP = torch.empty(R, C, dtype=f32, device=dev)
+            self.MLP = torch.empty(R, C, dtype=tdt, device=dev)
             self.ws = None
             self.MASK = None  # optional uint8 [R] padding mask aligned with the rows (coarse level only)
 

@@ -138,14 +138,14 @@ def posenc_add(x, pe, out_f32, out_t):
 
 
 def layernorm_residual(x, gamma, beta, res, out_f32, out_t, eps=1e-5):
-    """x fp32 row view [R, C]; out_f32 / out_t row views (either may be None)"""
+    """x fp32 / bf16 row view [R, C]; out_f32 / out_t row views (either may be None)"""
     _req_cuda(x, gamma, beta, res, out_f32, out_t)
     R, C = x.shape
     dt = gim_dtype(out_t) if out_t is not None else GIM_F32
     check(lib.gim_layernorm_residual(_p(x), _p(gamma), _p(beta), _p(res), _p(out_f32), _p(out_t), R, C,
                                      x.stride(0), res.stride(0) if res is not None else 4,
                                      out_f32.stride(0) if out_f32 is not None else 4,
-                                     out_t.stride(0) if out_t is not None else 4, dt, eps, _stream()),
+                                     out_t.stride(0) if out_t is not None else 4, gim_dtype(x), dt, eps, _stream()),
           "gim_layernorm_residual")
 
 

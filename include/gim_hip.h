@@ -110,10 +110,11 @@ int gim_linear_attention_short(const void* q, const void* k, const void* v, cons
                                gim_stream_t stream);
 
 /* LayerNorm (+ optional residual):  v = LN(x[m,:]) * gamma + beta ; if res: v += res[m,:]
- * (transformer.py:52,56,58).  Writes fp32 (out_f32, may be NULL) and/or `dtype` copy (out_t). */
-int gim_layernorm_residual(const float* x, const float* gamma, const float* beta, const float* res,
+ * (transformer.py:52,56,58).  x is `x_dtype` (fp32, or bf16 pre-norm activations in the throughput mode).
+ * Writes fp32 (out_f32, may be NULL) and/or `dtype` copy (out_t). */
+int gim_layernorm_residual(const void* x, const float* gamma, const float* beta, const float* res,
                            float* out_f32, void* out_t, int rows, int C, int ldx, int ldres,
-                           int ld_f32, int ld_t, int dtype, float eps, gim_stream_t stream);
+                           int ld_f32, int ld_t, int x_dtype, int dtype, float eps, gim_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * Coarse matching (utils/coarse_matching.py:88-259): dual-softmax + threshold + border + mutual-NN

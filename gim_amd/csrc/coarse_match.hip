@@ -96,6 +96,7 @@ struct CmGeom {
     const uint8_t* mask1;  // [N][S] or NULL
     int N, L, S, C;
     float inv_c, temperature, thr;
+    float inv_ct;  // 1 / (C * temperature)
 };
 
 // similarity tile -> LDS (St[i][j], i = feat0 row, j = feat1 row), scaled like the reference
@@ -128,10 +129,12 @@ __device__ __forceinline__ void sim_tile_to_lds(const CmGeom& g, const int* ktab
             for (int rg = 0; rg < 4; ++rg) {
                 const int j_loc = wn * 64 + i * 32 + rg * 8 + lh * 4;
                 float4 v;
-                v.x = (acc[i][j][rg * 4 + 0] * g.inv_c) / g.temperature;
-                v.y = (acc[i][j][rg * 4 + 1] * g.inv_c) / g.temperature;
-                v.z = (acc[i][j][rg * 4 + 2] * g.inv_c) / g.temperature;
-                v.w = (acc[i][j][rg * 4 + 3] * g.inv_c) / g.temperature;
+                // (f0/sqrt C).(f1/sqrt C)/T: 1/C is a power of two, so one multiply by 1/(C T) differs from the
+                // reference's divide by T by at most 1 ulp (an IEEE division costs ~12 VALU instructions per value)
+                v.x = acc[i][j][rg * 4 + 0] * g.inv_ct;
+                v.y = acc[i][j][rg * 4 + 1] * g.inv_ct;
+                v.z = acc[i][j][rg * 4 + 2] * g.inv_ct;
+                v.w = acc[i][j][rg * 4 + 3] * g.inv_ct;
                 if (masked) {
                     const int gj = n0 + j_loc;
                     const uint8_t* m1 = g.mask1 + (size_t)n * g.S;
@@ -165,29 +168,25 @@ __global__ void __launch_bounds__(256) cm_stats_kernel(const CmGeom g, const CmW
     float* colz = red + 896;
     const int t = threadIdx.x, idx = t & 127, half = t >> 7;
     const float NEG = -INFINITY;
-    // ---- rows: thread (row idx, column half) ----
+    // ---- rows: thread (row idx, column half).  nv = valid columns of this half (bounds test hoisted) ----
     {
+        const int nv = min(64, max(0, g.S - n0 - half * 64)), nv4 = nv & ~3;
+        const float* rp = St + idx * TLD + half * 64;
         float mx = NEG;
-        for (int jj = 0; jj < 64; jj += 4) {
-            const int j = half * 64 + jj;
-            const float4 v = *(const float4*)(St + idx * TLD + j);
-            if (n0 + j + 0 < g.S) mx = fmaxf(mx, v.x);
-            if (n0 + j + 1 < g.S) mx = fmaxf(mx, v.y);
-            if (n0 + j + 2 < g.S) mx = fmaxf(mx, v.z);
-            if (n0 + j + 3 < g.S) mx = fmaxf(mx, v.w);
+        for (int jj = 0; jj < nv4; jj += 4) {
+            const float4 v = *(const float4*)(rp + jj);
+            mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
         }
+        for (int jj = nv4; jj < nv; ++jj) mx = fmaxf(mx, rp[jj]);
         red[half * 128 + idx] = mx;
         __syncthreads();
         const float m = fmaxf(red[idx], red[128 + idx]);
         float z = 0.f;
-        for (int jj = 0; jj < 64; jj += 4) {
-            const int j = half * 64 + jj;
-            const float4 v = *(const float4*)(St + idx * TLD + j);
-            if (n0 + j + 0 < g.S) z += fast_exp(v.x - m);
-            if (n0 + j + 1 < g.S) z += fast_exp(v.y - m);
-            if (n0 + j + 2 < g.S) z += fast_exp(v.z - m);
-            if (n0 + j + 3 < g.S) z += fast_exp(v.w - m);
+        for (int jj = 0; jj < nv4; jj += 4) {
+            const float4 v = *(const float4*)(rp + jj);
+            z += (fast_exp(v.x - m) + fast_exp(v.y - m)) + (fast_exp(v.z - m) + fast_exp(v.w - m));
         }
+        for (int jj = nv4; jj < nv; ++jj) z += fast_exp(rp[jj] - m);
         red[256 + half * 128 + idx] = z;
         __syncthreads();
         if (half == 0) {
@@ -199,15 +198,14 @@ __global__ void __launch_bounds__(256) cm_stats_kernel(const CmGeom g, const CmW
     }
     // ---- columns: thread (column idx, row half) ----
     {
+        const int r0 = half * 64, r1 = r0 + min(64, max(0, g.L - m0 - r0));
         float mx = NEG;
-        for (int r = half * 64; r < half * 64 + 64; ++r)
-            if (m0 + r < g.L) mx = fmaxf(mx, St[r * TLD + idx]);
+        for (int r = r0; r < r1; ++r) mx = fmaxf(mx, St[r * TLD + idx]);
         red[half * 128 + idx] = mx;
         __syncthreads();
         const float m = fmaxf(red[idx], red[128 + idx]);
         float z = 0.f;
-        for (int r = half * 64; r < half * 64 + 64; ++r)
-            if (m0 + r < g.L) z += fast_exp(St[r * TLD + idx] - m);
+        for (int r = r0; r < r1; ++r) z += fast_exp(St[r * TLD + idx] - m);
         red[256 + half * 128 + idx] = z;
         __syncthreads();
         if (half == 0) {
@@ -233,16 +231,25 @@ __global__ void __launch_bounds__(256) cm_stats_kernel(const CmGeom g, const CmW
         const int i = m0 + idx;
         if (i < g.L) {
             const float trow = red[idx], rm = rowm[idx], rz = rowz[idx];
-            for (int jj = 0; jj < 64; ++jj) {
-                const int jl = half * 64 + jj, j = n0 + jl;
-                if (j >= g.S) break;
-                const float sv = St[idx * TLD + jl];
-                if (sv > trow && sv > red[128 + jl]) {
-                    const float pr = expf(sv - rm) / rz;
-                    const float pc = expf(sv - colm[jl]) / colz[jl];
-                    if (pr * pc > thr_pre) {
-                        const int k = atomicAdd(&pcnt[0], 1);
-                        if (k < PLIST) plist[k] = PreCand{i, j, sv};
+            const int nv = min(64, max(0, g.S - n0 - half * 64));
+            for (int jj = 0; jj < nv; jj += 4) {  // four columns per step; survivors are rare
+                const float4 s4 = *(const float4*)(St + idx * TLD + half * 64 + jj);
+                const float4 t4 = *(const float4*)(red + 128 + half * 64 + jj);
+                const float sv4[4] = {s4.x, s4.y, s4.z, s4.w}, tc4[4] = {t4.x, t4.y, t4.z, t4.w};
+                if (!((s4.x > trow && s4.x > t4.x) || (s4.y > trow && s4.y > t4.y) || (s4.z > trow && s4.z > t4.z) ||
+                      (s4.w > trow && s4.w > t4.w)))
+                    continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int jl = half * 64 + jj + e, j = n0 + jl;
+                    const float sv = sv4[e];
+                    if (jj + e < nv && sv > trow && sv > tc4[e]) {
+                        const float pr = expf(sv - rm) / rz;
+                        const float pc = expf(sv - colm[jl]) / colz[jl];
+                        if (pr * pc > thr_pre) {
+                            const int k = atomicAdd(&pcnt[0], 1);
+                            if (k < PLIST) plist[k] = PreCand{i, j, sv};
+                        }
                     }
                 }
             }
@@ -502,6 +509,7 @@ static int cm_prepare(const gim_coarse_args& a, CmWs& w, CmGeom& g) {
     carve(w, (char*)a.ws, a.N, a.L, a.S, a.C);
     g.feat0 = a.feat0; g.feat1 = a.feat1; g.mask0 = a.mask0; g.mask1 = a.mask1; g.N = a.N; g.L = a.L; g.S = a.S; g.C = a.C;
     g.inv_c = 1.0f / (float)a.C; g.temperature = a.temperature; g.thr = a.thr;
+    g.inv_ct = 1.0f / ((float)a.C * a.temperature);
     static bool attr = false;
     if (!attr) {
         int rc = set_smem(cm_stats_kernel);

@@ -11,7 +11,8 @@
 
 namespace {
 
-constexpr int CH = 128;  // rows of S per block in the KV reduction
+constexpr int CH = 128;   // rows of S per block in the KV reduction (VALU kernel)
+constexpr int CHM = 256;  // ... of the MFMA kernel (fewer partials: the finalize pass is pure latency)
 
 template <int D, bool BF16>
 __global__ void __launch_bounds__(256)
@@ -198,6 +199,135 @@ la_short_kernel(const void* __restrict__ q, const void* __restrict__ k, const vo
     }
 }
 
+
+// ---- MFMA versions for the coarse level (D = 32, H = 8) -----------------------------------------------------
+// Counters / arithmetic: the VALU kernels above fetch one LDS operand per 4 FMAs and ran at 1.1 TB/s of HBM
+// traffic (la_kv 35 us, la_apply 35 us per layer call at M = 38 400) although both are [rows x 32] x [32 x 32]
+// contractions.  v_mfma_f32_32x32x2_f32 (exact fp32, serves the parity mode too) does them at one LDS / register
+// operand per 2048 flops, which leaves both kernels HBM-bound.
+//
+//   la_kv_mfma:    KV_h[d][dv] = sum_s K[s][h,d] * V[s][h,dv]/S : A = K (m = d), B = V (n = dv), k = s -- row-major
+//                  [s][256] tiles in LDS feed both operands without any transposition (lane = channel).
+//   la_apply_mfma: out[row][dv] = sum_d Q[row][h,d] KV_h[d][dv]   : A = Q straight from global (lane = row; the k
+//                  order is permuted to d = 16*(lane>>5) + step so that every lane reads 16 contiguous channels),
+//                  B = KV_h from LDS; the row normaliser z = Q.Ksum is a 16-term dot product per lane, moved to the
+//                  accumulator layout with one shuffle per register.
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+la_kv_mfma_kernel(const void* __restrict__ k, const void* __restrict__ v, const uint8_t* __restrict__ kv_mask,
+                  float* __restrict__ part, int S, int ldk, int ldv, int nchunk) {
+    // workgroup = (sequence b, 128-row chunk, head group of 4): one head per wave.  Small workgroups (32 KiB LDS
+    // in bf16) keep 4 of them resident per CU, which is what hides the global -> LDS staging latency.
+    constexpr int D = 32, H = 8, HG = 4, ES = BF16 ? 2 : 4, ROWB = HG * D * ES, SUB = 64, PER = D * D + D;
+    extern __shared__ __attribute__((aligned(16))) char la_smem[];
+    char* Ks = la_smem;
+    char* Vs = la_smem + SUB * ROWB;
+    const int b = blockIdx.x, chunk = blockIdx.y, hg = blockIdx.z, s0 = chunk * CHM;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int h = hg * HG + wave;
+    const float slen = (float)S, inv_s = 1.0f / slen;
+    f32x16_t acc;
+    float ks = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const char* kb = (const char*)k + (size_t)hg * HG * D * ES;
+    const char* vb = (const char*)v + (size_t)hg * HG * D * ES;
+    for (int sub = 0; sub < CHM / SUB; ++sub) {
+        const int base = s0 + sub * SUB;
+        if (base >= S) break;
+        __syncthreads();
+        constexpr int CPR = ROWB / 16;  // 16-byte chunks per row
+        for (int c = t; c < SUB * CPR; c += 256) {
+            const int row = c / CPR, off = (c - row * CPR) * 16, sidx = base + row;
+            uint4 kk = make_uint4(0u, 0u, 0u, 0u), vv = kk;
+            if (sidx < S && (!kv_mask || kv_mask[(size_t)b * S + sidx])) {  // K * kv_mask, values * kv_mask (attentions.py:38-39)
+                kk = *(const uint4*)(kb + ((size_t)b * S + sidx) * ldk * ES + off);
+                vv = *(const uint4*)(vb + ((size_t)b * S + sidx) * ldv * ES + off);
+            }
+            *(uint4*)(Ks + row * ROWB + off) = kk;
+            *(uint4*)(Vs + row * ROWB + off) = vv;
+        }
+        __syncthreads();
+        const int col = (wave * D + l31) * ES;
+#pragma unroll 8
+        for (int st = 0; st < SUB / 2; ++st) {
+            const int row = 2 * st + lh;
+            float a, bv;
+            if constexpr (BF16) {
+                a = bf16_to_f32(*(const unsigned short*)(Ks + row * ROWB + col));
+                bv = bf16_to_f32(*(const unsigned short*)(Vs + row * ROWB + col)) * inv_s;
+            } else {
+                a = *(const float*)(Ks + row * ROWB + col);
+                bv = *(const float*)(Vs + row * ROWB + col) / slen;  // values / v_length (attentions.py:42)
+            }
+            ks += a;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+        }
+    }
+    float* out = part + ((size_t)(b * H + h) * nchunk + chunk) * PER;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[((r >> 2) * 8 + lh * 4 + (r & 3)) * D + l31] = acc[r];
+    const float kt = ks + __shfl_xor(ks, 32, 64);
+    if (lh == 0) out[D * D + l31] = kt;
+}
+
+template <bool BF16, bool OUT_BF16>
+__global__ void __launch_bounds__(256)
+la_apply_mfma_kernel(const void* __restrict__ q, const uint8_t* __restrict__ q_mask, const float* __restrict__ kvfin,
+                     void* __restrict__ out, int L, int S, int ldq, int ldo) {
+    // workgroup = 64 rows; wave = (32-row half, group of 4 heads).  All four heads' Q rows are requested before the
+    // first MFMA chain so that only one HBM round trip is exposed per wave.
+    constexpr int D = 32, H = 8, HG = 4, PER = D * D + D;
+    __shared__ __attribute__((aligned(16))) float kv[H * PER];
+    const int b = blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, lh = lane >> 5;
+    for (int i = t; i < H * PER / 4; i += 256) *(float4*)(kv + i * 4) = *(const float4*)(kvfin + (size_t)b * H * PER + i * 4);
+    const int row0 = blockIdx.y * 64 + (wave & 1) * 32, h0 = (wave >> 1) * HG;
+    const int row = row0 + l31, rowc = min(row, L - 1);
+    const bool qvalid = row < L && (!q_mask || q_mask[(size_t)b * L + rowc]);  // Q * q_mask (attentions.py:36)
+    const float slen = (float)S;
+    float qv[HG][16];
+#pragma unroll
+    for (int hh = 0; hh < HG; ++hh) {
+        const size_t qo = ((size_t)b * L + rowc) * ldq + (h0 + hh) * D + lh * 16;
+#pragma unroll
+        for (int c = 0; c < 16; c += 4) {
+            float4 x = ElemIO<BF16>::ld4(q, qo + c);
+            if (!qvalid) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            qv[hh][c] = x.x; qv[hh][c + 1] = x.y; qv[hh][c + 2] = x.z; qv[hh][c + 3] = x.w;
+        }
+    }
+    __syncthreads();
+    if (row0 >= L) return;
+#pragma unroll
+    for (int hh = 0; hh < HG; ++hh) {
+        const int h = h0 + hh;
+        const float* KV = kv + h * PER;
+        float z = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; c += 4) {
+            const float4 kq = *(const float4*)(KV + D * D + lh * 16 + c);
+            z = fmaf(qv[hh][c], kq.x, z); z = fmaf(qv[hh][c + 1], kq.y, z);
+            z = fmaf(qv[hh][c + 2], kq.z, z); z = fmaf(qv[hh][c + 3], kq.w, z);
+        }
+        z += __shfl_xor(z, 32, 64);  // every lane of row `l31` now holds Q[row].Ksum
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 16; ++st)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qv[hh][st], KV[(lh * 16 + st) * D + l31], acc, 0, 0, 0);
+        // acc[r] = out[row0 + rr][h*32 + l31],  rr = (r/4)*8 + lh*4 + r%4
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r >> 2) * 8 + lh * 4 + (r & 3);
+            const float zr = __shfl(z, rr, 64);
+            const float Z = __builtin_amdgcn_rcpf(zr + 1e-6f);  // v_rcp_f32, 1 ulp (an IEEE division is ~10 instructions x 64 per wave)
+            if (row0 + rr < L) ElemIO<OUT_BF16>::st(out, ((size_t)b * L + row0 + rr) * ldo + h * D + l31, acc[r] * Z * slen);
+        }
+    }
+}
+
 inline int nchunks(int S) { return (S + CH - 1) / CH; }
 
 }  // namespace
@@ -214,13 +344,27 @@ extern "C" int gim_linear_attention_kv(const void* k, const void* v, const uint8
     GIM_REQUIRE(D == 32 || D == 16, "linear_attention_kv: head dim %d unsupported (16 or 32)", D);
     GIM_REQUIRE(ldk % 4 == 0 && ldv % 4 == 0, "linear_attention_kv: ld alignment");
     hipStream_t s = (hipStream_t)stream;
-    const int nc = nchunks(S);
+    const bool mfma_path = D == 32 && H == 8 && (ldk * (dtype == GIM_BF16 ? 2 : 4)) % 16 == 0 &&
+                           (ldv * (dtype == GIM_BF16 ? 2 : 4)) % 16 == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0;
+    const int nc = mfma_path ? (S + CHM - 1) / CHM : nchunks(S);
     const int per = D * D + D;
     float* fin = kv_ws;
     float* part = nc > 1 ? kv_ws + (size_t)nb * H * per : kv_ws;
     dim3 grid((unsigned)(nb * H), (unsigned)nc);
     const bool bf = dtype == GIM_BF16;
-    if (D == 32) {
+    if (mfma_path) {
+        // coarse level: fp32-MFMA kernel, 4 heads of a 128-row chunk per workgroup
+        const int smem = 2 * 64 * 128 * (bf ? 2 : 4);
+        static bool attr = false;
+        if (!attr) {
+            hipFuncSetAttribute((const void*)la_kv_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 128 * 2);
+            hipFuncSetAttribute((const void*)la_kv_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 128 * 4);
+            attr = true;
+        }
+        const dim3 g2((unsigned)nb, (unsigned)nc, 2u);
+        if (bf) hipLaunchKernelGGL(la_kv_mfma_kernel<true>, g2, dim3(256), smem, s, k, v, kv_mask, part, S, ldk, ldv, nc);
+        else hipLaunchKernelGGL(la_kv_mfma_kernel<false>, g2, dim3(256), smem, s, k, v, kv_mask, part, S, ldk, ldv, nc);
+    } else if (D == 32) {
         if (bf) hipLaunchKernelGGL((la_kv_kernel<32, true>), grid, dim3(256), 0, s, k, v, kv_mask, part, S, H, ldk, ldv, nc);
         else hipLaunchKernelGGL((la_kv_kernel<32, false>), grid, dim3(256), 0, s, k, v, kv_mask, part, S, H, ldk, ldv, nc);
     } else {
@@ -248,6 +392,16 @@ extern "C" int gim_linear_attention_apply(const void* q, const uint8_t* q_mask, 
     const size_t smem = (size_t)H * (D * D + D) * 4;
     GIM_REQUIRE(smem <= 64 * 1024, "linear_attention_apply: H=%d too large", H);
     const bool bf = dtype == GIM_BF16, obf = out_dtype == GIM_BF16;
+    if (D == 32 && H == 8) {  // coarse level: fp32-MFMA kernel, 64 rows per workgroup
+        const dim3 g2((unsigned)nb, (unsigned)((L + 63) / 64));
+#define LA_APPLY_M(A, B) hipLaunchKernelGGL((la_apply_mfma_kernel<A, B>), g2, dim3(256), 0, s, q, q_mask, kv_ws, out, L, S, ldq, ldo)
+        if (bf && obf) LA_APPLY_M(true, true);
+        else if (bf) LA_APPLY_M(true, false);
+        else if (obf) LA_APPLY_M(false, true);
+        else LA_APPLY_M(false, false);
+#undef LA_APPLY_M
+        return gim_check_launch("la_apply_mfma");
+    }
 #define LA_APPLY(DD, A, B) hipLaunchKernelGGL((la_apply_kernel<DD, A, B>), grid, dim3(256), smem, s, q, q_mask, kv_ws, out, L, S, H, ldq, ldo)
     if (D == 32) {
         if (bf && obf) LA_APPLY(32, true, true);

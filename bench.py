@@ -140,7 +140,7 @@ def main():
     # planted-correspondence features (f1 = permuted f0 + noise) so that ~1500 matches per pair
     # (the mean of the reference's gim_loftr dumps) flow through fine gather / fine transformer / fine matching.
     realistic = None
-    if rank == 0:
+    if rank == 0 and world == 1:  # single-GPU runs only: in a multi-rank job every rank leaves together after the timed region
         gp = torch.Generator().manual_seed(7)
         L, C = (H // 8) * (W // 8), 256
         pf0 = torch.randn(nb, L, C, generator=gp) * 2.0

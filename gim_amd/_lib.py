@@ -101,6 +101,13 @@ def _load():
         raise ImportError(
             f"libgimhip.so not found at {LIB_PATH}: the HIP extension is required (no CPU fallback). "
             "Build it with `python -m gim_amd.build` (needs hipcc, gfx950).")
+    # torch ships its own libamdhip64.so; if libgimhip.so were loaded first it would pull in /opt/rocm's copy and the
+    # process would hold two HIP runtimes (the second one reports "no ROCm-capable device").  Loading torch first makes
+    # both resolve the same runtime.  The library itself has no torch dependency (C callers link libamdhip64 as usual).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly

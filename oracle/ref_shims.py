@@ -174,6 +174,64 @@ def reference_lightglue_models():
     return detector.eval(), model.eval()
 
 
+def install_dkm():
+    """Stand-ins that let `networks.dkm.*` import: an empty `cv2` (only host-side pose utilities use
+    it), `torchvision.transforms` names that `dkm/utils/utils.py:4-5,178-199` touches at import / construction,
+    and `torchvision.models.resnet50` restated from the reference's OWN ResNet/Bottleneck
+    (`networks/loftr/backbone/resnet.py:71-167`, a verbatim torchvision architecture with maxpool / layer4 / fc
+    commented out) by adding those three members back -- so the parameter names are torchvision's
+    (`encoder.net.conv1 ... layer4.2.bn3`), which is what gim_dkm checkpoints carry."""
+    import enum
+    import torch.nn as nn
+    install()
+    if "cv2" not in sys.modules:
+        sys.modules["cv2"] = types.ModuleType("cv2")
+    if "torchvision" not in sys.modules:
+        tv = types.ModuleType("torchvision")
+        tr = types.ModuleType("torchvision.transforms")
+        trf = types.ModuleType("torchvision.transforms.functional")
+        tvm = types.ModuleType("torchvision.models")
+
+        class InterpolationMode(enum.Enum):
+            NEAREST = "nearest"
+            BILINEAR = "bilinear"
+            BICUBIC = "bicubic"
+
+        def _unavailable(*a, **k):
+            raise NotImplementedError("torchvision is not installed; the oracle path feeds tensors directly")
+
+        def resnet50(pretrained=False, weights=None, replace_stride_with_dilation=None, **kw):
+            from networks.loftr.backbone.resnet import Bottleneck, ResNet
+            net = ResNet(Bottleneck, [3, 4, 6, 3], replace_stride_with_dilation=replace_stride_with_dilation)
+            net.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+            net.layer4 = net._make_layer(Bottleneck, 512, 3, stride=2)
+            net.fc = nn.Linear(2048, 1000)
+            return net
+
+        trf.InterpolationMode = InterpolationMode
+        tr.InterpolationMode = InterpolationMode
+        tr.functional = trf
+        tr.Resize = tr.Normalize = _unavailable
+        tvm.resnet50 = resnet50
+        tvm.resnet18 = _unavailable
+        tv.transforms, tv.models = tr, tvm
+        for name, m in (("torchvision", tv), ("torchvision.transforms", tr), ("torchvision.transforms.functional", trf),
+                        ("torchvision.models", tvm)):
+            sys.modules[name] = m
+
+
+def reference_dkm(h, w, upsample_res=None, **attrs):
+    """DKMv3 built and configured the way `trainer/lightning.py:30-37` / `demo.py:328` do (tensor inputs, symmetric)."""
+    install_dkm()
+    from networks.dkm.models.model_zoo.DKMv3 import DKMv3
+    model = DKMv3(None, h, w, upsample_preds=upsample_res is not None)
+    if upsample_res is not None:
+        model.upsample_res = tuple(upsample_res)
+    for k, v in attrs.items():
+        setattr(model, k, v)
+    return model.eval()
+
+
 def reference_loftr_config():
     """The effective gim_loftr config dict (`demo.py:333-335`: lower_config(get_cfg_defaults())['loftr'])."""
     install()

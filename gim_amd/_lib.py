@@ -89,6 +89,24 @@ PROTOTYPES = {
     "gim_lg_assign": (c_int, [ctypes.POINTER(LgAssignArgs), c_void_p]),
     "gim_lg_log_assignment": (c_int, [ctypes.POINTER(LgAssignArgs), c_void_p, c_void_p]),
     "gim_lg_emit_matches": (c_int, [c_void_p] * 13 + [c_int] * 3 + [c_void_p]),
+    # gim_dkm path
+    "gim_maxpool3x3s2": (c_int, [c_void_p] * 2 + [c_int] * 7 + [c_void_p]),
+    "gim_resize_bilinear": (c_int, [c_void_p] * 2 + [c_int] * 10 + [c_void_p]),
+    "gim_resize_image": (c_int, [c_void_p] * 2 + [c_int] * 9 + [c_void_p]),
+    "gim_grid_sample": (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p]),
+    "gim_dkm_disp_emb": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
+    "gim_local_corr": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
+    "gim_dwconv5x5_bn_relu": (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_void_p]),
+    "gim_row_norms": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
+    "gim_cos_kernel_finish": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_float] * 3 + [c_void_p]),
+    "gim_gp_solve_ws_bytes": (c_int64, [c_int] * 3),
+    "gim_gp_solve": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "gim_global_avgpool": (c_int, [c_void_p] * 2 + [c_int] * 7 + [c_void_p]),
+    "gim_cab_scale_add": (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p]),
+    "gim_dkm_flow_update": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_float, c_float, c_int, c_int, c_void_p]),
+    "gim_dkm_grid_coords": (c_int, [c_void_p] + [c_int] * 3 + [c_void_p]),
+    "gim_dkm_match_post": (c_int, [c_void_p] * 7 + [c_int] * 2 + [c_void_p]),
+    "gim_dkm_black_mask": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
 }
 
 

@@ -1,0 +1,533 @@
+// Glue kernels of the gim_dkm path (networks/dkm/models/dkm.py) for gfx950: everything around the convolutions
+// (which run on conv_igemm.hip) and the GP solve (gp_solve.hip).  All tensors are NHWC rows; flow / certainty maps
+// are small fp32 NHWC tensors ([b,h,w,2], [b,h,w,1]).  Everything here is HBM/L2-bound gather + elementwise work.
+//
+//   maxpool3x3s2        encoders.py:51 (torchvision resnet50 `maxpool`: kernel 3, stride 2, padding 1)
+//   resize_bilinear     F.interpolate(mode='bilinear', align_corners=False)   dkm.py:420-425,468-479,518-529,668-701
+//   grid_sample         F.grid_sample(bilinear, zeros, align_corners=False)   dkm.py:89
+//   disp_emb            disp_emb(flow - query_coords), a 1x1 conv on 2 channels dkm.py:91-101
+//   local_corr          local_correlation(x, y, r, flow)                      utils/local_correlation.py:5-40
+//   dwconv5x5_bn_relu   depthwise 5x5 conv + BatchNorm(eval) + ReLU           dkm.py:58-73 (create_block, dw=True)
+//   row_norms / cos_kernel_finish   CosKernel                                 dkm.py:135-144
+//   global_avgpool / cab_scale_add  CAB                                       dkm.py:160-168
+//   flow_update         dense_flow += ins * displacement / (4 w | 4 h), certainty += delta   dkm.py:505-514
+//   match_post          match(): certainty attenuation, sigmoid, out-of-range / black masks, clamp, symmetric layout
+//                                                                             dkm.py:693-741
+#include "gim_common.h"
+
+namespace {
+
+inline unsigned nblocks(size_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+// ---- 3x3 / stride 2 / pad 1 max pooling, one thread per 16-byte channel group of one output pixel ---------------
+template <bool BF16>
+__global__ void maxpool3x3s2_kernel(const void* __restrict__ x, void* __restrict__ y, int B, int H, int W, int Ho, int Wo,
+                                    int CG, int ldx, int ldy) {
+    constexpr int G = BF16 ? 8 : 4;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * Ho * Wo * CG) return;
+    const int cg = (int)(idx % CG);
+    const size_t pix = idx / CG;
+    const int xo = (int)(pix % Wo), yo = (int)((pix / Wo) % Ho), b = (int)(pix / ((size_t)Wo * Ho));
+#pragma unroll
+    for (int e = 0; e < G; e += 4) {
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = 2 * yo - 1 + dy;
+            if (yy < 0 || yy >= H) continue;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xx = 2 * xo - 1 + dx;
+                if (xx < 0 || xx >= W) continue;
+                const float4 v = ElemIO<BF16>::ld4(x, (((size_t)b * H + yy) * W + xx) * ldx + cg * G + e);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        ElemIO<BF16>::st4(y, pix * ldy + cg * G + e, m);
+    }
+}
+
+// ATen area_pixel_compute_source_index(scale, dst, align_corners=false, cubic=false)
+__device__ __forceinline__ void src_index(float scale, int dst, int in_size, int& i0, int& i1, float& l0, float& l1) {
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+    l0 = 1.f - l1;
+}
+
+// bilinear resize, align_corners=False; one thread per output element (channel fastest)
+template <bool IN_BF16, bool OUT_BF16>
+__global__ void resize_bilinear_kernel(const void* __restrict__ x, void* __restrict__ y, int B, int h, int w, int Ho, int Wo,
+                                       int C, int ldx, int ldy) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * Ho * Wo * C) return;
+    const int c = (int)(idx % C);
+    const size_t pix = idx / C;
+    const int X = (int)(pix % Wo), Y = (int)((pix / Wo) % Ho), b = (int)(pix / ((size_t)Wo * Ho));
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    src_index((float)h / (float)Ho, Y, h, y0, y1, ly0, ly1);
+    src_index((float)w / (float)Wo, X, w, x0, x1, lx0, lx1);
+    const size_t base = (size_t)b * h * w;
+    const float v00 = ElemIO<IN_BF16>::ld(x, (base + (size_t)y0 * w + x0) * ldx + c), v01 = ElemIO<IN_BF16>::ld(x, (base + (size_t)y0 * w + x1) * ldx + c);
+    const float v10 = ElemIO<IN_BF16>::ld(x, (base + (size_t)y1 * w + x0) * ldx + c), v11 = ElemIO<IN_BF16>::ld(x, (base + (size_t)y1 * w + x1) * ldx + c);
+    ElemIO<OUT_BF16>::st(y, pix * ldy + c, ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11));
+}
+
+// NCHW fp32 image -> bilinear resize (align_corners=False) -> NHWC rows with zero channel padding
+template <bool OUT_BF16>
+__global__ void resize_image_kernel(const float* __restrict__ x, void* __restrict__ y, int B, int C, int h, int w, int Ho,
+                                    int Wo, int cpad, int b_off) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * Ho * Wo) return;
+    const int X = (int)(idx % Wo), Y = (int)((idx / Wo) % Ho), b = (int)(idx / ((size_t)Wo * Ho));
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    src_index((float)h / (float)Ho, Y, h, y0, y1, ly0, ly1);
+    src_index((float)w / (float)Wo, X, w, x0, x1, lx0, lx1);
+    const size_t orow = (((size_t)(b + b_off) * Ho + Y) * Wo + X) * cpad;
+    for (int c = 0; c < cpad; ++c) {
+        float v = 0.f;
+        if (c < C) {
+            const float* p = x + ((size_t)b * C + c) * h * w;
+            v = ly0 * (lx0 * p[(size_t)y0 * w + x0] + lx1 * p[(size_t)y0 * w + x1]) +
+                ly1 * (lx0 * p[(size_t)y1 * w + x0] + lx1 * p[(size_t)y1 * w + x1]);
+        }
+        ElemIO<OUT_BF16>::st(y, orow + c, v);
+    }
+}
+
+// grid_sample: feat [b,h,w,C] at grid [b,ho,wo,2] (x, y in [-1,1]) -> out rows (channel slice of a wider row allowed)
+template <bool BF16>
+__global__ void grid_sample_kernel(const void* __restrict__ feat, const float* __restrict__ grid, void* __restrict__ out,
+                                   int B, int h, int w, int HoWo, int CG, int ldf, int ldo) {
+    constexpr int G = BF16 ? 8 : 4;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * HoWo * CG) return;
+    const int cg = (int)(idx % CG);
+    const size_t pix = idx / CG;
+    const int b = (int)(pix / HoWo);
+    const float gx = grid[pix * 2 + 0], gy = grid[pix * 2 + 1];
+    // grid_sampler_unnormalize(align_corners=false): ((g + 1) * size - 1) / 2
+    const float ix = ((gx + 1.f) * (float)w - 1.f) / 2.f, iy = ((gy + 1.f) * (float)h - 1.f) / 2.f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx1 = ix - fx, wx0 = (fx + 1.f) - ix, wy1 = iy - fy, wy0 = (fy + 1.f) - iy;
+    const float wt[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+#pragma unroll
+    for (int e = 0; e < G; e += 4) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+            if (xx < 0 || yy < 0 || xx >= w || yy >= h) continue;
+            const float4 v = ElemIO<BF16>::ld4(feat, (((size_t)b * h + yy) * w + xx) * ldf + cg * G + e);
+            acc.x += v.x * wt[k]; acc.y += v.y * wt[k]; acc.z += v.z * wt[k]; acc.w += v.w * wt[k];
+        }
+        ElemIO<BF16>::st4(out, pix * ldo + cg * G + e, acc);
+    }
+}
+
+// emb[c] = W[c,0] * (fx - qx) + W[c,1] * (fy - qy) + bias[c]; query grid = pixel centres (dkm.py:91-101)
+template <bool OUT_BF16>
+__global__ void disp_emb_kernel(const float* __restrict__ flow, const float* __restrict__ wgt, const float* __restrict__ bias,
+                                void* __restrict__ out, int B, int h, int w, int E, int ldo) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * h * w * E) return;
+    const int c = (int)(idx % E);
+    const size_t pix = idx / E;
+    const int X = (int)(pix % w), Y = (int)((pix / w) % h);
+    // torch.linspace(-1 + 1/n, 1 - 1/n, n)[i]: start + i * step for i < n/2, end - (n-1-i) * step otherwise
+    auto lin = [](int i, int n) {
+        const float start = -1.f + 1.f / (float)n, end = 1.f - 1.f / (float)n;
+        const float step = (end - start) / (float)(n - 1);
+        return i < n / 2 ? start + (float)i * step : end - (float)(n - 1 - i) * step;
+    };
+    const float dx = flow[pix * 2 + 0] - (w > 1 ? lin(X, w) : 0.f), dy = flow[pix * 2 + 1] - (h > 1 ? lin(Y, h) : 0.f);
+    ElemIO<OUT_BF16>::st(out, pix * ldo + c, wgt[c * 2 + 0] * dx + wgt[c * 2 + 1] * dy + bias[c]);
+}
+
+// ---- local correlation: one wave per query pixel ---------------------------------------------------------------
+// All (2r+1)^2 window taps are spaced exactly one pixel apart, so they share their bilinear fractions: the wave
+// computes the (2r+2)^2 integer-grid dot products D once and every tap is a 4-term combination of them (3.5x fewer
+// feature reads than sampling each tap's four corners).  Dot products: lanes split the channels (coalesced row
+// reads), 16 positions are reduced together with a halving butterfly (17 shuffles instead of 96).
+template <bool BF16, bool OUT_BF16>
+__global__ void __launch_bounds__(256) local_corr_kernel(const void* __restrict__ f0, const void* __restrict__ f1,
+                                                         const float* __restrict__ flow, void* __restrict__ out, int B, int h,
+                                                         int w, int C, int r, int ld0, int ld1, int ldo) {
+    __shared__ float Dall[4][18 * 18];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t q = (size_t)blockIdx.x * 4 + wv;
+    if (q >= (size_t)B * h * w) return;
+    const int b = (int)(q / ((size_t)h * w));
+    float* D = Dall[wv];
+    const int P = 2 * r + 2;  // patch side (<= 16)
+    const float gx = flow[q * 2 + 0], gy = flow[q * 2 + 1];
+    // tap (0,0) sits at flow + (-2r/w, -2r/h) in normalised units = -r pixels
+    const float ix = ((gx + 1.f) * (float)w - 1.f) / 2.f - (float)r, iy = ((gy + 1.f) * (float)h - 1.f) / 2.f - (float)r;
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx1 = ix - fx, wx0 = (fx + 1.f) - ix, wy1 = iy - fy, wy0 = (fy + 1.f) - iy;
+    const int nch = (C + 255) / 256;  // 4-channel groups per lane, strided by 64 lanes
+    for (int py = 0; py < P; ++py) {
+        const int yy = y0 + py;
+        float part[16];
+#pragma unroll
+        for (int px = 0; px < 16; ++px) part[px] = 0.f;
+        if (yy >= 0 && yy < h) {
+            for (int k = 0; k < nch; ++k) {
+                const int c = (k * 64 + lane) * 4;
+                if (c >= C) break;
+                const float4 a = ElemIO<BF16>::ld4(f0, q * ld0 + c);
+#pragma unroll
+                for (int px = 0; px < 16; ++px) {
+                    const int xx = x0 + px;
+                    if (px < P && xx >= 0 && xx < w) {
+                        const float4 v = ElemIO<BF16>::ld4(f1, (((size_t)b * h + yy) * w + xx) * ld1 + c);
+                        part[px] += (a.x * v.x + a.y * v.y) + (a.z * v.z + a.w * v.w);
+                    }
+                }
+            }
+        }
+        // halving butterfly: after the step with mask m the lane keeps the positions whose bit (log2 m) matches
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int m = 32 >> s, half = 8 >> s;  // half = positions kept
+            const bool up = (lane & m) != 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i < half) {
+                    const float mine = up ? part[i + half] : part[i];
+                    const float theirs = up ? part[i] : part[i + half];
+                    part[i] = mine + __shfl_xor(theirs, m, 64);
+                }
+            }
+        }
+        float v = part[0];
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 1, 64);
+        // lane now holds position px = bits (lane>>5&1)*8 + (lane>>4&1)*4 + (lane>>3&1)*2 + (lane>>2&1)
+        const int px = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+        if ((lane & 3) == 0 && px < P) D[py * 18 + px] = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes are visible to its own reads
+    const int K = 2 * r + 1;
+    const float inv = 1.0f / sqrtf((float)C);
+    for (int k = lane; k < K * K; k += 64) {
+        const int ky = k / K, kx = k - ky * K;
+        const float v = (D[ky * 18 + kx] * (wx0 * wy0) + D[ky * 18 + kx + 1] * (wx1 * wy0)) +
+                        (D[(ky + 1) * 18 + kx] * (wx0 * wy1) + D[(ky + 1) * 18 + kx + 1] * (wx1 * wy1));
+        ElemIO<OUT_BF16>::st(out, q * ldo + k, v * inv);
+    }
+}
+
+// depthwise 5x5 (pad 2) + per-channel affine (conv bias and eval BatchNorm folded) + ReLU; Cout = mult * Cin,
+// output channel co reads input channel co / mult; wgt [25][cpad] fp32, scale/shift [cpad]
+template <bool BF16>
+__global__ void dwconv5x5_kernel(const void* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ scale,
+                                 const float* __restrict__ shift, void* __restrict__ y, int B, int H, int W, int Cout4,
+                                 int mult, int cpad, int ldx, int ldy) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * H * W * Cout4) return;
+    const int co = (int)(idx % Cout4) * 4;
+    const size_t pix = idx / Cout4;
+    const int X = (int)(pix % W), Y = (int)((pix / W) % H), b = (int)(pix / ((size_t)W * H));
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int dy = 0; dy < 5; ++dy) {
+        const int yy = Y + dy - 2;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = 0; dx < 5; ++dx) {
+            const int xx = X + dx - 2;
+            if (xx < 0 || xx >= W) continue;
+            const size_t row = (((size_t)b * H + yy) * W + xx) * ldx;
+            const float4 wv = *(const float4*)(wgt + (size_t)(dy * 5 + dx) * cpad + co);
+            float4 v;
+            if (mult == 1) {
+                v = ElemIO<BF16>::ld4(x, row + co);
+            } else {
+                v.x = ElemIO<BF16>::ld(x, row + (co + 0) / mult); v.y = ElemIO<BF16>::ld(x, row + (co + 1) / mult);
+                v.z = ElemIO<BF16>::ld(x, row + (co + 2) / mult); v.w = ElemIO<BF16>::ld(x, row + (co + 3) / mult);
+            }
+            acc.x = fmaf(v.x, wv.x, acc.x); acc.y = fmaf(v.y, wv.y, acc.y);
+            acc.z = fmaf(v.z, wv.z, acc.z); acc.w = fmaf(v.w, wv.w, acc.w);
+        }
+    }
+    const float4 sc = *(const float4*)(scale + co), sh = *(const float4*)(shift + co);
+    acc.x = fmaxf(acc.x * sc.x + sh.x, 0.f); acc.y = fmaxf(acc.y * sc.y + sh.y, 0.f);
+    acc.z = fmaxf(acc.z * sc.z + sh.z, 0.f); acc.w = fmaxf(acc.w * sc.w + sh.w, 0.f);
+    ElemIO<BF16>::st4(y, pix * ldy + co, acc);
+}
+
+// one wave per row: L2 norm of x[r, 0:C]
+template <bool BF16>
+__global__ void __launch_bounds__(256) row_norms_kernel(const void* __restrict__ x, float* __restrict__ out, int rows, int C, int ld) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float s = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 v = ElemIO<BF16>::ld4(x, (size_t)r * ld + c);
+        s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[r] = sqrtf(s);
+}
+
+// K[b,i,j] = exp((dot / (nx_i * ny_j + eps) - 1) / T), in place on the dot-product matrix rows [b*n, ld]
+__global__ void cos_kernel_finish_kernel(float* __restrict__ k, const float* __restrict__ nx, const float* __restrict__ ny,
+                                         int B, int n, int m, int ld, float T, float eps, float diag_add) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * n * m) return;
+    const int j = (int)(idx % m);
+    const size_t row = idx / m;
+    const int b = (int)(row / n), i = (int)(row - (size_t)b * n);
+    const float c = k[row * ld + j] / (nx[row] * ny[(size_t)b * m + j] + eps);
+    float v = expf((c - 1.0f) / T);
+    if (i == j) v += diag_add;
+    k[row * ld + j] = v;
+}
+
+// mean over the spatial positions of NHWC rows: out[b, c] (fp32), one thread per (b, c); rows are L2-resident maps
+template <bool BF16>
+__global__ void global_avgpool_kernel(const void* __restrict__ x, float* __restrict__ out, int B, int HW, int C, int ld, int ldo,
+                                      int c_off) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * C) return;
+    const int c = idx % C, b = idx / C;
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += ElemIO<BF16>::ld(x, ((size_t)b * HW + p) * ld + c);
+    out[(size_t)b * ldo + c_off + c] = s / (float)HW;
+}
+
+// CAB: out = sigmoid(g[b, c]) * x2 + x1     (dkm.py:165-168)
+template <bool BF16>
+__global__ void cab_scale_add_kernel(const float* __restrict__ g, const void* __restrict__ x1, const void* __restrict__ x2,
+                                     void* __restrict__ out, int B, int HW, int C4, int ldg, int ld1, int ld2, int ldo) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * HW * C4) return;
+    const int c = (int)(idx % C4) * 4;
+    const size_t pix = idx / C4;
+    const int b = (int)(pix / HW);
+    const float4 gg = *(const float4*)(g + (size_t)b * ldg + c);
+    const float4 a = x1 ? ElemIO<BF16>::ld4(x1, pix * ld1 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v = ElemIO<BF16>::ld4(x2, pix * ld2 + c);
+    auto sg = [](float t) { return 1.0f / (1.0f + expf(-t)); };
+    ElemIO<BF16>::st4(out, pix * ldo + c, make_float4(sg(gg.x) * v.x + a.x, sg(gg.y) * v.y + a.y, sg(gg.z) * v.z + a.z, sg(gg.w) * v.w + a.w));
+}
+
+// flow[.,0] += ins * d[.,1] / (4 w_full), flow[.,1] += ins * d[.,2] / (4 h_full), cert += d[.,0]
+// d rows: [certainty, dx, dy] (ConvRefiner out_conv: d[:, :-2] certainty, d[:, -2:] displacement)
+template <bool BF16>
+__global__ void flow_update_kernel(float* __restrict__ flow, float* __restrict__ cert, const void* __restrict__ d, size_t npix,
+                                   int ldd, float sx, float sy, int cert_init) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const float dc = ElemIO<BF16>::ld(d, p * ldd + 0), dx = ElemIO<BF16>::ld(d, p * ldd + 1), dy = ElemIO<BF16>::ld(d, p * ldd + 2);
+    flow[p * 2 + 0] = flow[p * 2 + 0] + dx * sx;
+    flow[p * 2 + 1] = flow[p * 2 + 1] + dy * sy;
+    cert[p] = (cert_init ? 0.f : cert[p]) + dc;
+}
+
+// pixel-centre grid (dkm.py:437-448): flow[b,y,x] = (lin(x, w), lin(y, h))
+__global__ void grid_coords_kernel(float* __restrict__ flow, int B, int h, int w) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (size_t)B * h * w) return;
+    const int X = (int)(p % w), Y = (int)((p / w) % h);
+    auto lin = [](int i, int n) {
+        const float start = -1.f + 1.f / (float)n, end = 1.f - 1.f / (float)n;
+        const float step = (end - start) / (float)(n - 1);
+        return i < n / 2 ? start + (float)i * step : end - (float)(n - 1 - i) * step;
+    };
+    flow[p * 2 + 0] = w > 1 ? lin(X, w) : 0.f;
+    flow[p * 2 + 1] = h > 1 ? lin(Y, h) : 0.f;
+}
+
+// match() tail (dkm.py:693-741), symmetric: flow / cert hold [q->s ; s->q] (batch 2).
+// warp [H, 2W, 4], certainty [H, 2W]; black0/black1: uint8 masks already resized (nearest) to [H, W]
+__global__ void match_post_kernel(const float* __restrict__ flow, const float* __restrict__ cert, const float* __restrict__ low,
+                                  const uint8_t* __restrict__ black0, const uint8_t* __restrict__ black1, float* __restrict__ warp,
+                                  float* __restrict__ certainty, int H, int W) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (size_t)2 * H * W) return;
+    const int dir = (int)(p / ((size_t)H * W));
+    const size_t pp = p - (size_t)dir * H * W;
+    const int X = (int)(pp % W), Y = (int)(pp / W);
+    auto lin = [](int i, int n) {
+        const float start = -1.f + 1.f / (float)n, end = 1.f - 1.f / (float)n;
+        const float step = (end - start) / (float)(n - 1);
+        return i < n / 2 ? start + (float)i * step : end - (float)(n - 1 - i) * step;
+    };
+    const float qx = lin(X, W), qy = lin(Y, H);
+    float fx = flow[p * 2 + 0], fy = flow[p * 2 + 1];
+    float l = low[p];
+    l = 0.5f * l * (l < 0.f ? 1.f : 0.f);
+    float c = 1.0f / (1.0f + expf(-(cert[p] - l)));
+    if (fabsf(fx) > 1.f || fabsf(fy) > 1.f) c = 0.f;
+    if ((dir == 0 ? black0 : black1)[pp]) c = 0.f;
+    fx = fminf(fmaxf(fx, -1.f), 1.f);
+    fy = fminf(fmaxf(fy, -1.f), 1.f);
+    const size_t o = (size_t)Y * 2 * W + (size_t)dir * W + X;
+    if (dir == 0) { warp[o * 4 + 0] = qx; warp[o * 4 + 1] = qy; warp[o * 4 + 2] = fx; warp[o * 4 + 3] = fy; }
+    else { warp[o * 4 + 0] = fx; warp[o * 4 + 1] = fy; warp[o * 4 + 2] = qx; warp[o * 4 + 3] = qy; }
+    certainty[o] = c;
+}
+
+// black-pixel mask of an NCHW fp32 image resized with F.interpolate(mode='nearest') (dkm.py:726-729)
+__global__ void black_mask_kernel(const float* __restrict__ im, uint8_t* __restrict__ mask, int h, int w, int Ho, int Wo) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (size_t)Ho * Wo) return;
+    const int X = (int)(p % Wo), Y = (int)(p / Wo);
+    // nearest: src = floor(dst * in / out) with the float scale ATen uses
+    const int sy = min((int)floorf((float)Y * ((float)h / (float)Ho)), h - 1), sx = min((int)floorf((float)X * ((float)w / (float)Wo)), w - 1);
+    const size_t o = (size_t)sy * w + sx, hw = (size_t)h * w;
+    mask[p] = (im[o] < 0.03125f) && (im[hw + o] < 0.03125f) && (im[2 * hw + o] < 0.03125f);
+}
+
+}  // namespace
+
+#define DISPATCH_BF(KERN, bf, grid, ...)                                                                  \
+    do {                                                                                                  \
+        if (bf) hipLaunchKernelGGL(KERN<true>, grid, dim3(256), 0, s, __VA_ARGS__);                     \
+        else hipLaunchKernelGGL(KERN<false>, grid, dim3(256), 0, s, __VA_ARGS__);                       \
+    } while (0)
+
+extern "C" int gim_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int ldx, int ldy, int dtype, gim_stream_t stream) {
+    const int G = dtype == GIM_BF16 ? 8 : 4;
+    GIM_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0 && C % G == 0 && ldx % G == 0 && ldy % G == 0, "maxpool3x3s2: bad args");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(nblocks((size_t)B * Ho * Wo * (C / G), 256));
+    DISPATCH_BF(maxpool3x3s2_kernel, dtype == GIM_BF16, grid, x, y, B, H, W, Ho, Wo, C / G, ldx, ldy);
+    return gim_check_launch("maxpool3x3s2");
+}
+
+extern "C" int gim_resize_bilinear(const void* x, void* y, int B, int h, int w, int Ho, int Wo, int C, int ldx, int ldy,
+                                   int dtype, int out_dtype, gim_stream_t stream) {
+    GIM_REQUIRE(x && y && B > 0 && h > 0 && w > 0 && Ho > 0 && Wo > 0 && C > 0 && ldx >= C && ldy >= C, "resize_bilinear: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(nblocks((size_t)B * Ho * Wo * C, 256));
+    const bool ib = dtype == GIM_BF16, ob = out_dtype == GIM_BF16;
+    if (ib && ob) hipLaunchKernelGGL((resize_bilinear_kernel<true, true>), grid, dim3(256), 0, s, x, y, B, h, w, Ho, Wo, C, ldx, ldy);
+    else if (ib) hipLaunchKernelGGL((resize_bilinear_kernel<true, false>), grid, dim3(256), 0, s, x, y, B, h, w, Ho, Wo, C, ldx, ldy);
+    else if (ob) hipLaunchKernelGGL((resize_bilinear_kernel<false, true>), grid, dim3(256), 0, s, x, y, B, h, w, Ho, Wo, C, ldx, ldy);
+    else hipLaunchKernelGGL((resize_bilinear_kernel<false, false>), grid, dim3(256), 0, s, x, y, B, h, w, Ho, Wo, C, ldx, ldy);
+    return gim_check_launch("resize_bilinear");
+}
+
+extern "C" int gim_resize_image(const float* x, void* y, int B, int C, int h, int w, int Ho, int Wo, int cpad, int b_off,
+                                int out_dtype, gim_stream_t stream) {
+    GIM_REQUIRE(x && y && B > 0 && C > 0 && h > 0 && w > 0 && Ho > 0 && Wo > 0 && cpad >= C, "resize_image: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(nblocks((size_t)B * Ho * Wo, 256));
+    DISPATCH_BF(resize_image_kernel, out_dtype == GIM_BF16, grid, x, y, B, C, h, w, Ho, Wo, cpad, b_off);
+    return gim_check_launch("resize_image");
+}
+
+extern "C" int gim_grid_sample(const void* feat, const float* grid_xy, void* out, int B, int h, int w, int Ho, int Wo, int C,
+                               int ldf, int ldo, int dtype, gim_stream_t stream) {
+    const int G = dtype == GIM_BF16 ? 8 : 4;
+    GIM_REQUIRE(feat && grid_xy && out && B > 0 && h > 0 && w > 0 && Ho > 0 && Wo > 0 && C > 0, "grid_sample: bad args");
+    GIM_REQUIRE(C % G == 0 && ldf % G == 0 && ldo % G == 0, "grid_sample: C / strides must keep 16-byte groups (C=%d)", C);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(nblocks((size_t)B * Ho * Wo * (C / G), 256));
+    DISPATCH_BF(grid_sample_kernel, dtype == GIM_BF16, grid, feat, grid_xy, out, B, h, w, Ho * Wo, C / G, ldf, ldo);
+    return gim_check_launch("grid_sample");
+}
+
+extern "C" int gim_dkm_disp_emb(const float* flow, const float* wgt, const float* bias, void* out, int B, int h, int w, int E,
+                                int ldo, int out_dtype, gim_stream_t stream) {
+    GIM_REQUIRE(flow && wgt && bias && out && B > 0 && h > 0 && w > 0 && E > 0 && ldo >= E, "dkm_disp_emb: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(nblocks((size_t)B * h * w * E, 256));
+    DISPATCH_BF(disp_emb_kernel, out_dtype == GIM_BF16, grid, flow, wgt, bias, out, B, h, w, E, ldo);
+    return gim_check_launch("dkm_disp_emb");
+}
+
+extern "C" int gim_local_corr(const void* f0, const void* f1, const float* flow, void* out, int B, int h, int w, int C, int r,
+                              int ld0, int ld1, int ldo, int dtype, int out_dtype, gim_stream_t stream) {
+    GIM_REQUIRE(f0 && f1 && flow && out && B > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0, "local_corr: bad args");
+    GIM_REQUIRE(r >= 1 && r <= 7, "local_corr: radius %d unsupported (1..7)", r);
+    GIM_REQUIRE(ld0 % 4 == 0 && ld1 % 4 == 0 && ldo >= (2 * r + 1) * (2 * r + 1), "local_corr: strides");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(nblocks((size_t)B * h * w, 4));
+    const bool ib = dtype == GIM_BF16, ob = out_dtype == GIM_BF16;
+    if (ib && ob) hipLaunchKernelGGL((local_corr_kernel<true, true>), grid, dim3(256), 0, s, f0, f1, flow, out, B, h, w, C, r, ld0, ld1, ldo);
+    else if (ib) hipLaunchKernelGGL((local_corr_kernel<true, false>), grid, dim3(256), 0, s, f0, f1, flow, out, B, h, w, C, r, ld0, ld1, ldo);
+    else if (ob) hipLaunchKernelGGL((local_corr_kernel<false, true>), grid, dim3(256), 0, s, f0, f1, flow, out, B, h, w, C, r, ld0, ld1, ldo);
+    else hipLaunchKernelGGL((local_corr_kernel<false, false>), grid, dim3(256), 0, s, f0, f1, flow, out, B, h, w, C, r, ld0, ld1, ldo);
+    return gim_check_launch("local_corr");
+}
+
+extern "C" int gim_dwconv5x5_bn_relu(const void* x, const float* wgt, const float* scale, const float* shift, void* y, int B,
+                                     int H, int W, int Cin, int Cout, int cpad, int ldx, int ldy, int dtype, gim_stream_t stream) {
+    GIM_REQUIRE(x && wgt && scale && shift && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout % Cin == 0, "dwconv5x5: bad args");
+    GIM_REQUIRE(cpad % 4 == 0 && cpad >= Cout && ldx % 4 == 0 && ldy % 4 == 0 && ldy >= cpad, "dwconv5x5: cpad / strides");
+    GIM_REQUIRE((int64_t)ldx * (Cout / Cin) >= cpad, "dwconv5x5: input rows too narrow for the padded channel range");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(nblocks((size_t)B * H * W * (cpad / 4), 256));
+    DISPATCH_BF(dwconv5x5_kernel, dtype == GIM_BF16, grid, x, wgt, scale, shift, y, B, H, W, cpad / 4, Cout / Cin, cpad, ldx, ldy);
+    return gim_check_launch("dwconv5x5");
+}
+
+extern "C" int gim_row_norms(const void* x, float* out, int rows, int C, int ld, int dtype, gim_stream_t stream) {
+    GIM_REQUIRE(x && out && rows > 0 && C > 0 && C % 4 == 0 && ld % 4 == 0, "row_norms: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((rows + 3) / 4);
+    DISPATCH_BF(row_norms_kernel, dtype == GIM_BF16, grid, x, out, rows, C, ld);
+    return gim_check_launch("row_norms");
+}
+
+extern "C" int gim_cos_kernel_finish(float* k, const float* nx, const float* ny, int B, int n, int m, int ld, float T, float eps,
+                                     float diag_add, gim_stream_t stream) {
+    GIM_REQUIRE(k && nx && ny && B > 0 && n > 0 && m > 0 && ld >= m, "cos_kernel_finish: bad args");
+    hipLaunchKernelGGL(cos_kernel_finish_kernel, dim3(nblocks((size_t)B * n * m, 256)), dim3(256), 0, (hipStream_t)stream, k, nx, ny, B, n, m, ld, T, eps, diag_add);
+    return gim_check_launch("cos_kernel_finish");
+}
+
+extern "C" int gim_global_avgpool(const void* x, float* out, int B, int HW, int C, int ld, int ldo, int c_off, int dtype,
+                                  gim_stream_t stream) {
+    GIM_REQUIRE(x && out && B > 0 && HW > 0 && C > 0, "global_avgpool: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(nblocks((size_t)B * C, 256));
+    DISPATCH_BF(global_avgpool_kernel, dtype == GIM_BF16, grid, x, out, B, HW, C, ld, ldo, c_off);
+    return gim_check_launch("global_avgpool");
+}
+
+extern "C" int gim_cab_scale_add(const float* g, const void* x1, const void* x2, void* out, int B, int HW, int C, int ldg, int ld1,
+                                 int ld2, int ldo, int dtype, gim_stream_t stream) {
+    GIM_REQUIRE(g && x2 && out && B > 0 && HW > 0 && C > 0 && C % 4 == 0 && ldg % 4 == 0 && ld2 % 4 == 0 && ldo % 4 == 0 && (!x1 || ld1 % 4 == 0), "cab_scale_add: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(nblocks((size_t)B * HW * (C / 4), 256));
+    DISPATCH_BF(cab_scale_add_kernel, dtype == GIM_BF16, grid, g, x1, x2, out, B, HW, C / 4, ldg, ld1, ld2, ldo);
+    return gim_check_launch("cab_scale_add");
+}
+
+extern "C" int gim_dkm_flow_update(float* flow, float* cert, const void* d, int64_t npix, int ldd, float sx, float sy, int cert_init,
+                                   int dtype, gim_stream_t stream) {
+    GIM_REQUIRE(flow && cert && d && npix > 0 && ldd >= 3, "dkm_flow_update: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(nblocks((size_t)npix, 256));
+    DISPATCH_BF(flow_update_kernel, dtype == GIM_BF16, grid, flow, cert, d, (size_t)npix, ldd, sx, sy, cert_init);
+    return gim_check_launch("dkm_flow_update");
+}
+
+extern "C" int gim_dkm_grid_coords(float* flow, int B, int h, int w, gim_stream_t stream) {
+    GIM_REQUIRE(flow && B > 0 && h > 0 && w > 0, "dkm_grid_coords: bad args");
+    hipLaunchKernelGGL(grid_coords_kernel, dim3(nblocks((size_t)B * h * w, 256)), dim3(256), 0, (hipStream_t)stream, flow, B, h, w);
+    return gim_check_launch("dkm_grid_coords");
+}
+
+extern "C" int gim_dkm_match_post(const float* flow, const float* cert, const float* low, const uint8_t* black0,
+                                  const uint8_t* black1, float* warp, float* certainty, int H, int W, gim_stream_t stream) {
+    GIM_REQUIRE(flow && cert && low && black0 && black1 && warp && certainty && H > 1 && W > 1, "dkm_match_post: bad args");
+    hipLaunchKernelGGL(match_post_kernel, dim3(nblocks((size_t)2 * H * W, 256)), dim3(256), 0, (hipStream_t)stream, flow, cert, low, black0, black1, warp, certainty, H, W);
+    return gim_check_launch("dkm_match_post");
+}
+
+extern "C" int gim_dkm_black_mask(const float* im, uint8_t* mask, int h, int w, int Ho, int Wo, gim_stream_t stream) {
+    GIM_REQUIRE(im && mask && h > 0 && w > 0 && Ho > 0 && Wo > 0, "dkm_black_mask: bad args");
+    hipLaunchKernelGGL(black_mask_kernel, dim3(nblocks((size_t)Ho * Wo, 256)), dim3(256), 0, (hipStream_t)stream, im, mask, h, w, Ho, Wo);
+    return gim_check_launch("dkm_black_mask");
+}

@@ -410,3 +410,177 @@ def lg_emit_matches(r, total, kpts0=None, kpts1=None, scale0=None, scale1=None):
                                       _p(scale0), _p(scale1), _p(matches), _p(scores), _p(mk0), _p(mk1), _p(bids),
                                       a.B, a.M, a.N, _stream()), "gim_lg_emit_matches")
     return matches, scores, mk0, mk1, bids
+
+
+# ---- gim_dkm -------------------------------------------------------------------------------------------------
+def maxpool3x3s2(x):
+    """x [B,H,W,C] NHWC -> new [B,(H-1)//2+1,(W-1)//2+1,C] (kernel 3, stride 2, padding 1)"""
+    _req_cuda(x)
+    B, H, W, C = x.shape
+    y = torch.empty(B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C, dtype=x.dtype, device=x.device)
+    check(lib.gim_maxpool3x3s2(_p(x), _p(y), B, H, W, C, C, C, gim_dtype(x), _stream()), "gim_maxpool3x3s2")
+    return y
+
+
+def resize_bilinear(x, size, out_dtype=None):
+    """x [B,h,w,C] NHWC contiguous -> new [B,Ho,Wo,C] (bilinear, align_corners=False)"""
+    _req_cuda(x)
+    B, h, w, C = x.shape
+    y = torch.empty(B, size[0], size[1], C, dtype=out_dtype or x.dtype, device=x.device)
+    check(lib.gim_resize_bilinear(_p(x), _p(y), B, h, w, size[0], size[1], C, C, C, gim_dtype(x), gim_dtype(y), _stream()),
+          "gim_resize_bilinear")
+    return y
+
+
+def resize_image(img, dst, b_off=0):
+    """img [B,C,h,w] fp32 NCHW -> dst[b_off:b_off+B] ([.,Ho,Wo,cpad] NHWC), bilinear align_corners=False"""
+    _req_cuda(img, dst)
+    B, C, h, w = img.shape
+    check(lib.gim_resize_image(_p(img), _p(dst), B, C, h, w, dst.shape[1], dst.shape[2], dst.shape[3], b_off, gim_dtype(dst),
+                               _stream()), "gim_resize_image")
+
+
+def grid_sample(feat, grid, out):
+    """feat [B,h,w,C]; grid [B,Ho,Wo,2] fp32; out: row view [B*Ho*Wo, >=C] (may be a channel slice)"""
+    _req_cuda(feat, grid, out)
+    B, h, w, C = feat.shape
+    check(lib.gim_grid_sample(_p(feat), _p(grid), _p(out), B, h, w, grid.shape[1], grid.shape[2], C, C, out.stride(0),
+                              gim_dtype(feat), _stream()), "gim_grid_sample")
+
+
+def dkm_disp_emb(flow, wgt, bias, out):
+    """flow [B,h,w,2] fp32; wgt [E,2], bias [E] fp32; out row view [B*h*w, >=E]"""
+    _req_cuda(flow, wgt, bias, out)
+    B, h, w, _ = flow.shape
+    check(lib.gim_dkm_disp_emb(_p(flow), _p(wgt), _p(bias), _p(out), B, h, w, wgt.shape[0], out.stride(0), gim_dtype(out),
+                               _stream()), "gim_dkm_disp_emb")
+
+
+def local_corr(f0, f1, flow, r, out):
+    """f0, f1 [B,h,w,C] (C = valid channels, row stride = shape[-1]); out row view [B*h*w, >=(2r+1)^2]"""
+    _req_cuda(f0, f1, flow, out)
+    B, h, w, C = f0.shape
+    check(lib.gim_local_corr(_p(f0), _p(f1), _p(flow), _p(out), B, h, w, C, r, f0.stride(2), f1.stride(2), out.stride(0),
+                             gim_dtype(f0), gim_dtype(out), _stream()), "gim_local_corr")
+
+
+def dwconv5x5_bn_relu(x, wgt, scale, shift, cin, cout):
+    """x [B,H,W,ldx]; wgt [25,cpad], scale/shift [cpad] fp32 -> new [B,H,W,cpad]"""
+    _req_cuda(x, wgt, scale, shift)
+    B, H, W, ldx = x.shape
+    cpad = wgt.shape[1]
+    y = torch.empty(B, H, W, cpad, dtype=x.dtype, device=x.device)
+    check(lib.gim_dwconv5x5_bn_relu(_p(x), _p(wgt), _p(scale), _p(shift), _p(y), B, H, W, cin, cout, cpad, ldx, cpad,
+                                    gim_dtype(x), _stream()), "gim_dwconv5x5_bn_relu")
+    return y
+
+
+def row_norms(x, C):
+    """x row view [R, >=C] -> [R] fp32 L2 norms"""
+    _req_cuda(x)
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    check(lib.gim_row_norms(_p(x), _p(out), x.shape[0], C, x.stride(0), gim_dtype(x), _stream()), "gim_row_norms")
+    return out
+
+
+def cos_kernel_finish(k, nx, ny, B, n, m, T, eps, diag_add):
+    """k: fp32 dot products, rows [B*n, ld]; in place -> exp((k / (nx ny + eps) - 1) / T) (+ diag_add on i == j)"""
+    _req_cuda(k, nx, ny)
+    check(lib.gim_cos_kernel_finish(_p(k), _p(nx), _p(ny), B, n, m, k.stride(0), T, eps, diag_add, _stream()), "gim_cos_kernel_finish")
+
+
+def gp_solve(K, F, npad):
+    """K [B,n,ld] fp32 (SPD, sigma on the diagonal), F [B,n,nrhs] fp32 -> Xt [B,nrhs,npad] fp32 = (K^-1 F)^T, zero padded"""
+    _req_cuda(K, F)
+    B, n, ld = K.shape
+    nrhs = F.shape[2]
+    assert K.is_contiguous() and F.is_contiguous() and K.dtype == torch.float32 and F.dtype == torch.float32
+    ws = torch.empty(lib.gim_gp_solve_ws_bytes(B, n, nrhs), dtype=torch.uint8, device=K.device)
+    Xt = torch.empty(B, nrhs, npad, dtype=torch.float32, device=K.device)
+    check(lib.gim_gp_solve(_p(K), _p(F), _p(Xt), _p(ws), B, n, ld, nrhs, npad, _stream()), "gim_gp_solve")
+    return Xt
+
+
+def global_avgpool(x, out, c_off):
+    """x [B,h,w,C] -> out[b, c_off:c_off+C] (fp32 [B, ldo])"""
+    _req_cuda(x, out)
+    B, h, w, C = x.shape
+    check(lib.gim_global_avgpool(_p(x), _p(out), B, h * w, C, C, out.stride(0), c_off, gim_dtype(x), _stream()), "gim_global_avgpool")
+
+
+def cab_scale_add(g, x1, x2):
+    """sigmoid(g[b,c]) * x2 + x1 (x1 may be None = zeros); x2 [B,h,w,C] -> new tensor"""
+    _req_cuda(g, x1, x2)
+    B, h, w, C = x2.shape
+    out = torch.empty_like(x2)
+    check(lib.gim_cab_scale_add(_p(g), _p(x1), _p(x2), _p(out), B, h * w, C, g.stride(0), C, C, C, gim_dtype(x2), _stream()),
+          "gim_cab_scale_add")
+    return out
+
+
+def dkm_flow_update(flow, cert, d, sx, sy, cert_init=False):
+    """flow [B,h,w,2], cert [B,h,w,1] fp32 updated in place from d rows [B*h*w, >=3] = [dcert, dx, dy]"""
+    _req_cuda(flow, cert, d)
+    check(lib.gim_dkm_flow_update(_p(flow), _p(cert), _p(d), flow.numel() // 2, d.stride(0), sx, sy, 1 if cert_init else 0,
+                                  gim_dtype(d), _stream()), "gim_dkm_flow_update")
+
+
+def dkm_grid_coords(B, h, w, device):
+    flow = torch.empty(B, h, w, 2, dtype=torch.float32, device=device)
+    check(lib.gim_dkm_grid_coords(_p(flow), B, h, w, _stream()), "gim_dkm_grid_coords")
+    return flow
+
+
+def dkm_black_mask(im, size):
+    """im [1,3,h,w] fp32 NCHW -> uint8 [Ho,Wo]"""
+    _req_cuda(im)
+    m = torch.empty(size[0], size[1], dtype=torch.uint8, device=im.device)
+    check(lib.gim_dkm_black_mask(_p(im), _p(m), im.shape[2], im.shape[3], size[0], size[1], _stream()), "gim_dkm_black_mask")
+    return m
+
+
+def dkm_match_post(flow, cert, low, black0, black1):
+    """flow [2,H,W,2], cert / low [2,H,W,1] -> warp [H,2W,4], certainty [H,2W]"""
+    _req_cuda(flow, cert, low, black0, black1)
+    _, H, W, _ = flow.shape
+    warp = torch.empty(H, 2 * W, 4, dtype=torch.float32, device=flow.device)
+    certainty = torch.empty(H, 2 * W, dtype=torch.float32, device=flow.device)
+    check(lib.gim_dkm_match_post(_p(flow), _p(cert), _p(low), _p(black0), _p(black1), _p(warp), _p(certainty), H, W, _stream()),
+          "gim_dkm_match_post")
+    return warp, certainty
+
+
+class RowMatrixOperand:
+    """A row buffer [N_alloc, K] used as the [N][K] "weight" operand of gim_conv2d_bn_act (same fields as
+    packing.PackedConv): y[m, n] = sum_k x[m, k] * w[n, k].  N_alloc must cover n rounded up to 64 rows (rows past n
+    only produce columns that are never stored) and K must be a multiple of the 128-byte K slab."""
+    _ktabs = {}
+
+    def __init__(self, w, n, k):
+        from .packing import KTILE_BYTES, NPAD, elem_size, group_elems
+        dt = gim_dtype(w)
+        es, g = elem_size(dt), group_elems(dt)
+        assert w.dim() == 2 and w.stride(1) == 1 and w.stride(0) == k and (k * es) % KTILE_BYTES == 0, (w.shape, w.stride(), k)
+        self.npad = (n + NPAD - 1) // NPAD * NPAD
+        assert w.shape[0] >= self.npad, f"operand needs {self.npad} allocated rows, has {w.shape[0]}"
+        key = (k, dt, str(w.device))
+        if key not in RowMatrixOperand._ktabs:
+            nkt = k * es // KTILE_BYTES
+            gi = torch.arange((nkt + 2) * 8, dtype=torch.int64) * g
+            ent = torch.where(gi < k, gi, torch.full_like(gi, 0xFF000000))
+            ent = torch.where(ent >= 2 ** 31, ent - 2 ** 32, ent).to(torch.int32)
+            RowMatrixOperand._ktabs[key] = ent.to(w.device)
+        self.w, self.bias, self.ktab = w, None, RowMatrixOperand._ktabs[key]
+        self.kh = self.kw = 1
+        self.stride, self.pad = 1, 0
+        self.cin = self.cin_pad = k
+        self.cout = n
+        self.n_store = (n + 3) // 4 * 4 if dt == GIM_F32 else (n + 7) // 8 * 8
+        self.kpad, self.dtype = k, dt
+
+
+def matmul_nt(x, w_rows, n, y):
+    """y[:, :n] = x @ w_rows[:n].T on the igemm (x: row view [M, >=K]; w_rows: [N_alloc, K] contiguous; y: row view)."""
+    pk = RowMatrixOperand(w_rows, n, w_rows.shape[1])
+    M = x.shape[0]
+    conv_rows(x, pk, (1, 1, M, 1, M), y)

@@ -267,6 +267,62 @@ int gim_lg_emit_matches(const int64_t* matches0, const float* mscores0, const in
                         const float* scale1, int64_t* matches, float* scores, float* mkpts0, float* mkpts1,
                         int64_t* m_bids, int B, int M, int N, gim_stream_t stream);
 
+/* ======================================================================================================
+ * gim_dkm path (kernels D1-D9).  Convolutions / 1x1 projections / the cosine-kernel and
+ * posterior-mean products run on gim_conv2d_bn_act (runtime "weights" = row buffers in [N][K] layout).
+ * ====================================================================================================== */
+
+/* torchvision resnet50 `maxpool` (kernel 3, stride 2, padding 1) on NHWC rows -- encoders.py:51. */
+int gim_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int ldx, int ldy, int dtype,
+                     gim_stream_t stream);
+/* F.interpolate(mode='bilinear', align_corners=False) on NHWC rows -- dkm.py:420-425,468-479,518-529,668-701. */
+int gim_resize_bilinear(const void* x, void* y, int B, int h, int w, int Ho, int Wo, int C, int ldx, int ldy,
+                        int dtype, int out_dtype, gim_stream_t stream);
+/* The same resize for the NCHW fp32 input images, written as NHWC rows with cpad channels (images b_off..)
+ * -- dkm.py:668-669,700-701. */
+int gim_resize_image(const float* x, void* y, int B, int C, int h, int w, int Ho, int Wo, int cpad, int b_off,
+                     int out_dtype, gim_stream_t stream);
+/* F.grid_sample(bilinear, zeros padding, align_corners=False): feat [B,h,w,C] at grid [B,Ho,Wo,2] (x, y)
+ * -- dkm.py:89. */
+int gim_grid_sample(const void* feat, const float* grid_xy, void* out, int B, int h, int w, int Ho, int Wo, int C,
+                    int ldf, int ldo, int dtype, gim_stream_t stream);
+/* disp_emb(flow - query_coords): 1x1 conv 2 -> E on the displacement field -- dkm.py:91-101. wgt [E][2]. */
+int gim_dkm_disp_emb(const float* flow, const float* wgt, const float* bias, void* out, int B, int h, int w, int E,
+                     int ldo, int out_dtype, gim_stream_t stream);
+/* local_correlation(x, y, local_radius=r, flow) -- utils/local_correlation.py:5-40: out[b,y,x,k], k = (2r+1)^2
+ * bilinear window taps of f1 around the flow target, dotted with f0, / sqrt(C).  r <= 7. */
+int gim_local_corr(const void* f0, const void* f1, const float* flow, void* out, int B, int h, int w, int C, int r,
+                   int ld0, int ld1, int ldo, int dtype, int out_dtype, gim_stream_t stream);
+/* ConvRefiner.create_block, first half (dw=True): depthwise 5x5 conv (Cout = mult * Cin) + eval BatchNorm + ReLU
+ * -- dkm.py:58-73.  wgt [25][cpad], scale / shift [cpad] fp32 (conv bias and BN folded), zero padded. */
+int gim_dwconv5x5_bn_relu(const void* x, const float* wgt, const float* scale, const float* shift, void* y, int B,
+                          int H, int W, int Cin, int Cout, int cpad, int ldx, int ldy, int dtype, gim_stream_t stream);
+/* CosKernel pieces -- dkm.py:135-144: row L2 norms, and K = exp((dot / (nx ny + eps) - 1) / T) in place on the
+ * dot-product matrix (diag_add = sigma_noise on the diagonal, dkm.py:352). */
+int gim_row_norms(const void* x, float* out, int rows, int C, int ld, int dtype, gim_stream_t stream);
+int gim_cos_kernel_finish(float* k, const float* nx, const float* ny, int B, int n, int m, int ld, float T, float eps,
+                          float diag_add, gim_stream_t stream);
+/* (K_yy + sigma I)^-1 f of GP.forward -- dkm.py:352-359 -- as a blocked fp64 Cholesky solve (the reference inverts
+ * with LU in fp32).  K [B][n][ldk] fp32 with sigma on the diagonal, F [B][n][nrhs] fp32;
+ * Xt [B][nrhs][npad] fp32 = (K^-1 F)^T zero padded: the [N][K] operand layout of gim_conv2d_bn_act. */
+int64_t gim_gp_solve_ws_bytes(int B, int n, int nrhs);
+int gim_gp_solve(const float* K, const float* F, float* Xt, void* ws, int B, int n, int ldk, int nrhs, int npad,
+                 gim_stream_t stream);
+/* CAB -- dkm.py:160-168: global average pool of NHWC rows into out[b][c_off + c]; out = sigmoid(g) * x2 + x1. */
+int gim_global_avgpool(const void* x, float* out, int B, int HW, int C, int ld, int ldo, int c_off, int dtype,
+                       gim_stream_t stream);
+int gim_cab_scale_add(const float* g, const void* x1, const void* x2, void* out, int B, int HW, int C, int ldg, int ld1,
+                      int ld2, int ldo, int dtype, gim_stream_t stream);
+/* Decoder.forward flow / certainty update -- dkm.py:505-514: d rows = [delta certainty, dx, dy]. */
+int gim_dkm_flow_update(float* flow, float* cert, const void* d, int64_t npix, int ldd, float sx, float sy,
+                        int cert_init, int dtype, gim_stream_t stream);
+/* get_placeholder_flow -- dkm.py:437-448. */
+int gim_dkm_grid_coords(float* flow, int B, int h, int w, gim_stream_t stream);
+/* match() tail, symmetric -- dkm.py:693-741; black masks from gim_dkm_black_mask (dkm.py:726-729). */
+int gim_dkm_match_post(const float* flow, const float* cert, const float* low, const uint8_t* black0,
+                       const uint8_t* black1, float* warp, float* certainty, int H, int W, gim_stream_t stream);
+int gim_dkm_black_mask(const float* im, uint8_t* mask, int h, int w, int Ho, int Wo, gim_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,211 @@
+"""GPU parity tests of the gim_dkm building blocks, through the C ABI, against the torch fp32 op /
+oracle/dkm_oracle.py function each one replaces."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import dkm_oracle as O
+
+pytestmark = pytest.mark.gpu
+DTS = ["fp32", "bf16"]
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _tdt(dt):
+    return torch.bfloat16 if dt == "bf16" else torch.float32
+
+
+def _close(got, ref, tol, what=""):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    scale = max(1e-6, ref.abs().max().item())
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, f"{what}: max|err|={err:.3e} scale={scale:.3e} tol={tol}"
+
+
+def _nhwc(x, dt, dev):
+    return x.permute(0, 2, 3, 1).contiguous().to(_tdt(dt)).to(dev)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_maxpool3x3s2(dt):
+    from gim_amd import ops
+    x = torch.randn(2, 64, 21, 30, generator=torch.Generator().manual_seed(1)).to(_tdt(dt)).float()
+    y = ops.maxpool3x3s2(_nhwc(x, dt, _dev()))
+    assert torch.equal(y.float().cpu(), F.max_pool2d(x, 3, 2, 1).permute(0, 2, 3, 1))
+
+
+@pytest.mark.parametrize("size", [(24, 40), (7, 9), (40, 64)])
+def test_resize_bilinear_and_image(size):
+    from gim_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 6, 12, 20, generator=g)
+    ref = F.interpolate(x, size=size, mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    _close(ops.resize_bilinear(_nhwc(x, "fp32", dev), size), ref, 2e-6, "resize")
+    img = torch.rand(2, 3, 33, 47, generator=g)
+    dst = torch.full((3, size[0], size[1], 4), 9.0, device=dev)
+    ops.resize_image(img.to(dev), dst, b_off=1)
+    refi = F.interpolate(img, size=size, mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    _close(dst[1:, ..., :3], refi, 2e-6, "resize_image")
+    assert (dst[1:, ..., 3] == 0).all() and (dst[0] == 9.0).all()
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_grid_sample(dt):
+    from gim_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    feat = torch.randn(2, 16, 9, 13, generator=g).to(_tdt(dt)).float()
+    grid = torch.rand(2, 7, 11, 2, generator=g) * 2.4 - 1.2            # includes out-of-range targets (zeros padding)
+    ref = F.grid_sample(feat, grid, align_corners=False).permute(0, 2, 3, 1)
+    out = torch.zeros(2 * 7 * 11, 32, dtype=_tdt(dt), device=dev)
+    ops.grid_sample(_nhwc(feat, dt, dev), grid.to(dev), out[:, 16:])
+    _close(out[:, 16:].view(2, 7, 11, 16), ref, 1e-2 if dt == "bf16" else 2e-6, "grid_sample")
+    assert (out[:, :16] == 0).all()
+
+
+def test_disp_emb_and_grid_coords():
+    from gim_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(4)
+    b, h, w, E = 2, 9, 14, 6
+    flow = O.grid_coords(b, h, w) + 0.1 * torch.randn(b, 2, h, w, generator=g)
+    wgt, bias = torch.randn(E, 2, generator=g), torch.randn(E, generator=g)
+    ref = F.conv2d(flow - O.grid_coords(b, h, w), wgt[:, :, None, None], bias).permute(0, 2, 3, 1)
+    out = torch.empty(b * h * w, 8, device=dev)
+    ops.dkm_disp_emb(flow.permute(0, 2, 3, 1).contiguous().to(dev), wgt.to(dev), bias.to(dev), out)
+    _close(out[:, :E].view(b, h, w, E), ref, 2e-6, "disp_emb")
+    gc = ops.dkm_grid_coords(b, h, w, dev)
+    assert torch.equal(gc.cpu(), O.grid_coords(b, h, w).permute(0, 2, 3, 1))
+
+
+@pytest.mark.parametrize("dt,r,C", [("fp32", 7, 512), ("fp32", 3, 64), ("bf16", 2, 256), ("fp32", 1, 8)])
+def test_local_corr(dt, r, C):
+    from gim_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    b, h, w = 2, 10, 13
+    f0 = torch.randn(b, C, h, w, generator=g).to(_tdt(dt)).float()
+    f1 = torch.randn(b, C, h, w, generator=g).to(_tdt(dt)).float()
+    flow = O.grid_coords(b, h, w) + 0.3 * torch.randn(b, 2, h, w, generator=g)   # windows partly outside the map
+    ref = O.local_correlation(f0, f1, r, flow).permute(0, 2, 3, 1)
+    K = (2 * r + 1) ** 2
+    out = torch.zeros(b * h * w, (K + 7) // 8 * 8, dtype=torch.float32, device=dev)
+    ops.local_corr(_nhwc(f0, dt, dev), _nhwc(f1, dt, dev), flow.permute(0, 2, 3, 1).contiguous().to(dev), r, out)
+    _close(out[:, :K].view(b, h, w, K), ref, 2e-5, "local_corr")
+
+
+@pytest.mark.parametrize("dt,cin,mult", [("fp32", 24, 1), ("bf16", 40, 1), ("fp32", 12, 2)])
+def test_dwconv5x5_bn_relu(dt, cin, mult):
+    from gim_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(6)
+    b, h, w = 2, 11, 9
+    cout = cin * mult
+    x = torch.randn(b, cin, h, w, generator=g).to(_tdt(dt)).float()
+    wt, bias = torch.randn(cout, 1, 5, 5, generator=g) * 0.2, torch.randn(cout, generator=g) * 0.1
+    gam, bet = 1 + 0.1 * torch.randn(cout, generator=g), 0.1 * torch.randn(cout, generator=g)
+    mean, var = 0.1 * torch.randn(cout, generator=g), 0.5 + torch.rand(cout, generator=g)
+    ref = F.relu(F.batch_norm(F.conv2d(x, wt, bias, padding=2, groups=cin), mean, var, gam, bet, False, 0.0, 1e-5)).permute(0, 2, 3, 1)
+    cpad = (cout + 7) // 8 * 8
+    ldx = max((cin + 7) // 8 * 8, (cpad + mult - 1) // mult if mult > 1 else cpad)
+    ldx = (ldx + 7) // 8 * 8
+    xin = torch.zeros(b, h, w, ldx, dtype=_tdt(dt))
+    xin[..., :cin] = x.permute(0, 2, 3, 1)
+    s = gam / torch.sqrt(var + 1e-5)
+    W = torch.zeros(25, cpad); W[:, :cout] = wt.view(cout, 25).t()
+    sc = torch.zeros(cpad); sc[:cout] = s
+    sh = torch.zeros(cpad); sh[:cout] = bet + (bias - mean) * s
+    y = ops.dwconv5x5_bn_relu(xin.to(dev), W.to(dev), sc.to(dev), sh.to(dev), cin, cout)
+    _close(y[..., :cout], ref, 1e-2 if dt == "bf16" else 2e-6, "dwconv")
+    assert (y[..., cout:] == 0).all()
+
+
+def test_cos_kernel_and_gp_solve():
+    """CosKernel via igemm dot products + finish kernel; (K + sigma I)^-1 f via the fp64 Cholesky solve vs torch.linalg.inv"""
+    from gim_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(7)
+    B, n, C, nrhs = 2, 150, 64, 256
+    x = torch.randn(B, n, C, generator=g)
+    y = x.flip(0)
+    Kyy_ref = O.cos_kernel(y, y)
+    Kxy_ref = O.cos_kernel(x, y)
+    rows = torch.zeros(B * n + 64, C, device=dev)
+    rows[:B * n] = x.reshape(B * n, C).to(dev)
+    nrm = ops.row_norms(rows[:B * n], C)
+    _close(nrm, x.reshape(-1, C).norm(dim=-1), 2e-6, "norms")
+    ld = (n + 63) // 64 * 64
+    Kyy = torch.zeros(B, n, ld, device=dev)
+    Kxy = torch.zeros(B, n, ld, device=dev)
+    for b in range(B):
+        o = 1 - b
+        ops.matmul_nt(rows[o * n:(o + 1) * n], rows[o * n:], n, Kyy[b])
+        ops.matmul_nt(rows[b * n:(b + 1) * n], rows[o * n:], n, Kxy[b])
+    ny = nrm.view(B, n).flip(0).contiguous().view(-1)
+    ops.cos_kernel_finish(Kyy.view(B * n, ld), ny, ny, B, n, n, 0.2, 1e-6, 0.1)
+    ops.cos_kernel_finish(Kxy.view(B * n, ld), nrm, ny, B, n, n, 0.2, 1e-6, 0.0)
+    _close(Kyy[:, :, :n], Kyy_ref + 0.1 * torch.eye(n)[None], 2e-5, "K_yy")
+    _close(Kxy[:, :, :n], Kxy_ref, 2e-5, "K_xy")
+    f = torch.randn(B, n, nrhs, generator=g)
+    ref = torch.linalg.inv((Kyy_ref + 0.1 * torch.eye(n)[None]).double()).matmul(f.double()).float()
+    npad = (n + 31) // 32 * 32
+    Xt = ops.gp_solve(Kyy, f.to(dev).contiguous(), npad)
+    _close(Xt[:, :, :n].transpose(1, 2), ref, 2e-4, "gp_solve")
+    assert (Xt[:, :, n:] == 0).all()
+    # posterior mean on the igemm: mu = K_xy X
+    mu = torch.empty(B, n, nrhs, device=dev)
+    Kp = torch.zeros(B, n, npad, device=dev); Kp[:, :, :n] = Kxy[:, :, :n]
+    for b in range(B):
+        ops.matmul_nt(Kp[b], Xt[b], nrhs, mu[b])
+    _close(mu, Kxy_ref.matmul(ref), 5e-4, "mu")
+
+
+def test_gp_solve_full_size():
+    """n = 2352 (672x896 at stride 16): residual of the solve, SPD matrix with the GP's spectrum"""
+    from gim_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(8)
+    n, nrhs = 2352, 256
+    y = torch.randn(1, n, 48, generator=g)
+    K = (O.cos_kernel(y, y) + 0.1 * torch.eye(n)[None]).to(dev).contiguous()
+    f = torch.randn(1, n, nrhs, generator=g).to(dev)
+    Xt = ops.gp_solve(K, f, 2368)
+    X = Xt[0, :, :n].t().double()
+    res = (K[0].double() @ X - f[0].double()).abs().max().item()
+    assert res < 1e-4 * f.abs().max().item(), res
+
+
+def test_cab_pieces_and_flow_update():
+    from gim_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    b, h, w, C = 2, 6, 7, 32
+    x1, x2 = torch.randn(b, C, h, w, generator=g), torch.randn(b, C, h, w, generator=g)
+    pooled = torch.zeros(b, 2 * C, device=dev)
+    ops.global_avgpool(_nhwc(x1, "fp32", dev), pooled, 0)
+    ops.global_avgpool(_nhwc(x2, "fp32", dev), pooled, C)
+    _close(pooled, torch.cat([x1, x2], 1).mean((2, 3)), 2e-6, "avgpool")
+    gate = torch.randn(b, C, generator=g)
+    out = ops.cab_scale_add(gate.to(dev), _nhwc(x1, "fp32", dev), _nhwc(x2, "fp32", dev))
+    _close(out, (torch.sigmoid(gate)[:, :, None, None] * x2 + x1).permute(0, 2, 3, 1), 2e-6, "cab")
+    out0 = ops.cab_scale_add(gate.to(dev), None, _nhwc(x2, "fp32", dev))
+    _close(out0, (torch.sigmoid(gate)[:, :, None, None] * x2).permute(0, 2, 3, 1), 2e-6, "cab x1=0")
+    flow = torch.randn(b, h, w, 2, generator=g)
+    cert = torch.randn(b, h, w, 1, generator=g)
+    d = torch.randn(b * h * w, 4, generator=g)
+    fl, ce = flow.clone().to(dev), cert.clone().to(dev)
+    ops.dkm_flow_update(fl, ce, d.to(dev), 8 / (4 * 160.0), 8 / (4 * 128.0))
+    dd = d.view(b, h, w, 4)
+    _close(fl, torch.stack((flow[..., 0] + 8 * dd[..., 1] / (4 * 160.0), flow[..., 1] + 8 * dd[..., 2] / (4 * 128.0)), -1), 2e-6, "flow")
+    _close(ce, cert + dd[..., :1], 2e-6, "cert")
+    ops.dkm_flow_update(fl, ce, d.to(dev), 1.0, 1.0, cert_init=True)
+    _close(ce, dd[..., :1], 2e-6, "cert init")

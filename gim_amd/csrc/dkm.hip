@@ -385,6 +385,28 @@ __global__ void black_mask_kernel(const float* __restrict__ im, uint8_t* __restr
     mask[p] = (im[o] < 0.03125f) && (im[hw + o] < 0.03125f) && (im[2 * hw + o] < 0.03125f);
 }
 
+// kde (utils/kde.py:17-26): density[i] = sum_j exp(-|x_i - x_j|^2 / (2 std^2)), x [n,4]; j tiles staged in LDS
+__global__ void __launch_bounds__(256) kde_kernel(const float* __restrict__ x, float* __restrict__ density, int n, float inv2s2) {
+    __shared__ float4 tile[256];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float4 xi = i < n ? *(const float4*)(x + (size_t)i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc = 0.f;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        tile[threadIdx.x] = j < n ? *(const float4*)(x + (size_t)j * 4) : make_float4(1e18f, 1e18f, 1e18f, 1e18f);
+        __syncthreads();
+        const int m = min(256, n - j0);
+        for (int k = 0; k < m; ++k) {
+            const float4 v = tile[k];
+            const float dx = xi.x - v.x, dy = xi.y - v.y, dz = xi.z - v.z, dw = xi.w - v.w;
+            const float dist = sqrtf((dx * dx + dy * dy) + (dz * dz + dw * dw));   // torch.cdist, then ** 2
+            acc += expf(-(dist * dist) * inv2s2);
+        }
+        __syncthreads();
+    }
+    if (i < n) density[i] = acc;
+}
+
 }  // namespace
 
 #define DISPATCH_BF(KERN, bf, grid, ...)                                                                  \
@@ -530,4 +552,10 @@ extern "C" int gim_dkm_black_mask(const float* im, uint8_t* mask, int h, int w, 
     GIM_REQUIRE(im && mask && h > 0 && w > 0 && Ho > 0 && Wo > 0, "dkm_black_mask: bad args");
     hipLaunchKernelGGL(black_mask_kernel, dim3(nblocks((size_t)Ho * Wo, 256)), dim3(256), 0, (hipStream_t)stream, im, mask, h, w, Ho, Wo);
     return gim_check_launch("dkm_black_mask");
+}
+
+extern "C" int gim_kde(const float* x, float* density, int n, float std, gim_stream_t stream) {
+    GIM_REQUIRE(x && density && n > 0 && std > 0.f, "kde: bad args");
+    hipLaunchKernelGGL(kde_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, density, n, 1.0f / (2.0f * std * std));
+    return gim_check_launch("kde");
 }

@@ -1,0 +1,437 @@
+"""gim_dkm on MI355X: the reference's `DKMv3(...)` / `RegressionMatcher` surface
+(`networks/dkm/models/model_zoo/DKMv3.py:5-145`, `networks/dkm/models/dkm.py:537-752`) over hand-written HIP.
+
+Drop-in contract:
+  * `DKMv3(weights, h, w, symmetric=True, sample_mode='threshold_balanced', upsample_preds=...)` returns a module whose
+    `state_dict()` has the reference's 811 tensors (`encoder.net.*` = torchvision resnet50 names, `decoder.*`), so
+    gim_dkm checkpoints load with the reference's prefix rules (`demo.py:364-376`);
+  * `h_resized, w_resized, upsample_preds, upsample_res, symmetric, sample_thresh,
+    use_soft_mutual_nearest_neighbours` are plain attributes read at call time (callers mutate them after
+    construction, `trainer/lightning.py:32-37`);
+  * `match(im1, im2)` takes [1,3,H,W] fp32 tensors and returns `(warp [Hs, 2Ws, 4], certainty [Hs, 2Ws])`,
+    `sample(dense_matches, dense_certainty, num)` returns `([n,4], [n])` like `dkm.py:583-620`.
+  * built: symmetric, non-batched matching with or without the upsampling pass (the configuration gim runs).
+
+The nn.Module tree only holds parameters.  Every stage of `match()` is a libgimhip launch (convolutions, 1x1
+projections and the GP's kernel / posterior products on the implicit-GEMM kernel; the rest in `csrc/dkm.hip`,
+`csrc/gp_solve.hip`).  Constant tables (the GP's Fourier features of the pixel grid) are built once per shape on the
+host with the reference's own fp32 ops.  `sample()` draws with torch's generator like the reference (the RNG contract
+is "same distribution"); the KDE is a HIP kernel.  No CPU / eager fallback.
+"""
+import math
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .._lib import ACT_NONE, ACT_RELU, GIM_BF16, GIM_F32, GimHipError
+from ..packing import cstore, pack_conv, torch_dtype
+
+REFINER = {"16": (512, 128, 7), "8": (512, 64, 3), "4": (256, 32, 2), "2": (64, 16, None), "1": (3, 6, None)}
+GP_DIM, DFN_DIM, FEAT_DIM, HIDDEN_BLOCKS = 256, 384, 256, 8
+
+
+def _refiner_dims(scale):
+    c, e, r = REFINER[scale]
+    in_dim = 2 * c + e + ((2 * r + 1) ** 2 if r else 0)
+    return in_dim, {"2": 128 + 16, "1": 24}.get(scale, in_dim)
+
+
+# ---------------------------------------------------------------------------------------- parameter containers
+class _Bottleneck(nn.Module):
+    def __init__(self, inpl, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inpl, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class _ResNet50(nn.Module):
+    """torchvision resnet50 parameter layout without fc (encoders.py:30-41)"""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        inpl = 64
+        for li, (planes, nblk, stride) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)), start=1):
+            blocks = []
+            for bi in range(nblk):
+                ds = None
+                if bi == 0:
+                    ds = nn.Sequential(nn.Conv2d(inpl, planes * 4, 1, stride, bias=False), nn.BatchNorm2d(planes * 4))
+                blocks.append(_Bottleneck(inpl, planes, stride if bi == 0 else 1, ds))
+                inpl = planes * 4
+            setattr(self, f"layer{li}", nn.Sequential(*blocks))
+
+
+class _Encoder(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.net = _ResNet50()
+
+
+class _RRB(nn.Module):
+    def __init__(self, ci, co):
+        super().__init__()
+        self.conv1 = nn.Conv2d(ci, co, 1)
+        self.conv2 = nn.Conv2d(co, co, 3, 1, 1)
+        self.bn = nn.BatchNorm2d(co)
+        self.conv3 = nn.Conv2d(co, co, 3, 1, 1)
+
+
+class _CAB(nn.Module):
+    def __init__(self, ci, co):
+        super().__init__()
+        self.conv1 = nn.Conv2d(ci, co, 1)
+        self.conv2 = nn.Conv2d(co, co, 1)
+
+
+class _DFN(nn.Module):
+    def __init__(self):
+        super().__init__()
+        ks = ("32", "16")
+        self.feat_input_modules = nn.ModuleDict({k: nn.Conv2d(512, FEAT_DIM, 1) for k in ks})
+        self.pred_input_modules = nn.ModuleDict({k: nn.Identity() for k in ks})
+        self.rrb_d = nn.ModuleDict({k: _RRB(GP_DIM + FEAT_DIM, DFN_DIM) for k in ks})
+        self.cab = nn.ModuleDict({k: _CAB(2 * DFN_DIM, DFN_DIM) for k in ks})
+        self.rrb_u = nn.ModuleDict({k: _RRB(DFN_DIM, DFN_DIM) for k in ks})
+        self.terminal_module = nn.ModuleDict({k: nn.Conv2d(DFN_DIM, 3, 1) for k in ks})
+
+
+class _GP(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.pos_conv = nn.Conv2d(2, GP_DIM, 1)
+
+
+def _block(ci, co):
+    return nn.Sequential(nn.Conv2d(ci, co, 5, 1, 2, groups=ci), nn.BatchNorm2d(co), nn.ReLU(inplace=True), nn.Conv2d(co, co, 1))
+
+
+class _ConvRefiner(nn.Module):
+    def __init__(self, scale):
+        super().__init__()
+        in_dim, hid = _refiner_dims(scale)
+        self.block1 = _block(in_dim, hid)
+        self.hidden_blocks = nn.Sequential(*[_block(hid, hid) for _ in range(HIDDEN_BLOCKS)])
+        self.out_conv = nn.Conv2d(hid, 3, 1)
+        self.disp_emb = nn.Conv2d(2, REFINER[scale][1], 1)
+
+
+class _Decoder(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.embedding_decoder = _DFN()
+        self.gps = nn.ModuleDict({"32": _GP(), "16": _GP()})
+        self.proj = nn.ModuleDict({"16": nn.Conv2d(1024, 512, 1), "32": nn.Conv2d(2048, 512, 1)})
+        self.conv_refiner = nn.ModuleDict({s: _ConvRefiner(s) for s in REFINER})
+
+
+def _bn(m):
+    return (m.weight, m.bias, m.running_mean, m.running_var, m.eps)
+
+
+def _bn_after_bias(bn, bias):
+    """eval BatchNorm applied to conv(x) + bias == BatchNorm with mean - bias applied to conv(x)"""
+    return (bn.weight, bn.bias, bn.running_mean - bias, bn.running_var, bn.eps)
+
+
+class RegressionMatcher(nn.Module):
+    def __init__(self, h=384, w=512, sample_mode="threshold_balanced", upsample_preds=True, symmetric=True, name=None,
+                 use_soft_mutual_nearest_neighbours=False, precision=None, **kwargs):
+        super().__init__()
+        self.encoder = _Encoder()
+        self.decoder = _Decoder()
+        self.w_resized, self.h_resized = w, h
+        self.sample_mode = sample_mode
+        self.upsample_preds = upsample_preds
+        self.symmetric = symmetric
+        self.name = name
+        self.sample_thresh = 0.05
+        self.upsample_res = (1152, 1536)
+        self.use_soft_mutual_nearest_neighbours = use_soft_mutual_nearest_neighbours
+        self.precision = precision or os.environ.get("GIM_PRECISION", "bf16")
+        self._packed = None
+        self._gp_f = {}
+
+    def load_state_dict(self, state_dict, *a, **k):
+        self._packed = None
+        self._gp_f.clear()
+        return super().load_state_dict(state_dict, *a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        self._gp_f = {}
+        return super()._apply(fn, *a, **k)
+
+    # ---- one-time packing -------------------------------------------------------------------------------------
+    def _prepack(self, device):
+        dt = GIM_BF16 if self.precision == "bf16" else GIM_F32
+        P = {}
+        net = self.encoder.net
+        P["stem"] = pack_conv(net.conv1.weight, _bn(net.bn1), dt, device, stride=2, pad=3, cin_pad=cstore(3, dt))
+        for li in (1, 2, 3, 4):
+            for bi, blk in enumerate(getattr(net, f"layer{li}")):
+                p = f"l{li}.{bi}."
+                P[p + "c1"] = pack_conv(blk.conv1.weight, _bn(blk.bn1), dt, device)
+                P[p + "c2"] = pack_conv(blk.conv2.weight, _bn(blk.bn2), dt, device, stride=blk.stride, pad=1)
+                P[p + "c3"] = pack_conv(blk.conv3.weight, _bn(blk.bn3), dt, device)
+                if blk.downsample is not None:
+                    P[p + "ds"] = pack_conv(blk.downsample[0].weight, _bn(blk.downsample[1]), dt, device, stride=blk.stride)
+        dec = self.decoder
+        for s in ("32", "16"):
+            P["proj" + s] = pack_conv(dec.proj[s].weight, None, dt, device, bias=dec.proj[s].bias)
+            e = dec.embedding_decoder
+            P["fin" + s] = pack_conv(e.feat_input_modules[s].weight, None, dt, device, bias=e.feat_input_modules[s].bias)
+            for nm, rrb in (("rd" + s, e.rrb_d[s]), ("ru" + s, e.rrb_u[s])):
+                P[nm + ".c1"] = pack_conv(rrb.conv1.weight, None, dt, device, bias=rrb.conv1.bias)
+                P[nm + ".c2"] = pack_conv(rrb.conv2.weight, _bn_after_bias(rrb.bn, rrb.conv2.bias), dt, device, pad=1)
+                P[nm + ".c3"] = pack_conv(rrb.conv3.weight, None, dt, device, pad=1, bias=rrb.conv3.bias)
+            # CAB's two 1x1 convs act on [b, 768] pooled vectors: fp32 operands (a 2-row GEMM)
+            P["cab" + s + ".c1"] = pack_conv(e.cab[s].conv1.weight, None, GIM_F32, device, bias=e.cab[s].conv1.bias)
+            P["cab" + s + ".c2"] = pack_conv(e.cab[s].conv2.weight, None, GIM_F32, device, bias=e.cab[s].conv2.bias)
+            P["term" + s] = pack_conv(e.terminal_module[s].weight, None, dt, device, bias=e.terminal_module[s].bias)
+        for s, ref in dec.conv_refiner.items():
+            in_dim, hid = _refiner_dims(s)
+            cin_store = cstore(in_dim, dt)
+            blocks = [ref.block1] + list(ref.hidden_blocks)
+            for i, blk in enumerate(blocks):
+                conv, bn, _, pw = blk
+                ci = in_dim if i == 0 else hid
+                cpad = cstore(hid, dt)
+                sc = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+                W = torch.zeros(25, cpad)
+                W[:, :hid] = conv.weight.detach().float().reshape(hid, 25).t().cpu()
+                scale, shift = torch.zeros(cpad), torch.zeros(cpad)
+                scale[:hid] = sc.cpu()
+                shift[:hid] = (bn.bias.detach().float() + (conv.bias.detach().float() - bn.running_mean.detach().float()) * sc).cpu()
+                P[f"cr{s}.{i}.dw"] = (W.to(device), scale.to(device), shift.to(device), ci, hid)
+                P[f"cr{s}.{i}.pw"] = pack_conv(pw.weight, None, dt, device, cin_pad=cpad, bias=pw.bias)
+            P[f"cr{s}.out"] = pack_conv(ref.out_conv.weight, None, dt, device, cin_pad=cstore(hid, dt), bias=ref.out_conv.bias)
+            P[f"cr{s}.emb"] = (ref.disp_emb.weight.detach().float().reshape(-1, 2).contiguous().to(device),
+                               ref.disp_emb.bias.detach().float().contiguous().to(device))
+            P[f"cr{s}.cin_store"] = cin_store
+        self._packed = (P, dt, device)
+
+    def _gp_features(self, s, h, w, device):
+        """f = cos(8 pi pos_conv(coords)) of GP.get_pos_enc (dkm.py:314-331): constant per (scale, h, w); built once on the
+        host with the reference's fp32 ops, cached on the device as rows [h*w, 256]."""
+        key = (s, h, w, str(device))
+        if key not in self._gp_f:
+            ys = torch.linspace(-1 + 1 / h, 1 - 1 / h, h)
+            xs = torch.linspace(-1 + 1 / w, 1 - 1 / w, w)
+            gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+            coords = torch.stack((gx, gy))[None]
+            pc = self.decoder.gps[s].pos_conv
+            f = torch.cos(8 * math.pi * F.conv2d(coords, pc.weight.detach().float().cpu(), pc.bias.detach().float().cpu()))
+            self._gp_f[key] = f[0].permute(1, 2, 0).reshape(h * w, GP_DIM).contiguous().to(device)
+        return self._gp_f[key]
+
+    # ---- stages ---------------------------------------------------------------------------------------------------
+    def _encode(self, P, x):
+        """x [2,hs,ws,cpad] NHWC -> {1: x, 2, 4, 8, 16, 32} (encoders.py:43-62)"""
+        feats = {1: x}
+        x = ops.conv2d(x, P["stem"], ACT_RELU)
+        feats[2] = x
+        x = ops.maxpool3x3s2(x)
+        for li, nblk in ((1, 3), (2, 4), (3, 6), (4, 3)):
+            for bi in range(nblk):
+                p = f"l{li}.{bi}."
+                o = ops.conv2d(x, P[p + "c1"], ACT_RELU)
+                o = ops.conv2d(o, P[p + "c2"], ACT_RELU)
+                idn = ops.conv2d(x, P[p + "ds"], ACT_NONE) if (p + "ds") in P else x
+                x = ops.conv2d(o, P[p + "c3"], ACT_RELU, res=idn)
+            feats[2 ** (li + 1)] = x
+        return feats
+
+    def _rrb(self, P, nm, x):
+        x = ops.conv2d(x, P[nm + ".c1"])
+        r = ops.conv2d(x, P[nm + ".c2"], ACT_RELU)
+        return ops.conv2d(r, P[nm + ".c3"], ACT_RELU, res=x)       # relu(x + conv3(r))
+
+    def _gp(self, P, s, a32, h, w, tdt, out):
+        """GP.forward, no_cov (dkm.py:340-370) for both directions.  a32: fp32 rows [2*hw (+64 slack), 512] of the
+        projected features; writes mu into `out` (row view [2*hw, 256], dtype tdt)."""
+        dev = a32.device
+        n = h * w
+        nrm = ops.row_norms(a32[:2 * n], 512)
+        ld = (n + 63) // 64 * 64
+        npad = (n + 31) // 32 * 32
+        Kyy = torch.zeros(2, n, ld, dtype=torch.float32, device=dev)
+        Kxy = torch.zeros(2, n, max(ld, npad), dtype=torch.float32, device=dev)
+        for b in range(2):
+            o = 1 - b                                        # support of direction b = the other image
+            ops.matmul_nt(a32[o * n:(o + 1) * n], a32[o * n:], n, Kyy[b])
+            ops.matmul_nt(a32[b * n:(b + 1) * n], a32[o * n:], n, Kxy[b])
+        ny = nrm.view(2, n).flip(0).contiguous().view(-1)
+        ops.cos_kernel_finish(Kyy.view(2 * n, ld), ny, ny, 2, n, n, 0.2, 1e-6, 0.1)        # K_yy + sigma_noise I
+        ops.cos_kernel_finish(Kxy.view(2 * n, Kxy.shape[2]), nrm, ny, 2, n, n, 0.2, 1e-6, 0.0)
+        f = self._gp_features(s, h, w, dev)
+        Xt = ops.gp_solve(Kyy, f[None].expand(2, n, GP_DIM).contiguous(), npad)
+        for b in range(2):
+            ops.matmul_nt(Kxy[b][:, :npad], Xt[b], GP_DIM, out[b * n:(b + 1) * n])      # mu = K_xy (K_yy + sigma I)^-1 f
+
+    def _refine(self, P, s, dt, x, y, flow, cert, ins, full_hw):
+        """ConvRefiner.forward + the flow / certainty update of Decoder.forward (dkm.py:75-123, 498-514)."""
+        tdt = torch_dtype(dt)
+        b, h, w, _ = x.shape
+        c, e, r = REFINER[s]
+        in_dim, hid = _refiner_dims(s)
+        cs = P[f"cr{s}.cin_store"]
+        dev = x.device
+        g = 8 if dt == GIM_BF16 else 4
+        if c % g == 0:
+            D = torch.zeros(b, h, w, cs, dtype=tdt, device=dev)
+            rows = D.view(b * h * w, cs)
+            D[..., :c].copy_(x[..., :c])
+            ops.grid_sample(y, flow, rows[:, c:2 * c])
+            ops.dkm_disp_emb(flow, *P[f"cr{s}.emb"], rows[:, 2 * c:])
+            if r:
+                ops.local_corr(x, y, flow, r, rows[:, 2 * c + e:])
+        else:  # scale 1: 3 image channels (stored with padding) -> assemble the 12-channel input with a copy
+            xh = torch.empty(b * h * w, x.shape[3], dtype=tdt, device=dev)
+            ops.grid_sample(y, flow, xh)
+            emb = torch.empty(b * h * w, cstore(e, dt), dtype=tdt, device=dev)
+            ops.dkm_disp_emb(flow, *P[f"cr{s}.emb"], emb)
+            D = torch.zeros(b, h, w, cs, dtype=tdt, device=dev)
+            D[..., :c].copy_(x[..., :c])
+            D[..., c:2 * c].copy_(xh.view(b, h, w, -1)[..., :c])
+            D[..., 2 * c:2 * c + e].copy_(emb.view(b, h, w, -1)[..., :e])
+        d = D
+        for i in range(1 + HIDDEN_BLOCKS):
+            W_, sc, sh, ci, co = P[f"cr{s}.{i}.dw"]
+            d = ops.dwconv5x5_bn_relu(d, W_, sc, sh, ci, co)
+            d = ops.conv2d(d, P[f"cr{s}.{i}.pw"])
+        out = torch.empty(b * h * w, P[f"cr{s}.out"].n_store, dtype=torch.float32, device=dev)
+        ops.linear(d.view(b * h * w, d.shape[3]), P[f"cr{s}.out"], out)
+        ops.dkm_flow_update(flow, cert, out, ins / (4.0 * full_hw[1]), ins / (4.0 * full_hw[0]))
+
+    def _decode(self, P, dt, f1, upsample=False, dense_flow=None, dense_certainty=None):
+        """Decoder.forward on the symmetric pair (f2 = f1 with the two images swapped) -> {scale: (flow, certainty)}"""
+        tdt = torch_dtype(dt)
+        scales = ["8", "4", "2", "1"] if upsample else ["32", "16", "8", "4", "2", "1"]
+        sizes = {s: tuple(f1[s].shape[1:3]) for s in f1}
+        full = sizes[1]
+        dev = f1[1].device
+        coarsest = int(scales[0])
+        if not upsample:
+            flow = ops.dkm_grid_coords(2, *sizes[coarsest], dev)
+            cert = torch.zeros(2, *sizes[coarsest], 1, dtype=torch.float32, device=dev)
+        else:
+            flow = ops.resize_bilinear(dense_flow, sizes[coarsest])
+            cert = ops.resize_bilinear(dense_certainty, sizes[coarsest])
+        old = None
+        out = {}
+        for s in scales:
+            ins = int(s)
+            h, w = sizes[ins]
+            n = h * w
+            a = f1[ins]
+            if s in ("32", "16"):
+                a32 = torch.zeros(2 * n + 64, 512, dtype=torch.float32, device=dev)
+                ops.linear(a.view(2 * n, a.shape[3]), P["proj" + s], a32)
+                if dt == GIM_F32:
+                    a = a32[:2 * n].view(2, h, w, 512)
+                else:
+                    a = torch.empty(2, h, w, 512, dtype=tdt, device=dev)
+                    ops.cast_rows(a32[:2 * n], a.view(2 * n, 512))
+                emb_in = torch.empty(2 * n, FEAT_DIM + GP_DIM, dtype=tdt, device=dev)
+                ops.linear(a.view(2 * n, 512), P["fin" + s], emb_in[:, :FEAT_DIM])
+                self._gp(P, s, a32, h, w, tdt, emb_in[:, FEAT_DIM:])
+                emb = self._rrb(P, "rd" + s, emb_in.view(2, h, w, FEAT_DIM + GP_DIM))
+                if old is not None:
+                    old = ops.resize_bilinear(old, (h, w))
+                # CAB (dkm.py:160-168): global average of cat[context, emb] -> 1x1 -> relu -> 1x1 -> sigmoid gate
+                pooled = torch.zeros(2, 2 * DFN_DIM, dtype=torch.float32, device=dev)
+                if old is not None:
+                    ops.global_avgpool(old, pooled, 0)
+                ops.global_avgpool(emb, pooled, DFN_DIM)
+                g1 = torch.empty(2, DFN_DIM, dtype=torch.float32, device=dev)
+                ops.linear(pooled, P["cab" + s + ".c1"], g1, ACT_RELU)
+                g2 = torch.empty(2, DFN_DIM, dtype=torch.float32, device=dev)
+                ops.linear(g1, P["cab" + s + ".c2"], g2)
+                ctx = ops.cab_scale_add(g2, old, emb)
+                old = self._rrb(P, "ru" + s, ctx)
+                preds = torch.empty(2 * n, P["term" + s].n_store, dtype=torch.float32, device=dev)
+                ops.linear(old.view(2 * n, DFN_DIM), P["term" + s], preds)
+                flow = torch.zeros(2, h, w, 2, dtype=torch.float32, device=dev)
+                cert = torch.empty(2, h, w, 1, dtype=torch.float32, device=dev)
+                ops.dkm_flow_update(flow, cert, preds, 1.0, 1.0, cert_init=True)       # flow, certainty = preds
+            if s in REFINER:
+                self._refine(P, s, dt, a, a.flip(0).contiguous(), flow, cert, ins, full)
+            out[ins] = (flow, cert)
+            if s != "1":
+                flow = ops.resize_bilinear(flow, sizes[ins // 2])
+                cert = ops.resize_bilinear(cert, sizes[ins // 2])
+        return out
+
+    def _pass(self, P, dt, im1, im2, hs, ws, **kw):
+        x = torch.empty(2, hs, ws, cstore(3, dt), dtype=torch_dtype(dt), device=im1.device)
+        ops.resize_image(im1, x, 0)
+        ops.resize_image(im2, x, 1)
+        return self._decode(P, dt, self._encode(P, x), **kw)
+
+    @torch.no_grad()
+    def match(self, im1_path, im2_path, *args, batched=False):
+        """RegressionMatcher.match (dkm.py:654-752), tensor inputs as gim calls it (`demo.py:433`, `lightning.py:135`)."""
+        if batched or not self.symmetric:
+            raise NotImplementedError("gim runs DKM symmetric and non-batched (lightning.py:30-37); only that path is built")
+        im1, im2 = im1_path, im2_path
+        if not im1.is_cuda:
+            raise GimHipError("gim_amd DKM needs device (cuda/HIP) tensors: there is no CPU fallback")
+        if im1.shape[0] != 1 or im1.shape[1] != 3:
+            raise GimHipError(f"match() takes [1,3,H,W] images, got {tuple(im1.shape)}")
+        dev = im1.device
+        want = GIM_BF16 if self.precision == "bf16" else GIM_F32
+        if self._packed is None or self._packed[2] != dev or self._packed[1] != want:
+            self._prepack(dev)
+        P, dt, _ = self._packed
+        im1, im2 = im1.contiguous().float(), im2.contiguous().float()
+        hs, ws = self.h_resized, self.w_resized
+        if hs % 32 or ws % 32:
+            raise GimHipError(f"h_resized / w_resized must be multiples of 32, got {(hs, ws)}")
+        cor = self._pass(P, dt, im1, im2, hs, ws)
+        if self.upsample_preds:
+            hs, ws = self.upsample_res
+        low = ops.resize_bilinear(cor[16][1], (hs, ws))
+        if self.upsample_preds:
+            cor = self._pass(P, dt, im1, im2, hs, ws, upsample=True, dense_flow=cor[1][0], dense_certainty=cor[1][1])
+        flow, cert = cor[1]
+        warp, certainty = ops.dkm_match_post(flow, cert, low, ops.dkm_black_mask(im1, (hs, ws)), ops.dkm_black_mask(im2, (hs, ws)))
+        self._debug = {"corresps": cor}
+        return warp, certainty
+
+    @torch.no_grad()
+    def sample(self, dense_matches, dense_certainty, num=10000):
+        """RegressionMatcher.sample (dkm.py:583-620).  The two multinomial draws use torch's generator on the tensors'
+        device like the reference's; the balanced-sampling density is the HIP KDE kernel."""
+        if "threshold" not in self.sample_mode or "balanced" not in self.sample_mode:
+            raise NotImplementedError("gim uses sample_mode='threshold_balanced' (DKMv3.py:5)")
+        cert = dense_certainty.clone()
+        cert_ = dense_certainty.reshape(-1)
+        cert[cert > self.sample_thresh] = 1
+        matches, cert = dense_matches.reshape(-1, 4), cert.reshape(-1)
+        if not cert.sum():
+            cert = cert + 1e-8
+        good = torch.multinomial(cert, num_samples=min(4 * num, len(cert)), replacement=False)
+        gm, gc = matches[good].contiguous(), cert_[good]
+        density = ops.kde(gm, 0.1)
+        p = 1 / (density + 1)
+        p[density < 10] = 1e-7
+        bal = torch.multinomial(p, num_samples=min(num, len(gc)), replacement=False)
+        return gm[bal], gc[bal]
+
+
+def DKMv3(weights, h, w, symmetric=True, sample_mode="threshold_balanced", **kwargs):
+    """`networks/dkm/models/model_zoo/DKMv3.py:5-145`; `weights` is ignored like in the reference (load_state_dict is
+    the caller's job, `demo.py:364-376`)."""
+    kwargs.pop("device", None)
+    return RegressionMatcher(h=h, w=w, name="DKMv3", sample_mode=sample_mode, symmetric=symmetric, **kwargs)

@@ -584,3 +584,12 @@ def matmul_nt(x, w_rows, n, y):
     pk = RowMatrixOperand(w_rows, n, w_rows.shape[1])
     M = x.shape[0]
     conv_rows(x, pk, (1, 1, M, 1, M), y)
+
+
+def kde(x, std):
+    """x [n,4] fp32 contiguous -> density [n]"""
+    _req_cuda(x)
+    assert x.dim() == 2 and x.shape[1] == 4 and x.is_contiguous() and x.dtype == torch.float32
+    d = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    check(lib.gim_kde(_p(x), _p(d), x.shape[0], std, _stream()), "gim_kde")
+    return d

@@ -322,6 +322,9 @@ int gim_dkm_grid_coords(float* flow, int B, int h, int w, gim_stream_t stream);
 int gim_dkm_match_post(const float* flow, const float* cert, const float* low, const uint8_t* black0,
                        const uint8_t* black1, float* warp, float* certainty, int H, int W, gim_stream_t stream);
 int gim_dkm_black_mask(const float* im, uint8_t* mask, int h, int w, int Ho, int Wo, gim_stream_t stream);
+/* kde(x, std) -- utils/kde.py:17-26: density[i] = sum_j exp(-cdist(x_i, x_j)^2 / (2 std^2)), x [n,4] fp32 (the
+ * reference materialises the n x n distance matrix: 1.6 GB at n = 20000). */
+int gim_kde(const float* x, float* density, int n, float std, gim_stream_t stream);
 
 #ifdef __cplusplus
 }

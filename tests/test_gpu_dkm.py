@@ -209,3 +209,75 @@ def test_cab_pieces_and_flow_update():
     _close(ce, cert + dd[..., :1], 2e-6, "cert")
     ops.dkm_flow_update(fl, ce, d.to(dev), 1.0, 1.0, cert_init=True)
     _close(ce, dd[..., :1], 2e-6, "cert init")
+
+
+def test_kde():
+    from gim_amd import ops
+    x = torch.rand(700, 4, generator=torch.Generator().manual_seed(10)) * 2 - 1
+    _close(ops.kde(x.to(_dev()), 0.1), O.kde(x, 0.1), 2e-5, "kde")
+
+
+# ------------------------------------------------------------------------------------------------ whole model
+def _model(precision, h, w, up):
+    from gim_amd.dkm import DKMv3
+    m = DKMv3(None, h, w, upsample_preds=up is not None, precision=precision)
+    if up is not None:
+        m.upsample_res = up
+    m.load_state_dict(O.make_state_dict(0))
+    return m.eval()
+
+
+def test_match_golden_fp32(golden_dir):
+    """engine (fp32 mode) vs the reference's own DKMv3.match() at 128x160 -> 192x256 (tests/golden/dkm_match.npz)"""
+    import os
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, "dkm_match.npz"))
+    H, W = (int(v) for v in g["hw"])
+    up = tuple(int(v) for v in g["up"])
+    im0, im1 = O.seeded_pair(*(int(v) for v in g["image_hw"]), int(g["seed"]))
+    dev = _dev()
+    # low-resolution pass only: intermediate flow / certainty of both directions
+    m = _model("fp32", H, W, None)
+    warp_lo, cert_lo = m.match(im0.to(dev), im1.to(dev))
+    cor = m._debug["corresps"]
+    _close(cor[16][0].permute(0, 3, 1, 2), torch.as_tensor(g["flow16"]), 2e-3, "flow16")
+    _close(cor[16][1].permute(0, 3, 1, 2), torch.as_tensor(g["cert16"]), 2e-3, "cert16")
+    _close(cor[1][0].permute(0, 3, 1, 2), torch.as_tensor(g["flow1"]), 2e-3, "flow1")
+    assert warp_lo.shape == (H, 2 * W, 4) and cert_lo.shape == (H, 2 * W)
+    # with the upsampling pass
+    m2 = _model("fp32", H, W, up)
+    warp, cert = m2.match(im0.to(dev), im1.to(dev))
+    assert warp.shape == (up[0], 2 * up[1], 4) and cert.shape == (up[0], 2 * up[1])
+    _close(warp[::2, ::2], torch.as_tensor(g["warp"]), 2e-3, "warp")
+    _close(cert[::2, ::2], torch.as_tensor(g["certainty"]), 5e-3, "certainty")
+    qc = O.grid_coords(1, *up).permute(0, 2, 3, 1)[0]
+    assert torch.equal(warp[:, :up[1], :2].cpu(), qc) and torch.equal(warp[:, up[1]:, 2:].cpu(), qc)
+
+
+def test_match_bf16_and_sample():
+    """throughput mode stays close to the fp32 oracle on this (smooth) problem; sample() contract"""
+    dev = _dev()
+    im0, im1 = O.seeded_pair(160, 224, 3)
+    sd = O.make_state_dict(0)
+    with torch.no_grad():
+        warp_ref, cert_ref = O.match(sd, im0, im1, 128, 160, None)
+    m = _model("bf16", 128, 160, None)
+    warp, cert = m.match(im0.to(dev), im1.to(dev))
+    assert torch.isfinite(warp).all() and torch.isfinite(cert).all()
+    assert (warp.cpu() - warp_ref).abs().mean().item() < 0.02 and (cert.cpu() - cert_ref).abs().mean().item() < 0.05
+    torch.manual_seed(0)
+    sm, sc = m.sample(warp, cert, 300)
+    assert sm.shape == (300, 4) and sc.shape == (300,) and sm.abs().max() <= 1
+    # every sample is a row of the dense warp with its own certainty
+    flat = warp.reshape(-1, 4)
+    idx = torch.randint(0, 300, (5,))
+    for i in idx.tolist():
+        hit = (flat == sm[i]).all(-1)
+        assert hit.any() and (cert.reshape(-1)[hit] == sc[i]).any()
+
+
+def test_dkm_no_cpu_fallback():
+    from gim_amd._lib import GimHipError
+    m = _model("fp32", 128, 160, None)
+    with pytest.raises(GimHipError):
+        m.match(torch.rand(1, 3, 64, 64), torch.rand(1, 3, 64, 64))

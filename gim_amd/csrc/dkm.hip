@@ -260,6 +260,76 @@ __global__ void dwconv5x5_kernel(const void* __restrict__ x, const float* __rest
     ElemIO<BF16>::st4(y, pix * ldy + co, acc);
 }
 
+// depthwise 5x5, channel multiplier 1, register-tiled: one thread = 4 consecutive output pixels x one 16-byte channel
+// group.  Each of the 5 input rows is read once as 8 pixels (x0-2 .. x0+5) and feeds all 4 outputs: 40 16-byte loads
+// per 4 outputs instead of 100 8-byte loads (the first version, 40 % of match() time on the 1152x1536 / 576x768 maps).
+template <bool BF16>
+__global__ void __launch_bounds__(256) dwconv5x5_tiled_kernel(const void* __restrict__ x, const float* __restrict__ wgt,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              void* __restrict__ y, int B, int H, int W, int CG, int cpad, int ldx,
+                                                              int ldy) {
+    constexpr int G = BF16 ? 8 : 4;
+    const int WS = (W + 3) / 4;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * H * WS * CG) return;
+    const int cg = (int)(idx % CG);
+    const size_t strip = idx / CG;
+    const int xs = (int)(strip % WS) * 4, Y = (int)((strip / WS) % H), b = (int)(strip / ((size_t)WS * H));
+    const int co = cg * G;
+    float acc[4][G];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int e = 0; e < G; ++e) acc[p][e] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy) {
+        const int yy = Y + dy - 2;
+        if (yy < 0 || yy >= H) continue;
+        float in[8][G];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int xx = xs + q - 2;
+            const bool ok = xx >= 0 && xx < W;
+            const size_t off = (((size_t)b * H + yy) * W + (ok ? xx : 0)) * ldx + co;
+#pragma unroll
+            for (int e = 0; e < G; e += 4) {
+                float4 v = ElemIO<BF16>::ld4(x, off + e);
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                in[q][e] = v.x; in[q][e + 1] = v.y; in[q][e + 2] = v.z; in[q][e + 3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+            float wv[G];
+#pragma unroll
+            for (int e = 0; e < G; e += 4) {
+                const float4 w4 = *(const float4*)(wgt + (size_t)(dy * 5 + dx) * cpad + co + e);
+                wv[e] = w4.x; wv[e + 1] = w4.y; wv[e + 2] = w4.z; wv[e + 3] = w4.w;
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int e = 0; e < G; ++e) acc[p][e] = fmaf(in[p + dx][e], wv[e], acc[p][e]);
+        }
+    }
+    float sc[G], sh[G];
+#pragma unroll
+    for (int e = 0; e < G; e += 4) {
+        const float4 a = *(const float4*)(scale + co + e), c = *(const float4*)(shift + co + e);
+        sc[e] = a.x; sc[e + 1] = a.y; sc[e + 2] = a.z; sc[e + 3] = a.w;
+        sh[e] = c.x; sh[e + 1] = c.y; sh[e + 2] = c.z; sh[e + 3] = c.w;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (xs + p >= W) break;
+        const size_t o = (((size_t)b * H + Y) * W + xs + p) * ldy + co;
+#pragma unroll
+        for (int e = 0; e < G; e += 4)
+            ElemIO<BF16>::st4(y, o + e, make_float4(fmaxf(acc[p][e] * sc[e] + sh[e], 0.f), fmaxf(acc[p][e + 1] * sc[e + 1] + sh[e + 1], 0.f),
+                                                    fmaxf(acc[p][e + 2] * sc[e + 2] + sh[e + 2], 0.f), fmaxf(acc[p][e + 3] * sc[e + 3] + sh[e + 3], 0.f)));
+    }
+}
+
 // one wave per row: L2 norm of x[r, 0:C]
 template <bool BF16>
 __global__ void __launch_bounds__(256) row_norms_kernel(const void* __restrict__ x, float* __restrict__ out, int rows, int C, int ld) {
@@ -289,16 +359,19 @@ __global__ void cos_kernel_finish_kernel(float* __restrict__ k, const float* __r
     k[row * ld + j] = v;
 }
 
-// mean over the spatial positions of NHWC rows: out[b, c] (fp32), one thread per (b, c); rows are L2-resident maps
+// mean over the spatial positions of NHWC rows: out[b, c_off + c] (fp32).  Workgroup = (image, 64-channel chunk):
+// 4 pixel phases x 64 channels, coalesced along the channels, LDS reduction over the phases.
 template <bool BF16>
-__global__ void global_avgpool_kernel(const void* __restrict__ x, float* __restrict__ out, int B, int HW, int C, int ld, int ldo,
-                                      int c_off) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * C) return;
-    const int c = idx % C, b = idx / C;
+__global__ void __launch_bounds__(256) global_avgpool_kernel(const void* __restrict__ x, float* __restrict__ out, int B, int HW, int C,
+                                                             int ld, int ldo, int c_off) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
     float s = 0.f;
-    for (int p = 0; p < HW; ++p) s += ElemIO<BF16>::ld(x, ((size_t)b * HW + p) * ld + c);
-    out[(size_t)b * ldo + c_off + c] = s / (float)HW;
+    if (c < C)
+        for (int p = ph; p < HW; p += 4) s += ElemIO<BF16>::ld(x, ((size_t)b * HW + p) * ld + c);
+    red[ph][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (ph == 0 && c < C) out[(size_t)b * ldo + c_off + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) / (float)HW;
 }
 
 // CAB: out = sigmoid(g[b, c]) * x2 + x1     (dkm.py:165-168)
@@ -488,6 +561,12 @@ extern "C" int gim_dwconv5x5_bn_relu(const void* x, const float* wgt, const floa
     GIM_REQUIRE(cpad % 4 == 0 && cpad >= Cout && ldx % 4 == 0 && ldy % 4 == 0 && ldy >= cpad, "dwconv5x5: cpad / strides");
     GIM_REQUIRE((int64_t)ldx * (Cout / Cin) >= cpad, "dwconv5x5: input rows too narrow for the padded channel range");
     hipStream_t s = (hipStream_t)stream;
+    const int G = dtype == GIM_BF16 ? 8 : 4;
+    if (Cout == Cin && cpad % G == 0 && ldx % G == 0 && ldy % G == 0) {
+        const dim3 gt(nblocks((size_t)B * H * ((W + 3) / 4) * (cpad / G), 256));
+        DISPATCH_BF(dwconv5x5_tiled_kernel, dtype == GIM_BF16, gt, x, wgt, scale, shift, y, B, H, W, cpad / G, cpad, ldx, ldy);
+        return gim_check_launch("dwconv5x5_tiled");
+    }
     const dim3 grid(nblocks((size_t)B * H * W * (cpad / 4), 256));
     DISPATCH_BF(dwconv5x5_kernel, dtype == GIM_BF16, grid, x, wgt, scale, shift, y, B, H, W, cpad / 4, Cout / Cin, cpad, ldx, ldy);
     return gim_check_launch("dwconv5x5");
@@ -512,7 +591,7 @@ extern "C" int gim_global_avgpool(const void* x, float* out, int B, int HW, int 
                                   gim_stream_t stream) {
     GIM_REQUIRE(x && out && B > 0 && HW > 0 && C > 0, "global_avgpool: bad args");
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(nblocks((size_t)B * C, 256));
+    const dim3 grid((C + 63) / 64, B);
     DISPATCH_BF(global_avgpool_kernel, dtype == GIM_BF16, grid, x, out, B, HW, C, ld, ldo, c_off);
     return gim_check_launch("global_avgpool");
 }

@@ -23,59 +23,105 @@ __global__ void to_f64_kernel(const float* __restrict__ src, double* __restrict_
     dst[r * ldd + c] = (double)src[r * lds_ + c];
 }
 
-// unblocked Cholesky of the nb x nb diagonal block at k0 (lower), one workgroup per matrix
-__global__ void __launch_bounds__(256) potrf_diag_kernel(double* __restrict__ A, int n, int k0, int nb, size_t bstride, int* __restrict__ info) {
-    __shared__ double T[NB][NB + 1];
-    double* a = A + blockIdx.x * bstride;
-    const int t = threadIdx.x;
-    for (int e = t; e < nb * nb; e += 256) {
-        const int i = e / nb, j = e - i * nb;
-        T[i][j] = j <= i ? a[(size_t)(k0 + i) * n + k0 + j] : 0.0;
-    }
-    __syncthreads();
-    for (int j = 0; j < nb; ++j) {
-        if (t == 0) {
-            const double d = T[j][j];
-            if (!(d > 0.0)) { info[blockIdx.x] = k0 + j + 1; T[j][j] = 1.0; } else T[j][j] = sqrt(d);
-        }
-        __syncthreads();
-        const double djj = T[j][j];
-        for (int i = j + 1 + t; i < nb; i += 256) T[i][j] /= djj;
-        __syncthreads();
-        // trailing update of the block: T[i][c] -= T[i][j] * T[c][j] for j < c <= i
-        const int m = nb - j - 1;
-        for (int e = t; e < m * m; e += 256) {
-            const int i = j + 1 + e / m, c = j + 1 + e % m;
-            if (c <= i) T[i][c] -= T[i][j] * T[c][j];
-        }
-        __syncthreads();
-    }
-    for (int e = t; e < nb * nb; e += 256) {
-        const int i = e / nb, j = e - i * nb;
-        if (j <= i) a[(size_t)(k0 + i) * n + k0 + j] = T[i][j];
-    }
+// Cholesky of the nb x nb diagonal block at k0 (lower) and its inverse Linv = L_kk^-1 ([NB][NB] row-major, zero
+// padded), by ONE WAVE per matrix: lane i owns row i (factorisation, left-looking) / column j (inversion).  No
+// workgroup barriers -- LDS accesses of a wave execute in order -- so the 64 dependent column steps cost ~100 cycles
+// each instead of three __syncthreads (the 256-thread version took 166 us per block and ran on 2 CUs while the
+// whole chip waited).  With Linv every triangular solve against the diagonal block becomes a 64-wide GEMM.
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+    const int lo = __shfl(__double2loint(v), src, 64), hi = __shfl(__double2hiint(v), src, 64);
+    return __hiloint2double(hi, lo);
 }
 
-// rows below the diagonal block: A[i][k0 : k0+nb] <- A[i][k0 : k0+nb] L_kk^-T   (one thread per row)
-__global__ void __launch_bounds__(256) trsm_panel_kernel(double* __restrict__ A, int n, int k0, int nb, size_t bstride) {
-    __shared__ double L[NB][NB + 1];
-    double* a = A + blockIdx.y * bstride;
-    const int t = threadIdx.x;
-    for (int e = t; e < nb * nb; e += 256) {
-        const int i = e / nb, j = e - i * nb;
-        L[i][j] = j <= i ? a[(size_t)(k0 + i) * n + k0 + j] : 0.0;
+__global__ void __launch_bounds__(64) potrf_diag_kernel(double* __restrict__ A, int n, int k0, int nb, size_t bstride, int* __restrict__ info,
+                                                        double* __restrict__ Linv, size_t lstride) {
+    __shared__ double T[NB][NB + 1];
+    __shared__ double Ti[NB][NB + 1];
+    double* a = A + blockIdx.x * bstride;
+    const int lane = threadIdx.x;
+    for (int r = 0; r < NB; ++r) T[r][lane] = (r < nb && lane <= r) ? a[(size_t)(k0 + r) * n + k0 + lane] : 0.0;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const int i = lane;
+    for (int j = 0; j < nb; ++j) {
+        // dot products of this wave are latency chains on LDS reads: unrolled by 8 with split accumulators so that the
+        // reads of a group are issued together
+        double s0 = T[i][j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int k = 0;
+        for (; k + 8 <= j; k += 8) {
+            const double a0 = T[i][k], a1 = T[i][k + 1], a2 = T[i][k + 2], a3 = T[i][k + 3], a4 = T[i][k + 4], a5 = T[i][k + 5], a6 = T[i][k + 6], a7 = T[i][k + 7];
+            const double b0 = T[j][k], b1 = T[j][k + 1], b2 = T[j][k + 2], b3 = T[j][k + 3], b4 = T[j][k + 4], b5 = T[j][k + 5], b6 = T[j][k + 6], b7 = T[j][k + 7];
+            s0 -= a0 * b0; s1 -= a1 * b1; s2 -= a2 * b2; s3 -= a3 * b3;
+            s0 -= a4 * b4; s1 -= a5 * b5; s2 -= a6 * b6; s3 -= a7 * b7;
+        }
+        for (; k < j; ++k) s0 -= T[i][k] * T[j][k];
+        double sdot = (s0 + s1) + (s2 + s3);
+        double d = shfl_f64(sdot, j);
+        if (!(d > 0.0)) { if (lane == 0) info[blockIdx.x] = k0 + j + 1; d = 1.0; }
+        d = sqrt(d);
+        if (i >= j && i < nb) T[i][j] = i == j ? d : sdot / d;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    for (int r = 0; r < nb; ++r)
+        if (lane <= r) a[(size_t)(k0 + r) * n + k0 + lane] = T[r][lane];
+    // inverse, column j = lane: forward substitution L x = e_j
+    const int j = lane;
+    for (int r = 0; r < NB; ++r) {
+        double v = 0.0;
+        if (j < nb && r < nb && r >= j) {
+            double v0 = r == j ? 1.0 : 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+            int k = j;
+            for (; k + 8 <= r; k += 8) {
+                const double a0 = T[r][k], a1 = T[r][k + 1], a2 = T[r][k + 2], a3 = T[r][k + 3], a4 = T[r][k + 4], a5 = T[r][k + 5], a6 = T[r][k + 6], a7 = T[r][k + 7];
+                const double b0 = Ti[k][j], b1 = Ti[k + 1][j], b2 = Ti[k + 2][j], b3 = Ti[k + 3][j], b4 = Ti[k + 4][j], b5 = Ti[k + 5][j], b6 = Ti[k + 6][j], b7 = Ti[k + 7][j];
+                v0 -= a0 * b0; v1 -= a1 * b1; v2 -= a2 * b2; v3 -= a3 * b3;
+                v0 -= a4 * b4; v1 -= a5 * b5; v2 -= a6 * b6; v3 -= a7 * b7;
+            }
+            for (; k < r; ++k) v0 -= T[r][k] * Ti[k][j];
+            v = ((v0 + v1) + (v2 + v3)) / T[r][r];
+        }
+        Ti[r][j] = v;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    double* li = Linv + blockIdx.x * lstride + (size_t)(k0 / NB) * NB * NB;
+    for (int r = 0; r < NB; ++r) li[r * NB + lane] = Ti[r][lane];
+}
+
+// C[i][c] = sum_k Aop[i][k] * Bop[k][c]  (same operand conventions as gemm_sub_kernel, K = 64, plain store)
+__global__ void __launch_bounds__(256) gemm_set_kernel(double* __restrict__ C, int ldc, const double* __restrict__ Am, int lda, int ta,
+                                                       const double* __restrict__ Bm, int ldb, int tb, int M, int N, int kk,
+                                                       size_t cstride, size_t astride, size_t bstride2) {
+    __shared__ double As[NB][NB + 1];
+    __shared__ double Bs[NB][NB + 1];
+    const int t = threadIdx.x, i0 = blockIdx.y * NB, c0 = blockIdx.x * NB;
+    double* c = C + blockIdx.z * cstride;
+    const double* am = Am + blockIdx.z * astride;
+    const double* bm = Bm + blockIdx.z * bstride2;
+    for (int e = t; e < NB * NB; e += 256) {
+        if (ta) { const int k = e / NB, i = e - k * NB; As[i][k] = (k < kk && i0 + i < M) ? am[(size_t)k * lda + i0 + i] : 0.0; }
+        else { const int i = e / NB, k = e - i * NB; As[i][k] = (k < kk && i0 + i < M) ? am[(size_t)(i0 + i) * lda + k] : 0.0; }
+        if (tb) { const int cc = e / NB, k = e - cc * NB; Bs[k][cc] = (k < kk && c0 + cc < N) ? bm[(size_t)(c0 + cc) * ldb + k] : 0.0; }
+        else { const int k = e / NB, cc = e - k * NB; Bs[k][cc] = (k < kk && c0 + cc < N) ? bm[(size_t)k * ldb + c0 + cc] : 0.0; }
     }
     __syncthreads();
-    const int i = k0 + nb + blockIdx.x * 256 + t;
-    if (i >= n) return;
-    double* row = a + (size_t)i * n + k0;
-    double x[NB];
-    for (int j = 0; j < nb; ++j) {
-        double v = row[j];
-        for (int k = 0; k < j; ++k) v -= x[k] * L[j][k];
-        x[j] = v / L[j][j];
+    const int ti = (t >> 4) * 4, tc = (t & 15) * 4;
+    double acc[4][4] = {};
+    for (int k = 0; k < kk; ++k) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { av[x] = As[ti + x][k]; bv[x] = Bs[k][tc + x]; }
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) acc[x][y] = fma(av[x], bv[y], acc[x][y]);
     }
-    for (int j = 0; j < nb; ++j) row[j] = x[j];
+    __syncthreads();  // all reads of the inputs are done: C may alias Am or Bm (in-place panel / right-hand-side update)
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const int i = i0 + ti + x, cc = c0 + tc + y;
+            if (i < M && cc < N) c[(size_t)i * ldc + cc] = acc[x][y];
+        }
 }
 
 // C[i][c] -= sum_k Aop[i][k] * Bop[k][c] on a 64 x 64 tile, K = kk (<= 64).
@@ -119,39 +165,6 @@ __global__ void __launch_bounds__(256) gemm_sub_kernel(double* __restrict__ C, i
         }
 }
 
-// diagonal-block triangular solves with the right-hand sides: one thread per RHS column.
-//   forward : Y[k0+j][c] = (F[k0+j][c] - sum_{k<j} L[j][k] Y[k0+k][c]) / L[j][j]
-//   backward: X[k0+j][c] = (Y[k0+j][c] - sum_{k>j} L[k][j] X[k0+k][c]) / L[j][j]
-__global__ void __launch_bounds__(256) tri_solve_diag_kernel(const double* __restrict__ A, double* __restrict__ F, int n, int nrhs,
-                                                             int k0, int nb, int backward, size_t astride, size_t fstride) {
-    __shared__ double L[NB][NB + 1];
-    const double* a = A + blockIdx.y * astride;
-    double* f = F + blockIdx.y * fstride;
-    const int t = threadIdx.x;
-    for (int e = t; e < nb * nb; e += 256) {
-        const int i = e / nb, j = e - i * nb;
-        L[i][j] = j <= i ? a[(size_t)(k0 + i) * n + k0 + j] : 0.0;
-    }
-    __syncthreads();
-    const int c = blockIdx.x * 256 + t;
-    if (c >= nrhs) return;
-    double x[NB];
-    if (!backward) {
-        for (int j = 0; j < nb; ++j) {
-            double v = f[(size_t)(k0 + j) * nrhs + c];
-            for (int k = 0; k < j; ++k) v -= L[j][k] * x[k];
-            x[j] = v / L[j][j];
-        }
-    } else {
-        for (int j = nb - 1; j >= 0; --j) {
-            double v = f[(size_t)(k0 + j) * nrhs + c];
-            for (int k = j + 1; k < nb; ++k) v -= L[k][j] * x[k];
-            x[j] = v / L[j][j];
-        }
-    }
-    for (int j = 0; j < nb; ++j) f[(size_t)(k0 + j) * nrhs + c] = x[j];
-}
-
 // Xt[b][c][i] = (float) X[b][i][c], zero for i in [n, npad)
 __global__ void store_xt_kernel(const double* __restrict__ X, float* __restrict__ Xt, int n, int nrhs, int npad) {
     __shared__ float tile[64][65];
@@ -173,17 +186,22 @@ inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 }  // namespace
 
 extern "C" int64_t gim_gp_solve_ws_bytes(int B, int n, int nrhs) {
-    return (int64_t)(al((size_t)B * n * n * 8) + al((size_t)B * n * nrhs * 8) + 256);
+    const size_t nblk = (n + NB - 1) / NB;
+    return (int64_t)(al((size_t)B * n * n * 8) + al((size_t)B * n * nrhs * 8) + al((size_t)B * nblk * NB * NB * 8) +
+                     al((size_t)B * NB * (nrhs > n ? nrhs : n) * 8) + 256);
 }
 
 extern "C" int gim_gp_solve(const float* K, const float* F, float* Xt, void* ws, int B, int n, int ldk, int nrhs, int npad,
                             gim_stream_t stream) {
     GIM_REQUIRE(K && F && Xt && ws && B > 0 && B <= 16 && n > 0 && nrhs > 0 && ldk >= n && npad >= n, "gp_solve: bad args");
     hipStream_t s = (hipStream_t)stream;
+    const size_t nblk_ = (n + NB - 1) / NB;
     double* A = (double*)ws;
-    double* R = (double*)((char*)ws + al((size_t)B * n * n * 8));
-    int* info = (int*)((char*)R + al((size_t)B * n * nrhs * 8));
-    const size_t as = (size_t)n * n, fs = (size_t)n * nrhs;
+    double* R = (double*)((char*)A + al((size_t)B * n * n * 8));
+    double* Li = (double*)((char*)R + al((size_t)B * n * nrhs * 8));
+    double* Tmp = (double*)((char*)Li + al((size_t)B * nblk_ * NB * NB * 8));   // [B][NB][max(n, nrhs)] staging for in-place products
+    int* info = (int*)((char*)Tmp + al((size_t)B * NB * (nrhs > n ? nrhs : n) * 8));
+    const size_t as = (size_t)n * n, fs = (size_t)n * nrhs, ls = nblk_ * NB * NB, ts = (size_t)NB * (nrhs > n ? nrhs : n);
     if (hipMemsetAsync(info, 0, 64, s) != hipSuccess) return gim_check_launch("gp_solve memset");
     for (int b = 0; b < B; ++b) {
         hipLaunchKernelGGL(to_f64_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, s, K + (size_t)b * n * ldk, A + b * as, n, n, ldk, n);
@@ -192,34 +210,40 @@ extern "C" int gim_gp_solve(const float* K, const float* F, float* Xt, void* ws,
     // ---- A = L L^T (lower triangle of A overwritten by L) ----
     for (int k0 = 0; k0 < n; k0 += NB) {
         const int nb = n - k0 < NB ? n - k0 : NB;
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(B), dim3(256), 0, s, A, n, k0, nb, as, info);
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(B), dim3(64), 0, s, A, n, k0, nb, as, info, Li, ls);
         const int m = n - k0 - nb;
         if (m <= 0) break;
-        hipLaunchKernelGGL(trsm_panel_kernel, dim3((m + 255) / 256, B), dim3(256), 0, s, A, n, k0, nb, as);
         const int tiles = (m + NB - 1) / NB;
         const size_t off = (size_t)(k0 + nb) * n;
-        // trailing[i][j] -= sum_k P[i][k] P[j][k],  P = A[k0+nb :, k0 : k0+nb]
+        const double* li = Li + (size_t)(k0 / NB) * NB * NB;
+        // panel: P <- P L_kk^-T  = P (Linv)^T : Aop = P rows, Bop[k][c] = Linv[c][k]   (in place: one 64-column tile per row tile)
+        hipLaunchKernelGGL(gemm_set_kernel, dim3(1, tiles, B), dim3(256), 0, s, A + off + k0, n, A + off + k0, n, 0, li, NB, 1, m, nb, nb, as, as, ls);
+        // trailing[i][j] -= sum_k P[i][k] P[j][k]
         hipLaunchKernelGGL(gemm_sub_kernel, dim3(tiles, tiles, B), dim3(256), 0, s, A + off + k0 + nb, n, A + off + k0, n, 0,
                            A + off + k0, n, 1, m, m, nb, 1, as, as, as);
     }
     // ---- L Y = F ----
+    const int ctiles = (nrhs + NB - 1) / NB;
     for (int k0 = 0; k0 < n; k0 += NB) {
         const int nb = n - k0 < NB ? n - k0 : NB;
-        hipLaunchKernelGGL(tri_solve_diag_kernel, dim3((nrhs + 255) / 256, B), dim3(256), 0, s, A, R, n, nrhs, k0, nb, 0, as, fs);
+        const double* li = Li + (size_t)(k0 / NB) * NB * NB;
+        // Y_k = Linv F_k
+        // in place: every workgroup stages its whole 64 x 64 column tile of F_k in LDS before it stores
+        hipLaunchKernelGGL(gemm_set_kernel, dim3(ctiles, 1, B), dim3(256), 0, s, R + (size_t)k0 * nrhs, nrhs, li, NB, 0, R + (size_t)k0 * nrhs, nrhs, 0, nb, nrhs, nb, fs, ls, fs);
         const int m = n - k0 - nb;
         if (m <= 0) break;
-        // F[i][c] -= sum_k L[i][k0+k] Y[k0+k][c]  for i >= k0+nb
-        hipLaunchKernelGGL(gemm_sub_kernel, dim3((nrhs + NB - 1) / NB, (m + NB - 1) / NB, B), dim3(256), 0, s, R + (size_t)(k0 + nb) * nrhs, nrhs,
+        hipLaunchKernelGGL(gemm_sub_kernel, dim3(ctiles, (m + NB - 1) / NB, B), dim3(256), 0, s, R + (size_t)(k0 + nb) * nrhs, nrhs,
                            A + (size_t)(k0 + nb) * n + k0, n, 0, R + (size_t)k0 * nrhs, nrhs, 0, m, nrhs, nb, 0, fs, as, fs);
     }
     // ---- L^T X = Y ----
     const int nblk = (n + NB - 1) / NB;
     for (int kb = nblk - 1; kb >= 0; --kb) {
         const int k0 = kb * NB, nb = n - k0 < NB ? n - k0 : NB;
-        hipLaunchKernelGGL(tri_solve_diag_kernel, dim3((nrhs + 255) / 256, B), dim3(256), 0, s, A, R, n, nrhs, k0, nb, 1, as, fs);
+        const double* li = Li + (size_t)kb * NB * NB;
+        // X_k = Linv^T Y_k : Aop[i][k] = Linv[k][i]
+        hipLaunchKernelGGL(gemm_set_kernel, dim3(ctiles, 1, B), dim3(256), 0, s, R + (size_t)k0 * nrhs, nrhs, li, NB, 1, R + (size_t)k0 * nrhs, nrhs, 0, nb, nrhs, nb, fs, ls, fs);
         if (k0 == 0) break;
-        // Y[i][c] -= sum_k L[k0+k][i] X[k0+k][c]  for i < k0   (Aop transposed)
-        hipLaunchKernelGGL(gemm_sub_kernel, dim3((nrhs + NB - 1) / NB, (k0 + NB - 1) / NB, B), dim3(256), 0, s, R, nrhs,
+        hipLaunchKernelGGL(gemm_sub_kernel, dim3(ctiles, (k0 + NB - 1) / NB, B), dim3(256), 0, s, R, nrhs,
                            A + (size_t)k0 * n, n, 1, R + (size_t)k0 * nrhs, nrhs, 0, k0, nrhs, nb, 0, fs, as, fs);
     }
     hipLaunchKernelGGL(store_xt_kernel, dim3((npad + 63) / 64, (nrhs + 63) / 64, B), dim3(256), 0, s, R, Xt, n, nrhs, npad);

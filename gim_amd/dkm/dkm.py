@@ -411,22 +411,22 @@ class RegressionMatcher(nn.Module):
 
     @torch.no_grad()
     def sample(self, dense_matches, dense_certainty, num=10000):
-        """RegressionMatcher.sample (dkm.py:583-620).  The two multinomial draws use torch's generator on the tensors'
-        device like the reference's; the balanced-sampling density is the HIP KDE kernel."""
+        """RegressionMatcher.sample (dkm.py:583-620).  The two multinomial draws are `gim_weighted_sample` (seeded from
+        torch's generator), the balanced-sampling density is the HIP KDE kernel; samples come back as an unordered set."""
         if "threshold" not in self.sample_mode or "balanced" not in self.sample_mode:
             raise NotImplementedError("gim uses sample_mode='threshold_balanced' (DKMv3.py:5)")
-        cert = dense_certainty.clone()
-        cert_ = dense_certainty.reshape(-1)
-        cert[cert > self.sample_thresh] = 1
-        matches, cert = dense_matches.reshape(-1, 4), cert.reshape(-1)
-        if not cert.sum():
-            cert = cert + 1e-8
-        good = torch.multinomial(cert, num_samples=min(4 * num, len(cert)), replacement=False)
+        cert_ = dense_certainty.reshape(-1).contiguous()
+        matches = dense_matches.reshape(-1, 4)
+        cert = torch.where(cert_ > self.sample_thresh, torch.ones_like(cert_), cert_)   # dense_certainty[> thresh] = 1
+        n_pos = int((cert > 0).sum())
+        if n_pos == 0:
+            cert, n_pos = cert + 1e-8, cert.numel()
+        seeds = torch.randint(0, 2 ** 31 - 1, (2,)).tolist()      # torch's (CPU) generator: torch.manual_seed makes sample() reproducible
+        good = ops.weighted_sample(cert, min(4 * num, cert.numel(), n_pos), seeds[0])
         gm, gc = matches[good].contiguous(), cert_[good]
         density = ops.kde(gm, 0.1)
-        p = 1 / (density + 1)
-        p[density < 10] = 1e-7
-        bal = torch.multinomial(p, num_samples=min(num, len(gc)), replacement=False)
+        p = torch.where(density < 10, torch.full_like(density, 1e-7), 1 / (density + 1))
+        bal = ops.weighted_sample(p.contiguous(), min(num, len(gc)), seeds[1])
         return gm[bal], gc[bal]
 
 

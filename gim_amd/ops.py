@@ -593,3 +593,14 @@ def kde(x, std):
     d = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
     check(lib.gim_kde(_p(x), _p(d), x.shape[0], std, _stream()), "gim_kde")
     return d
+
+
+def weighted_sample(w, k, seed):
+    """k distinct indices drawn with probability ~ w (fp32 [n], >= k positive entries) -> int64 [k], unordered"""
+    _req_cuda(w)
+    assert w.dim() == 1 and w.is_contiguous() and w.dtype == torch.float32
+    n = w.shape[0]
+    ws = torch.empty(lib.gim_weighted_sample_ws_bytes(n), dtype=torch.uint8, device=w.device)
+    out = torch.empty(k, dtype=torch.int64, device=w.device)
+    check(lib.gim_weighted_sample(_p(w), _p(out), _p(ws), n, k, seed & 0xffffffff, _stream()), "gim_weighted_sample")
+    return out

@@ -325,6 +325,11 @@ int gim_dkm_black_mask(const float* im, uint8_t* mask, int h, int w, int Ho, int
 /* kde(x, std) -- utils/kde.py:17-26: density[i] = sum_j exp(-cdist(x_i, x_j)^2 / (2 std^2)), x [n,4] fp32 (the
  * reference materialises the n x n distance matrix: 1.6 GB at n = 20000). */
 int gim_kde(const float* x, float* density, int n, float std, gim_stream_t stream);
+/* torch.multinomial(w, k, replacement=False) of RegressionMatcher.sample -- dkm.py:603-605,617-619: k distinct indices
+ * drawn with probability proportional to w (exponential clocks + radix-select top-k), as an unordered set; reproducible
+ * from `seed`.  Needs at least k positive weights. */
+int64_t gim_weighted_sample_ws_bytes(int n);
+int gim_weighted_sample(const float* w, int64_t* out, void* ws, int n, int k, uint32_t seed, gim_stream_t stream);
 
 #ifdef __cplusplus
 }

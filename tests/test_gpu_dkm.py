@@ -281,3 +281,29 @@ def test_dkm_no_cpu_fallback():
     m = _model("fp32", 128, 160, None)
     with pytest.raises(GimHipError):
         m.match(torch.rand(1, 3, 64, 64), torch.rand(1, 3, 64, 64))
+
+
+def test_weighted_sample():
+    """k distinct indices, only where w > 0, reproducible from the seed, frequencies proportional to w"""
+    from gim_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    n = 200000
+    w = torch.rand(n, generator=g)
+    w[::3] = 0.0
+    w[1::7] = 1.0
+    wd = w.to(dev)
+    a = ops.weighted_sample(wd, 5000, 1234).cpu()
+    b = ops.weighted_sample(wd, 5000, 1234).cpu()
+    c = ops.weighted_sample(wd, 5000, 99).cpu()
+    assert a.unique().numel() == 5000 and (w[a] > 0).all()
+    assert torch.equal(a.sort().values, b.sort().values) and not torch.equal(a.sort().values, c.sort().values)
+    # inclusion frequency ~ w for k << n: mean weight of the sample = E[w^2] / E[w]
+    exp = (w * w).sum() / w.sum()
+    assert abs(w[a].mean().item() - exp.item()) < 0.02
+    # taking everything positive returns exactly the positive set
+    small = torch.tensor([0.0, 0.5, 0.0, 2.0, 1.0, 0.0, 3.0], device=dev)
+    assert sorted(ops.weighted_sample(small, 4, 7).cpu().tolist()) == [1, 3, 4, 6]
+    # heavy items first: with one dominant weight it is (almost) always drawn
+    dom = torch.full((1000,), 1e-4, device=dev); dom[123] = 10.0
+    assert all(123 in ops.weighted_sample(dom, 5, s).cpu().tolist() for s in range(20))

@@ -263,7 +263,7 @@ __global__ void dwconv5x5_kernel(const void* __restrict__ x, const float* __rest
 // depthwise 5x5, channel multiplier 1, register-tiled: one thread = 4 consecutive output pixels x one 16-byte channel
 // group.  Each of the 5 input rows is read once as 8 pixels (x0-2 .. x0+5) and feeds all 4 outputs: 40 16-byte loads
 // per 4 outputs instead of 100 8-byte loads (the first version, 40 % of match() time on the 1152x1536 / 576x768 maps).
-template <bool BF16>
+template <bool BF16, int MULT>
 __global__ void __launch_bounds__(256) dwconv5x5_tiled_kernel(const void* __restrict__ x, const float* __restrict__ wgt,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               void* __restrict__ y, int B, int H, int W, int CG, int cpad, int ldx,
@@ -290,12 +290,22 @@ __global__ void __launch_bounds__(256) dwconv5x5_tiled_kernel(const void* __rest
         for (int q = 0; q < 8; ++q) {
             const int xx = xs + q - 2;
             const bool ok = xx >= 0 && xx < W;
-            const size_t off = (((size_t)b * H + yy) * W + (ok ? xx : 0)) * ldx + co;
+            const size_t off = (((size_t)b * H + yy) * W + (ok ? xx : 0)) * ldx + co / MULT;
+            if constexpr (MULT == 1) {
 #pragma unroll
-            for (int e = 0; e < G; e += 4) {
-                float4 v = ElemIO<BF16>::ld4(x, off + e);
-                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                in[q][e] = v.x; in[q][e + 1] = v.y; in[q][e + 2] = v.z; in[q][e + 3] = v.w;
+                for (int e = 0; e < G; e += 4) {
+                    float4 v = ElemIO<BF16>::ld4(x, off + e);
+                    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    in[q][e] = v.x; in[q][e + 1] = v.y; in[q][e + 2] = v.z; in[q][e + 3] = v.w;
+                }
+            } else {  // channel multiplier 2: output channels (2c, 2c+1) read input channel c
+#pragma unroll
+                for (int e = 0; e < G; e += 8) {
+                    float4 v = ElemIO<BF16>::ld4(x, off + e / 2);
+                    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    in[q][e] = v.x; in[q][e + 1] = v.x; in[q][e + 2] = v.y; in[q][e + 3] = v.y;
+                    if (e + 4 < G) { in[q][e + 4] = v.z; in[q][e + 5] = v.z; in[q][e + 6] = v.w; in[q][e + 7] = v.w; }
+                }
             }
         }
 #pragma unroll
@@ -562,9 +572,15 @@ extern "C" int gim_dwconv5x5_bn_relu(const void* x, const float* wgt, const floa
     GIM_REQUIRE((int64_t)ldx * (Cout / Cin) >= cpad, "dwconv5x5: input rows too narrow for the padded channel range");
     hipStream_t s = (hipStream_t)stream;
     const int G = dtype == GIM_BF16 ? 8 : 4;
-    if (Cout == Cin && cpad % G == 0 && ldx % G == 0 && ldy % G == 0) {
+    const int mult = Cout / Cin;
+    if ((mult == 1 || (mult == 2 && dtype == GIM_BF16)) && cpad % G == 0 && ldx % 4 == 0 && ldy % G == 0 && (mult == 2 || ldx % G == 0)) {
         const dim3 gt(nblocks((size_t)B * H * ((W + 3) / 4) * (cpad / G), 256));
-        DISPATCH_BF(dwconv5x5_tiled_kernel, dtype == GIM_BF16, gt, x, wgt, scale, shift, y, B, H, W, cpad / G, cpad, ldx, ldy);
+        if (mult == 1) {
+            if (dtype == GIM_BF16) hipLaunchKernelGGL((dwconv5x5_tiled_kernel<true, 1>), gt, dim3(256), 0, s, x, wgt, scale, shift, y, B, H, W, cpad / G, cpad, ldx, ldy);
+            else hipLaunchKernelGGL((dwconv5x5_tiled_kernel<false, 1>), gt, dim3(256), 0, s, x, wgt, scale, shift, y, B, H, W, cpad / G, cpad, ldx, ldy);
+        } else {
+            hipLaunchKernelGGL((dwconv5x5_tiled_kernel<true, 2>), gt, dim3(256), 0, s, x, wgt, scale, shift, y, B, H, W, cpad / G, cpad, ldx, ldy);
+        }
         return gim_check_launch("dwconv5x5_tiled");
     }
     const dim3 grid(nblocks((size_t)B * H * W * (cpad / 4), 256));

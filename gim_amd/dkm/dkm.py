@@ -161,6 +161,7 @@ class RegressionMatcher(nn.Module):
         self.precision = precision or os.environ.get("GIM_PRECISION", "bf16")
         self._packed = None
         self._gp_f = {}
+        self.overlap_gp = os.environ.get("GIM_DKM_OVERLAP", "1") != "0"   # GP on a side stream beside the high-res encoder
 
     def load_state_dict(self, state_dict, *a, **k):
         self._packed = None
@@ -314,7 +315,26 @@ class RegressionMatcher(nn.Module):
         ops.linear(d.view(b * h * w, d.shape[3]), P[f"cr{s}.out"], out)
         ops.dkm_flow_update(flow, cert, out, ins / (4.0 * full_hw[1]), ins / (4.0 * full_hw[0]))
 
-    def _decode(self, P, dt, f1, upsample=False, dense_flow=None, dense_certainty=None):
+    def _gp_stage(self, P, dt, f1, s):
+        """proj + GP + DFN feature input of scale s: everything of that scale that does not depend on the coarser
+        scales' flow (GP.forward ignores `dense_flow`, dkm.py:340) -> (projected features a, emb_in = [feats | mu])"""
+        tdt = torch_dtype(dt)
+        feat = f1[int(s)]
+        _, h, w, _ = feat.shape
+        n, dev = h * w, feat.device
+        a32 = torch.zeros(2 * n + 64, 512, dtype=torch.float32, device=dev)
+        ops.linear(feat.view(2 * n, feat.shape[3]), P["proj" + s], a32)
+        if dt == GIM_F32:
+            a = a32[:2 * n].view(2, h, w, 512)
+        else:
+            a = torch.empty(2, h, w, 512, dtype=tdt, device=dev)
+            ops.cast_rows(a32[:2 * n], a.view(2 * n, 512))
+        emb_in = torch.empty(2 * n, FEAT_DIM + GP_DIM, dtype=tdt, device=dev)
+        ops.linear(a.view(2 * n, 512), P["fin" + s], emb_in[:, :FEAT_DIM])
+        self._gp(P, s, a32, h, w, tdt, emb_in[:, FEAT_DIM:])
+        return a, emb_in
+
+    def _decode(self, P, dt, f1, upsample=False, dense_flow=None, dense_certainty=None, gp=None):
         """Decoder.forward on the symmetric pair (f2 = f1 with the two images swapped) -> {scale: (flow, certainty)}"""
         tdt = torch_dtype(dt)
         scales = ["8", "4", "2", "1"] if upsample else ["32", "16", "8", "4", "2", "1"]
@@ -336,16 +356,7 @@ class RegressionMatcher(nn.Module):
             n = h * w
             a = f1[ins]
             if s in ("32", "16"):
-                a32 = torch.zeros(2 * n + 64, 512, dtype=torch.float32, device=dev)
-                ops.linear(a.view(2 * n, a.shape[3]), P["proj" + s], a32)
-                if dt == GIM_F32:
-                    a = a32[:2 * n].view(2, h, w, 512)
-                else:
-                    a = torch.empty(2, h, w, 512, dtype=tdt, device=dev)
-                    ops.cast_rows(a32[:2 * n], a.view(2 * n, 512))
-                emb_in = torch.empty(2 * n, FEAT_DIM + GP_DIM, dtype=tdt, device=dev)
-                ops.linear(a.view(2 * n, 512), P["fin" + s], emb_in[:, :FEAT_DIM])
-                self._gp(P, s, a32, h, w, tdt, emb_in[:, FEAT_DIM:])
+                a, emb_in = gp[s] if gp is not None else self._gp_stage(P, dt, f1, s)
                 emb = self._rrb(P, "rd" + s, emb_in.view(2, h, w, FEAT_DIM + GP_DIM))
                 if old is not None:
                     old = ops.resize_bilinear(old, (h, w))
@@ -373,11 +384,16 @@ class RegressionMatcher(nn.Module):
                 cert = ops.resize_bilinear(cert, sizes[ins // 2])
         return out
 
-    def _pass(self, P, dt, im1, im2, hs, ws, **kw):
+    def _images(self, dt, im1, im2, hs, ws):
         x = torch.empty(2, hs, ws, cstore(3, dt), dtype=torch_dtype(dt), device=im1.device)
         ops.resize_image(im1, x, 0)
         ops.resize_image(im2, x, 1)
-        return self._decode(P, dt, self._encode(P, x), **kw)
+        return x
+
+    def _side_stream(self, dev):
+        if getattr(self, "_side", None) is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
 
     @torch.no_grad()
     def match(self, im1_path, im2_path, *args, batched=False):
@@ -398,12 +414,30 @@ class RegressionMatcher(nn.Module):
         hs, ws = self.h_resized, self.w_resized
         if hs % 32 or ws % 32:
             raise GimHipError(f"h_resized / w_resized must be multiples of 32, got {(hs, ws)}")
-        cor = self._pass(P, dt, im1, im2, hs, ws)
+        # The GP of both coarse scales (a latency-bound chain of ~150 small launches) only needs the low-resolution
+        # pyramid: it runs on a side stream while the main stream encodes the high-resolution images.
+        pyr = self._encode(P, self._images(dt, im1, im2, hs, ws))
+        main = torch.cuda.current_stream()
+        if self.upsample_preds and self.overlap_gp:
+            side = self._side_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                gp = {s: self._gp_stage(P, dt, pyr, s) for s in ("32", "16")}
+            for s in ("32", "16"):
+                pyr[int(s)].record_stream(side)
+                for t in gp[s]:
+                    t.record_stream(main)
+            pyr_hi = self._encode(P, self._images(dt, im1, im2, *self.upsample_res))
+            main.wait_stream(side)
+        else:
+            gp = None
+            pyr_hi = self._encode(P, self._images(dt, im1, im2, *self.upsample_res)) if self.upsample_preds else None
+        cor = self._decode(P, dt, pyr, gp=gp)
         if self.upsample_preds:
             hs, ws = self.upsample_res
         low = ops.resize_bilinear(cor[16][1], (hs, ws))
         if self.upsample_preds:
-            cor = self._pass(P, dt, im1, im2, hs, ws, upsample=True, dense_flow=cor[1][0], dense_certainty=cor[1][1])
+            cor = self._decode(P, dt, pyr_hi, upsample=True, dense_flow=cor[1][0], dense_certainty=cor[1][1])
         flow, cert = cor[1]
         warp, certainty = ops.dkm_match_post(flow, cert, low, ops.dkm_black_mask(im1, (hs, ws)), ops.dkm_black_mask(im2, (hs, ws)))
         self._debug = {"corresps": cor}

@@ -103,7 +103,7 @@ def test_local_corr(dt, r, C):
     _close(out[:, :K].view(b, h, w, K), ref, 2e-5, "local_corr")
 
 
-@pytest.mark.parametrize("dt,cin,mult", [("fp32", 24, 1), ("bf16", 40, 1), ("fp32", 12, 2)])
+@pytest.mark.parametrize("dt,cin,mult", [("fp32", 24, 1), ("bf16", 40, 1), ("fp32", 12, 2), ("bf16", 12, 2)])
 def test_dwconv5x5_bn_relu(dt, cin, mult):
     from gim_amd import ops
     dev = _dev()

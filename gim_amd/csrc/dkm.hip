@@ -263,6 +263,7 @@ __global__ void dwconv5x5_kernel(const void* __restrict__ x, const float* __rest
 // depthwise 5x5, channel multiplier 1, register-tiled: one thread = 4 consecutive output pixels x one 16-byte channel
 // group.  Each of the 5 input rows is read once as 8 pixels (x0-2 .. x0+5) and feeds all 4 outputs: 40 16-byte loads
 // per 4 outputs instead of 100 8-byte loads (the first version, 40 % of match() time on the 1152x1536 / 576x768 maps).
+// (An LDS-staged 16 x 8 tile variant with the weights in LDS was measured slower: 46.9 vs 44.4 ms per match().)
 template <bool BF16, int MULT>
 __global__ void __launch_bounds__(256) dwconv5x5_tiled_kernel(const void* __restrict__ x, const float* __restrict__ wgt,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,

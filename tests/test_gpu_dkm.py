@@ -103,12 +103,14 @@ def test_local_corr(dt, r, C):
     _close(out[:, :K].view(b, h, w, K), ref, 2e-5, "local_corr")
 
 
-@pytest.mark.parametrize("dt,cin,mult", [("fp32", 24, 1), ("bf16", 40, 1), ("fp32", 12, 2), ("bf16", 12, 2)])
-def test_dwconv5x5_bn_relu(dt, cin, mult):
+@pytest.mark.parametrize("dt,cin,mult,hw", [("fp32", 24, 1, (11, 9)), ("bf16", 40, 1, (11, 9)), ("fp32", 12, 2, (11, 9)),
+                                             ("bf16", 12, 2, (11, 9)), ("bf16", 144, 1, (70, 93)), ("fp32", 24, 1, (67, 80)),
+                                             ("bf16", 1377, 1, (42, 100))])
+def test_dwconv5x5_bn_relu(dt, cin, mult, hw):
     from gim_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(6)
-    b, h, w = 2, 11, 9
+    b, (h, w) = 2, hw
     cout = cin * mult
     x = torch.randn(b, cin, h, w, generator=g).to(_tdt(dt)).float()
     wt, bias = torch.randn(cout, 1, 5, 5, generator=g) * 0.2, torch.randn(cout, generator=g) * 0.1

@@ -264,12 +264,18 @@ __global__ void dwconv5x5_kernel(const void* __restrict__ x, const float* __rest
 // group.  Each of the 5 input rows is read once as 8 pixels (x0-2 .. x0+5) and feeds all 4 outputs: 40 16-byte loads
 // per 4 outputs instead of 100 8-byte loads (the first version, 40 % of match() time on the 1152x1536 / 576x768 maps).
 // (An LDS-staged 16 x 8 tile variant with the weights in LDS was measured slower: 46.9 vs 44.4 ms per match().)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
 template <bool BF16, int MULT>
 __global__ void __launch_bounds__(256) dwconv5x5_tiled_kernel(const void* __restrict__ x, const float* __restrict__ wgt,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               void* __restrict__ y, int B, int H, int W, int CG, int cpad, int ldx,
                                                               int ldy) {
-    constexpr int G = BF16 ? 8 : 4;
+    // The first register-tiled version was VALU-bound (1500 instructions per thread: 770 scalar FMAs, 450 v_cndmask for
+    // the border zeroing of unpacked values, 64-bit address arithmetic per load): accumulate in float2 (v_pk_fma_f32),
+    // zero the raw 16-byte group instead of its 8 unpacked values, one row base + 32-bit pixel offsets.
+    constexpr int G = BF16 ? 8 : 4, ES = BF16 ? 2 : 4, G2 = G / 2;
+    constexpr int LG = G / MULT;                 // input channels feeding this output group
     const int WS = (W + 3) / 4;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)B * H * WS * CG) return;
@@ -277,67 +283,76 @@ __global__ void __launch_bounds__(256) dwconv5x5_tiled_kernel(const void* __rest
     const size_t strip = idx / CG;
     const int xs = (int)(strip % WS) * 4, Y = (int)((strip / WS) % H), b = (int)(strip / ((size_t)WS * H));
     const int co = cg * G;
-    float acc[4][G];
+    f32x2_t acc[4][G2];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int e = 0; e < G; ++e) acc[p][e] = 0.f;
+        for (int e = 0; e < G2; ++e) acc[p][e] = (f32x2_t){0.f, 0.f};
+    const unsigned pstride = (unsigned)ldx * ES;
 #pragma unroll
     for (int dy = 0; dy < 5; ++dy) {
         const int yy = Y + dy - 2;
         if (yy < 0 || yy >= H) continue;
-        float in[8][G];
+        const char* rp = (const char*)x + (((size_t)b * H + yy) * W) * pstride + (size_t)(co / MULT) * ES;
+        f32x2_t in[8][G2];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int xx = xs + q - 2;
             const bool ok = xx >= 0 && xx < W;
-            const size_t off = (((size_t)b * H + yy) * W + (ok ? xx : 0)) * ldx + co / MULT;
-            if constexpr (MULT == 1) {
-#pragma unroll
-                for (int e = 0; e < G; e += 4) {
-                    float4 v = ElemIO<BF16>::ld4(x, off + e);
-                    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    in[q][e] = v.x; in[q][e + 1] = v.y; in[q][e + 2] = v.z; in[q][e + 3] = v.w;
+            const unsigned off = (unsigned)(ok ? xx : 0) * pstride;
+            if constexpr (BF16) {
+                if constexpr (MULT == 1) {
+                    uint4 u = *(const uint4*)(rp + off);
+                    if (!ok) u = make_uint4(0u, 0u, 0u, 0u);
+                    in[q][0] = (f32x2_t){__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u)};
+                    in[q][1] = (f32x2_t){__uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+                    in[q][2] = (f32x2_t){__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u)};
+                    in[q][3] = (f32x2_t){__uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+                } else {  // multiplier 2: output channels (2c, 2c+1) read input channel c
+                    uint2 u = *(const uint2*)(rp + off);
+                    if (!ok) u = make_uint2(0u, 0u);
+                    const float c0 = __uint_as_float(u.x << 16), c1 = __uint_as_float(u.x & 0xffff0000u);
+                    const float c2 = __uint_as_float(u.y << 16), c3 = __uint_as_float(u.y & 0xffff0000u);
+                    in[q][0] = (f32x2_t){c0, c0}; in[q][1] = (f32x2_t){c1, c1}; in[q][2] = (f32x2_t){c2, c2}; in[q][3] = (f32x2_t){c3, c3};
                 }
-            } else {  // channel multiplier 2: output channels (2c, 2c+1) read input channel c
-#pragma unroll
-                for (int e = 0; e < G; e += 8) {
-                    float4 v = ElemIO<BF16>::ld4(x, off + e / 2);
-                    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    in[q][e] = v.x; in[q][e + 1] = v.x; in[q][e + 2] = v.y; in[q][e + 3] = v.y;
-                    if (e + 4 < G) { in[q][e + 4] = v.z; in[q][e + 5] = v.z; in[q][e + 6] = v.w; in[q][e + 7] = v.w; }
-                }
+            } else {
+                static_assert(BF16 || MULT == 1, "fp32 tiled kernel: multiplier 1 only");
+                float4 v = *(const float4*)(rp + off);
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                in[q][0] = (f32x2_t){v.x, v.y}; in[q][1] = (f32x2_t){v.z, v.w};
             }
         }
+        (void)LG;
 #pragma unroll
         for (int dx = 0; dx < 5; ++dx) {
-            float wv[G];
+            f32x2_t wv[G2];
 #pragma unroll
-            for (int e = 0; e < G; e += 4) {
-                const float4 w4 = *(const float4*)(wgt + (size_t)(dy * 5 + dx) * cpad + co + e);
-                wv[e] = w4.x; wv[e + 1] = w4.y; wv[e + 2] = w4.z; wv[e + 3] = w4.w;
+            for (int e = 0; e < G2; e += 2) {
+                const float4 w4 = *(const float4*)(wgt + (size_t)(dy * 5 + dx) * cpad + co + 2 * e);
+                wv[e] = (f32x2_t){w4.x, w4.y}; wv[e + 1] = (f32x2_t){w4.z, w4.w};
             }
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
-                for (int e = 0; e < G; ++e) acc[p][e] = fmaf(in[p + dx][e], wv[e], acc[p][e]);
+                for (int e = 0; e < G2; ++e) acc[p][e] = __builtin_elementwise_fma(in[p + dx][e], wv[e], acc[p][e]);
         }
     }
-    float sc[G], sh[G];
+    f32x2_t sc[G2], sh[G2];
 #pragma unroll
-    for (int e = 0; e < G; e += 4) {
-        const float4 a = *(const float4*)(scale + co + e), c = *(const float4*)(shift + co + e);
-        sc[e] = a.x; sc[e + 1] = a.y; sc[e + 2] = a.z; sc[e + 3] = a.w;
-        sh[e] = c.x; sh[e + 1] = c.y; sh[e + 2] = c.z; sh[e + 3] = c.w;
+    for (int e = 0; e < G2; e += 2) {
+        const float4 a = *(const float4*)(scale + co + 2 * e), c = *(const float4*)(shift + co + 2 * e);
+        sc[e] = (f32x2_t){a.x, a.y}; sc[e + 1] = (f32x2_t){a.z, a.w};
+        sh[e] = (f32x2_t){c.x, c.y}; sh[e + 1] = (f32x2_t){c.z, c.w};
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         if (xs + p >= W) break;
         const size_t o = (((size_t)b * H + Y) * W + xs + p) * ldy + co;
 #pragma unroll
-        for (int e = 0; e < G; e += 4)
-            ElemIO<BF16>::st4(y, o + e, make_float4(fmaxf(acc[p][e] * sc[e] + sh[e], 0.f), fmaxf(acc[p][e + 1] * sc[e + 1] + sh[e + 1], 0.f),
-                                                    fmaxf(acc[p][e + 2] * sc[e + 2] + sh[e + 2], 0.f), fmaxf(acc[p][e + 3] * sc[e + 3] + sh[e + 3], 0.f)));
+        for (int e = 0; e < G2; e += 2) {
+            const f32x2_t r0 = acc[p][e] * sc[e] + sh[e], r1 = acc[p][e + 1] * sc[e + 1] + sh[e + 1];
+            ElemIO<BF16>::st4(y, o + 2 * e, make_float4(fmaxf(r0.x, 0.f), fmaxf(r0.y, 0.f), fmaxf(r1.x, 0.f), fmaxf(r1.y, 0.f)));
+        }
     }
 }
 

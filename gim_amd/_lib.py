@@ -105,7 +105,7 @@ PROTOTYPES = {
     "gim_cab_scale_add": (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p]),
     "gim_dkm_flow_update": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_float, c_float, c_int, c_int, c_void_p]),
     "gim_dkm_grid_coords": (c_int, [c_void_p] + [c_int] * 3 + [c_void_p]),
-    "gim_dkm_match_post": (c_int, [c_void_p] * 7 + [c_int] * 2 + [c_void_p]),
+    "gim_dkm_match_post": (c_int, [c_void_p] * 10 + [c_int] * 2 + [c_void_p]),
     "gim_dkm_black_mask": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
     "gim_kde": (c_int, [c_void_p] * 2 + [c_int, c_float, c_void_p]),
     "gim_weighted_sample_ws_bytes": (c_int64, [c_int]),

@@ -443,9 +443,10 @@ __global__ void grid_coords_kernel(float* __restrict__ flow, int B, int h, int w
     flow[p * 2 + 1] = h > 1 ? lin(Y, h) : 0.f;
 }
 
-// match() tail (dkm.py:693-741), symmetric: flow / cert hold [q->s ; s->q] (batch 2).
+// match() tail (dkm.py:693-741), symmetric, one pair: direction 0 = query -> support, direction 1 = support -> query.
 // warp [H, 2W, 4], certainty [H, 2W]; black0/black1: uint8 masks already resized (nearest) to [H, W]
-__global__ void match_post_kernel(const float* __restrict__ flow, const float* __restrict__ cert, const float* __restrict__ low,
+__global__ void match_post_kernel(const float* __restrict__ flow0, const float* __restrict__ flow1, const float* __restrict__ cert0,
+                                  const float* __restrict__ cert1, const float* __restrict__ low0, const float* __restrict__ low1,
                                   const uint8_t* __restrict__ black0, const uint8_t* __restrict__ black1, float* __restrict__ warp,
                                   float* __restrict__ certainty, int H, int W) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -459,10 +460,11 @@ __global__ void match_post_kernel(const float* __restrict__ flow, const float* _
         return i < n / 2 ? start + (float)i * step : end - (float)(n - 1 - i) * step;
     };
     const float qx = lin(X, W), qy = lin(Y, H);
-    float fx = flow[p * 2 + 0], fy = flow[p * 2 + 1];
-    float l = low[p];
+    const float* flow = dir == 0 ? flow0 : flow1;
+    float fx = flow[pp * 2 + 0], fy = flow[pp * 2 + 1];
+    float l = (dir == 0 ? low0 : low1)[pp];
     l = 0.5f * l * (l < 0.f ? 1.f : 0.f);
-    float c = 1.0f / (1.0f + expf(-(cert[p] - l)));
+    float c = 1.0f / (1.0f + expf(-((dir == 0 ? cert0 : cert1)[pp] - l)));
     if (fabsf(fx) > 1.f || fabsf(fy) > 1.f) c = 0.f;
     if ((dir == 0 ? black0 : black1)[pp]) c = 0.f;
     fx = fminf(fmaxf(fx, -1.f), 1.f);
@@ -652,10 +654,12 @@ extern "C" int gim_dkm_grid_coords(float* flow, int B, int h, int w, gim_stream_
     return gim_check_launch("dkm_grid_coords");
 }
 
-extern "C" int gim_dkm_match_post(const float* flow, const float* cert, const float* low, const uint8_t* black0,
-                                  const uint8_t* black1, float* warp, float* certainty, int H, int W, gim_stream_t stream) {
-    GIM_REQUIRE(flow && cert && low && black0 && black1 && warp && certainty && H > 1 && W > 1, "dkm_match_post: bad args");
-    hipLaunchKernelGGL(match_post_kernel, dim3(nblocks((size_t)2 * H * W, 256)), dim3(256), 0, (hipStream_t)stream, flow, cert, low, black0, black1, warp, certainty, H, W);
+extern "C" int gim_dkm_match_post(const float* flow0, const float* flow1, const float* cert0, const float* cert1, const float* low0,
+                                  const float* low1, const uint8_t* black0, const uint8_t* black1, float* warp, float* certainty,
+                                  int H, int W, gim_stream_t stream) {
+    GIM_REQUIRE(flow0 && flow1 && cert0 && cert1 && low0 && low1 && black0 && black1 && warp && certainty && H > 1 && W > 1, "dkm_match_post: bad args");
+    hipLaunchKernelGGL(match_post_kernel, dim3(nblocks((size_t)2 * H * W, 256)), dim3(256), 0, (hipStream_t)stream, flow0, flow1, cert0, cert1,
+                       low0, low1, black0, black1, warp, certainty, H, W);
     return gim_check_launch("dkm_match_post");
 }
 

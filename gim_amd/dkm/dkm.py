@@ -258,26 +258,28 @@ class RegressionMatcher(nn.Module):
         r = ops.conv2d(x, P[nm + ".c2"], ACT_RELU)
         return ops.conv2d(r, P[nm + ".c3"], ACT_RELU, res=x)       # relu(x + conv3(r))
 
-    def _gp(self, P, s, a32, h, w, tdt, out):
-        """GP.forward, no_cov (dkm.py:340-370) for both directions.  a32: fp32 rows [2*hw (+64 slack), 512] of the
-        projected features; writes mu into `out` (row view [2*hw, 256], dtype tdt)."""
+    def _gp(self, P, s, a32, nb, h, w, tdt, out):
+        """GP.forward, no_cov (dkm.py:340-370) for all nb = 2 * pairs directions (image d is matched against image
+        (d + nb/2) % nb).  a32: fp32 rows [nb*hw (+64 slack), 512] of the projected features; writes mu into `out`
+        (row view [nb*hw, 256], dtype tdt)."""
         dev = a32.device
         n = h * w
-        nrm = ops.row_norms(a32[:2 * n], 512)
+        half = nb // 2
+        nrm = ops.row_norms(a32[:nb * n], 512)
         ld = (n + 63) // 64 * 64
         npad = (n + 31) // 32 * 32
-        Kyy = torch.zeros(2, n, ld, dtype=torch.float32, device=dev)
-        Kxy = torch.zeros(2, n, max(ld, npad), dtype=torch.float32, device=dev)
-        for b in range(2):
-            o = 1 - b                                        # support of direction b = the other image
+        Kyy = torch.zeros(nb, n, ld, dtype=torch.float32, device=dev)
+        Kxy = torch.zeros(nb, n, max(ld, npad), dtype=torch.float32, device=dev)
+        for b in range(nb):
+            o = (b + half) % nb                              # support of direction b = the other image of its pair
             ops.matmul_nt(a32[o * n:(o + 1) * n], a32[o * n:], n, Kyy[b])
             ops.matmul_nt(a32[b * n:(b + 1) * n], a32[o * n:], n, Kxy[b])
-        ny = nrm.view(2, n).flip(0).contiguous().view(-1)
-        ops.cos_kernel_finish(Kyy.view(2 * n, ld), ny, ny, 2, n, n, 0.2, 1e-6, 0.1)        # K_yy + sigma_noise I
-        ops.cos_kernel_finish(Kxy.view(2 * n, Kxy.shape[2]), nrm, ny, 2, n, n, 0.2, 1e-6, 0.0)
+        ny = nrm.view(nb, n).roll(-half, 0).contiguous().view(-1)
+        ops.cos_kernel_finish(Kyy.view(nb * n, ld), ny, ny, nb, n, n, 0.2, 1e-6, 0.1)        # K_yy + sigma_noise I
+        ops.cos_kernel_finish(Kxy.view(nb * n, Kxy.shape[2]), nrm, ny, nb, n, n, 0.2, 1e-6, 0.0)
         f = self._gp_features(s, h, w, dev)
-        Xt = ops.gp_solve(Kyy, f[None].expand(2, n, GP_DIM).contiguous(), npad)
-        for b in range(2):
+        Xt = ops.gp_solve(Kyy, f[None].expand(nb, n, GP_DIM).contiguous(), npad)
+        for b in range(nb):
             ops.matmul_nt(Kxy[b][:, :npad], Xt[b], GP_DIM, out[b * n:(b + 1) * n])      # mu = K_xy (K_yy + sigma I)^-1 f
 
     def _refine(self, P, s, dt, x, y, flow, cert, ins, full_hw):
@@ -320,18 +322,18 @@ class RegressionMatcher(nn.Module):
         scales' flow (GP.forward ignores `dense_flow`, dkm.py:340) -> (projected features a, emb_in = [feats | mu])"""
         tdt = torch_dtype(dt)
         feat = f1[int(s)]
-        _, h, w, _ = feat.shape
+        nb, h, w, _ = feat.shape
         n, dev = h * w, feat.device
-        a32 = torch.zeros(2 * n + 64, 512, dtype=torch.float32, device=dev)
-        ops.linear(feat.view(2 * n, feat.shape[3]), P["proj" + s], a32)
+        a32 = torch.zeros(nb * n + 64, 512, dtype=torch.float32, device=dev)
+        ops.linear(feat.view(nb * n, feat.shape[3]), P["proj" + s], a32)
         if dt == GIM_F32:
-            a = a32[:2 * n].view(2, h, w, 512)
+            a = a32[:nb * n].view(nb, h, w, 512)
         else:
-            a = torch.empty(2, h, w, 512, dtype=tdt, device=dev)
-            ops.cast_rows(a32[:2 * n], a.view(2 * n, 512))
-        emb_in = torch.empty(2 * n, FEAT_DIM + GP_DIM, dtype=tdt, device=dev)
-        ops.linear(a.view(2 * n, 512), P["fin" + s], emb_in[:, :FEAT_DIM])
-        self._gp(P, s, a32, h, w, tdt, emb_in[:, FEAT_DIM:])
+            a = torch.empty(nb, h, w, 512, dtype=tdt, device=dev)
+            ops.cast_rows(a32[:nb * n], a.view(nb * n, 512))
+        emb_in = torch.empty(nb * n, FEAT_DIM + GP_DIM, dtype=tdt, device=dev)
+        ops.linear(a.view(nb * n, 512), P["fin" + s], emb_in[:, :FEAT_DIM])
+        self._gp(P, s, a32, nb, h, w, tdt, emb_in[:, FEAT_DIM:])
         return a, emb_in
 
     def _decode(self, P, dt, f1, upsample=False, dense_flow=None, dense_certainty=None, gp=None):
@@ -341,10 +343,12 @@ class RegressionMatcher(nn.Module):
         sizes = {s: tuple(f1[s].shape[1:3]) for s in f1}
         full = sizes[1]
         dev = f1[1].device
+        nb = f1[1].shape[0]
+        half = nb // 2
         coarsest = int(scales[0])
         if not upsample:
-            flow = ops.dkm_grid_coords(2, *sizes[coarsest], dev)
-            cert = torch.zeros(2, *sizes[coarsest], 1, dtype=torch.float32, device=dev)
+            flow = ops.dkm_grid_coords(nb, *sizes[coarsest], dev)
+            cert = torch.zeros(nb, *sizes[coarsest], 1, dtype=torch.float32, device=dev)
         else:
             flow = ops.resize_bilinear(dense_flow, sizes[coarsest])
             cert = ops.resize_bilinear(dense_certainty, sizes[coarsest])
@@ -357,27 +361,27 @@ class RegressionMatcher(nn.Module):
             a = f1[ins]
             if s in ("32", "16"):
                 a, emb_in = gp[s] if gp is not None else self._gp_stage(P, dt, f1, s)
-                emb = self._rrb(P, "rd" + s, emb_in.view(2, h, w, FEAT_DIM + GP_DIM))
+                emb = self._rrb(P, "rd" + s, emb_in.view(nb, h, w, FEAT_DIM + GP_DIM))
                 if old is not None:
                     old = ops.resize_bilinear(old, (h, w))
                 # CAB (dkm.py:160-168): global average of cat[context, emb] -> 1x1 -> relu -> 1x1 -> sigmoid gate
-                pooled = torch.zeros(2, 2 * DFN_DIM, dtype=torch.float32, device=dev)
+                pooled = torch.zeros(nb, 2 * DFN_DIM, dtype=torch.float32, device=dev)
                 if old is not None:
                     ops.global_avgpool(old, pooled, 0)
                 ops.global_avgpool(emb, pooled, DFN_DIM)
-                g1 = torch.empty(2, DFN_DIM, dtype=torch.float32, device=dev)
+                g1 = torch.empty(nb, DFN_DIM, dtype=torch.float32, device=dev)
                 ops.linear(pooled, P["cab" + s + ".c1"], g1, ACT_RELU)
-                g2 = torch.empty(2, DFN_DIM, dtype=torch.float32, device=dev)
+                g2 = torch.empty(nb, DFN_DIM, dtype=torch.float32, device=dev)
                 ops.linear(g1, P["cab" + s + ".c2"], g2)
                 ctx = ops.cab_scale_add(g2, old, emb)
                 old = self._rrb(P, "ru" + s, ctx)
-                preds = torch.empty(2 * n, P["term" + s].n_store, dtype=torch.float32, device=dev)
-                ops.linear(old.view(2 * n, DFN_DIM), P["term" + s], preds)
-                flow = torch.zeros(2, h, w, 2, dtype=torch.float32, device=dev)
-                cert = torch.empty(2, h, w, 1, dtype=torch.float32, device=dev)
+                preds = torch.empty(nb * n, P["term" + s].n_store, dtype=torch.float32, device=dev)
+                ops.linear(old.view(nb * n, DFN_DIM), P["term" + s], preds)
+                flow = torch.zeros(nb, h, w, 2, dtype=torch.float32, device=dev)
+                cert = torch.empty(nb, h, w, 1, dtype=torch.float32, device=dev)
                 ops.dkm_flow_update(flow, cert, preds, 1.0, 1.0, cert_init=True)       # flow, certainty = preds
             if s in REFINER:
-                self._refine(P, s, dt, a, a.flip(0).contiguous(), flow, cert, ins, full)
+                self._refine(P, s, dt, a, torch.cat((a[half:], a[:half])), flow, cert, ins, full)   # support = the other image of each pair
             out[ins] = (flow, cert)
             if s != "1":
                 flow = ops.resize_bilinear(flow, sizes[ins // 2])
@@ -385,9 +389,11 @@ class RegressionMatcher(nn.Module):
         return out
 
     def _images(self, dt, im1, im2, hs, ws):
-        x = torch.empty(2, hs, ws, cstore(3, dt), dtype=torch_dtype(dt), device=im1.device)
+        """[B,3,H,W] x 2 -> NHWC [2B, hs, ws, cpad]: queries first, then supports (extract_backbone_features, dkm.py:572-581)"""
+        B = im1.shape[0]
+        x = torch.empty(2 * B, hs, ws, cstore(3, dt), dtype=torch_dtype(dt), device=im1.device)
         ops.resize_image(im1, x, 0)
-        ops.resize_image(im2, x, 1)
+        ops.resize_image(im2, x, B)
         return x
 
     def _side_stream(self, dev):
@@ -397,15 +403,29 @@ class RegressionMatcher(nn.Module):
 
     @torch.no_grad()
     def match(self, im1_path, im2_path, *args, batched=False):
-        """RegressionMatcher.match (dkm.py:654-752), tensor inputs as gim calls it (`demo.py:433`, `lightning.py:135`)."""
+        """RegressionMatcher.match (dkm.py:654-752), tensor inputs as gim calls it (`demo.py:433`, `lightning.py:135`):
+        [1,3,H,W] x 2 -> (warp [Hs, 2Ws, 4], certainty [Hs, 2Ws])."""
         if batched or not self.symmetric:
-            raise NotImplementedError("gim runs DKM symmetric and non-batched (lightning.py:30-37); only that path is built")
-        im1, im2 = im1_path, im2_path
+            raise NotImplementedError("gim runs DKM symmetric and non-batched (lightning.py:30-37); use match_batch for several pairs")
+        if im1_path.dim() != 4 or im1_path.shape[0] != 1:
+            raise GimHipError(f"match() takes [1,3,H,W] images, got {tuple(im1_path.shape)}")
+        warp, certainty = self.match_batch(im1_path, im2_path)
+        return warp[0], certainty[0]
+
+    @torch.no_grad()
+    def match_batch(self, ims1, ims2):
+        """B independent pairs in one pass ([B,3,H,W] x 2 -> warp [B,Hs,2Ws,4], certainty [B,Hs,2Ws]); result b equals
+        `match(ims1[b:b+1], ims2[b:b+1])`.  (The reference's own batched mode cannot upsample and masks with pair 0's
+        black pixels, dkm.py:662,723-724; batching here is the engine's, as SURVEY 8d prescribes for the batch-4 config.)"""
+        if not self.symmetric:
+            raise NotImplementedError("only symmetric matching is built")
+        im1, im2 = ims1, ims2
         if not im1.is_cuda:
             raise GimHipError("gim_amd DKM needs device (cuda/HIP) tensors: there is no CPU fallback")
-        if im1.shape[0] != 1 or im1.shape[1] != 3:
-            raise GimHipError(f"match() takes [1,3,H,W] images, got {tuple(im1.shape)}")
+        if im1.dim() != 4 or im1.shape[1] != 3 or im1.shape != im2.shape or not 1 <= im1.shape[0] <= 8:
+            raise GimHipError(f"match takes two [B,3,H,W] batches of equal shape with B <= 8, got {tuple(im1.shape)} / {tuple(im2.shape)}")
         dev = im1.device
+        B = im1.shape[0]
         want = GIM_BF16 if self.precision == "bf16" else GIM_F32
         if self._packed is None or self._packed[2] != dev or self._packed[1] != want:
             self._prepack(dev)
@@ -439,7 +459,11 @@ class RegressionMatcher(nn.Module):
         if self.upsample_preds:
             cor = self._decode(P, dt, pyr_hi, upsample=True, dense_flow=cor[1][0], dense_certainty=cor[1][1])
         flow, cert = cor[1]
-        warp, certainty = ops.dkm_match_post(flow, cert, low, ops.dkm_black_mask(im1, (hs, ws)), ops.dkm_black_mask(im2, (hs, ws)))
+        warp = torch.empty(B, hs, 2 * ws, 4, dtype=torch.float32, device=dev)
+        certainty = torch.empty(B, hs, 2 * ws, dtype=torch.float32, device=dev)
+        for b in range(B):
+            ops.dkm_match_post((flow[b], flow[b + B]), (cert[b], cert[b + B]), (low[b], low[b + B]),
+                               ops.dkm_black_mask(im1[b:b + 1], (hs, ws)), ops.dkm_black_mask(im2[b:b + 1], (hs, ws)), warp[b], certainty[b])
         self._debug = {"corresps": cor}
         return warp, certainty
 

@@ -539,15 +539,14 @@ def dkm_black_mask(im, size):
     return m
 
 
-def dkm_match_post(flow, cert, low, black0, black1):
-    """flow [2,H,W,2], cert / low [2,H,W,1] -> warp [H,2W,4], certainty [H,2W]"""
-    _req_cuda(flow, cert, low, black0, black1)
-    _, H, W, _ = flow.shape
-    warp = torch.empty(H, 2 * W, 4, dtype=torch.float32, device=flow.device)
-    certainty = torch.empty(H, 2 * W, dtype=torch.float32, device=flow.device)
-    check(lib.gim_dkm_match_post(_p(flow), _p(cert), _p(low), _p(black0), _p(black1), _p(warp), _p(certainty), H, W, _stream()),
-          "gim_dkm_match_post")
-    return warp, certainty
+def dkm_match_post(flow, cert, low, black0, black1, warp, certainty):
+    """flow (f0, f1) [H,W,2], cert / low (c0, c1) [H,W,1] of the two directions -> warp [H,2W,4], certainty [H,2W] (written in place)"""
+    _req_cuda(flow[0], cert[0], low[0], black0, black1, warp, certainty)
+    H, W, _ = flow[0].shape
+    for t in (*flow, *cert, *low, warp, certainty):
+        assert t.is_contiguous()
+    check(lib.gim_dkm_match_post(_p(flow[0]), _p(flow[1]), _p(cert[0]), _p(cert[1]), _p(low[0]), _p(low[1]), _p(black0), _p(black1),
+                                 _p(warp), _p(certainty), H, W, _stream()), "gim_dkm_match_post")
 
 
 class RowMatrixOperand:

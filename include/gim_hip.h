@@ -318,9 +318,11 @@ int gim_dkm_flow_update(float* flow, float* cert, const void* d, int64_t npix, i
                         int cert_init, int dtype, gim_stream_t stream);
 /* get_placeholder_flow -- dkm.py:437-448. */
 int gim_dkm_grid_coords(float* flow, int B, int h, int w, gim_stream_t stream);
-/* match() tail, symmetric -- dkm.py:693-741; black masks from gim_dkm_black_mask (dkm.py:726-729). */
-int gim_dkm_match_post(const float* flow, const float* cert, const float* low, const uint8_t* black0,
-                       const uint8_t* black1, float* warp, float* certainty, int H, int W, gim_stream_t stream);
+/* match() tail of one symmetric pair -- dkm.py:693-741: flow / certainty / low-res certainty maps [H,W,.] of the two
+ * directions (0 = query -> support) -> warp [H,2W,4], certainty [H,2W]; black masks from gim_dkm_black_mask (:726-729). */
+int gim_dkm_match_post(const float* flow0, const float* flow1, const float* cert0, const float* cert1, const float* low0,
+                       const float* low1, const uint8_t* black0, const uint8_t* black1, float* warp, float* certainty,
+                       int H, int W, gim_stream_t stream);
 int gim_dkm_black_mask(const float* im, uint8_t* mask, int h, int w, int Ho, int Wo, gim_stream_t stream);
 /* kde(x, std) -- utils/kde.py:17-26: density[i] = sum_j exp(-cdist(x_i, x_j)^2 / (2 std^2)), x [n,4] fp32 (the
  * reference materialises the n x n distance matrix: 1.6 GB at n = 20000). */

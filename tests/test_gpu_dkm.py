@@ -309,3 +309,17 @@ def test_weighted_sample():
     # heavy items first: with one dominant weight it is (almost) always drawn
     dom = torch.full((1000,), 1e-4, device=dev); dom[123] = 10.0
     assert all(123 in ops.weighted_sample(dom, 5, s).cpu().tolist() for s in range(20))
+
+
+def test_match_batch_equals_single_pairs():
+    """engine-side batching: result b of match_batch == match() of pair b (fp32 mode, no upsampling pass)"""
+    dev = _dev()
+    a0, a1 = O.seeded_pair(160, 224, 3)
+    b0, b1 = O.seeded_pair(160, 224, 5, shift=(4, 14))
+    m = _model("fp32", 128, 160, (192, 256))
+    wa, ca = m.match(a0.to(dev), a1.to(dev))
+    wb, cb = m.match(b0.to(dev), b1.to(dev))
+    W, C = m.match_batch(torch.cat((a0, b0)).to(dev), torch.cat((a1, b1)).to(dev))
+    assert W.shape == (2, 192, 512, 4) and C.shape == (2, 192, 512)
+    _close(W[0], wa, 1e-5, "pair 0 warp"); _close(W[1], wb, 1e-5, "pair 1 warp")
+    _close(C[0], ca, 1e-4, "pair 0 certainty"); _close(C[1], cb, 1e-4, "pair 1 certainty")

@@ -674,3 +674,23 @@ extern "C" int gim_kde(const float* x, float* density, int n, float std, gim_str
     hipLaunchKernelGGL(kde_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, density, n, 1.0f / (2.0f * std * std));
     return gim_check_launch("kde");
 }
+
+namespace {
+// normalised (x0, y0, x1, y1) in [-1, 1] -> pixel coordinates of the two images (trainer/lightning.py:141-144, demo.py:438-443)
+__global__ void to_pixels_kernel(const float* __restrict__ m, float* __restrict__ k0, float* __restrict__ k1, int n, float w0, float h0,
+                                 float w1, float h1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 v = *(const float4*)(m + (size_t)i * 4);
+    k0[i * 2 + 0] = w0 * (v.x + 1.f) / 2.f; k0[i * 2 + 1] = h0 * (v.y + 1.f) / 2.f;
+    k1[i * 2 + 0] = w1 * (v.z + 1.f) / 2.f; k1[i * 2 + 1] = h1 * (v.w + 1.f) / 2.f;
+}
+}  // namespace
+
+extern "C" int gim_dense_to_pixels(const float* matches, float* kpts0, float* kpts1, int n, float w0, float h0, float w1, float h1,
+                                   gim_stream_t stream) {
+    GIM_REQUIRE(matches && kpts0 && kpts1 && n >= 0, "dense_to_pixels: bad args");
+    if (n == 0) return GIM_OK;
+    hipLaunchKernelGGL(to_pixels_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, matches, kpts0, kpts1, n, w0, h0, w1, h1);
+    return gim_check_launch("dense_to_pixels");
+}

@@ -1,1 +1,1 @@
-from .dkm import DKMv3, RegressionMatcher  # noqa: F401
+from .dkm import DKMv3, RegressionMatcher, gim_dkm_inference  # noqa: F401

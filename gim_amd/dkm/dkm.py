@@ -480,11 +480,12 @@ class RegressionMatcher(nn.Module):
         if n_pos == 0:
             cert, n_pos = cert + 1e-8, cert.numel()
         seeds = torch.randint(0, 2 ** 31 - 1, (2,)).tolist()      # torch's (CPU) generator: torch.manual_seed makes sample() reproducible
-        good = ops.weighted_sample(cert, min(4 * num, cert.numel(), n_pos), seeds[0])
+        # the kernel returns an unordered set (atomic compaction); sorting makes sample() reproducible from the seed
+        good = ops.weighted_sample(cert, min(4 * num, cert.numel(), n_pos), seeds[0]).sort().values
         gm, gc = matches[good].contiguous(), cert_[good]
         density = ops.kde(gm, 0.1)
         p = torch.where(density < 10, torch.full_like(density, 1e-7), 1 / (density + 1))
-        bal = ops.weighted_sample(p.contiguous(), min(num, len(gc)), seeds[1])
+        bal = ops.weighted_sample(p.contiguous(), min(num, len(gc)), seeds[1]).sort().values
         return gm[bal], gc[bal]
 
 
@@ -493,3 +494,18 @@ def DKMv3(weights, h, w, symmetric=True, sample_mode="threshold_balanced", **kwa
     the caller's job, `demo.py:364-376`)."""
     kwargs.pop("device", None)
     return RegressionMatcher(h=h, w=w, name="DKMv3", sample_mode=sample_mode, symmetric=symmetric, **kwargs)
+
+
+@torch.no_grad()
+def gim_dkm_inference(model, data, num=5000):
+    """`Trainer.gim_dkm_inference` (trainer/lightning.py:134-156): match + sample + pixel coordinates + `mconf > 0` filter,
+    written into `data` (hw0_i, hw1_i, mkpts0_f, mkpts1_f, m_bids, mconf).  data: color0 / color1 [1,3,H,W], imsize0 /
+    imsize1 [1,2] = (height, width) of the un-padded images."""
+    dense_matches, dense_certainty = model.match(data["color0"], data["color1"])
+    sparse_matches, mconf = model.sample(dense_matches, dense_certainty, num)
+    h0, w0 = (float(v) for v in data["imsize0"][0])
+    h1, w1 = (float(v) for v in data["imsize1"][0])
+    kpts0, kpts1 = ops.dense_to_pixels(sparse_matches, (h0, w0), (h1, w1))
+    mask = mconf > 0
+    data.update({"hw0_i": data["color0"].shape[2:], "hw1_i": data["color1"].shape[2:], "mkpts0_f": kpts0[mask], "mkpts1_f": kpts1[mask],
+                 "m_bids": torch.where(mconf[None])[0], "mconf": mconf[mask]})

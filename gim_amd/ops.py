@@ -603,3 +603,15 @@ def weighted_sample(w, k, seed):
     out = torch.empty(k, dtype=torch.int64, device=w.device)
     check(lib.gim_weighted_sample(_p(w), _p(out), _p(ws), n, k, seed & 0xffffffff, _stream()), "gim_weighted_sample")
     return out
+
+
+def dense_to_pixels(matches, hw0, hw1):
+    """matches [n,4] fp32 normalised -> (kpts0 [n,2], kpts1 [n,2]) in pixels of images of size hw0 / hw1 (h, w)"""
+    _req_cuda(matches)
+    n = matches.shape[0]
+    m = matches.contiguous()
+    k0 = torch.empty(n, 2, dtype=torch.float32, device=m.device)
+    k1 = torch.empty(n, 2, dtype=torch.float32, device=m.device)
+    check(lib.gim_dense_to_pixels(_p(m), _p(k0), _p(k1), n, float(hw0[1]), float(hw0[0]), float(hw1[1]), float(hw1[0]), _stream()),
+          "gim_dense_to_pixels")
+    return k0, k1

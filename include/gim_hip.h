@@ -330,6 +330,10 @@ int gim_kde(const float* x, float* density, int n, float std, gim_stream_t strea
 /* torch.multinomial(w, k, replacement=False) of RegressionMatcher.sample -- dkm.py:603-605,617-619: k distinct indices
  * drawn with probability proportional to w (exponential clocks + radix-select top-k), as an unordered set; reproducible
  * from `seed`.  Needs at least k positive weights. */
+/* Caller-side dense adapter -- trainer/lightning.py:141-144 / demo.py:438-443: normalised [n,4] matches -> pixel
+ * coordinates in the two images, kpts = size * (x + 1) / 2. */
+int gim_dense_to_pixels(const float* matches, float* kpts0, float* kpts1, int n, float w0, float h0, float w1, float h1,
+                        gim_stream_t stream);
 int64_t gim_weighted_sample_ws_bytes(int n);
 int gim_weighted_sample(const float* w, int64_t* out, void* ws, int n, int k, uint32_t seed, gim_stream_t stream);
 

@@ -323,3 +323,26 @@ def test_match_batch_equals_single_pairs():
     assert W.shape == (2, 192, 512, 4) and C.shape == (2, 192, 512)
     _close(W[0], wa, 1e-5, "pair 0 warp"); _close(W[1], wb, 1e-5, "pair 1 warp")
     _close(C[0], ca, 1e-4, "pair 0 certainty"); _close(C[1], cb, 1e-4, "pair 1 certainty")
+
+
+def test_gim_dkm_inference_adapter():
+    """caller-side adapter (trainer/lightning.py:134-156) vs the oracle's restatement on the engine's own samples"""
+    from gim_amd.dkm import gim_dkm_inference
+    dev = _dev()
+    im0, im1 = O.seeded_pair(160, 224, 3)
+    m = _model("fp32", 128, 160, None)
+    data = {"color0": im0.to(dev), "color1": im1.to(dev), "imsize0": torch.tensor([[150, 200]]), "imsize1": torch.tensor([[160, 224]])}
+    torch.manual_seed(1)
+    gim_dkm_inference(m, data, num=200)
+    assert tuple(data["hw0_i"]) == (160, 224) and data["mkpts0_f"].shape == data["mkpts1_f"].shape
+    torch.manual_seed(1)
+    warp, cert = m.match(im0.to(dev), im1.to(dev))
+    sm, sc = m.sample(warp, cert, 200)
+    ref = O.gim_dkm_adapter(sm.cpu(), sc.cpu(), (150, 200), (160, 224))
+
+    def canon(k0, k1, c):   # samples are an unordered set: sort rows
+        rows = torch.cat((k0.cpu(), k1.cpu(), c.cpu()[:, None]), 1)
+        return rows[torch.argsort(rows[:, 0] * 1e6 + rows[:, 1] * 1e3 + rows[:, 2])]
+
+    _close(canon(data["mkpts0_f"], data["mkpts1_f"], data["mconf"]), canon(ref["mkpts0_f"], ref["mkpts1_f"], ref["mconf"]), 1e-6, "adapter rows")
+    assert data["m_bids"].numel() == ref["m_bids"].numel() and (data["m_bids"] == 0).all()

@@ -232,6 +232,63 @@ def reference_dkm(h, w, upsample_res=None, **attrs):
     return model.eval()
 
 
+def install_roma(dino_state_dict=None):
+    """Stand-ins that let `networks.roma.*` import and construct:
+      * `xformers.ops` (memory_efficient_attention = scaled-dot-product attention on [B,N,H,D], unbind, a SwiGLU base
+        class) -- without it `dino.py:275` fails at import;
+      * `torchvision.models.vgg19_bn` restated from its published configuration "E" with BatchNorm (`roma.py:142` takes
+        `.features[:40]`);
+      * `torch.hub.load_state_dict_from_url` patched to return `dino_state_dict` (the reference downloads the DINOv2
+        ViT-L/14 weights in `CNNandDinov2.__init__`, roma.py:591-595; there is no network here)."""
+    import torch.nn as nn
+    install_dkm()
+    if "xformers" not in sys.modules:
+        xf = types.ModuleType("xformers")
+        xo = types.ModuleType("xformers.ops")
+
+        def memory_efficient_attention(q, k, v, attn_bias=None):
+            assert attn_bias is None
+            o = torch.nn.functional.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2))
+            return o.transpose(1, 2)
+
+        class SwiGLU(nn.Module):
+            def __init__(self, in_features, hidden_features=None, out_features=None, bias=True):
+                super().__init__()
+
+        xo.memory_efficient_attention, xo.unbind, xo.SwiGLU = memory_efficient_attention, torch.unbind, SwiGLU
+        xf.ops = xo
+        sys.modules["xformers"], sys.modules["xformers.ops"] = xf, xo
+    tvm = sys.modules["torchvision.models"]
+    if not hasattr(tvm, "vgg19_bn"):
+        def vgg19_bn(pretrained=False, **kw):
+            cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+            layers, ci = [], 3
+            for v in cfg:
+                if v == "M":
+                    layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+                else:
+                    layers += [nn.Conv2d(ci, v, kernel_size=3, padding=1), nn.BatchNorm2d(v), nn.ReLU(inplace=True)]
+                    ci = v
+            m = nn.Module()
+            m.features = nn.Sequential(*layers)
+            return m
+        tvm.vgg19_bn = vgg19_bn
+    if dino_state_dict is not None:
+        torch.hub.load_state_dict_from_url = lambda *a, **k: dino_state_dict
+
+
+def reference_roma(h, w, dino_state_dict, upsample_res=None, **attrs):
+    """RoMa built the way `demo.py:332` / `trainer/lightning.py:41` do (`RoMa(img_size=[672])`), at a test resolution."""
+    install_roma(dino_state_dict)
+    from networks.roma.roma import RoMa
+    model = RoMa(img_size=[h, w], upsample_preds=upsample_res is not None)
+    if upsample_res is not None:
+        model.upsample_res = tuple(upsample_res)
+    for k, v in attrs.items():
+        setattr(model, k, v)
+    return model.eval()
+
+
 def reference_loftr_config():
     """The effective gim_loftr config dict (`demo.py:333-335`: lower_config(get_cfg_defaults())['loftr'])."""
     install()

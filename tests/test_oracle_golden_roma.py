@@ -1,0 +1,52 @@
+"""CPU: oracle/roma_oracle.py replayed against the vectors oracle/make_golden_roma.py recorded from the reference's own
+RoMa (networks/roma/roma.py, networks/roma/dino.py) -- SURVEY 8a row a14."""
+import os
+
+import numpy as np
+import torch
+
+import dkm_oracle as DO
+import roma_oracle as O
+
+
+def _close(a, b, tol=1e-4):
+    a, b = torch.as_tensor(np.asarray(a)), torch.as_tensor(np.asarray(b))
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(1.0, b.abs().max().item())
+    assert (a - b).abs().max().item() <= tol * scale
+
+
+def test_param_specs():
+    sd, dsd = O.make_state_dicts(0)
+    assert len(sd) == len(O.roma_param_spec()) and len(dsd) == len(O.dino_param_spec())
+    assert sum(v.numel() for v in dsd.values()) == 304368640                       # DINOv2 ViT-L/14 (with mask token)
+    assert sd["decoder.embedding_decoder.to_out.weight"].shape == (4097, 1024)
+    assert sd["decoder.conv_refiner.1.block1.0.weight"].shape == (24, 1, 5, 5)      # 2*9 + 6 = 24 input channels, depthwise
+
+
+def test_stage_and_match_goldens(golden_dir):
+    g = np.load(os.path.join(golden_dir, "roma_stages.npz"))
+    gm = np.load(os.path.join(golden_dir, "roma_match.npz"))
+    sd, dsd = O.make_state_dicts(0)
+    H, W = (int(v) for v in g["hw"])
+    im0, im1 = DO.seeded_pair(*(int(v) for v in g["image_hw"]), int(g["seed"]))
+    up = lambda t, s: torch.nn.functional.interpolate(t, size=s, mode="bilinear", align_corners=False)  # noqa: E731
+    with torch.no_grad():
+        q, s_ = up(im0, (H, W)), up(im1, (H, W))
+        pyr = O.encoder(sd, dsd, torch.cat((q, s_)))
+        _close(pyr[16], g["dino16"], 2e-4)
+        _close(pyr[8][:, ::8], g["vgg8_sub"])
+        _close(pyr[1][:, ::16, ::4, ::4], g["vgg1_sub"])
+        a = O._proj(sd, "16", pyr[16])
+        c = torch.cat((a.chunk(2)[1], a.chunk(2)[0]))
+        gp = O.gp_forward(sd, a, c)
+        _close(gp, g["gp"], 1e-3)
+        cls, cert = O.transformer_decoder(sd, torch.as_tensor(g["gp"]), a)
+        _close(cls[:, ::64], g["cls_sub"], 1e-3)
+        _close(cert, g["gm_certainty"], 1e-3)
+        _close(O.cls_to_flow_refine(cls), g["gm_flow"], 1e-3)
+        up_res = tuple(int(v) for v in gm["up"])
+        warp, cc = O.match(sd, dsd, im0, im1, H, W, up_res)
+    _close(warp[::2, ::2], gm["warp"], 2e-3)
+    _close(cc[::2, ::2], gm["certainty"], 5e-3)
+    assert warp.shape == (up_res[0], 2 * up_res[1], 4) and warp.abs().max() <= 1

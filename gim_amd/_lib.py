@@ -108,6 +108,7 @@ PROTOTYPES = {
     "gim_dkm_match_post": (c_int, [c_void_p] * 10 + [c_int] * 2 + [c_void_p]),
     "gim_dkm_black_mask": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
     "gim_kde": (c_int, [c_void_p] * 2 + [c_int, c_float, c_void_p]),
+    "gim_cls_to_flow": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
     "gim_dense_to_pixels": (c_int, [c_void_p] * 3 + [c_int] + [c_float] * 4 + [c_void_p]),
     "gim_weighted_sample_ws_bytes": (c_int64, [c_int]),
     "gim_weighted_sample": (c_int, [c_void_p] * 3 + [c_int, c_int, ctypes.c_uint32, c_void_p]),

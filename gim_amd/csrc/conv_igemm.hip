@@ -33,6 +33,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == GIM_ACT_RELU) return fmaxf(v, 0.f);
     if (act == GIM_ACT_LEAKY) return v > 0.f ? v : 0.01f * v;
     if (act == GIM_ACT_ELU1) return v > 0.f ? v + 1.f : (expf(v) - 1.f) + 1.f;  // elu(x)+1 exactly as torch
+    if (act == GIM_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));  // F.gelu (erf form)
     return v;
 }
 
@@ -247,6 +248,11 @@ struct Epilogue {
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[nh * 2 + i][j][r] = apply_act(acc[nh * 2 + i][j][r], GIM_ACT_ELU1);
+                } else if (act == GIM_ACT_GELU) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[nh * 2 + i][j][r] = apply_act(acc[nh * 2 + i][j][r], GIM_ACT_GELU);
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)

@@ -420,13 +420,15 @@ __global__ void cab_scale_add_kernel(const float* __restrict__ g, const void* __
 // d rows: [certainty, dx, dy] (ConvRefiner out_conv: d[:, :-2] certainty, d[:, -2:] displacement)
 template <bool BF16>
 __global__ void flow_update_kernel(float* __restrict__ flow, float* __restrict__ cert, const void* __restrict__ d, size_t npix,
-                                   int ldd, float sx, float sy, int cert_init) {
+                                   int ldd, float sx, float sy, int flags) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
-    const float dc = ElemIO<BF16>::ld(d, p * ldd + 0), dx = ElemIO<BF16>::ld(d, p * ldd + 1), dy = ElemIO<BF16>::ld(d, p * ldd + 2);
+    const bool roma = flags & 2;     // RoMa's refiners emit (dx, dy, certainty), DKM's (certainty, dx, dy)
+    const float dc = ElemIO<BF16>::ld(d, p * ldd + (roma ? 2 : 0));
+    const float dx = ElemIO<BF16>::ld(d, p * ldd + (roma ? 0 : 1)), dy = ElemIO<BF16>::ld(d, p * ldd + (roma ? 1 : 2));
     flow[p * 2 + 0] = flow[p * 2 + 0] + dx * sx;
     flow[p * 2 + 1] = flow[p * 2 + 1] + dy * sy;
-    cert[p] = (cert_init ? 0.f : cert[p]) + dc;
+    cert[p] = ((flags & 1) ? 0.f : cert[p]) + dc;
 }
 
 // pixel-centre grid (dkm.py:437-448): flow[b,y,x] = (lin(x, w), lin(y, h))
@@ -487,14 +489,21 @@ __global__ void black_mask_kernel(const float* __restrict__ im, uint8_t* __restr
 }
 
 // kde (utils/kde.py:17-26): density[i] = sum_j exp(-|x_i - x_j|^2 / (2 std^2)), x [n,4]; j tiles staged in LDS
-__global__ void __launch_bounds__(256) kde_kernel(const float* __restrict__ x, float* __restrict__ density, int n, float inv2s2) {
+__device__ __forceinline__ float4 round_half4(float4 v) {
+    return make_float4((float)(_Float16)v.x, (float)(_Float16)v.y, (float)(_Float16)v.z, (float)(_Float16)v.w);
+}
+
+__global__ void __launch_bounds__(256) kde_kernel(const float* __restrict__ x, float* __restrict__ density, int n, float inv2s2, int half) {
     __shared__ float4 tile[256];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const float4 xi = i < n ? *(const float4*)(x + (size_t)i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 xi = i < n ? *(const float4*)(x + (size_t)i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (half) xi = round_half4(xi);
     float acc = 0.f;
     for (int j0 = 0; j0 < n; j0 += 256) {
         const int j = j0 + threadIdx.x;
-        tile[threadIdx.x] = j < n ? *(const float4*)(x + (size_t)j * 4) : make_float4(1e18f, 1e18f, 1e18f, 1e18f);
+        float4 xj = j < n ? *(const float4*)(x + (size_t)j * 4) : make_float4(1e18f, 1e18f, 1e18f, 1e18f);
+        if (half && j < n) xj = round_half4(xj);
+        tile[threadIdx.x] = xj;
         __syncthreads();
         const int m = min(256, n - j0);
         for (int k = 0; k < m; ++k) {
@@ -644,7 +653,7 @@ extern "C" int gim_dkm_flow_update(float* flow, float* cert, const void* d, int6
     GIM_REQUIRE(flow && cert && d && npix > 0 && ldd >= 3, "dkm_flow_update: bad args");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(nblocks((size_t)npix, 256));
-    DISPATCH_BF(flow_update_kernel, dtype == GIM_BF16, grid, flow, cert, d, (size_t)npix, ldd, sx, sy, cert_init);
+    DISPATCH_BF(flow_update_kernel, dtype == GIM_BF16, grid, flow, cert, d, (size_t)npix, ldd, sx, sy, cert_init);  // cert_init: flag bits
     return gim_check_launch("dkm_flow_update");
 }
 
@@ -670,8 +679,9 @@ extern "C" int gim_dkm_black_mask(const float* im, uint8_t* mask, int h, int w, 
 }
 
 extern "C" int gim_kde(const float* x, float* density, int n, float std, gim_stream_t stream) {
-    GIM_REQUIRE(x && density && n > 0 && std > 0.f, "kde: bad args");
-    hipLaunchKernelGGL(kde_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, density, n, 1.0f / (2.0f * std * std));
+    GIM_REQUIRE(x && density && n > 0 && std != 0.f, "kde: bad args");
+    // std < 0: coordinates rounded to fp16 first (RoMa evaluates its KDE on x.half(), roma.py:1018-1023)
+    hipLaunchKernelGGL(kde_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, density, n, 1.0f / (2.0f * std * std), std < 0.f ? 1 : 0);
     return gim_check_launch("kde");
 }
 
@@ -693,4 +703,61 @@ extern "C" int gim_dense_to_pixels(const float* matches, float* kpts0, float* kp
     if (n == 0) return GIM_OK;
     hipLaunchKernelGGL(to_pixels_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, matches, kpts0, kpts1, n, w0, h0, w1, h1);
     return gim_check_launch("dense_to_pixels");
+}
+
+namespace {
+// cls_to_flow_refine (roma.py:1092-1121) + the certainty channel: one wave per pixel over C = res^2 class logits.
+// softmax, arg-max (first index on ties), the arg-max and its 4-neighbourhood (indices clamped to [0, C-1], duplicates
+// counted twice like torch.gather does), anchor-weighted mean / total probability.
+__global__ void __launch_bounds__(256) cls_to_flow_kernel(const float* __restrict__ logits, float* __restrict__ flow, float* __restrict__ cert,
+                                                          int npix, int C, int res, int ld) {
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= npix) return;
+    const float* row = logits + (size_t)p * ld;
+    float mx = -INFINITY;
+    int arg = 0;
+    for (int c = lane; c < C; c += 64) {
+        const float v = row[c];
+        if (v > mx) { mx = v; arg = c; }
+    }
+    // wave arg-max, smallest index on ties
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(mx, o, 64);
+        const int oa = __shfl_xor(arg, o, 64);
+        if (om > mx || (om == mx && oa < arg)) { mx = om; arg = oa; }
+    }
+    float z = 0.f;
+    for (int c = lane; c < C; c += 64) z += expf(row[c] - mx);
+    z = wave_sum(z);
+    if (lane == 0) {
+        auto lin = [res](int i) {
+            const float start = -1.f + 1.f / (float)res, end = 1.f - 1.f / (float)res;
+            const float step = (end - start) / (float)(res - 1);
+            return i < res / 2 ? start + (float)i * step : end - (float)(res - 1 - i) * step;
+        };
+        const int idx[5] = {arg - 1, arg, arg + 1, arg - res, arg + res};
+        float fx = 0.f, fy = 0.f, tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int c = min(max(idx[k], 0), C - 1);
+            const float pr = expf(row[c] - mx) / z;
+            fx += pr * lin(c % res);
+            fy += pr * lin(c / res);
+            tot += pr;
+        }
+        flow[(size_t)p * 2 + 0] = fx / tot;
+        flow[(size_t)p * 2 + 1] = fy / tot;
+        cert[p] = row[C];
+    }
+}
+}  // namespace
+
+extern "C" int gim_cls_to_flow(const float* logits, float* flow, float* cert, int npix, int ncls, int ld, gim_stream_t stream) {
+    GIM_REQUIRE(logits && flow && cert && npix > 0 && ncls > 0 && ld > ncls, "cls_to_flow: bad args");
+    const int res = (int)(sqrtf((float)ncls) + 0.5f);
+    GIM_REQUIRE(res * res == ncls, "cls_to_flow: %d classes are not a square grid", ncls);
+    hipLaunchKernelGGL(cls_to_flow_kernel, dim3((npix + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, flow, cert, npix, ncls, res, ld);
+    return gim_check_launch("cls_to_flow");
 }

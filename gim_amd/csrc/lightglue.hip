@@ -17,6 +17,7 @@
 //     LDS reads per fragment from a V^T tile stored [d][key] (hence lg_transpose).
 //   * LDS tiles are XOR-swizzled so that both the 16-byte K reads and the 8-byte V^T reads are conflict-free.
 #include "gim_common.h"
+#include <math.h>
 
 namespace {
 
@@ -82,7 +83,7 @@ __global__ void cast_rows_kernel(const float* __restrict__ src, void* __restrict
     ElemIO<BF16>::st4(dst, r * ldd + c, *(const float4*)(src + r * lds_ + c));
 }
 
-// LayerNorm over C <= 512 (one wave per row) followed by exact GELU (F.gelu default: 0.5 x (1 + erf(x / sqrt 2)))
+// LayerNorm over C <= 1024 (one wave per row, fp32 input) optionally followed by exact GELU (F.gelu: 0.5 x (1 + erf(x / sqrt 2)))
 template <bool BF16, bool GELU>
 __global__ void __launch_bounds__(256)
 layernorm_act_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -90,10 +91,10 @@ layernorm_act_kernel(const float* __restrict__ x, const float* __restrict__ gamm
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    float4 v[2];
+    float4 v[4];
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 4; ++k) {
         const int c = lane * 4 + k * 256;
         v[k] = c < C ? *(const float4*)(x + (size_t)row * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
@@ -101,7 +102,7 @@ layernorm_act_kernel(const float* __restrict__ x, const float* __restrict__ gamm
     const float mean = wave_sum(s) / (float)C;
     float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 4; ++k) {
         const int c = lane * 4 + k * 256;
         if (c < C) {
             const float dx = v[k].x - mean, dy = v[k].y - mean, dz = v[k].z - mean, dw = v[k].w - mean;
@@ -110,7 +111,7 @@ layernorm_act_kernel(const float* __restrict__ x, const float* __restrict__ gamm
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 4; ++k) {
         const int c = lane * 4 + k * 256;
         if (c >= C) continue;
         const float4 g = *(const float4*)(gamma + c), bt = *(const float4*)(beta + c);
@@ -134,100 +135,105 @@ struct SdpaArgs {
     float scale_log2e;  // d^-0.5 * log2(e)
 };
 
-template <bool BF16> struct SdpaCfg;
-template <> struct SdpaCfg<true> { static constexpr int ES = 2, ROWB = 128; };   // bytes per LDS row (64 elements)
-template <> struct SdpaCfg<false> { static constexpr int ES = 4, ROWB = 256; };
-
 // raw v_exp_f32 (exp2f() wraps it in a 6-instruction denormal-range fix-up; arguments here are <= 0 and a
 // flushed denormal probability is exactly what the softmax wants)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-template <bool BF16, bool OUT_BF16>
+// D = head dimension (64: LightGlue, DINOv2 ViT-L; 128: RoMa's match decoder)
+template <bool BF16, bool OUT_BF16, int D>
 __global__ void __launch_bounds__(256, 2) sdpa_kernel(const SdpaArgs a) {
-    constexpr int ES = SdpaCfg<BF16>::ES, ROWB = SdpaCfg<BF16>::ROWB;
-    constexpr int NSLOT = ROWB / 16;               // 16-byte slots per LDS row: 8 (bf16) / 16 (f32)
+    constexpr int ES = BF16 ? 2 : 4;
+    constexpr int KROW = D * ES;                   // bytes of one K tile row (one key, D channels)
+    constexpr int VROW = 64 * ES;                  // bytes of one V^T tile row (one channel, 64 keys)
+    constexpr int KSLOT = KROW / 16, VSLOT = VROW / 16;
+    constexpr int KBYTES = 64 * KROW, VBYTES = D * VROW;
+    constexpr int NPK = 64 * KSLOT / 256, NPV = D * VSLOT / 256;   // 16-byte chunks per thread and tile
+    constexpr int NDB = D / 32;                    // 32-channel blocks of the output
+    extern __shared__ __attribute__((aligned(16))) char sdpa_smem[];
     // K / V^T tiles, double-buffered: tile t lives in buffer t & 1
-    __shared__ __attribute__((aligned(16))) char sKb[2][64 * ROWB];
-    __shared__ __attribute__((aligned(16))) char sVb[2][64 * ROWB];
+    char* const sK0 = sdpa_smem;
+    char* const sV0 = sdpa_smem + 2 * KBYTES;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, lh = lane >> 5;
     const int seq = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
     const int kvseq = (seq + a.kv_shift) % a.nb;
+    // 16-byte-slot swizzles of the tiles (conflict-free fragment reads): 128-byte rows pair up over the bank cycle
+    auto kswz = [](int row) { return KROW == 128 ? ((row >> 1) & 7) : (row & 15); };
     // ---- Q fragments (B operand of S^T = K Q^T), held for the whole kernel --------------------------------
     const int qrow = min(q0 + l31, a.L - 1);
-    const char* qp = (const char*)a.q + ((size_t)(seq * (size_t)a.L + qrow) * a.ldq + h * 64) * ES;
-    bf16x8_t qb[4];
-    f32x4_t qf[8];
+    const char* qp = (const char*)a.q + ((size_t)(seq * (size_t)a.L + qrow) * a.ldq + h * D) * ES;
+    bf16x8_t qb[BF16 ? D / 16 : 1];
+    f32x4_t qf[BF16 ? 1 : D / 8];
     if constexpr (BF16) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qb[ks] = *(const bf16x8_t*)(qp + (ks * 16 + lh * 8) * 2);
+        for (int ks = 0; ks < D / 16; ++ks) qb[ks] = *(const bf16x8_t*)(qp + (ks * 16 + lh * 8) * 2);
     } else {
-        // f32 MFMA (k = 2 per step): step st of half lh uses d = lh*32 + st (any bijection works as long as A matches)
+        // f32 MFMA (k = 2 per step): step st of half lh uses d = lh*(D/2) + st (any bijection works as long as A matches)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) qf[i] = *(const f32x4_t*)(qp + (lh * 32 + i * 4) * 4);
+        for (int i = 0; i < D / 8; ++i) qf[i] = *(const f32x4_t*)(qp + (lh * (D / 2) + i * 4) * 4);
     }
-    f32x16_t accO[2];
+    f32x16_t accO[NDB];
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+    for (int d = 0; d < NDB; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accO[d][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    // ---- staging roles: thread t moves 16-byte chunks (row = t/NSLOT (+ passes), slot = t % NSLOT) ---------
-    constexpr int RPP = 256 / NSLOT;               // rows per pass: 32 (bf16) / 16 (f32)
-    constexpr int NP = 64 / RPP;                   // passes: 2 / 4
-    const int srow = t / NSLOT, sslot = t % NSLOT;
-    const char* kbase = (const char*)a.k + ((size_t)kvseq * a.S * a.ldk + h * 64) * ES + sslot * 16;
-    const char* vbase = (const char*)a.vt + ((size_t)(kvseq * (size_t)a.H + h) * 64 * a.Sp) * ES + sslot * 16;
-    uint4 rk[NP], rv[NP];
+    // ---- staging: thread t moves 16-byte chunks c = t + 256 p of the K tile (row = c / KSLOT) and of the V^T tile ----
+    const char* kbase = (const char*)a.k + ((size_t)kvseq * a.S * a.ldk + h * D) * ES;
+    const char* vbase = (const char*)a.vt + ((size_t)(kvseq * (size_t)a.H + h) * D * a.Sp) * ES;
+    uint4 rk[NPK], rv[NPV];
     auto fetch = [&](int key0) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int row = p * RPP + srow;
-            const int key = key0 + row;
-            rk[p] = key < a.S ? *(const uint4*)(kbase + (size_t)key * a.ldk * ES) : make_uint4(0, 0, 0, 0);
-            // V^T row = d, 16 bytes = 8 (bf16) / 4 (f32) consecutive keys starting at key0 + slot*(16/ES)
-            rv[p] = *(const uint4*)(vbase + ((size_t)row * a.Sp + key0) * ES);
+        for (int p = 0; p < NPK; ++p) {
+            const int c = t + 256 * p, row = c / KSLOT, slot = c % KSLOT, key = key0 + row;
+            rk[p] = key < a.S ? *(const uint4*)(kbase + (size_t)key * a.ldk * ES + slot * 16) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < NPV; ++p) {
+            const int c = t + 256 * p, row = c / VSLOT, slot = c % VSLOT;
+            rv[p] = *(const uint4*)(vbase + ((size_t)row * a.Sp + key0) * ES + slot * 16);
         }
     };
     auto stash = [&](int buf) {
-        char* sK = sKb[buf];
-        char* sV = sVb[buf];
+        char* sK = sK0 + buf * KBYTES;
+        char* sV = sV0 + buf * VBYTES;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int row = p * RPP + srow;
-            if constexpr (BF16) {
-                *(uint4*)(sK + row * ROWB + ((sslot ^ ((row >> 1) & 7)) << 4)) = rk[p];
-                // V^T: 8-byte chunks c = 2*slot, 2*slot+1, swizzled by (d >> 1) & 15
+        for (int p = 0; p < NPK; ++p) {
+            const int c = t + 256 * p, row = c / KSLOT, slot = c % KSLOT;
+            *(uint4*)(sK + row * KROW + ((slot ^ kswz(row)) << 4)) = rk[p];
+        }
+#pragma unroll
+        for (int p = 0; p < NPV; ++p) {
+            const int c = t + 256 * p, row = c / VSLOT, slot = c % VSLOT;
+            if constexpr (BF16) {  // V^T: 8-byte chunks 2*slot, 2*slot+1, swizzled by (d >> 1) & 15
                 const int sw = (row >> 1) & 15;
-                *(uint2*)(sV + row * ROWB + (((2 * sslot) ^ sw) << 3)) = make_uint2(rv[p].x, rv[p].y);
-                *(uint2*)(sV + row * ROWB + (((2 * sslot + 1) ^ sw) << 3)) = make_uint2(rv[p].z, rv[p].w);
+                *(uint2*)(sV + row * VROW + (((2 * slot) ^ sw) << 3)) = make_uint2(rv[p].x, rv[p].y);
+                *(uint2*)(sV + row * VROW + (((2 * slot + 1) ^ sw) << 3)) = make_uint2(rv[p].z, rv[p].w);
             } else {
-                *(uint4*)(sK + row * ROWB + ((sslot ^ (row & 15)) << 4)) = rk[p];
-                *(uint4*)(sV + row * ROWB + ((sslot ^ (row & 15)) << 4)) = rv[p];
+                *(uint4*)(sV + row * VROW + ((slot ^ (row & 15)) << 4)) = rv[p];
             }
         }
     };
     // S^T = K Q^T of the tile in buffer `buf`: accS[kb][r] = key kb*32 + (r/4)*8 + lh*4 + r%4, query l31
     auto scores = [&](int buf, f32x16_t (&accS)[2]) {
-        const char* sK = sKb[buf];
+        const char* sK = sK0 + buf * KBYTES;
         const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             accS[kb] = zero16;  // folded into the first MFMA's inline-constant C operand
             const int krow = kb * 32 + l31;
-            const char* rp = sK + krow * ROWB;
+            const char* rp = sK + krow * KROW;
+            const int sw = kswz(krow);
             if constexpr (BF16) {
-                const int sw = (krow >> 1) & 7;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
+                for (int ks = 0; ks < D / 16; ++ks) {
                     const bf16x8_t fa = *(const bf16x8_t*)(rp + (((2 * ks + lh) ^ sw) << 4));
                     accS[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, qb[ks], accS[kb], 0, 0, 0);
                 }
             } else {
-                const int sw = krow & 15;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const f32x4_t fa = *(const f32x4_t*)(rp + (((lh * 8 + i) ^ sw) << 4));
+                for (int i = 0; i < D / 8; ++i) {
+                    const f32x4_t fa = *(const f32x4_t*)(rp + (((lh * (D / 8) + i) ^ sw) << 4));
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         accS[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], qf[i][e], accS[kb], 0, 0, 0);
@@ -237,7 +243,7 @@ __global__ void __launch_bounds__(256, 2) sdpa_kernel(const SdpaArgs a) {
     };
     // online softmax of tile kt (scores in accS) and O^T += V^T P^T with the V^T tile in buffer `buf`
     auto softmax_pv = [&](int buf, int key0, f32x16_t (&accS)[2]) {
-        const char* sV = sVb[buf];
+        const char* sV = sV0 + buf * VBYTES;
         if (key0 + 64 > a.S) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -270,7 +276,7 @@ __global__ void __launch_bounds__(256, 2) sdpa_kernel(const SdpaArgs a) {
             const float alpha = fast_exp2((m_run - m_new) * a.scale_log2e);
             l_run *= alpha;
 #pragma unroll
-            for (int d = 0; d < 2; ++d)
+            for (int d = 0; d < NDB; ++d)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accO[d][r] *= alpha;
         }
@@ -286,12 +292,12 @@ __global__ void __launch_bounds__(256, 2) sdpa_kernel(const SdpaArgs a) {
                     for (int e = 0; e < 4; ++e) pb.u[e] = cvt_pk_bf16(accS[kb][8 * s + 2 * e], accS[kb][8 * s + 2 * e + 1]);
                     const int c = kb * 8 + 4 * s + lh;  // 8-byte chunk of keys kb*32 + 16 s + lh*4 .. +3 ; c + 2 = +8 keys
 #pragma unroll
-                    for (int d = 0; d < 2; ++d) {
+                    for (int d = 0; d < NDB; ++d) {
                         const int drow = d * 32 + l31;
                         const int sw = (drow >> 1) & 15;
                         union { uint2 h2[2]; bf16x8_t v; } va;
-                        va.h2[0] = *(const uint2*)(sV + drow * ROWB + ((c ^ sw) << 3));
-                        va.h2[1] = *(const uint2*)(sV + drow * ROWB + (((c + 2) ^ sw) << 3));
+                        va.h2[0] = *(const uint2*)(sV + drow * VROW + ((c ^ sw) << 3));
+                        va.h2[1] = *(const uint2*)(sV + drow * VROW + (((c + 2) ^ sw) << 3));
                         accO[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va.v, pb.v, accO[d], 0, 0, 0);
                     }
                 }
@@ -300,9 +306,9 @@ __global__ void __launch_bounds__(256, 2) sdpa_kernel(const SdpaArgs a) {
                 for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 = keys kb*32 + g*8 + lh*4 + 0..3
                     const int slot = kb * 8 + g * 2 + lh;
 #pragma unroll
-                    for (int d = 0; d < 2; ++d) {
+                    for (int d = 0; d < NDB; ++d) {
                         const int drow = d * 32 + l31;
-                        const f32x4_t va = *(const f32x4_t*)(sV + drow * ROWB + ((slot ^ (drow & 15)) << 4));
+                        const f32x4_t va = *(const f32x4_t*)(sV + drow * VROW + ((slot ^ (drow & 15)) << 4));
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             accO[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[e], accS[kb][4 * g + e], accO[d], 0, 0, 0);
@@ -335,9 +341,9 @@ __global__ void __launch_bounds__(256, 2) sdpa_kernel(const SdpaArgs a) {
     const float inv = 1.f / l_tot;
     const int q = q0 + l31;
     if (q < a.L) {
-        const size_t orow = (size_t)(seq * (size_t)a.L + q) * a.ldo + h * 64;
+        const size_t orow = (size_t)(seq * (size_t)a.L + q) * a.ldo + h * D;
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+        for (int d = 0; d < NDB; ++d)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const float4 o = make_float4(accO[d][rg * 4 + 0] * inv, accO[d][rg * 4 + 1] * inv,
@@ -345,6 +351,24 @@ __global__ void __launch_bounds__(256, 2) sdpa_kernel(const SdpaArgs a) {
                 ElemIO<OUT_BF16>::st4(a.out, orow + d * 32 + rg * 8 + lh * 4, o);
             }
     }
+}
+
+template <bool BF16, bool OUT_BF16, int D>
+int launch_sdpa(const SdpaArgs& a, hipStream_t s) {
+    constexpr int ES = BF16 ? 2 : 4;
+    constexpr int smem = 2 * (64 * D * ES + D * 64 * ES);
+    auto kern = sdpa_kernel<BF16, OUT_BF16, D>;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+            gim_set_error("sdpa: hipFuncSetAttribute(%d B LDS) failed", smem);
+            return GIM_ERR_LAUNCH;
+        }
+        attr = true;
+    }
+    const dim3 grid((a.L + 127) / 128, a.H, a.nb), blk(256);
+    hipLaunchKernelGGL(kern, grid, blk, smem, s, a);
+    return gim_check_launch("sdpa");
 }
 
 }  // namespace
@@ -389,7 +413,7 @@ extern "C" int gim_cast_rows(const float* src, void* dst, int rows, int C, int l
 extern "C" int gim_layernorm_act(const float* x, const float* gamma, const float* beta, void* out, int rows, int C,
                                  int ldx, int ldo, int act, int out_dtype, float eps, gim_stream_t stream) {
     GIM_REQUIRE(x && gamma && beta && out && rows > 0, "layernorm_act: bad args");
-    GIM_REQUIRE(C > 0 && C % 4 == 0 && C <= 512 && ldx % 4 == 0 && ldo % 4 == 0, "layernorm_act: C=%d (multiple of 4, <= 512)", C);
+    GIM_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ldo % 4 == 0, "layernorm_act: C=%d (multiple of 4, <= 1024)", C);
     GIM_REQUIRE(act == GIM_ACT_NONE || act == GIM_ACT_GELU, "layernorm_act: act must be NONE or GELU");
     hipStream_t s = (hipStream_t)stream;
     const dim3 g((rows + 3) / 4), b(256);
@@ -404,7 +428,7 @@ extern "C" int gim_layernorm_act(const float* x, const float* gamma, const float
 extern "C" int gim_sdpa(const void* q, const void* k, const void* vt, void* out, int nb, int H, int L, int S, int Sp,
                         int D, int ldq, int ldk, int ldo, int kv_shift, int dtype, int out_dtype, gim_stream_t stream) {
     GIM_REQUIRE(q && k && vt && out && nb > 0 && H > 0 && L > 0 && S > 0, "sdpa: bad args");
-    GIM_REQUIRE(D == 64, "sdpa: head dim %d unsupported (64)", D);
+    GIM_REQUIRE(D == 64 || D == 128, "sdpa: head dim %d unsupported (64, 128)", D);
     GIM_REQUIRE(Sp >= S && Sp % 64 == 0, "sdpa: Sp=%d must be S rounded up to a multiple of 64", Sp);
     const int g = dtype == GIM_BF16 ? 8 : 4;
     GIM_REQUIRE(ldq % g == 0 && ldk % g == 0 && ldo % 4 == 0, "sdpa: row strides must keep 16-byte alignment");
@@ -412,13 +436,17 @@ extern "C" int gim_sdpa(const void* q, const void* k, const void* vt, void* out,
     SdpaArgs a;
     a.q = q; a.k = k; a.vt = vt; a.out = out;
     a.nb = nb; a.H = H; a.L = L; a.S = S; a.Sp = Sp; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.kv_shift = kv_shift;
-    a.scale_log2e = 0.125f * 1.44269504088896340736f;
+    a.scale_log2e = (1.0f / sqrtf((float)D)) * 1.44269504088896340736f;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((L + 127) / 128, H, nb), blk(256);
     const bool bf = dtype == GIM_BF16, obf = out_dtype == GIM_BF16;
-    if (bf && obf) hipLaunchKernelGGL((sdpa_kernel<true, true>), grid, blk, 0, s, a);
-    else if (bf) hipLaunchKernelGGL((sdpa_kernel<true, false>), grid, blk, 0, s, a);
-    else if (obf) hipLaunchKernelGGL((sdpa_kernel<false, true>), grid, blk, 0, s, a);
-    else hipLaunchKernelGGL((sdpa_kernel<false, false>), grid, blk, 0, s, a);
-    return gim_check_launch("sdpa");
+    if (D == 64) {
+        if (bf && obf) return launch_sdpa<true, true, 64>(a, s);
+        if (bf) return launch_sdpa<true, false, 64>(a, s);
+        if (obf) return launch_sdpa<false, true, 64>(a, s);
+        return launch_sdpa<false, false, 64>(a, s);
+    }
+    if (bf && obf) return launch_sdpa<true, true, 128>(a, s);
+    if (bf) return launch_sdpa<true, false, 128>(a, s);
+    if (obf) return launch_sdpa<false, true, 128>(a, s);
+    return launch_sdpa<false, false, 128>(a, s);
 }

@@ -471,22 +471,29 @@ class RegressionMatcher(nn.Module):
     def sample(self, dense_matches, dense_certainty, num=10000):
         """RegressionMatcher.sample (dkm.py:583-620).  The two multinomial draws are `gim_weighted_sample` (seeded from
         torch's generator), the balanced-sampling density is the HIP KDE kernel; samples come back as an unordered set."""
-        if "threshold" not in self.sample_mode or "balanced" not in self.sample_mode:
-            raise NotImplementedError("gim uses sample_mode='threshold_balanced' (DKMv3.py:5)")
-        cert_ = dense_certainty.reshape(-1).contiguous()
-        matches = dense_matches.reshape(-1, 4)
-        cert = torch.where(cert_ > self.sample_thresh, torch.ones_like(cert_), cert_)   # dense_certainty[> thresh] = 1
-        n_pos = int((cert > 0).sum())
-        if n_pos == 0:
-            cert, n_pos = cert + 1e-8, cert.numel()
-        seeds = torch.randint(0, 2 ** 31 - 1, (2,)).tolist()      # torch's (CPU) generator: torch.manual_seed makes sample() reproducible
-        # the kernel returns an unordered set (atomic compaction); sorting makes sample() reproducible from the seed
-        good = ops.weighted_sample(cert, min(4 * num, cert.numel(), n_pos), seeds[0]).sort().values
-        gm, gc = matches[good].contiguous(), cert_[good]
-        density = ops.kde(gm, 0.1)
-        p = torch.where(density < 10, torch.full_like(density, 1e-7), 1 / (density + 1))
-        bal = ops.weighted_sample(p.contiguous(), min(num, len(gc)), seeds[1]).sort().values
-        return gm[bal], gc[bal]
+        return balanced_sample(dense_matches, dense_certainty, num, self.sample_mode, self.sample_thresh, kde_half=False)
+
+
+@torch.no_grad()
+def balanced_sample(dense_matches, dense_certainty, num, sample_mode, sample_thresh, kde_half):
+    """`sample()` of both dense matchers (dkm.py:583-620, roma.py:680-714): certainty above the threshold counts as 1, draw
+    4 * num matches without replacement, re-draw num of them with weights 1 / (1 + KDE density)."""
+    if "threshold" not in sample_mode or "balanced" not in sample_mode:
+        raise NotImplementedError("gim uses sample_mode='threshold_balanced' (DKMv3.py:5, roma.py:645)")
+    cert_ = dense_certainty.reshape(-1).contiguous()
+    matches = dense_matches.reshape(-1, 4)
+    cert = torch.where(cert_ > sample_thresh, torch.ones_like(cert_), cert_)   # dense_certainty[> thresh] = 1
+    n_pos = int((cert > 0).sum())
+    if n_pos == 0:
+        cert, n_pos = cert + 1e-8, cert.numel()
+    seeds = torch.randint(0, 2 ** 31 - 1, (2,)).tolist()      # torch's (CPU) generator: torch.manual_seed makes sample() reproducible
+    # the kernel returns an unordered set (atomic compaction); sorting makes sample() reproducible from the seed
+    good = ops.weighted_sample(cert, min(4 * num, cert.numel(), n_pos), seeds[0]).sort().values
+    gm, gc = matches[good].contiguous(), cert_[good]
+    density = ops.kde(gm, 0.1, half=kde_half)
+    p = torch.where(density < 10, torch.full_like(density, 1e-7), 1 / (density + 1))
+    bal = ops.weighted_sample(p.contiguous(), min(num, len(gc)), seeds[1]).sort().values
+    return gm[bal], gc[bal]
 
 
 def DKMv3(weights, h, w, symmetric=True, sample_mode="threshold_balanced", **kwargs):

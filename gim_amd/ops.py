@@ -329,11 +329,11 @@ def lg_transpose(src, dst, nb, S, Sp, C):
     check(lib.gim_lg_transpose(_p(src), _p(dst), nb, S, Sp, C, src.stride(0), gim_dtype(src), _stream()), "gim_lg_transpose")
 
 
-def sdpa(q, k, vt, out, nb, H, L, S, Sp, kv_shift=0):
-    """q row view [nb*L, ..], k row view [nb*S, ..], vt [nb, H*64, Sp], out row view [nb*L, ..]"""
+def sdpa(q, k, vt, out, nb, H, L, S, Sp, kv_shift=0, D=64):
+    """q row view [nb*L, ..], k row view [nb*S, ..], vt [nb, H*D, Sp], out row view [nb*L, ..]; head dim D in {64, 128}"""
     _req_cuda(q, k, vt, out)
     assert q.dtype == k.dtype == vt.dtype
-    check(lib.gim_sdpa(_p(q), _p(k), _p(vt), _p(out), nb, H, L, S, Sp, 64, q.stride(0), k.stride(0), out.stride(0),
+    check(lib.gim_sdpa(_p(q), _p(k), _p(vt), _p(out), nb, H, L, S, Sp, D, q.stride(0), k.stride(0), out.stride(0),
                        kv_shift, gim_dtype(q), gim_dtype(out), _stream()), "gim_sdpa")
 
 
@@ -518,11 +518,12 @@ def cab_scale_add(g, x1, x2):
     return out
 
 
-def dkm_flow_update(flow, cert, d, sx, sy, cert_init=False):
-    """flow [B,h,w,2], cert [B,h,w,1] fp32 updated in place from d rows [B*h*w, >=3] = [dcert, dx, dy]"""
+def dkm_flow_update(flow, cert, d, sx, sy, cert_init=False, roma_layout=False):
+    """flow [B,h,w,2], cert [B,h,w,1] fp32 updated in place from d rows [B*h*w, >=3] = [dcert, dx, dy] (DKM) or
+    [dx, dy, dcert] (RoMa, roma.py:579)"""
     _req_cuda(flow, cert, d)
-    check(lib.gim_dkm_flow_update(_p(flow), _p(cert), _p(d), flow.numel() // 2, d.stride(0), sx, sy, 1 if cert_init else 0,
-                                  gim_dtype(d), _stream()), "gim_dkm_flow_update")
+    check(lib.gim_dkm_flow_update(_p(flow), _p(cert), _p(d), flow.numel() // 2, d.stride(0), sx, sy,
+                                  (1 if cert_init else 0) | (2 if roma_layout else 0), gim_dtype(d), _stream()), "gim_dkm_flow_update")
 
 
 def dkm_grid_coords(B, h, w, device):
@@ -585,13 +586,22 @@ def matmul_nt(x, w_rows, n, y):
     conv_rows(x, pk, (1, 1, M, 1, M), y)
 
 
-def kde(x, std):
-    """x [n,4] fp32 contiguous -> density [n]"""
+def kde(x, std, half=False):
+    """x [n,4] fp32 contiguous -> density [n]; half: coordinates rounded to fp16 first (RoMa's kde, roma.py:1018-1023)"""
     _req_cuda(x)
     assert x.dim() == 2 and x.shape[1] == 4 and x.is_contiguous() and x.dtype == torch.float32
     d = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
-    check(lib.gim_kde(_p(x), _p(d), x.shape[0], std, _stream()), "gim_kde")
+    check(lib.gim_kde(_p(x), _p(d), x.shape[0], -std if half else std, _stream()), "gim_kde")
     return d
+
+
+def cls_to_flow(logits, B, h, w, ncls):
+    """logits rows [B*h*w, >= ncls + 1] fp32 (64x64 anchor classes + certainty) -> (flow [B,h,w,2], certainty [B,h,w,1])"""
+    _req_cuda(logits)
+    flow = torch.empty(B, h, w, 2, dtype=torch.float32, device=logits.device)
+    cert = torch.empty(B, h, w, 1, dtype=torch.float32, device=logits.device)
+    check(lib.gim_cls_to_flow(_p(logits), _p(flow), _p(cert), B * h * w, ncls, logits.stride(0), _stream()), "gim_cls_to_flow")
+    return flow, cert
 
 
 def weighted_sample(w, k, seed):

@@ -76,10 +76,13 @@ def pack_conv(weight, bn, dtype, device, stride=1, pad=0, cin_pad=None, bias=Non
     k = kh * kw * cin_pad
     kpad = _round_up(k, kslab)
     npad = _round_up(cout, NPAD)
-    wp = torch.zeros(npad, kh, kw, cin_pad, dtype=torch.float32)
-    wp[:cout, :, :, :cin] = w.permute(0, 2, 3, 1).cpu()
     wk = torch.zeros(npad, kpad, dtype=torch.float32)
-    wk[:, :k] = wp.reshape(npad, k)
+    if kh == 1 and kw == 1:          # Linear / 1x1 conv: one pass (the 300 M-parameter ViT packs in seconds)
+        wk[:cout, :cin] = w.reshape(cout, cin).cpu()
+    else:
+        wp = torch.zeros(npad, kh, kw, cin_pad, dtype=torch.float32)
+        wp[:cout, :, :, :cin] = w.permute(0, 2, 3, 1).cpu()
+        wk[:, :k] = wp.reshape(npad, k)
     nkt = kpad // kslab
     ngrp = (nkt + 2) * 8
     gidx = torch.arange(ngrp, dtype=torch.int64) * g
@@ -91,7 +94,7 @@ def pack_conv(weight, bn, dtype, device, stride=1, pad=0, cin_pad=None, bias=Non
     ent = torch.where(ent >= 2 ** 31, ent - 2 ** 32, ent).to(torch.int32)
 
     p = PackedConv()
-    p.w = wk.to(torch_dtype(dtype)).to(device).contiguous()
+    p.w = wk.to(device).to(torch_dtype(dtype)).contiguous()     # rounding (RNE) on the device: same bits, no host pass
     if b is not None:
         bp = torch.zeros(npad, dtype=torch.float32)
         bp[:cout] = b.cpu()

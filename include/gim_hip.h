@@ -25,7 +25,7 @@ extern "C" {
 typedef void* gim_stream_t; /* hipStream_t */
 
 enum { GIM_F32 = 0, GIM_BF16 = 1 };
-enum { GIM_ACT_NONE = 0, GIM_ACT_RELU = 1, GIM_ACT_LEAKY = 2, GIM_ACT_ELU1 = 3 /* elu(x)+1 */, GIM_ACT_GELU = 4 /* exact erf GELU, gim_layernorm_act only */ };
+enum { GIM_ACT_NONE = 0, GIM_ACT_RELU = 1, GIM_ACT_LEAKY = 2, GIM_ACT_ELU1 = 3 /* elu(x)+1 */, GIM_ACT_GELU = 4 /* exact erf GELU */ };
 enum { GIM_OK = 0, GIM_ERR_INVALID = -1, GIM_ERR_LAUNCH = -2, GIM_ERR_UNSUPPORTED = -3 };
 
 int gim_version(void);
@@ -313,7 +313,8 @@ int gim_global_avgpool(const void* x, float* out, int B, int HW, int C, int ld, 
                        gim_stream_t stream);
 int gim_cab_scale_add(const float* g, const void* x1, const void* x2, void* out, int B, int HW, int C, int ldg, int ld1,
                       int ld2, int ldo, int dtype, gim_stream_t stream);
-/* Decoder.forward flow / certainty update -- dkm.py:505-514: d rows = [delta certainty, dx, dy]. */
+/* Decoder.forward flow / certainty update -- dkm.py:505-514, roma.py:318-331.  cert_init bit 0: certainty = delta
+ * (instead of +=); bit 1: d rows = [dx, dy, delta certainty] (RoMa, roma.py:579) instead of [delta certainty, dx, dy]. */
 int gim_dkm_flow_update(float* flow, float* cert, const void* d, int64_t npix, int ldd, float sx, float sy,
                         int cert_init, int dtype, gim_stream_t stream);
 /* get_placeholder_flow -- dkm.py:437-448. */
@@ -326,7 +327,10 @@ int gim_dkm_match_post(const float* flow0, const float* flow1, const float* cert
 int gim_dkm_black_mask(const float* im, uint8_t* mask, int h, int w, int Ho, int Wo, gim_stream_t stream);
 /* kde(x, std) -- utils/kde.py:17-26: density[i] = sum_j exp(-cdist(x_i, x_j)^2 / (2 std^2)), x [n,4] fp32 (the
  * reference materialises the n x n distance matrix: 1.6 GB at n = 20000). */
-int gim_kde(const float* x, float* density, int n, float std, gim_stream_t stream);
+int gim_kde(const float* x, float* density, int n, float std, gim_stream_t stream);  /* std < 0: |std| on fp16-rounded x (roma.py:1018-1023) */
+/* cls_to_flow_refine + the certainty channel of TransformerDecoder's output -- roma.py:1092-1121, 1013-1014: logits rows
+ * [npix][ld] fp32 = ncls (= res^2) anchor classes then the certainty logit -> flow [npix,2], cert [npix]. */
+int gim_cls_to_flow(const float* logits, float* flow, float* cert, int npix, int ncls, int ld, gim_stream_t stream);
 /* torch.multinomial(w, k, replacement=False) of RegressionMatcher.sample -- dkm.py:603-605,617-619: k distinct indices
  * drawn with probability proportional to w (exponential clocks + radix-select top-k), as an unordered set; reproducible
  * from `seed`.  Needs at least k positive weights. */

@@ -1,0 +1,254 @@
+"""GPU parity tests of the gim_roma path, through the C ABI, against oracle/roma_oracle.py on the same seeded
+inputs and against the golden vectors recorded from the reference's own modules (tests/golden/roma_*.npz).
+
+Bars: fp32 mode 2e-5 of the output scale for single kernels (summation order only), 1e-4 for the stages of the
+whole pipeline; bf16 mode 3e-2."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import roma_oracle as O
+
+pytestmark = pytest.mark.gpu
+DTS = ["fp32", "bf16"]
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _tdt(dt):
+    return torch.bfloat16 if dt == "bf16" else torch.float32
+
+
+def _close(got, ref, tol, what=""):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    scale = max(1e-6, ref.abs().max().item())
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, f"{what}: max|err|={err:.3e} scale={scale:.3e} tol={tol}"
+
+
+# ----------------------------------------------------------------------------------------------- kernels
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("L,S", [(80, 80), (257, 257), (1370, 1370)])
+def test_sdpa_head_dim_128(dt, L, S):
+    """flash SDPA with 128-wide heads (RoMa's decoder blocks, 8 x 128; DINOv2 uses 16 x 64) vs fp64 softmax attention"""
+    from gim_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(8)
+    nb, H, D = 2, 2, 128
+    C = H * D
+    tdt = _tdt(dt)
+    q = torch.randn(nb * L, 3 * C, generator=g).to(tdt)
+    q[:, C:2 * C] *= 1.5
+    Sp = (S + 63) // 64 * 64
+    vt = torch.empty(nb, C, Sp, dtype=tdt, device=dev)
+    qd = q.to(dev)
+    ops.lg_transpose(qd[:, 2 * C:], vt, nb, S, Sp, C)
+    out = torch.empty(nb * L, C, dtype=tdt, device=dev)
+    ops.sdpa(qd[:, :C], qd[:, C:2 * C], vt, out, nb, H, L, S, Sp, D=D)
+    qq = q.double()[:, :C].reshape(nb, L, H, D).transpose(1, 2)
+    kk = q.double()[:, C:2 * C].reshape(nb, S, H, D).transpose(1, 2)
+    vv = q.double()[:, 2 * C:].reshape(nb, S, H, D).transpose(1, 2)
+    ref = (torch.softmax(qq @ kk.transpose(-1, -2) / math.sqrt(D), -1) @ vv).transpose(1, 2).reshape(nb * L, C)
+    _close(out, ref.float(), 1e-5 if dt == "fp32" else 1.5e-2, f"sdpa D=128 L={L}")
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_layernorm_1024(dt):
+    from gim_amd import ops
+    from gim_amd._lib import ACT_NONE
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    x = 2 * torch.randn(77, 1024, generator=g) + 0.3
+    gamma, beta = 1 + 0.1 * torch.randn(1024, generator=g), 0.1 * torch.randn(1024, generator=g)
+    out = torch.empty(77, 1024, dtype=_tdt(dt), device=dev)
+    ops.layernorm_act(x.to(dev), gamma.to(dev), beta.to(dev), out, ACT_NONE, eps=1e-6)
+    _close(out, F.layer_norm(x, (1024,), gamma, beta, 1e-6), 1e-2 if dt == "bf16" else 2e-6, "layernorm 1024")
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_linear_gelu_epilogue(dt):
+    """exact (erf) GELU in the igemm epilogue: fc1 of the ViT MLPs"""
+    from gim_amd import ops
+    from gim_amd._lib import ACT_GELU, GIM_BF16, GIM_F32
+    from gim_amd.packing import pack_conv
+    dev = _dev()
+    g = torch.Generator().manual_seed(10)
+    tdt = _tdt(dt)
+    x = torch.randn(333, 256, generator=g).to(tdt)
+    w = (torch.randn(512, 256, generator=g) / 16).to(tdt)
+    b = torch.randn(512, generator=g)
+    pk = pack_conv(w.float(), None, GIM_BF16 if dt == "bf16" else GIM_F32, dev, bias=b)
+    y = torch.empty(333, pk.n_store, dtype=tdt, device=dev)
+    ops.linear(x.to(dev), pk, y, ACT_GELU)
+    ref = F.gelu(x.double() @ w.double().t() + b.double()).float()
+    _close(y[:, :512], ref, 1e-2 if dt == "bf16" else 2e-5, "linear+gelu")
+
+
+def test_cls_to_flow():
+    """arg-max + 4-neighbourhood anchor regression vs the oracle, incl. modes on the class-grid border (clamped gathers)"""
+    from gim_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    B, h, w, res = 2, 7, 9, 64
+    C = res * res
+    logits = torch.randn(B, C + 1, h, w, generator=g) * 2
+    # force some modes to the corners / edges of the anchor grid
+    flat = logits.permute(0, 2, 3, 1).reshape(-1, C + 1)
+    for r, c in enumerate([0, 1, res - 1, res, C - 1, C - res, C - 2, 63 * 64 + 5, 5, 2080]):
+        flat[r, c] = 12.0
+    logits = flat.reshape(B, h, w, C + 1).permute(0, 3, 1, 2).contiguous()
+    ref = O.cls_to_flow_refine(logits[:, :-1])
+    rows = logits.permute(0, 2, 3, 1).reshape(-1, C + 1).contiguous().to(dev)
+    flow, cert = ops.cls_to_flow(rows, B, h, w, C)
+    _close(flow, ref, 2e-6, "cls_to_flow")
+    assert torch.equal(cert.cpu()[..., 0], logits[:, -1])
+
+
+def test_kde_half():
+    from gim_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(3000, 4, generator=g) * 2 - 1
+    ref = O.kde_half(x, 0.1)
+    got = ops.kde(x.to(dev), 0.1, half=True)
+    _close(got, ref, 2e-5, "kde half")
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_flow_update_roma_layout(dt):
+    from gim_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(13)
+    B, h, w = 2, 5, 6
+    flow = torch.randn(B, h, w, 2, generator=g)
+    cert = torch.randn(B, h, w, 1, generator=g)
+    d = torch.randn(B * h * w, 8, generator=g).to(_tdt(dt))
+    f, c = flow.to(dev), cert.to(dev)
+    ops.dkm_flow_update(f, c, d.to(dev), 0.5, 0.25, roma_layout=True)
+    df = d.float().reshape(B, h, w, 8)
+    _close(f, flow + df[..., :2] * torch.tensor([0.5, 0.25]), 1e-6, "flow")
+    _close(c, cert + df[..., 2:3], 1e-6, "cert")
+
+
+# ----------------------------------------------------------------------------------------------- whole path
+_SD = {}
+
+
+def _weights():
+    if not _SD:
+        _SD["roma"], _SD["dino"] = O.make_state_dicts(0)
+    return _SD["roma"], _SD["dino"]
+
+
+_MODELS = {}
+
+
+def _model(precision, h, w, up):
+    """one module per precision (packing the 300 M-parameter ViT takes a while); resolutions are plain attributes read at
+    call time, exactly how gim's callers reconfigure the reference's module"""
+    from gim_amd.roma import RoMa
+    if precision not in _MODELS:
+        sd, dsd = _weights()
+        m = RoMa([h, w], precision=precision, dinov2_weights=dsd)
+        m.load_state_dict(sd)
+        _MODELS[precision] = m.eval()
+    m = _MODELS[precision]
+    m.h_resized, m.w_resized = h, w
+    m.upsample_preds = up is not None
+    if up is not None:
+        m.upsample_res = up
+    return m
+
+
+def _golden_inputs(golden_dir, name):
+    import dkm_oracle as DO
+    g = np.load(os.path.join(golden_dir, name))
+    H, W = (int(v) for v in g["hw"])
+    im0, im1 = DO.seeded_pair(*(int(v) for v in g["image_hw"]), int(g["seed"]))
+    return g, H, W, im0, im1
+
+
+def test_state_dict_surface():
+    """the module's state_dict is the reference's (oracle spec = names / shapes recorded from the reference's RoMa)"""
+    from gim_amd.roma import RoMa
+    spec = O.roma_param_spec()
+    sd = RoMa([112, 140]).state_dict()
+    assert set(sd) == set(spec)
+    for k, shp in spec.items():
+        assert tuple(sd[k].shape) == tuple(shp), k
+
+
+def test_stage_goldens_fp32(golden_dir):
+    """encoder / GP / transformer decoder / anchor regression vs the reference's own intermediate tensors"""
+    g, H, W, im0, im1 = _golden_inputs(golden_dir, "roma_stages.npz")
+    dev = _dev()
+    m = _model("fp32", H, W, None)
+    m.match(im0.to(dev), im1.to(dev))
+    P, dt, _ = m._packed
+    pyr = m._encode(P, dt, m._images(dt, im0.to(dev), im1.to(dev), H, W))
+    _close(pyr[16].permute(0, 3, 1, 2), torch.as_tensor(g["dino16"]), 2e-4, "dino16")
+    _close(pyr[8].permute(0, 3, 1, 2)[:, ::8], torch.as_tensor(g["vgg8_sub"]), 1e-4, "vgg8")
+    _close(pyr[1].permute(0, 3, 1, 2)[:, ::16, ::4, ::4], torch.as_tensor(g["vgg1_sub"]), 1e-4, "vgg1")
+    gm_flow, gm_cert = m._debug["low"]["gm"]
+    _close(gm_cert.permute(0, 3, 1, 2), torch.as_tensor(g["gm_certainty"]), 1e-3, "gm_certainty")
+    _close(gm_flow, torch.as_tensor(g["gm_flow"]), 1e-3, "gm_flow")
+
+
+def test_match_golden_fp32(golden_dir):
+    """engine (fp32 mode) vs the reference's own RoMa.match() at 112x140 -> 168x224 (tests/golden/roma_match.npz)"""
+    g, H, W, im0, im1 = _golden_inputs(golden_dir, "roma_match.npz")
+    up = tuple(int(v) for v in g["up"])
+    dev = _dev()
+    m = _model("fp32", H, W, up)
+    warp, cert = m.match(im0.to(dev), im1.to(dev))
+    low = m._debug["low"]
+    _close(low[16][0].permute(0, 3, 1, 2), torch.as_tensor(g["flow16"]), 2e-3, "flow16")
+    _close(low[16][1].permute(0, 3, 1, 2), torch.as_tensor(g["cert16"]), 2e-3, "cert16")
+    _close(low[1][0].permute(0, 3, 1, 2), torch.as_tensor(g["flow1"]), 2e-3, "flow1")
+    assert warp.shape == (up[0], 2 * up[1], 4) and cert.shape == (up[0], 2 * up[1])
+    _close(warp[::2, ::2], torch.as_tensor(g["warp"]), 2e-3, "warp")
+    _close(cert[::2, ::2], torch.as_tensor(g["certainty"]), 5e-3, "certainty")
+
+
+def test_match_bf16_batch_and_sample(golden_dir):
+    """throughput mode: finite, close on average to the reference's fp32 result; batch of 2 pairs == 2 single calls;
+    sample() contract"""
+    g, H, W, im0, im1 = _golden_inputs(golden_dir, "roma_match.npz")
+    up = tuple(int(v) for v in g["up"])
+    dev = _dev()
+    m = _model("bf16", H, W, up)
+    a, b = im0.to(dev), im1.to(dev)
+    warp, cert = m.match(a, b)
+    assert torch.isfinite(warp).all() and torch.isfinite(cert).all()
+    e_w = (warp[::2, ::2].cpu() - torch.as_tensor(g["warp"])).abs().mean().item()
+    e_c = (cert[::2, ::2].cpu() - torch.as_tensor(g["certainty"])).abs().mean().item()
+    print(f"bf16 vs fp32 reference: mean |warp err| {e_w:.4f}, mean |certainty err| {e_c:.4f}")
+    assert e_w < 0.05 and e_c < 0.1
+    wb, cb = m.match_batch(torch.cat((a, b)), torch.cat((b, a)))
+    assert torch.equal(wb[0], warp) and torch.equal(cb[0], cert)
+    w2, c2 = m.match(b, a)
+    assert torch.equal(wb[1], w2) and torch.equal(cb[1], c2)
+    torch.manual_seed(0)
+    sm, sc = m.sample(warp, cert, 300)
+    assert sm.shape == (300, 4) and sc.shape == (300,) and sm.abs().max() <= 1
+
+
+def test_roma_fails_loudly():
+    from gim_amd._lib import GimHipError
+    from gim_amd.roma import RoMa
+    m = _model("fp32", 112, 140, None)
+    with pytest.raises(GimHipError):
+        m.match(torch.rand(1, 3, 64, 64), torch.rand(1, 3, 64, 64))             # host tensors: no CPU fallback
+    m2 = RoMa([112, 140])
+    m2.load_state_dict(_weights()[0])
+    with pytest.raises(GimHipError):
+        m2.match(torch.rand(1, 3, 64, 64, device=_dev()), torch.rand(1, 3, 64, 64, device=_dev()))   # no DINOv2 weights

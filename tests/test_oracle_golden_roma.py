@@ -18,11 +18,11 @@ def _close(a, b, tol=1e-4):
 
 
 def test_param_specs():
-    sd, dsd = O.make_state_dicts(0)
-    assert len(sd) == len(O.roma_param_spec()) and len(dsd) == len(O.dino_param_spec())
-    assert sum(v.numel() for v in dsd.values()) == 304368640                       # DINOv2 ViT-L/14 (with mask token)
-    assert sd["decoder.embedding_decoder.to_out.weight"].shape == (4097, 1024)
-    assert sd["decoder.conv_refiner.1.block1.0.weight"].shape == (24, 1, 5, 5)      # 2*9 + 6 = 24 input channels, depthwise
+    spec, dspec = O.roma_param_spec(), O.dino_param_spec()
+    assert len(spec) == 603
+    assert sum(int(np.prod(v)) for v in dspec.values()) == 304368640               # DINOv2 ViT-L/14 (with mask token)
+    assert spec["decoder.embedding_decoder.to_out.weight"] == (4097, 1024)
+    assert spec["decoder.conv_refiner.1.block1.0.weight"] == (24, 1, 5, 5)          # 2*9 + 6 = 24 input channels, depthwise
 
 
 def _run(golden_dir, with_match):

@@ -202,6 +202,59 @@ def main():
                      "note": "algorithmic 334 GFLOP/pair (SURVEY 8d); kernel split in profiles/r01_lightglue_*"}
         del det, lgm
 
+    # ---- secondary workloads: the two dense matchers at the reference's own configurations (one pair per call) ----
+    dense = {}
+    if rank == 0 and world == 1 and not os.environ.get("GIM_BENCH_SKIP_DENSE"):
+        gg = torch.Generator().manual_seed(1)
+        base = torch.nn.functional.interpolate(torch.rand(1, 3, 60, 80, generator=gg), size=(480, 640), mode="bicubic").clamp(0.05, 1)
+        im0 = base.to(dev)
+        im1 = torch.roll(base, shifts=(12, 20), dims=(2, 3)).to(dev)
+
+        def dense_bench(name, build, note):
+            try:
+                torch.manual_seed(0)
+                m = build().eval()
+                with torch.no_grad():   # random init; refiner outputs scaled down so the flow stays in range (what trained weights do)
+                    for s_ in ("16", "8", "4", "2", "1"):
+                        m.decoder.conv_refiner[s_].out_conv.weight.mul_(0.05)
+                        m.decoder.conv_refiner[s_].out_conv.bias.mul_(0.05)
+                for _ in range(2):
+                    warp, cert = m.match(im0, im1)
+                    m.sample(warp, cert, 5000)
+                torch.cuda.synchronize()
+                n_it = 5
+                td = time.perf_counter()
+                for _ in range(n_it):
+                    warp, cert = m.match(im0, im1)
+                torch.cuda.synchronize()
+                t_match = (time.perf_counter() - td) / n_it
+                td = time.perf_counter()
+                for _ in range(n_it):
+                    m.sample(warp, cert, 5000)
+                torch.cuda.synchronize()
+                t_sample = (time.perf_counter() - td) / n_it
+                dense[name] = {"workload": note, "pairs_per_s": round(1.0 / (t_match + t_sample), 2),
+                               "match_ms": round(1e3 * t_match, 2), "sample_ms": round(1e3 * t_sample, 2), "dtype": args.precision}
+                del m
+                torch.cuda.empty_cache()
+            except Exception as e:  # a secondary line must never cost the headline measurement
+                dense[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+        def build_dkm():
+            from gim_amd.dkm import DKMv3
+            m = DKMv3(None, 672, 896, upsample_preds=True, precision=args.precision)
+            m.upsample_res = (1152, 1536)
+            return m
+
+        def build_roma():
+            from gim_amd.roma import RoMa, random_dinov2_weights
+            return RoMa([672], precision=args.precision, dinov2_weights=random_dinov2_weights(dev))
+
+        dense_bench("gim_dkm", build_dkm, "gim_dkm match() + sample(5000), 672x896 -> upsampling pass 1152x1536, one pair per call, "
+                    "random-init weights (trainer/lightning.py:29-37 configuration)")
+        dense_bench("gim_roma", build_roma, "gim_roma match() + sample(5000), 672x672 -> upsampling pass 1344x1344, one pair per call, "
+                    "random-init weights incl. a synthetic DINOv2 ViT-L/14 (RoMa(img_size=[672]), trainer/lightning.py:38-41)")
+
     # ---- CPU baseline: the oracle on this host's cores, bounded sample ------------------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -238,7 +291,7 @@ def main():
                        "parallelism": f"pairs sharded over {world} GPU(s), no collective per step",
                        "hip_graph": bool(model.use_graph)},
             "roofline": roof, "cpu_baseline": cpu, "realistic_fine": realistic,
-            "secondary_workloads": {"gim_lightglue": lightglue},
+            "secondary_workloads": {"gim_lightglue": lightglue, **dense},
         }
         print(json.dumps(out), flush=True)
     if world > 1:

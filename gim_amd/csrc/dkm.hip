@@ -13,6 +13,8 @@
 //   flow_update         dense_flow += ins * displacement / (4 w | 4 h), certainty += delta   dkm.py:505-514
 //   match_post          match(): certainty attenuation, sigmoid, out-of-range / black masks, clamp, symmetric layout
 //                                                                             dkm.py:693-741
+#include <cstdlib>
+#include <type_traits>
 #include "gim_common.h"
 
 namespace {
@@ -153,51 +155,86 @@ __global__ void disp_emb_kernel(const float* __restrict__ flow, const float* __r
 // computes the (2r+2)^2 integer-grid dot products D once and every tap is a 4-term combination of them (3.5x fewer
 // feature reads than sampling each tap's four corners).  Dot products: lanes split the channels (coalesced row
 // reads), 16 positions are reduced together with a halving butterfly (17 shuffles instead of 96).
-template <bool BF16, bool OUT_BF16>
+// Everything that depends only on the query (its flow, the patch origin, row bases, bounds) is wave-uniform: the wave index
+// goes through readfirstlane so that the compiler keeps it in SGPRs -- scalar loads for the flow, SGPR base + lane offset
+// addressing, bounds as scalar selects.  Out-of-range taps load a clamped (valid) address and are multiplied by 0, so all
+// PT loads of a patch row are in flight together (scalar branches around single loads serialise them; per-lane predication,
+// the first version, cost ~650 VALU instructions per patch row: 3 ms for the 226 k queries of the 336 x 336 level).
+// PT: compile-time patch side (6 / 8 / 16 >= 2r + 2).  V8: 16-byte loads, 8 channels per lane (C % 512 == 0).
+template <bool BF16, bool OUT_BF16, bool V8, int PT>
 __global__ void __launch_bounds__(256) local_corr_kernel(const void* __restrict__ f0, const void* __restrict__ f1,
                                                          const float* __restrict__ flow, void* __restrict__ out, int B, int h,
                                                          int w, int C, int r, int ld0, int ld1, int ldo) {
+    static_assert(!V8 || BF16, "16-byte channel groups are the bf16 layout");
+    static_assert(PT == 6 || PT == 8 || PT == 16, "patch side");
     __shared__ float Dall[4][18 * 18];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int VEC = V8 ? 8 : 4, ES = BF16 ? 2 : 4, NPOS = PT <= 8 ? 8 : 16;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t q = (size_t)blockIdx.x * 4 + wv;
     if (q >= (size_t)B * h * w) return;
     const int b = (int)(q / ((size_t)h * w));
     float* D = Dall[wv];
-    const int P = 2 * r + 2;  // patch side (<= 16)
+    const int P = 2 * r + 2;  // patch side (<= PT)
     const float gx = flow[q * 2 + 0], gy = flow[q * 2 + 1];
     // tap (0,0) sits at flow + (-2r/w, -2r/h) in normalised units = -r pixels
     const float ix = ((gx + 1.f) * (float)w - 1.f) / 2.f - (float)r, iy = ((gy + 1.f) * (float)h - 1.f) / 2.f - (float)r;
     const float fx = floorf(ix), fy = floorf(iy);
-    const int x0 = (int)fx, y0 = (int)fy;
+    // flows far outside the image (random weights) would overflow the int conversion: every tap is out of range anyway
+    const int x0 = __builtin_amdgcn_readfirstlane((int)fminf(fmaxf(fx, -65536.f), 65536.f));
+    const int y0 = __builtin_amdgcn_readfirstlane((int)fminf(fmaxf(fy, -65536.f), 65536.f));
     const float wx1 = ix - fx, wx0 = (fx + 1.f) - ix, wy1 = iy - fy, wy0 = (fy + 1.f) - iy;
-    const int nch = (C + 255) / 256;  // 4-channel groups per lane, strided by 64 lanes
+    const int nch = (C + 64 * VEC - 1) / (64 * VEC);  // channel groups per lane, strided by 64 lanes
+    const char* q0 = (const char*)f0 + q * (size_t)ld0 * ES;
+    float qa[VEC];                                      // the query's channels of this lane (nch == 1: loaded once)
+    auto load_vec = [&](const char* base, int c, float* dst) {
+        if constexpr (V8) {
+            const uint4 u = *(const uint4*)(base + (size_t)c * ES);
+            dst[0] = __uint_as_float(u.x << 16); dst[1] = __uint_as_float(u.x & 0xffff0000u);
+            dst[2] = __uint_as_float(u.y << 16); dst[3] = __uint_as_float(u.y & 0xffff0000u);
+            dst[4] = __uint_as_float(u.z << 16); dst[5] = __uint_as_float(u.z & 0xffff0000u);
+            dst[6] = __uint_as_float(u.w << 16); dst[7] = __uint_as_float(u.w & 0xffff0000u);
+        } else {
+            const float4 v = ElemIO<BF16>::ld4(base, c);
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+    };
+    if (nch == 1 && lane * VEC < C) load_vec(q0, lane * VEC, qa);
     for (int py = 0; py < P; ++py) {
         const int yy = y0 + py;
-        float part[16];
+        float part[NPOS];
 #pragma unroll
-        for (int px = 0; px < 16; ++px) part[px] = 0.f;
+        for (int px = 0; px < NPOS; ++px) part[px] = 0.f;
         if (yy >= 0 && yy < h) {
+            const char* rowp = (const char*)f1 + (((size_t)b * h + yy) * w) * (size_t)ld1 * ES;
             for (int k = 0; k < nch; ++k) {
-                const int c = (k * 64 + lane) * 4;
+                const int c = (k * 64 + lane) * VEC;
                 if (c >= C) break;
-                const float4 a = ElemIO<BF16>::ld4(f0, q * ld0 + c);
+                if (nch > 1) load_vec(q0, c, qa);
+                float v[PT][VEC];
 #pragma unroll
-                for (int px = 0; px < 16; ++px) {
+                for (int px = 0; px < PT; ++px) {
                     const int xx = x0 + px;
-                    if (px < P && xx >= 0 && xx < w) {
-                        const float4 v = ElemIO<BF16>::ld4(f1, (((size_t)b * h + yy) * w + xx) * ld1 + c);
-                        part[px] += (a.x * v.x + a.y * v.y) + (a.z * v.z + a.w * v.w);
-                    }
+                    load_vec(rowp + (size_t)min(max(xx, 0), w - 1) * ld1 * ES, c, v[px]);
+                }
+#pragma unroll
+                for (int px = 0; px < PT; ++px) {
+                    const int xx = x0 + px;
+                    const float m = (px < P && xx >= 0 && xx < w) ? 1.f : 0.f;   // wave-uniform
+                    float sum = (qa[0] * v[px][0] + qa[1] * v[px][1]) + (qa[2] * v[px][2] + qa[3] * v[px][3]);
+                    if constexpr (V8) sum += (qa[4] * v[px][4] + qa[5] * v[px][5]) + (qa[6] * v[px][6] + qa[7] * v[px][7]);
+                    part[px] = fmaf(m, sum, part[px]);
                 }
             }
         }
-        // halving butterfly: after the step with mask m the lane keeps the positions whose bit (log2 m) matches
+        // halving butterfly over NPOS positions: after the step with mask m the lane keeps the positions whose bit matches
+        constexpr int M0 = NPOS == 16 ? 32 : 16;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int m = 32 >> s, half = 8 >> s;  // half = positions kept
+        for (int s = 0; s < (NPOS == 16 ? 4 : 3); ++s) {
+            const int m = M0 >> s, half = (NPOS / 2) >> s;  // half = positions kept
             const bool up = (lane & m) != 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NPOS / 2; ++i) {
                 if (i < half) {
                     const float mine = up ? part[i + half] : part[i];
                     const float theirs = up ? part[i] : part[i + half];
@@ -206,11 +243,13 @@ __global__ void __launch_bounds__(256) local_corr_kernel(const void* __restrict_
             }
         }
         float v = part[0];
+        if constexpr (NPOS == 8) v += __shfl_xor(v, 32, 64);
         v += __shfl_xor(v, 2, 64);
         v += __shfl_xor(v, 1, 64);
-        // lane now holds position px = bits (lane>>5&1)*8 + (lane>>4&1)*4 + (lane>>3&1)*2 + (lane>>2&1)
-        const int px = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-        if ((lane & 3) == 0 && px < P) D[py * 18 + px] = v;
+        // 16 positions: px = bits 5..2 of the lane (MSB first); 8 positions: bits 4..2 (both 32-lane halves hold the sums)
+        const int px = NPOS == 16 ? ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1)
+                                  : ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+        if ((lane & 3) == 0 && (NPOS == 16 || lane < 32) && px < P) D[py * 18 + px] = v;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes are visible to its own reads
     const int K = 2 * r + 1;
@@ -355,6 +394,154 @@ __global__ void __launch_bounds__(256) dwconv5x5_tiled_kernel(const void* __rest
         }
     }
 }
+
+// depthwise 5x5, channel multiplier 1, second generation.  The 4-pixel kernel above turned out to be bound by the
+// vector-memory front end (16 clk per 1 KB wave load): per 4 outputs it issues 40 input loads AND 50 weight loads (25 taps x
+// 2 float4; L1 hits, but the same TA slots), and every input row is fetched by 5 workgroups on different CUs.  Here
+//   * one thread = 2 rows x 4 pixels x one 16-byte channel group: 6 input rows x 8 pixels feed 8 outputs (6 loads per
+//     output pixel instead of 10) and one weight read serves both rows;
+//   * the 25 x (channels of the block) weights sit in LDS (two float4 planes, lane stride 16 B: conflict-free
+//     ds_read_b128, 4 clk per wave read, on the LDS pipe instead of the TA);
+//   * a block covers CGB <= 32 channel groups x 256 / CGB strips; blocks are XCD-remapped so that vertically adjacent
+//     row pairs (which share 4 of their 6 input rows) run on the same XCD's L2;
+//   * one 16-byte store per output pixel.
+// compiler fence for memory operations (IR level) + scheduling barrier (machine level): pins the software pipeline
+#define ORDER_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+template <bool BF16>
+__global__ void __launch_bounds__(256, 2) dwconv5x5_rows2_kernel(const void* __restrict__ x, const float* __restrict__ wgt,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 void* __restrict__ y, int B, int H, int W, int CG, int CGB, int NCH,
+                                                                 int cpad, int ldx, int ldy, unsigned nblk) {
+    constexpr int G = BF16 ? 8 : 4, ES = BF16 ? 2 : 4, G2 = G / 2, NP = G / 4;   // NP float4 planes of weights
+    extern __shared__ float4 wl[];                                              // [NP][25][CGB]
+    const unsigned lb = xcd_remap(blockIdx.x, nblk);
+    const int chunk = (int)(lb % (unsigned)NCH);
+    const unsigned sblk = lb / (unsigned)NCH;
+    const int cg0 = chunk * CGB;
+    const int ncg = min(CGB, CG - cg0);
+    for (int e = threadIdx.x; e < NP * 25 * ncg; e += 256) {
+        const int c = e % ncg, tp = e / ncg;            // tp = plane * 25 + tap
+        const int pl = tp / 25, tap = tp - pl * 25;
+        wl[(pl * 25 + tap) * CGB + c] = *(const float4*)(wgt + (size_t)tap * cpad + (size_t)(cg0 + c) * G + pl * 4);
+    }
+    __syncthreads();
+    const int SPB = 256 / CGB;
+    const int cgl = threadIdx.x % CGB, sl = threadIdx.x / CGB;
+    const int WS = (W + 3) / 4, HS = (H + 1) / 2;
+    const size_t strip = (size_t)sblk * SPB + sl;
+    if (sl >= SPB || cgl >= ncg || strip >= (size_t)B * HS * WS) return;
+    const int xs = (int)(strip % WS) * 4, Y = (int)((strip / WS) % HS) * 2, b = (int)(strip / ((size_t)WS * HS));
+    const int co = (cg0 + cgl) * G;
+    f32x2_t acc[2][4][G2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int p_ = 0; p_ < 4; ++p_)
+#pragma unroll
+            for (int e = 0; e < G2; ++e) acc[o][p_][e] = (f32x2_t){0.f, 0.f};
+    const unsigned pstride = (unsigned)ldx * ES;
+    // Software pipeline over the 6 input rows: the 8 raw 16-byte groups of row r + 1 are requested before row r is
+    // accumulated (the kernel runs at 2 waves per SIMD; without the prefetch every row exposed a full memory latency).
+    // Out-of-range rows / pixels load a clamped address and are zeroed when unpacked: straight-line code.
+    typedef typename std::conditional<BF16, uint4, float4>::type Raw;
+    Raw raw[8];
+    auto issue = [&](int r) {
+        const int yy = min(max(Y + r - 2, 0), H - 1);
+        const char* rp = (const char*)x + (((size_t)b * H + yy) * W) * pstride + (size_t)co * ES;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) raw[q] = *(const Raw*)(rp + (unsigned)min(max(xs + q - 2, 0), W - 1) * pstride);
+    };
+    issue(0);
+    // a real loop (not unrolled): each iteration is its own scheduling region, so the prefetch stays one row deep (fully
+    // unrolled, the compiler hoisted all 48 loads and all 50 weight reads to the top and spilled 2 KB per thread)
+#pragma unroll 1
+    for (int r = 0; r < 6; ++r) {
+        const int yy = Y + r - 2;
+        const bool rok = yy >= 0 && yy < H;
+        f32x2_t in[8][G2];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int xx = xs + q - 2;
+            const bool ok = rok && xx >= 0 && xx < W;
+            if constexpr (BF16) {
+                uint4 u = raw[q];
+                if (!ok) u = make_uint4(0u, 0u, 0u, 0u);
+                in[q][0] = (f32x2_t){__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u)};
+                in[q][1] = (f32x2_t){__uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+                in[q][2] = (f32x2_t){__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u)};
+                in[q][3] = (f32x2_t){__uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+            } else {
+                float4 v = raw[q];
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                in[q][0] = (f32x2_t){v.x, v.y}; in[q][1] = (f32x2_t){v.z, v.w};
+            }
+        }
+        ORDER_FENCE();
+        if (r < 5) issue(r + 1);
+        ORDER_FENCE();
+        // output row Y + o takes this input row with dy = r - o
+        if (r <= 4) {
+#pragma unroll
+            for (int dx = 0; dx < 5; ++dx) {
+                f32x2_t wv[G2];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+                    const float4 w4 = wl[(pl * 25 + r * 5 + dx) * CGB + cgl];
+                    wv[2 * pl] = (f32x2_t){w4.x, w4.y}; wv[2 * pl + 1] = (f32x2_t){w4.z, w4.w};
+                }
+#pragma unroll
+                for (int p_ = 0; p_ < 4; ++p_)
+#pragma unroll
+                    for (int e = 0; e < G2; ++e) acc[0][p_][e] = __builtin_elementwise_fma(in[p_ + dx][e], wv[e], acc[0][p_][e]);
+            }
+        }
+        if (r >= 1) {
+#pragma unroll
+            for (int dx = 0; dx < 5; ++dx) {
+                f32x2_t wv[G2];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+                    const float4 w4 = wl[(pl * 25 + (r - 1) * 5 + dx) * CGB + cgl];
+                    wv[2 * pl] = (f32x2_t){w4.x, w4.y}; wv[2 * pl + 1] = (f32x2_t){w4.z, w4.w};
+                }
+#pragma unroll
+                for (int p_ = 0; p_ < 4; ++p_)
+#pragma unroll
+                    for (int e = 0; e < G2; ++e) acc[1][p_][e] = __builtin_elementwise_fma(in[p_ + dx][e], wv[e], acc[1][p_][e]);
+            }
+        }
+    }
+    f32x2_t sc[G2], sh[G2];
+#pragma unroll
+    for (int e = 0; e < G2; e += 2) {
+        const float4 a = *(const float4*)(scale + co + 2 * e), c = *(const float4*)(shift + co + 2 * e);
+        sc[e] = (f32x2_t){a.x, a.y}; sc[e + 1] = (f32x2_t){a.z, a.w};
+        sh[e] = (f32x2_t){c.x, c.y}; sh[e + 1] = (f32x2_t){c.z, c.w};
+    }
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        if (Y + o >= H) break;
+#pragma unroll
+        for (int p_ = 0; p_ < 4; ++p_) {
+            if (xs + p_ >= W) break;
+            const size_t oo = (((size_t)b * H + Y + o) * W + xs + p_) * ldy + co;
+            float rr[G];
+#pragma unroll
+            for (int e = 0; e < G2; ++e) {
+                const f32x2_t v = acc[o][p_][e] * sc[e] + sh[e];
+                rr[2 * e] = fmaxf(v.x, 0.f); rr[2 * e + 1] = fmaxf(v.y, 0.f);
+            }
+            if constexpr (BF16) {
+                *(uint4*)((unsigned short*)y + oo) = make_uint4(pack_bf16x2(rr[0], rr[1]), pack_bf16x2(rr[2], rr[3]),
+                                                                pack_bf16x2(rr[4], rr[5]), pack_bf16x2(rr[6], rr[7]));
+            } else {
+                *(float4*)((float*)y + oo) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+            }
+        }
+    }
+}
+
+#undef ORDER_FENCE
 
 // one wave per row: L2 norm of x[r, 0:C]
 template <bool BF16>
@@ -585,10 +772,18 @@ extern "C" int gim_local_corr(const void* f0, const void* f1, const float* flow,
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(nblocks((size_t)B * h * w, 4));
     const bool ib = dtype == GIM_BF16, ob = out_dtype == GIM_BF16;
-    if (ib && ob) hipLaunchKernelGGL((local_corr_kernel<true, true>), grid, dim3(256), 0, s, f0, f1, flow, out, B, h, w, C, r, ld0, ld1, ldo);
-    else if (ib) hipLaunchKernelGGL((local_corr_kernel<true, false>), grid, dim3(256), 0, s, f0, f1, flow, out, B, h, w, C, r, ld0, ld1, ldo);
-    else if (ob) hipLaunchKernelGGL((local_corr_kernel<false, true>), grid, dim3(256), 0, s, f0, f1, flow, out, B, h, w, C, r, ld0, ld1, ldo);
-    else hipLaunchKernelGGL((local_corr_kernel<false, false>), grid, dim3(256), 0, s, f0, f1, flow, out, B, h, w, C, r, ld0, ld1, ldo);
+    const bool v8 = ib && C % 512 == 0 && ld0 % 8 == 0 && ld1 % 8 == 0;
+    const int P = 2 * r + 2;
+#define LC_LAUNCH(I, O, V, PT) hipLaunchKernelGGL((local_corr_kernel<I, O, V, PT>), grid, dim3(256), 0, s, f0, f1, flow, out, B, h, w, C, r, ld0, ld1, ldo)
+#define LC_PT(I, O, V) do { if (P <= 6) LC_LAUNCH(I, O, V, 6); else if (P <= 8) LC_LAUNCH(I, O, V, 8); else LC_LAUNCH(I, O, V, 16); } while (0)
+    if (v8 && ob) LC_PT(true, true, true);
+    else if (ib && ob) LC_PT(true, true, false);
+    else if (!ib && !ob) LC_PT(false, false, false);
+    else if (v8) LC_LAUNCH(true, false, true, 16);
+    else if (ib) LC_LAUNCH(true, false, false, 16);
+    else LC_LAUNCH(false, true, false, 16);
+#undef LC_PT
+#undef LC_LAUNCH
     return gim_check_launch("local_corr");
 }
 
@@ -602,6 +797,18 @@ extern "C" int gim_dwconv5x5_bn_relu(const void* x, const float* wgt, const floa
     const int mult = Cout / Cin;
     if ((mult == 1 || (mult == 2 && dtype == GIM_BF16)) && cpad % G == 0 && ldx % 4 == 0 && ldy % G == 0 && (mult == 2 || ldx % G == 0)) {
         const dim3 gt(nblocks((size_t)B * H * ((W + 3) / 4) * (cpad / G), 256));
+        static const bool rows2 = getenv("GIM_DWCONV_ROWS2") == nullptr || atoi(getenv("GIM_DWCONV_ROWS2")) != 0;
+        if (mult == 1 && rows2) {
+            const int CG = cpad / G;
+            const int NCH = (CG + 31) / 32, CGB = (CG + NCH - 1) / NCH, SPB = 256 / CGB;
+            const size_t strips = (size_t)B * ((H + 1) / 2) * ((W + 3) / 4);
+            const size_t nblk = (strips + SPB - 1) / SPB * NCH;
+            GIM_REQUIRE(nblk < 0x7fffffffull, "dwconv5x5: grid too large");
+            const size_t shm = (size_t)(G / 4) * 25 * CGB * 16;
+            if (dtype == GIM_BF16) hipLaunchKernelGGL((dwconv5x5_rows2_kernel<true>), dim3((unsigned)nblk), dim3(256), shm, s, x, wgt, scale, shift, y, B, H, W, CG, CGB, NCH, cpad, ldx, ldy, (unsigned)nblk);
+            else hipLaunchKernelGGL((dwconv5x5_rows2_kernel<false>), dim3((unsigned)nblk), dim3(256), shm, s, x, wgt, scale, shift, y, B, H, W, CG, CGB, NCH, cpad, ldx, ldy, (unsigned)nblk);
+            return gim_check_launch("dwconv5x5_rows2");
+        }
         if (mult == 1) {
             if (dtype == GIM_BF16) hipLaunchKernelGGL((dwconv5x5_tiled_kernel<true, 1>), gt, dim3(256), 0, s, x, wgt, scale, shift, y, B, H, W, cpad / G, cpad, ldx, ldy);
             else hipLaunchKernelGGL((dwconv5x5_tiled_kernel<false, 1>), gt, dim3(256), 0, s, x, wgt, scale, shift, y, B, H, W, cpad / G, cpad, ldx, ldy);

@@ -1,1 +1,1 @@
-from .roma import RegressionMatcher, RoMa, gim_roma_inference  # noqa: F401
+from .roma import RegressionMatcher, RoMa, gim_roma_inference, random_dinov2_weights  # noqa: F401

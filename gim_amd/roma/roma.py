@@ -551,6 +551,29 @@ def RoMa(img_size, pretrained_backbone=False, **kwargs):
     return RegressionMatcher(h=h, w=w, **kwargs)
 
 
+def random_dinov2_weights(dev, seed=0):
+    """Synthetic ViT-L/14 weights with the magnitudes of a trained network (LayerScale ~0.2) for benchmarks -- there is no
+    checkpoint in the container; generated on `dev` (300 M values), returned on the host by `dino.py` name."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    D = VIT_DIM
+
+    def rn(*shape, s=1.0):
+        return (torch.randn(*shape, generator=g, device=dev) * s).cpu()
+    sd = {"cls_token": rn(1, 1, D, s=0.02), "pos_embed": rn(1, VIT_GRID ** 2 + 1, D, s=0.02),
+          "patch_embed.proj.weight": rn(D, 3, 14, 14, s=1 / 24.0), "patch_embed.proj.bias": rn(D, s=0.02),
+          "norm.weight": 1 + rn(D, s=0.1), "norm.bias": rn(D, s=0.02)}
+    for i in range(VIT_DEPTH):
+        b = f"blocks.{i}."
+        for nm in ("norm1", "norm2"):
+            sd[b + nm + ".weight"], sd[b + nm + ".bias"] = 1 + rn(D, s=0.1), rn(D, s=0.02)
+        sd[b + "attn.qkv.weight"], sd[b + "attn.qkv.bias"] = rn(3 * D, D, s=1 / 32.0), rn(3 * D, s=0.02)
+        sd[b + "attn.proj.weight"], sd[b + "attn.proj.bias"] = rn(D, D, s=1 / 32.0), rn(D, s=0.02)
+        sd[b + "mlp.fc1.weight"], sd[b + "mlp.fc1.bias"] = rn(4 * D, D, s=1 / 32.0), rn(4 * D, s=0.02)
+        sd[b + "mlp.fc2.weight"], sd[b + "mlp.fc2.bias"] = rn(D, 4 * D, s=1 / 64.0), rn(D, s=0.02)
+        sd[b + "ls1.gamma"], sd[b + "ls2.gamma"] = 0.2 + rn(D, s=0.05), 0.2 + rn(D, s=0.05)
+    return sd
+
+
 @torch.no_grad()
 def gim_roma_inference(model, data, num=5000):
     """`Trainer.gim_dkm_inference` (trainer/lightning.py:134-156) -- the same adapter serves gim_roma (lightning.py:125)."""

@@ -14,29 +14,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def random_dinov2(dev, seed=0):
-    """random ViT-L/14 weights with the magnitudes of a trained network (LayerScale ~0.2), generated on the device"""
-    from gim_amd.roma.roma import VIT_DEPTH, VIT_DIM, VIT_GRID
-    g = torch.Generator(device=dev).manual_seed(seed)
-    D = VIT_DIM
-
-    def rn(*shape, s=1.0):
-        return (torch.randn(*shape, generator=g, device=dev) * s).cpu()
-    sd = {"cls_token": rn(1, 1, D, s=0.02), "pos_embed": rn(1, VIT_GRID ** 2 + 1, D, s=0.02),
-          "patch_embed.proj.weight": rn(D, 3, 14, 14, s=1 / 24.0), "patch_embed.proj.bias": rn(D, s=0.02),
-          "norm.weight": 1 + rn(D, s=0.1), "norm.bias": rn(D, s=0.02)}
-    for i in range(VIT_DEPTH):
-        b = f"blocks.{i}."
-        for nm in ("norm1", "norm2"):
-            sd[b + nm + ".weight"], sd[b + nm + ".bias"] = 1 + rn(D, s=0.1), rn(D, s=0.02)
-        sd[b + "attn.qkv.weight"], sd[b + "attn.qkv.bias"] = rn(3 * D, D, s=1 / 32.0), rn(3 * D, s=0.02)
-        sd[b + "attn.proj.weight"], sd[b + "attn.proj.bias"] = rn(D, D, s=1 / 32.0), rn(D, s=0.02)
-        sd[b + "mlp.fc1.weight"], sd[b + "mlp.fc1.bias"] = rn(4 * D, D, s=1 / 32.0), rn(4 * D, s=0.02)
-        sd[b + "mlp.fc2.weight"], sd[b + "mlp.fc2.bias"] = rn(D, 4 * D, s=1 / 64.0), rn(D, s=0.02)
-        sd[b + "ls1.gamma"], sd[b + "ls2.gamma"] = 0.2 + rn(D, s=0.05), 0.2 + rn(D, s=0.05)
-    return sd
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=672)
@@ -48,10 +25,10 @@ def main():
     ap.add_argument("--stages", action="store_true", help="per-stage wall times (synchronising: run separately from the headline)")
     a = ap.parse_args()
     from gim_amd import ops
-    from gim_amd.roma import RoMa
+    from gim_amd.roma import RoMa, random_dinov2_weights
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    m = RoMa([a.size], precision=a.precision, dinov2_weights=random_dinov2(dev)).eval()
+    m = RoMa([a.size], precision=a.precision, dinov2_weights=random_dinov2_weights(dev)).eval()
     m.upsample_preds = not a.no_up
     with torch.no_grad():      # refiner outputs scaled down so the flow stays in range (what trained weights do)
         for s in ("16", "8", "4", "2", "1"):

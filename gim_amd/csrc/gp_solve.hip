@@ -24,62 +24,86 @@ __global__ void to_f64_kernel(const float* __restrict__ src, double* __restrict_
 }
 
 // Cholesky of the nb x nb diagonal block at k0 (lower) and its inverse Linv = L_kk^-1 ([NB][NB] row-major, zero
-// padded), by ONE WAVE per matrix: lane i owns row i (factorisation, left-looking) / column j (inversion).  No
-// workgroup barriers -- LDS accesses of a wave execute in order -- so the 64 dependent column steps cost ~100 cycles
-// each instead of three __syncthreads (the 256-thread version took 166 us per block and ran on 2 CUs while the
-// whole chip waited).  With Linv every triangular solve against the diagonal block becomes a 64-wide GEMM.
-__device__ __forceinline__ double shfl_f64(double v, int src) {
-    const int lo = __shfl(__double2loint(v), src, 64), hi = __shfl(__double2hiint(v), src, 64);
+// padded), by ONE WAVE per matrix: lane i owns row i (factorisation) / column j (inversion).  No workgroup barriers --
+// LDS accesses of a wave execute in order.  (A 256-thread version with three __syncthreads per column took 166 us per
+// block and ran on 2 CUs while the whole chip waited.)  With Linv every triangular solve against the diagonal block
+// becomes a 64-wide GEMM.
+__device__ __forceinline__ double readlane_f64(double v, int src) {   // src wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
 }
 
+// Second version.  The first one was left-looking column by column with the block in LDS: 64 dependent steps, each a dot
+// product whose LDS reads form a latency chain (111 us per block, the longest serial piece of the whole solve).  Now in
+// panels of 16 columns: the contribution of all earlier columns to a panel is one batched rank-k update (per k one row
+// read + 16 broadcast reads feed 16 independent FMAs, nothing waits on a previous result), the 16 panel columns live in
+// registers, and inside the panel pivots / multipliers travel by v_readlane (SGPR broadcast) instead of LDS round trips.
+// The inverse uses the same shape: row panels of 16, batched update from the finished rows, 16 in-register steps.
 __global__ void __launch_bounds__(64) potrf_diag_kernel(double* __restrict__ A, int n, int k0, int nb, size_t bstride, int* __restrict__ info,
                                                         double* __restrict__ Linv, size_t lstride) {
     __shared__ double T[NB][NB + 1];
     __shared__ double Ti[NB][NB + 1];
+    __shared__ double Rinv[NB];
     double* a = A + blockIdx.x * bstride;
     const int lane = threadIdx.x;
     for (int r = 0; r < NB; ++r) T[r][lane] = (r < nb && lane <= r) ? a[(size_t)(k0 + r) * n + k0 + lane] : 0.0;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const int i = lane;
-    for (int j = 0; j < nb; ++j) {
-        // dot products of this wave are latency chains on LDS reads: unrolled by 8 with split accumulators so that the
-        // reads of a group are issued together
-        double s0 = T[i][j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        int k = 0;
-        for (; k + 8 <= j; k += 8) {
-            const double a0 = T[i][k], a1 = T[i][k + 1], a2 = T[i][k + 2], a3 = T[i][k + 3], a4 = T[i][k + 4], a5 = T[i][k + 5], a6 = T[i][k + 6], a7 = T[i][k + 7];
-            const double b0 = T[j][k], b1 = T[j][k + 1], b2 = T[j][k + 2], b3 = T[j][k + 3], b4 = T[j][k + 4], b5 = T[j][k + 5], b6 = T[j][k + 6], b7 = T[j][k + 7];
-            s0 -= a0 * b0; s1 -= a1 * b1; s2 -= a2 * b2; s3 -= a3 * b3;
-            s0 -= a4 * b4; s1 -= a5 * b5; s2 -= a6 * b6; s3 -= a7 * b7;
+#pragma unroll 1
+    for (int pb = 0; pb < NB / 16; ++pb) {
+        const int c0 = pb * 16;
+        double p[16];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) p[jj] = T[i][c0 + jj];
+#pragma unroll 2
+        for (int k = 0; k < c0; ++k) {
+            const double ak = T[i][k];
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) p[jj] = fma(-ak, T[c0 + jj][k], p[jj]);
         }
-        for (; k < j; ++k) s0 -= T[i][k] * T[j][k];
-        double sdot = (s0 + s1) + (s2 + s3);
-        double d = shfl_f64(sdot, j);
-        if (!(d > 0.0)) { if (lane == 0) info[blockIdx.x] = k0 + j + 1; d = 1.0; }
-        d = sqrt(d);
-        if (i >= j && i < nb) T[i][j] = i == j ? d : sdot / d;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = c0 + jj;
+            double d = readlane_f64(p[jj], j);
+            const bool live = j < nb;
+            if (live && !(d > 0.0)) { if (lane == 0) info[blockIdx.x] = k0 + j + 1; d = 1.0; }
+            if (!live) d = 1.0;
+            const double sd = sqrt(d), rinv = 1.0 / sd;
+            const double l = !live ? 0.0 : (i == j ? sd : (i > j ? p[jj] * rinv : 0.0));
+            p[jj] = l;
+            if (i == j) Rinv[j] = live ? rinv : 0.0;
+#pragma unroll
+            for (int kk = jj + 1; kk < 16; ++kk) p[kk] = fma(-l, readlane_f64(l, c0 + kk), p[kk]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) T[i][c0 + jj] = p[jj];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     for (int r = 0; r < nb; ++r)
         if (lane <= r) a[(size_t)(k0 + r) * n + k0 + lane] = T[r][lane];
-    // inverse, column j = lane: forward substitution L x = e_j
+    // inverse, column j = lane: forward substitution L x = e_j in row panels of 16
     const int j = lane;
-    for (int r = 0; r < NB; ++r) {
-        double v = 0.0;
-        if (j < nb && r < nb && r >= j) {
-            double v0 = r == j ? 1.0 : 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-            int k = j;
-            for (; k + 8 <= r; k += 8) {
-                const double a0 = T[r][k], a1 = T[r][k + 1], a2 = T[r][k + 2], a3 = T[r][k + 3], a4 = T[r][k + 4], a5 = T[r][k + 5], a6 = T[r][k + 6], a7 = T[r][k + 7];
-                const double b0 = Ti[k][j], b1 = Ti[k + 1][j], b2 = Ti[k + 2][j], b3 = Ti[k + 3][j], b4 = Ti[k + 4][j], b5 = Ti[k + 5][j], b6 = Ti[k + 6][j], b7 = Ti[k + 7][j];
-                v0 -= a0 * b0; v1 -= a1 * b1; v2 -= a2 * b2; v3 -= a3 * b3;
-                v0 -= a4 * b4; v1 -= a5 * b5; v2 -= a6 * b6; v3 -= a7 * b7;
-            }
-            for (; k < r; ++k) v0 -= T[r][k] * Ti[k][j];
-            v = ((v0 + v1) + (v2 + v3)) / T[r][r];
+#pragma unroll 1
+    for (int rb = 0; rb < NB / 16; ++rb) {
+        const int r0 = rb * 16;
+        double sacc[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) sacc[rr] = (r0 + rr == j) ? 1.0 : 0.0;
+#pragma unroll 2
+        for (int k = 0; k < r0; ++k) {
+            const double xk = Ti[k][j];
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) sacc[rr] = fma(-T[r0 + rr][k], xk, sacc[rr]);
         }
-        Ti[r][j] = v;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const double xv = sacc[rr] * Rinv[r0 + rr];
+            sacc[rr] = xv;
+#pragma unroll
+            for (int r2 = rr + 1; r2 < 16; ++r2) sacc[r2] = fma(-T[r0 + r2][r0 + rr], xv, sacc[r2]);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) Ti[r0 + rr][j] = sacc[rr];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     double* li = Linv + blockIdx.x * lstride + (size_t)(k0 / NB) * NB * NB;

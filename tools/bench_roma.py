@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--pairs", type=int, default=1)
+    ap.add_argument("--layers", type=int, default=0, help="print the N most expensive implicit-GEMM layer shapes (stderr)")
     ap.add_argument("--stages", action="store_true", help="per-stage wall times (synchronising: run separately from the headline)")
     a = ap.parse_args()
     from gim_amd import ops
@@ -64,10 +65,20 @@ def main():
     ops.PROFILE = []
     m.match_batch(im0, im1)
     torch.cuda.synchronize()
-    fl = sum(p[2] for p in ops.PROFILE)
-    ms = sum(p[0].elapsed_time(p[1]) for p in ops.PROFILE)
-    ops.PROFILE = None
+    prof = ops.PROFILE
+    fl = sum(p[2] for p in prof)
+    ms = sum(p[0].elapsed_time(p[1]) for p in prof)
+    prof, ops.PROFILE = ops.PROFILE, None
     out.update({"igemm_tflop_per_match": fl / 1e12, "igemm_ms": ms, "igemm_tflops": fl / ms / 1e9})
+    if a.layers:
+        agg = {}
+        for e0, e1, f, label in prof:
+            t = e0.elapsed_time(e1)
+            g = agg.setdefault(label, [0, 0.0, 0.0])
+            g[0] += 1; g[1] += t; g[2] += f
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])[:a.layers]
+        for label, (cnt, t, f) in rows:
+            print(f"{label:40s} x{cnt:4d} {t:8.3f} ms {f / t / 1e9:8.1f} TFLOP/s", file=sys.stderr)
     if a.stages:
         st = {}
 

@@ -260,7 +260,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import loftr_oracle as O
-        ncore = os.cpu_count() or 1
+        # torch's CPU kernels oversubscribe badly on a 256-thread host (119.9 s per pair with all hardware threads): use at
+        # most 64 threads unless told otherwise; `cores` reports what was actually used
+        ncore = min(os.cpu_count() or 1, int(os.environ.get("GIM_CPU_THREADS", "64")))
         torch.set_num_threads(ncore)
         n = args.cpu_pairs
         cc0, cc1 = c0[:n].cpu(), c1[:n].cpu()

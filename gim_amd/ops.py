@@ -622,6 +622,8 @@ def dense_to_pixels(matches, hw0, hw1):
     m = matches.contiguous()
     k0 = torch.empty(n, 2, dtype=torch.float32, device=m.device)
     k1 = torch.empty(n, 2, dtype=torch.float32, device=m.device)
+    if n == 0:
+        return k0, k1
     check(lib.gim_dense_to_pixels(_p(m), _p(k0), _p(k1), n, float(hw0[1]), float(hw0[0]), float(hw1[1]), float(hw1[0]), _stream()),
           "gim_dense_to_pixels")
     return k0, k1

@@ -135,11 +135,19 @@ def _fill(spec, g, small=()):
     return sd
 
 
-def make_state_dicts(seed=0):
-    """(roma_sd, dino_sd): seeded stand-in weights; refiner outputs scaled down so the flow stays in range."""
-    g = torch.Generator().manual_seed(seed)
+def make_roma_state_dict(seed=0, _g=None):
+    """the 603 tensors of the module's own state_dict (cheap); same values as make_state_dicts(seed)[0]"""
+    g = _g or torch.Generator().manual_seed(seed)
     roma = _fill(roma_param_spec(), g, small=tuple(f"decoder.conv_refiner.{s}.out_conv" for s in REFINER))
     roma["decoder.gps.16.pos_conv.weight"] = roma["decoder.gps.16.pos_conv.weight"] * 0.25
+    return roma
+
+
+def make_state_dicts(seed=0):
+    """(roma_sd, dino_sd): seeded stand-in weights; refiner outputs scaled down so the flow stays in range.  The DINOv2
+    part continues the same generator stream (304 M values: ~40 s on a few cores)."""
+    g = torch.Generator().manual_seed(seed)
+    roma = make_roma_state_dict(seed, g)
     dino = _fill(dino_param_spec(), g)
     return roma, dino
 

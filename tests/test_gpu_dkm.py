@@ -346,3 +346,55 @@ def test_gim_dkm_inference_adapter():
 
     _close(canon(data["mkpts0_f"], data["mkpts1_f"], data["mconf"]), canon(ref["mkpts0_f"], ref["mkpts1_f"], ref["mconf"]), 1e-6, "adapter rows")
     assert data["m_bids"].numel() == ref["m_bids"].numel() and (data["m_bids"] == 0).all()
+
+
+def test_demo_and_hloc_adapters():
+    """a15: demo.py:420-462 and hloc/matchers/dkm.py:41-154 restated inline (padding, pixel conversion, un-pad, in-bounds mask,
+    swapped image order, class-id masks, top-k) against gim_amd.adapters on the same sampler stream"""
+    import torch.nn.functional as F
+    from gim_amd.adapters import HlocDenseMatcher, dense_demo_inference, get_padding_size
+    dev = _dev()
+    m = _model("fp32", 128, 160, None)
+    im0, im1 = O.seeded_pair(100, 150, 5)
+    im1 = im1[:, :, :90]                                      # different sizes -> different paddings
+    a, b = im0.to(dev), im1.to(dev)
+    assert get_padding_size(im0, 128, 160) == (150, 100, 0, 0, 10, 10)
+    torch.manual_seed(7)
+    k0, k1, bid, conf = dense_demo_inference(m, a, b, 128, 160, num=400)
+    # inline restatement of demo.py:425-462
+    p0, p1 = get_padding_size(a, 128, 160), get_padding_size(b, 128, 160)
+    a_, b_ = F.pad(a, p0[2:]), F.pad(b, p1[2:])
+    torch.manual_seed(7)
+    dm, dc = m.match(a_, b_)
+    sm, mc = m.sample(dm, dc, 400)
+    h0, w0 = a_.shape[-2:]
+    h1, w1 = b_.shape[-2:]
+    r0 = torch.stack((w0 * (sm[:, 0] + 1) / 2, h0 * (sm[:, 1] + 1) / 2), -1) - sm.new_tensor((p0[2], p0[4]))
+    r1 = torch.stack((w1 * (sm[:, 2] + 1) / 2, h1 * (sm[:, 3] + 1) / 2), -1) - sm.new_tensor((p1[2], p1[4]))
+    mk = (r0[:, 0] > 0) & (r0[:, 1] > 0) & (r1[:, 0] > 0) & (r1[:, 1] > 0)
+    mk = mk & (r0[:, 0] <= p0[0] - 1) & (r1[:, 0] <= p1[0] - 1) & (r0[:, 1] <= p0[1] - 1) & (r1[:, 1] <= p1[1] - 1)
+    assert 0 < int(mk.sum()) < 400                            # the mask does remove samples that fell into the padding
+    assert torch.equal(conf, mc[mk]) and bid.numel() == int(mk.sum())
+    _close(k0, r0[mk], 1e-6, "demo kpts0")
+    _close(k1, r1[mk], 1e-6, "demo kpts1")
+    # hloc plugin: swapped order, class-id masks, top-k
+    mask0 = torch.ones(100, 150, dtype=torch.uint8)
+    mask0[:, :40] = 0
+    hm = HlocDenseMatcher(m, 128, 160, max_num_matches=50, num_samples=300)
+    torch.manual_seed(9)
+    pred = hm({"image0": a, "image1": b, "mask0": mask0})
+    torch.manual_seed(9)
+    dm, dc = m.match(F.pad(b, p1[2:]), F.pad(a * (mask0.to(dev) != 0)[None, None], p0[2:]))       # model sees (image1, image0)
+    sm, mc = m.sample(dm, dc, 300)
+    keep = mc > 0
+    sm, mc = sm[keep], mc[keep]
+    q0 = torch.stack((w1 * (sm[:, 0] + 1) / 2, h1 * (sm[:, 1] + 1) / 2), -1) - sm.new_tensor((p1[2], p1[4]))
+    q1 = torch.stack((w0 * (sm[:, 2] + 1) / 2, h0 * (sm[:, 3] + 1) / 2), -1) - sm.new_tensor((p0[2], p0[4]))
+    mk = (q0[:, 0] > 0) & (q0[:, 1] > 0) & (q1[:, 0] > 0) & (q1[:, 1] > 0)
+    mk = mk & (q0[:, 0] <= p1[0] - 1) & (q1[:, 0] <= p0[0] - 1) & (q0[:, 1] <= p1[1] - 1) & (q1[:, 1] <= p0[1] - 1)
+    sc = mc[mk]
+    top = torch.argsort(sc, descending=True)[:50]
+    assert pred["scores"].numel() == min(50, int(mk.sum()))
+    assert torch.equal(pred["scores"], sc[top])
+    _close(pred["keypoints1"], q0[mk][top], 1e-6, "hloc keypoints1 (= the model's first image)")
+    _close(pred["keypoints0"], q1[mk][top], 1e-6, "hloc keypoints0")

@@ -297,6 +297,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()      # rank 0 is still measuring / printing: leave the group together
         dist.destroy_process_group()
 
 

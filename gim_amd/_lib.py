@@ -36,7 +36,7 @@ class CoarseArgs(ctypes.Structure):
         ("N", c_int), ("L", c_int), ("S", c_int), ("C", c_int),
         ("h0c", c_int), ("w0c", c_int), ("h1c", c_int), ("w1c", c_int),
         ("cap", c_int), ("temperature", c_float), ("thr", c_float), ("border_rm", c_int),
-        ("scale", c_float),
+        ("scale", c_float), ("feat_dtype", c_int), ("ldf", c_int),
     ]
 
 

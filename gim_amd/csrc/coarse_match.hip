@@ -90,8 +90,9 @@ size_t carve(CmWs& w, char* base, int N, int L, int S, int C) {
 }
 
 struct CmGeom {
-    const float* feat0;
-    const float* feat1;
+    const void* feat0;     // [N][L][ldf] rows, fp32 or bf16 (bf16: the token buffers the coarse transformer already holds)
+    const void* feat1;
+    int bf16, ldf;
     const uint8_t* mask0;  // [N][L] or NULL
     const uint8_t* mask1;  // [N][S] or NULL
     int N, L, S, C;
@@ -100,18 +101,21 @@ struct CmGeom {
 };
 
 // similarity tile -> LDS (St[i][j], i = feat0 row, j = feat1 row), scaled like the reference
-template <int MODE>
+// BF16: bf16 x bf16 products are exact in fp32 and accumulate in fp32, so on bf16-valued features the bf16 MFMA (8x the fp32
+// matrix rate) computes the same similarity as the fp32 path up to summation order.
+template <int MODE, bool BF16>
 __device__ __forceinline__ void sim_tile_to_lds(const CmGeom& g, const int* ktab, int n, int m0, int n0, char* smem) {
+    constexpr int ES = BF16 ? 2 : 4;
     gim::MainloopArgs ml;
-    ml.x = g.feat0 + (size_t)n * g.L * g.C;
-    ml.w = g.feat1 + (size_t)n * g.S * g.C;
+    ml.x = (const char*)g.feat0 + (size_t)n * g.L * g.ldf * ES;
+    ml.w = (const char*)g.feat1 + (size_t)n * g.S * g.ldf * ES;
     ml.ktab = ktab;
-    ml.x_bytes = (unsigned)((size_t)g.L * g.C * 4);
-    ml.w_bytes = (unsigned)((size_t)g.S * g.C * 4);
-    ml.H = 1; ml.W = g.L; ml.Ho = 1; ml.Wo = g.L; ml.stride = 1; ml.pad = 0; ml.ldx = g.C;
-    ml.kpad = g.C; ml.M = g.L;
+    ml.x_bytes = (unsigned)(((size_t)(g.L - 1) * g.ldf + g.C) * ES);
+    ml.w_bytes = (unsigned)(((size_t)(g.S - 1) * g.ldf + g.C) * ES);
+    ml.H = 1; ml.W = g.L; ml.Ho = 1; ml.Wo = g.L; ml.stride = 1; ml.pad = 0; ml.ldx = g.ldf;
+    ml.kpad = g.C; ml.ldw = g.ldf; ml.M = g.L;
     f32x16_t acc[2][2];
-    gim::igemm_mainloop<BM, BN, WM, WN, false, true>(ml, smem, m0, n0, acc);
+    gim::igemm_mainloop<BM, BN, WM, WN, BF16, true>(ml, smem, m0, n0, acc);
     // mainloop ends with a barrier: stage buffers are free, reuse them as the similarity tile
     float* St = (float*)smem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -154,12 +158,13 @@ __device__ __forceinline__ void sim_tile_to_lds(const CmGeom& g, const int* ktab
 // final confidences is evaluated with the accurate expf (cm_precand / cm_cand).
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 
+template <bool BF16>
 __global__ void __launch_bounds__(256) cm_stats_kernel(const CmGeom g, const CmWs w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = blockIdx.y;
     const int mt = blockIdx.x / w.ntS, nt = blockIdx.x - mt * w.ntS;
     const int m0 = mt * BM, n0 = nt * BN;
-    sim_tile_to_lds<0>(g, w.ktab, n, m0, n0, smem);
+    sim_tile_to_lds<0, BF16>(g, w.ktab, n, m0, n0, smem);
     const float* St = (const float*)smem;
     float* red = (float*)(smem + BM * TLD * 4);  // [4][128] reduction scratch
     float* rowm = red + 512;                     // tile-local row max / sum, column max / sum
@@ -315,21 +320,21 @@ __global__ void cm_init_kernel(const CmWs w, int N, int L, int S) {
     if (idx <= (size_t)N) w.npre[idx] = 0;
 }
 
-__global__ void cm_ktab_kernel(int* ktab, int C) {  // dense table: K group g -> channel 4g; 2 padding slabs
+__global__ void cm_ktab_kernel(int* ktab, int C, int ge) {  // dense table: K group g -> channel ge * g (ge = 4 fp32 / 8 bf16 per 16 B); 2 padding slabs
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const int ng = (C / 32 + 2) * 8;
-    if (g < ng) ktab[g] = (g * 4 < C) ? g * 4 : (int)0xFF000000;
+    if (g < ng) ktab[g] = (g * ge < C) ? g * ge : (int)0xFF000000;
 }
 
 // MODE 0: emit candidates.  MODE 1: write the conf tile to `conf` (lazy data['conf_matrix']).
-template <int MODE>
+template <int MODE, bool BF16>
 __global__ void __launch_bounds__(256) cm_cand_kernel(const CmGeom g, const CmWs w, float* __restrict__ conf) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (MODE == 0 && !w.npre[g.N]) return;  // fallback only: the pre-candidate path did the work
     const int n = blockIdx.y;
     const int mt = blockIdx.x / w.ntS, nt = blockIdx.x - mt * w.ntS;
     const int m0 = mt * BM, n0 = nt * BN;
-    sim_tile_to_lds<1>(g, w.ktab, n, m0, n0, smem);
+    sim_tile_to_lds<1, BF16>(g, w.ktab, n, m0, n0, smem);
     const float* St = (const float*)smem;
     float2* rs = (float2*)(smem + BM * TLD * 4);  // [128] row stats
     float2* cs = rs + 128;                         // [128] col stats
@@ -483,9 +488,11 @@ __global__ void cm_emit_kernel(const CmWs w, const EmitArgs e) {
 int validate(const gim_coarse_args& a) {
     GIM_REQUIRE(a.feat0 && a.feat1 && a.ws && a.count, "coarse_match: NULL pointer");
     GIM_REQUIRE(a.N > 0 && a.L > 0 && a.S > 0, "coarse_match: bad sizes");
-    GIM_REQUIRE(a.C > 0 && a.C % 32 == 0, "coarse_match: C=%d must be a multiple of 32", a.C);
+    GIM_REQUIRE(a.feat_dtype == GIM_F32 || a.feat_dtype == GIM_BF16, "coarse_match: feat_dtype %d", a.feat_dtype);
+    GIM_REQUIRE(a.C > 0 && a.C % (a.feat_dtype == GIM_BF16 ? 64 : 32) == 0, "coarse_match: C=%d must be a multiple of the 128-byte K slab", a.C);
+    GIM_REQUIRE(a.ldf == 0 || (a.ldf >= a.C && a.ldf % (a.feat_dtype == GIM_BF16 ? 8 : 4) == 0), "coarse_match: ldf=%d", a.ldf);
     GIM_REQUIRE(a.h0c * a.w0c == a.L && a.h1c * a.w1c == a.S, "coarse_match: hw0_c/hw1_c do not match L/S");
-    GIM_REQUIRE((int64_t)a.L * a.C * 4 < (int64_t)0xFFFFFFF0ll && (int64_t)a.S * a.C * 4 < (int64_t)0xFFFFFFF0ll, "coarse_match: feature map too large");
+    GIM_REQUIRE((int64_t)a.L * (a.ldf ? a.ldf : a.C) * 4 < (int64_t)0xFFFFFFF0ll && (int64_t)a.S * (a.ldf ? a.ldf : a.C) * 4 < (int64_t)0xFFFFFFF0ll, "coarse_match: feature map too large");
     GIM_REQUIRE(a.temperature > 0.f && a.thr > 0.f, "coarse_match: temperature and thr must be positive");
     GIM_REQUIRE((a.mask0 == nullptr) == (a.mask1 == nullptr), "coarse_match: mask0 and mask1 must be given together");
     return GIM_OK;
@@ -507,14 +514,17 @@ extern "C" int64_t gim_coarse_match_ws_bytes(int N, int L, int S) {
 
 static int cm_prepare(const gim_coarse_args& a, CmWs& w, CmGeom& g) {
     carve(w, (char*)a.ws, a.N, a.L, a.S, a.C);
-    g.feat0 = a.feat0; g.feat1 = a.feat1; g.mask0 = a.mask0; g.mask1 = a.mask1; g.N = a.N; g.L = a.L; g.S = a.S; g.C = a.C;
+    g.feat0 = a.feat0; g.feat1 = a.feat1; g.bf16 = a.feat_dtype == GIM_BF16; g.ldf = a.ldf ? a.ldf : a.C; g.mask0 = a.mask0; g.mask1 = a.mask1; g.N = a.N; g.L = a.L; g.S = a.S; g.C = a.C;
     g.inv_c = 1.0f / (float)a.C; g.temperature = a.temperature; g.thr = a.thr;
     g.inv_ct = 1.0f / ((float)a.C * a.temperature);
     static bool attr = false;
     if (!attr) {
-        int rc = set_smem(cm_stats_kernel);
-        if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<0>);
-        if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<1>);
+        int rc = set_smem(cm_stats_kernel<false>);
+        if (rc == GIM_OK) rc = set_smem(cm_stats_kernel<true>);
+        if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<0, false>);
+        if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<1, false>);
+        if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<0, true>);
+        if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<1, true>);
         if (rc != GIM_OK) return rc;
         attr = true;
     }
@@ -533,13 +543,15 @@ extern "C" int gim_coarse_match(const gim_coarse_args* ap, gim_stream_t stream) 
     hipStream_t s = (hipStream_t)stream;
     const size_t nmax = (size_t)a.N * (a.L > a.S ? a.L : a.S);
     hipLaunchKernelGGL(cm_init_kernel, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, s, w, a.N, a.L, a.S);
-    hipLaunchKernelGGL(cm_ktab_kernel, dim3(1), dim3(256), 0, s, w.ktab, a.C);
+    hipLaunchKernelGGL(cm_ktab_kernel, dim3(1), dim3(256), 0, s, w.ktab, a.C, g.bf16 ? 8 : 4);
     dim3 tgrid((unsigned)(w.ntL * w.ntS), (unsigned)a.N);
-    hipLaunchKernelGGL(cm_stats_kernel, tgrid, dim3(256), TILE_SMEM, s, g, w);
+    if (g.bf16) hipLaunchKernelGGL(cm_stats_kernel<true>, tgrid, dim3(256), TILE_SMEM, s, g, w);
+    else hipLaunchKernelGGL(cm_stats_kernel<false>, tgrid, dim3(256), TILE_SMEM, s, g, w);
     hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.L + 255) / 256)), dim3(256), 0, s, w.rowpart, w.rowstat, a.N, a.L, w.ntS);
     hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.S + 255) / 256)), dim3(256), 0, s, w.colpart, w.colstat, a.N, a.S, w.ntL);
     hipLaunchKernelGGL(cm_precand_kernel, dim3((unsigned)((w.capp + 255) / 256), (unsigned)a.N), dim3(256), 0, s, g, w);
-    hipLaunchKernelGGL(cm_cand_kernel<0>, tgrid, dim3(256), TILE_SMEM, s, g, w, (float*)nullptr);
+    if (g.bf16) hipLaunchKernelGGL((cm_cand_kernel<0, true>), tgrid, dim3(256), TILE_SMEM, s, g, w, (float*)nullptr);
+    else hipLaunchKernelGGL((cm_cand_kernel<0, false>), tgrid, dim3(256), TILE_SMEM, s, g, w, (float*)nullptr);
     if (a.mask0) hipLaunchKernelGGL(cm_mask_extent_kernel, dim3((unsigned)a.N), dim3(256), 0, s, a.mask0, a.mask1, w.ext, a.h0c, a.w0c, a.h1c, a.w1c);
     BorderGeom bg{a.h0c, a.w0c, a.h1c, a.w1c, a.border_rm, a.mask0 ? w.ext : nullptr};
     dim3 cgrid((unsigned)((w.capc + 255) / 256), (unsigned)a.N);
@@ -561,6 +573,7 @@ extern "C" int gim_coarse_conf_matrix(const gim_coarse_args* ap, float* conf, gi
     rc = cm_prepare(a, w, g);
     if (rc != GIM_OK) return rc;
     dim3 tgrid((unsigned)(w.ntL * w.ntS), (unsigned)a.N);
-    hipLaunchKernelGGL(cm_cand_kernel<1>, tgrid, dim3(256), TILE_SMEM, (hipStream_t)stream, g, w, conf);
+    if (g.bf16) hipLaunchKernelGGL((cm_cand_kernel<1, true>), tgrid, dim3(256), TILE_SMEM, (hipStream_t)stream, g, w, conf);
+    else hipLaunchKernelGGL((cm_cand_kernel<1, false>), tgrid, dim3(256), TILE_SMEM, (hipStream_t)stream, g, w, conf);
     return gim_check_launch("coarse_conf_matrix");
 }

@@ -103,7 +103,7 @@ igemm_kernel(const gim_conv_args a, const int mtiles, const int ntiles, const in
     ml.x_bytes = (unsigned)a.x_bytes;
     ml.w_bytes = (unsigned)a.npad * (unsigned)a.kpad * ES;
     ml.H = a.H; ml.W = a.W; ml.Ho = a.Ho; ml.Wo = a.Wo; ml.stride = a.stride; ml.pad = a.pad; ml.ldx = a.ldx;
-    ml.kpad = a.kpad; ml.M = M;
+    ml.kpad = a.kpad; ml.ldw = a.kpad; ml.M = M;
     f32x16_t acc[TN][TM];
     gim::igemm_mainloop<BM, BN, WM, WN, BF16, LDSDMA>(ml, smem, m0, n0, acc);
 
@@ -301,7 +301,7 @@ __device__ __forceinline__ gim::MainloopArgs mainloop_args(const gim_conv_args& 
     ml.x_bytes = (unsigned)a.x_bytes;
     ml.w_bytes = (unsigned)a.npad * (unsigned)a.kpad * ES;
     ml.H = a.H; ml.W = a.W; ml.Ho = a.Ho; ml.Wo = a.Wo; ml.stride = a.stride; ml.pad = a.pad; ml.ldx = a.ldx;
-    ml.kpad = a.kpad; ml.M = M;
+    ml.kpad = a.kpad; ml.ldw = a.kpad; ml.M = M;
     return ml;
 }
 

@@ -15,6 +15,7 @@ struct MainloopArgs {
     unsigned w_bytes;   // buffer bound of w
     int H, W, Ho, Wo, stride, pad, ldx;
     int kpad;
+    int ldw;            // row stride of w in elements (kpad for packed weights; larger for a run-time row operand)
     int M;              // valid output rows
 };
 
@@ -67,7 +68,7 @@ struct Igemm {
             ix0[i] = x;
             rowoff[i] = (pix + (unsigned)(y * a.W + x)) * (unsigned)a.ldx * ES;
         }
-        wrow = (unsigned)(n0 + srow) * (unsigned)a.kpad * ES + sgrp * 16;
+        wrow = (unsigned)(n0 + srow) * (unsigned)a.ldw * ES + sgrp * 16;
     }
 
     static __device__ __forceinline__ int ktab_index(int kt) {
@@ -101,7 +102,7 @@ struct Igemm {
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            const unsigned voff = wrow + (unsigned)(i * RPP) * (unsigned)a.kpad * ES + (unsigned)kt * KTB;
+            const unsigned voff = wrow + (unsigned)(i * RPP) * (unsigned)a.ldw * ES + (unsigned)kt * KTB;
             if constexpr (LDSDMA) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(sB + (i * RPP + wave * 8) * KTB), 16, voff, 0, 0, 0);
             } else {

@@ -114,7 +114,7 @@ __device__ __forceinline__ void sim_tile_to_lds(const LgaGeom& g, const int* kta
     ml.x_bytes = (unsigned)((size_t)g.M * g.C * 4);
     ml.w_bytes = (unsigned)((size_t)g.N * g.C * 4);
     ml.H = 1; ml.W = g.M; ml.Ho = 1; ml.Wo = g.M; ml.stride = 1; ml.pad = 0; ml.ldx = g.C;
-    ml.kpad = g.C; ml.M = g.M;
+    ml.kpad = g.C; ml.ldw = g.C; ml.M = g.M;
     f32x16_t acc[2][2];
     gim::igemm_mainloop<BM, BN, WM, WN, false, true>(ml, smem, m0, n0, acc);
     float* St = (float*)smem;

@@ -403,7 +403,16 @@ class LoFTR(nn.Module):
         if self.bench_override_coarse is not None:
             T.X32[r0].copy_(self.bench_override_coarse[0].reshape(-1, C))
             T.X32[r1].copy_(self.bench_override_coarse[1].reshape(-1, C))
-        cr = ops.coarse_match(T.X32[r0].view(bs, L, C), T.X32[r1].view(bs, S, C), hw0_c, hw1_c, scale,
+            T.CAT[r0, :C].copy_(self.bench_override_coarse[0].reshape(-1, C))
+            T.CAT[r1, :C].copy_(self.bench_override_coarse[1].reshape(-1, C))
+        if dt == GIM_BF16:
+            # the operand-dtype copy of the final tokens (written by the last LayerNorm for the next GEMM) feeds the
+            # similarity: bf16 MFMA with fp32 accumulation, the same arithmetic as every other matrix op of this mode
+            fc0 = T.CAT[r0].view(bs, L, 2 * C)[:, :, :C]
+            fc1 = T.CAT[r1].view(bs, S, 2 * C)[:, :, :C]
+        else:
+            fc0, fc1 = T.X32[r0].view(bs, L, C), T.X32[r1].view(bs, S, C)
+        cr = ops.coarse_match(fc0, fc1, hw0_c, hw1_c, scale,
                               mc["dsmax_temperature"], mc["thr"], mc["border_rm"], scale0, scale1,
                               T.MASK[r0] if mask0 is not None else None, T.MASK[r1] if mask0 is not None else None)
         return {"c0": c0, "c1": c1, "f0": f0, "f1": f1, "cr": cr,

@@ -179,10 +179,15 @@ class CoarseResult:
 
 def coarse_match(feat0, feat1, hw0_c, hw1_c, scale, temperature=0.1, thr=0.2, border_rm=2,
                  scale0=None, scale1=None, mask0=None, mask1=None):
-    """feat0 [N,L,C], feat1 [N,S,C] fp32 contiguous.  Returns CoarseResult with cap-sized device buffers;
-    count[0] (device int32) is the number of valid leading entries."""
+    """feat0 [N,L,C], feat1 [N,S,C], fp32 or bf16, rows possibly strided (stride(1) = ldf >= C, the same for both; e.g. a
+    column range of the transformer's token buffers).  bf16 features run the similarity on the bf16 MFMA (exact products,
+    fp32 accumulation).  Returns CoarseResult with cap-sized device buffers; count[0] (device int32) is the number of
+    valid leading entries."""
     _req_cuda(feat0, feat1, scale0, scale1)
-    assert feat0.dtype == torch.float32 and feat0.is_contiguous() and feat1.is_contiguous()
+    assert feat0.dtype == feat1.dtype and feat0.dtype in (torch.float32, torch.bfloat16)
+    ldf = feat0.stride(1)
+    for f in (feat0, feat1):
+        assert f.dim() == 3 and f.stride(2) == 1 and f.stride(1) == ldf and f.stride(0) == f.shape[1] * ldf, (f.shape, f.stride())
     N, L, C = feat0.shape
     S = feat1.shape[1]
     dev = feat0.device
@@ -215,6 +220,7 @@ def coarse_match(feat0, feat1, hw0_c, hw1_c, scale, temperature=0.1, thr=0.2, bo
     a.N, a.L, a.S, a.C = N, L, S, C
     a.h0c, a.w0c, a.h1c, a.w1c = hw0_c[0], hw0_c[1], hw1_c[0], hw1_c[1]
     a.cap, a.temperature, a.thr, a.border_rm, a.scale = cap, temperature, thr, border_rm, scale
+    a.feat_dtype, a.ldf = gim_dtype(feat0), ldf
     r.args = a
     check(lib.gim_coarse_match(ctypes.byref(a), _stream()), "gim_coarse_match")
     return r

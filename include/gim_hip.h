@@ -124,8 +124,8 @@ int gim_layernorm_residual(const void* x, const float* gamma, const float* beta,
  * `count` (device int32[1 + N]): count[0] = M, count[1+b] = matches of pair b.
  * scale0/scale1: NULL or fp32 [N,2] per-pair (w,h) scales (coarse_matching.py:237-245). */
 typedef struct gim_coarse_args {
-    const float* feat0;
-    const float* feat1;
+    const void* feat0;    /* [N, L, ldf] rows of C features, fp32 or bf16 (feat_dtype) */
+    const void* feat1;    /* [N, S, ldf] */
     const float* scale0;
     const float* scale1;
     const uint8_t* mask0; /* NULL or [N, L] padding mask of image0's coarse cells (coarse_matching.py:116-117) */
@@ -145,6 +145,9 @@ typedef struct gim_coarse_args {
     float thr;            /* 0.2 */
     int border_rm;        /* 2 */
     float scale;          /* hw0_i[0] / hw0_c[0] */
+    int feat_dtype;       /* GIM_F32 (0, default) or GIM_BF16: bf16 features run the similarity on the bf16 MFMA -- exact
+                           * products, fp32 accumulation, i.e. the fp32 result for bf16-valued inputs up to summation order */
+    int ldf;              /* row stride of feat0 / feat1 in elements; 0 = C (contiguous) */
 } gim_coarse_args;
 int64_t gim_coarse_match_ws_bytes(int N, int L, int S);
 int gim_coarse_match(const gim_coarse_args* a, gim_stream_t stream);

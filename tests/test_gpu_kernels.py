@@ -287,6 +287,33 @@ def test_coarse_match_different_shapes_and_empty():
     assert int(r.count[0]) == 0
 
 
+def test_coarse_match_bf16_features_strided():
+    """bf16 features (the throughput mode's token buffers, rows strided inside a wider buffer): the bf16 MFMA computes exact
+    products with fp32 accumulation, so against the oracle evaluated on the SAME bf16-valued features the indices are
+    exact and the confidences differ by summation order only"""
+    from gim_amd import ops
+    dev = _dev()
+    N, h0, w0 = 2, 15, 20
+    f0, f1, _ = O.planted_coarse_features(N, (h0, w0), sigma=1.0, eps=0.5, seed=33)
+    b0, b1 = f0.bfloat16(), f1.bfloat16()
+    conf = O.conf_matrix_dual_softmax(b0.float(), b1.float(), 0.1)
+    ref = O.get_coarse_match(conf, (h0 * 8, w0 * 8), (h0 * 8, w0 * 8), (h0, w0), (h0, w0), 0.2, 2)
+    C = 256
+    buf = torch.zeros(2 * N * h0 * w0, 2 * C, dtype=torch.bfloat16, device=dev)           # [x | other columns], like T.CAT
+    buf[:N * h0 * w0, :C] = b0.reshape(-1, C).to(dev)
+    buf[N * h0 * w0:, :C] = b1.reshape(-1, C).to(dev)
+    buf[:, C:] = 7.0                                                                          # must never be read
+    v0 = buf[:N * h0 * w0].view(N, h0 * w0, 2 * C)[:, :, :C]
+    v1 = buf[N * h0 * w0:].view(N, h0 * w0, 2 * C)[:, :, :C]
+    r = ops.coarse_match(v0, v1, (h0, w0), (h0, w0), 8.0, 0.1, 0.2, 2)
+    M = int(r.count[0])
+    assert ref["b_ids"].numel() > 100 and M == ref["b_ids"].numel()
+    for k in ("b_ids", "i_ids", "j_ids"):
+        assert torch.equal(getattr(r, k)[:M].cpu(), ref[k]), k
+    _assert_close(r.mconf[:M], ref["mconf"], 1e-5, "mconf")
+    _assert_close(ops.coarse_conf_matrix(r), conf, 1e-5, "conf_matrix")
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_fine_gather_and_match(dt):
     """fine_preprocess.py:40-47 windows (incl. zero padded border cells) and fine_matching.py:43-74"""

@@ -163,6 +163,8 @@ class LoFTR(nn.Module):
         if config["fine_concat_coarse_feat"]:
             raise NotImplementedError("fine_concat_coarse_feat=True is not used by gim_loftr and is not built")
         self.precision = _precision_from(config)
+        # bf16 mode: similarity of coarse matching on the bf16 token copy (bf16 MFMA) unless asked to keep the fp32 tokens
+        self.coarse_sim_fp32 = bool(config.get("coarse_sim_fp32", False)) or os.environ.get("GIM_COARSE_SIM_FP32", "0") == "1"
         self.backbone = _ResNetFPN_8_2(config["resnetfpn"])
         self.loftr_coarse = _LocalFeatureTransformer(config["coarse"])
         self.loftr_fine = _LocalFeatureTransformer(config["fine"])
@@ -405,7 +407,7 @@ class LoFTR(nn.Module):
             T.X32[r1].copy_(self.bench_override_coarse[1].reshape(-1, C))
             T.CAT[r0, :C].copy_(self.bench_override_coarse[0].reshape(-1, C))
             T.CAT[r1, :C].copy_(self.bench_override_coarse[1].reshape(-1, C))
-        if dt == GIM_BF16:
+        if dt == GIM_BF16 and not self.coarse_sim_fp32:
             # the operand-dtype copy of the final tokens (written by the last LayerNorm for the next GEMM) feeds the
             # similarity: bf16 MFMA with fp32 accumulation, the same arithmetic as every other matrix op of this mode
             fc0 = T.CAT[r0].view(bs, L, 2 * C)[:, :, :C]

@@ -210,7 +210,7 @@ def main():
         im0 = base.to(dev)
         im1 = torch.roll(base, shifts=(12, 20), dims=(2, 3)).to(dev)
 
-        def dense_bench(name, build, note):
+        def dense_bench(name, build, note, batch=1):
             try:
                 torch.manual_seed(0)
                 m = build().eval()
@@ -235,6 +235,19 @@ def main():
                 t_sample = (time.perf_counter() - td) / n_it
                 dense[name] = {"workload": note, "pairs_per_s": round(1.0 / (t_match + t_sample), 2),
                                "match_ms": round(1e3 * t_match, 2), "sample_ms": round(1e3 * t_sample, 2), "dtype": args.precision}
+                if batch > 1:   # BASELINE's batched configuration: `batch` independent pairs in one engine pass (match_batch)
+                    b0, b1 = im0.expand(batch, -1, -1, -1).contiguous(), im1.expand(batch, -1, -1, -1).contiguous()
+                    for _ in range(2):
+                        wb, cb = m.match_batch(b0, b1)
+                    torch.cuda.synchronize()
+                    td = time.perf_counter()
+                    for _ in range(3):
+                        wb, cb = m.match_batch(b0, b1)
+                    torch.cuda.synchronize()
+                    t_b = (time.perf_counter() - td) / 3
+                    dense[name].update({f"batch{batch}_match_ms_per_pair": round(1e3 * t_b / batch, 2),
+                                        f"batch{batch}_pairs_per_s": round(batch / (t_b + batch * t_sample), 2)})
+                    del wb, cb
                 del m
                 torch.cuda.empty_cache()
             except Exception as e:  # a secondary line must never cost the headline measurement
@@ -251,7 +264,7 @@ def main():
             return RoMa([672], precision=args.precision, dinov2_weights=random_dinov2_weights(dev))
 
         dense_bench("gim_dkm", build_dkm, "gim_dkm match() + sample(5000), 672x896 -> upsampling pass 1152x1536, one pair per call, "
-                    "random-init weights (trainer/lightning.py:29-37 configuration)")
+                    "random-init weights (trainer/lightning.py:29-37 configuration)", batch=4)
         dense_bench("gim_roma", build_roma, "gim_roma match() + sample(5000), 672x672 -> upsampling pass 1344x1344, one pair per call, "
                     "random-init weights incl. a synthetic DINOv2 ViT-L/14 (RoMa(img_size=[672]), trainer/lightning.py:38-41)")
 

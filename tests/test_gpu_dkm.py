@@ -398,3 +398,28 @@ def test_demo_and_hloc_adapters():
     assert torch.equal(pred["scores"], sc[top])
     _close(pred["keypoints1"], q0[mk][top], 1e-6, "hloc keypoints1 (= the model's first image)")
     _close(pred["keypoints0"], q1[mk][top], 1e-6, "hloc keypoints0")
+
+
+def test_full_size_swap_symmetry_bf16():
+    """BASELINE size (672 x 896 -> 1152 x 1536, bf16): swapping the two images swaps the two halves of warp / certainty bit
+    for bit; query coordinates are the exact pixel-centre grid; warp in [-1, 1], certainty in [0, 1]"""
+    from gim_amd.dkm import DKMv3
+    dev = _dev()
+    torch.manual_seed(0)
+    m = DKMv3(None, 672, 896, upsample_preds=True, precision="bf16").eval()
+    m.upsample_res = (1152, 1536)
+    with torch.no_grad():
+        for s in ("16", "8", "4", "2", "1"):
+            m.decoder.conv_refiner[s].out_conv.weight.mul_(0.05)
+            m.decoder.conv_refiner[s].out_conv.bias.mul_(0.05)
+    a, b = (t.to(dev) for t in O.seeded_pair(480, 640, 11))
+    w_ab, c_ab = m.match(a, b)
+    w_ba, c_ba = m.match(b, a)
+    H, W = m.upsample_res
+    assert w_ab.shape == (H, 2 * W, 4) and c_ab.shape == (H, 2 * W)
+    assert torch.isfinite(w_ab).all() and torch.isfinite(c_ab).all()
+    assert w_ab.abs().max() <= 1 and c_ab.min() >= 0 and c_ab.max() <= 1
+    assert torch.equal(w_ab[:, W:, 0:2], w_ba[:, :W, 2:4]) and torch.equal(w_ab[:, :W, 2:4], w_ba[:, W:, 0:2])
+    assert torch.equal(c_ab[:, W:], c_ba[:, :W]) and torch.equal(c_ab[:, :W], c_ba[:, W:])
+    qc = O.grid_coords(1, H, W).permute(0, 2, 3, 1)[0]
+    assert torch.equal(w_ab[:, :W, :2].cpu(), qc) and torch.equal(w_ab[:, W:, 2:].cpu(), qc)

@@ -252,3 +252,29 @@ def test_roma_fails_loudly():
     m2.load_state_dict(_weights()[0])
     with pytest.raises(GimHipError):
         m2.match(torch.rand(1, 3, 64, 64, device=_dev()), torch.rand(1, 3, 64, 64, device=_dev()))   # no DINOv2 weights
+
+
+def test_full_size_swap_symmetry_bf16():
+    """BASELINE size (672 x 672 -> 1344 x 1344, bf16): size-independent properties of the symmetric matcher -- swapping the
+    two images swaps the two halves of warp / certainty bit for bit (every kernel is batch-position invariant), query
+    coordinates are the exact pixel-centre grid, warp in [-1, 1], certainty in [0, 1]"""
+    from gim_amd.roma import RoMa, random_dinov2_weights
+    import dkm_oracle as DO
+    dev = _dev()
+    torch.manual_seed(0)
+    m = RoMa([672], precision="bf16", dinov2_weights=random_dinov2_weights(dev)).eval()
+    with torch.no_grad():
+        for s in ("16", "8", "4", "2", "1"):
+            m.decoder.conv_refiner[s].out_conv.weight.mul_(0.05)
+            m.decoder.conv_refiner[s].out_conv.bias.mul_(0.05)
+    a, b = (t.to(dev) for t in DO.seeded_pair(480, 640, 11))
+    w_ab, c_ab = m.match(a, b)
+    w_ba, c_ba = m.match(b, a)
+    H, W = m.upsample_res
+    assert w_ab.shape == (H, 2 * W, 4) and c_ab.shape == (H, 2 * W)
+    assert torch.isfinite(w_ab).all() and torch.isfinite(c_ab).all()
+    assert w_ab.abs().max() <= 1 and c_ab.min() >= 0 and c_ab.max() <= 1
+    assert torch.equal(w_ab[:, W:, 0:2], w_ba[:, :W, 2:4]) and torch.equal(w_ab[:, :W, 2:4], w_ba[:, W:, 0:2])
+    assert torch.equal(c_ab[:, W:], c_ba[:, :W]) and torch.equal(c_ab[:, :W], c_ba[:, W:])
+    qc = DO.grid_coords(1, H, W).permute(0, 2, 3, 1)[0]
+    assert torch.equal(w_ab[:, :W, :2].cpu(), qc) and torch.equal(w_ab[:, W:, 2:].cpu(), qc)

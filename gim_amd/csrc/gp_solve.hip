@@ -40,7 +40,7 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {   // src wav
 // registers, and inside the panel pivots / multipliers travel by v_readlane (SGPR broadcast) instead of LDS round trips.
 // The inverse uses the same shape: row panels of 16, batched update from the finished rows, 16 in-register steps.
 __global__ void __launch_bounds__(64) potrf_diag_kernel(double* __restrict__ A, int n, int k0, int nb, size_t bstride, int* __restrict__ info,
-                                                        double* __restrict__ Linv, size_t lstride) {
+                                                        double* __restrict__ Linv, size_t lstride, int ldl) {
     __shared__ double T[NB][NB + 1];
     __shared__ double Ti[NB][NB + 1];
     __shared__ double Rinv[NB];
@@ -106,8 +106,39 @@ __global__ void __launch_bounds__(64) potrf_diag_kernel(double* __restrict__ A, 
         for (int rr = 0; rr < 16; ++rr) Ti[r0 + rr][j] = sacc[rr];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    double* li = Linv + blockIdx.x * lstride + (size_t)(k0 / NB) * NB * NB;
-    for (int r = 0; r < NB; ++r) li[r * NB + lane] = Ti[r][lane];
+    // the inverse goes onto the diagonal of the full n x n matrix L^-1 (zero elsewhere; completed by invert_levels below)
+    double* li = Linv + blockIdx.x * lstride + (size_t)k0 * ldl + k0;
+    for (int r = 0; r < nb; ++r)
+        if (lane < nb) li[(size_t)r * ldl + lane] = Ti[r][lane];
+}
+
+// 64 x 64 operand tiles -> LDS, coalesced along the contiguous source dimension.  All 32 loads of a thread are issued before
+// the first LDS write (the rolled load -> store loop made every tile pay 16 dependent memory round trips).
+__device__ __forceinline__ void load_tiles(double (*As)[NB + 1], double (*Bs)[NB + 1], const double* __restrict__ am, int lda, int ta,
+                                           const double* __restrict__ bm, int ldb, int tb, int i0, int c0, int M, int N, int kk) {
+    constexpr int NL = NB * NB / 256;
+    const int t = threadIdx.x;
+    double ra[NL], rb[NL];
+    if (ta) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) { const int e = t + 256 * j, k = e / NB, i = e - k * NB; ra[j] = (k < kk && i0 + i < M) ? am[(size_t)k * lda + i0 + i] : 0.0; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) { const int e = t + 256 * j, i = e / NB, k = e - i * NB; ra[j] = (k < kk && i0 + i < M) ? am[(size_t)(i0 + i) * lda + k] : 0.0; }
+    }
+    if (tb) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) { const int e = t + 256 * j, cc = e / NB, k = e - cc * NB; rb[j] = (k < kk && c0 + cc < N) ? bm[(size_t)(c0 + cc) * ldb + k] : 0.0; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) { const int e = t + 256 * j, k = e / NB, cc = e - k * NB; rb[j] = (k < kk && c0 + cc < N) ? bm[(size_t)k * ldb + c0 + cc] : 0.0; }
+    }
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int e = t + 256 * j, hi = e / NB, lo = e - hi * NB;
+        if (ta) As[lo][hi] = ra[j]; else As[hi][lo] = ra[j];      // ta: (k, i) = (hi, lo); else (i, k) = (hi, lo)
+        if (tb) Bs[lo][hi] = rb[j]; else Bs[hi][lo] = rb[j];      // tb: (c, k) = (hi, lo); else (k, c) = (hi, lo)
+    }
 }
 
 // C[i][c] = sum_k Aop[i][k] * Bop[k][c]  (same operand conventions as gemm_sub_kernel, K = 64, plain store)
@@ -120,12 +151,7 @@ __global__ void __launch_bounds__(256) gemm_set_kernel(double* __restrict__ C, i
     double* c = C + blockIdx.z * cstride;
     const double* am = Am + blockIdx.z * astride;
     const double* bm = Bm + blockIdx.z * bstride2;
-    for (int e = t; e < NB * NB; e += 256) {
-        if (ta) { const int k = e / NB, i = e - k * NB; As[i][k] = (k < kk && i0 + i < M) ? am[(size_t)k * lda + i0 + i] : 0.0; }
-        else { const int i = e / NB, k = e - i * NB; As[i][k] = (k < kk && i0 + i < M) ? am[(size_t)(i0 + i) * lda + k] : 0.0; }
-        if (tb) { const int cc = e / NB, k = e - cc * NB; Bs[k][cc] = (k < kk && c0 + cc < N) ? bm[(size_t)(c0 + cc) * ldb + k] : 0.0; }
-        else { const int k = e / NB, cc = e - k * NB; Bs[k][cc] = (k < kk && c0 + cc < N) ? bm[(size_t)k * ldb + c0 + cc] : 0.0; }
-    }
+    load_tiles(As, Bs, am, lda, ta, bm, ldb, tb, i0, c0, M, N, kk);
     __syncthreads();
     const int ti = (t >> 4) * 4, tc = (t & 15) * 4;
     double acc[4][4] = {};
@@ -161,13 +187,7 @@ __global__ void __launch_bounds__(256) gemm_sub_kernel(double* __restrict__ C, i
     double* c = C + blockIdx.z * cstride;
     const double* am = Am + blockIdx.z * astride;
     const double* bm = Bm + blockIdx.z * bstride2;
-    for (int e = t; e < NB * NB; e += 256) {
-        // coalesce along the contiguous source dimension
-        if (ta) { const int k = e / NB, i = e - k * NB; As[i][k] = (k < kk && i0 + i < M) ? am[(size_t)k * lda + i0 + i] : 0.0; }
-        else { const int i = e / NB, k = e - i * NB; As[i][k] = (k < kk && i0 + i < M) ? am[(size_t)(i0 + i) * lda + k] : 0.0; }
-        if (tb) { const int cc = e / NB, k = e - cc * NB; Bs[k][cc] = (k < kk && c0 + cc < N) ? bm[(size_t)(c0 + cc) * ldb + k] : 0.0; }
-        else { const int k = e / NB, cc = e - k * NB; Bs[k][cc] = (k < kk && c0 + cc < N) ? bm[(size_t)k * ldb + c0 + cc] : 0.0; }
-    }
+    load_tiles(As, Bs, am, lda, ta, bm, ldb, tb, i0, c0, M, N, kk);
     __syncthreads();
     const int ti = (t >> 4) * 4, tc = (t & 15) * 4;
     double acc[4][4] = {};
@@ -187,6 +207,108 @@ __global__ void __launch_bounds__(256) gemm_sub_kernel(double* __restrict__ C, i
             const int i = i0 + ti + x, cc = c0 + tc + y;
             if (i < M && cc < N) c[(size_t)i * ldc + cc] -= acc[x][y];
         }
+}
+
+// General fp64 product on 64 x 64 tiles with a K loop:  C[i][c] = sign * sum_{k in range} Aop[i][k] * Bop[k][c]
+//   Aop[i][k] = ta ? A[k*lda + i] : A[i*lda + k]        Bop[k][c] = tb ? B[c*ldb + k] : B[k*ldb + c]
+// tri restricts the K range of a tile to where a triangular operand is non-zero:
+//   1: A lower triangular (k < i0 + 64)   2: A = transposed lower (k >= i0)   3: B lower triangular (k >= c0)
+// blockIdx.z = b * npair + p: matrix b (strides bsA/bsB/bsC) and sub-problem p (strides psA/psB/psC); the last sub-problem
+// has Mlast rows.
+struct GemmArgs {
+    double* C; const double* A; const double* B;
+    int ldc, lda, ldb, ta, tb, M, Mlast, N, K, Klast, tri, npair;
+    double sign;
+    size_t bsC, bsA, bsB, psC, psA, psB;
+};
+
+// 128 x 64 block tile, 8 x 4 per thread (rows q*32 + ty*2 + {0,1}, columns h*32 + tx*2 + {0,1}: every ds_read_b128 of a
+// wave covers 256 contiguous bytes or is a broadcast), K in slabs of 32.  5.3 FMAs per LDS read -- the 4 x 4 version (2 FMAs
+// per read) was LDS-bound at 3.9 TFLOP/s on the n = 2304 triangular products.
+constexpr int GBM = 128, GBN = 64, GKT = 32;
+
+__global__ void __launch_bounds__(256) gemm_f64_kernel(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) double As[GKT][GBM + 2];  // [k][i]
+    __shared__ __attribute__((aligned(16))) double Bs[GKT][GBN + 2];  // [k][c]
+    const int b = blockIdx.z / g.npair, p = blockIdx.z - b * g.npair;
+    const int M = p == g.npair - 1 ? g.Mlast : g.M;
+    const int K = p == g.npair - 1 ? g.Klast : g.K;
+    const int t = threadIdx.x, i0 = blockIdx.y * GBM, c0 = blockIdx.x * GBN;
+    if (i0 >= M || c0 >= g.N) return;
+    double* c = g.C + b * g.bsC + p * g.psC;
+    const double* am = g.A + b * g.bsA + p * g.psA;
+    const double* bm = g.B + b * g.bsB + p * g.psB;
+    int kb = 0, ke = K;
+    if (g.tri == 1) ke = min(K, i0 + GBM);
+    else if (g.tri == 2) kb = i0;
+    else if (g.tri == 3) kb = c0;
+    const int ty = t >> 4, tx = t & 15;
+    double acc[8][4] = {};
+    for (int k0 = kb; k0 < ke; k0 += GKT) {
+        // coalesce along the contiguous source dimension; all loads of the slab are issued before the first LDS write (a
+        // rolled load -> wait -> store loop cost 24 dependent memory round trips per slab: 0.7 ms for the n = 2304 products)
+        double ra[GBM * GKT / 256], rb[GBN * GKT / 256];
+        if (g.ta) {
+#pragma unroll
+            for (int j = 0; j < GBM * GKT / 256; ++j) {
+                const int e = t + 256 * j, k = e / GBM, i = e - k * GBM;
+                ra[j] = (k0 + k < ke && i0 + i < M) ? am[(size_t)(k0 + k) * g.lda + i0 + i] : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < GBM * GKT / 256; ++j) {
+                const int e = t + 256 * j, i = e / GKT, k = e - i * GKT;
+                ra[j] = (k0 + k < ke && i0 + i < M) ? am[(size_t)(i0 + i) * g.lda + k0 + k] : 0.0;
+            }
+        }
+        if (g.tb) {
+#pragma unroll
+            for (int j = 0; j < GBN * GKT / 256; ++j) {
+                const int e = t + 256 * j, cc = e / GKT, k = e - cc * GKT;
+                rb[j] = (k0 + k < ke && c0 + cc < g.N) ? bm[(size_t)(c0 + cc) * g.ldb + k0 + k] : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < GBN * GKT / 256; ++j) {
+                const int e = t + 256 * j, k = e / GBN, cc = e - k * GBN;
+                rb[j] = (k0 + k < ke && c0 + cc < g.N) ? bm[(size_t)(k0 + k) * g.ldb + c0 + cc] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < GBM * GKT / 256; ++j) {
+            const int e = t + 256 * j;
+            if (g.ta) { const int k = e / GBM; As[k][e - k * GBM] = ra[j]; } else { const int i = e / GKT; As[e - i * GKT][i] = ra[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < GBN * GKT / 256; ++j) {
+            const int e = t + 256 * j;
+            if (g.tb) { const int cc = e / GKT; Bs[e - cc * GKT][cc] = rb[j]; } else { const int k = e / GBN; Bs[k][e - k * GBN] = rb[j]; }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < GKT; ++k) {
+            double av[8], bv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { av[2 * q] = As[k][q * 32 + ty * 2]; av[2 * q + 1] = As[k][q * 32 + ty * 2 + 1]; }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { bv[2 * h] = Bs[k][h * 32 + tx * 2]; bv[2 * h + 1] = Bs[k][h * 32 + tx * 2 + 1]; }
+#pragma unroll
+            for (int x = 0; x < 8; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) acc[x][y] = fma(av[x], bv[y], acc[x][y]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+        const int i = i0 + (x >> 1) * 32 + ty * 2 + (x & 1);
+        if (i >= M) continue;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const int cc = c0 + (y >> 1) * 32 + tx * 2 + (y & 1);
+            if (cc < g.N) c[(size_t)i * g.ldc + cc] = g.sign * acc[x][y];
+        }
+    }
 }
 
 // Xt[b][c][i] = (float) X[b][i][c], zero for i in [n, npad)
@@ -210,66 +332,82 @@ inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 }  // namespace
 
 extern "C" int64_t gim_gp_solve_ws_bytes(int B, int n, int nrhs) {
-    const size_t nblk = (n + NB - 1) / NB;
-    return (int64_t)(al((size_t)B * n * n * 8) + al((size_t)B * n * nrhs * 8) + al((size_t)B * nblk * NB * NB * 8) +
-                     al((size_t)B * NB * (nrhs > n ? nrhs : n) * 8) + 256);
+    // A (L), full L^-1, product scratch: n x n each; right-hand sides twice: n x nrhs
+    return (int64_t)(3 * al((size_t)B * n * n * 8) + 2 * al((size_t)B * n * nrhs * 8) + 256);
 }
+
+namespace {
+void launch_gemm(hipStream_t s, int B, const GemmArgs& g) {
+    const int mt = ((g.M > g.Mlast ? g.M : g.Mlast) + GBM - 1) / GBM, nt = (g.N + GBN - 1) / GBN;
+    hipLaunchKernelGGL(gemm_f64_kernel, dim3(nt, mt, B * g.npair), dim3(256), 0, s, g);
+}
+}  // namespace
 
 extern "C" int gim_gp_solve(const float* K, const float* F, float* Xt, void* ws, int B, int n, int ldk, int nrhs, int npad,
                             gim_stream_t stream) {
     GIM_REQUIRE(K && F && Xt && ws && B > 0 && B <= 16 && n > 0 && nrhs > 0 && ldk >= n && npad >= n, "gp_solve: bad args");
     hipStream_t s = (hipStream_t)stream;
-    const size_t nblk_ = (n + NB - 1) / NB;
     double* A = (double*)ws;
-    double* R = (double*)((char*)A + al((size_t)B * n * n * 8));
-    double* Li = (double*)((char*)R + al((size_t)B * n * nrhs * 8));
-    double* Tmp = (double*)((char*)Li + al((size_t)B * nblk_ * NB * NB * 8));   // [B][NB][max(n, nrhs)] staging for in-place products
-    int* info = (int*)((char*)Tmp + al((size_t)B * NB * (nrhs > n ? nrhs : n) * 8));
-    const size_t as = (size_t)n * n, fs = (size_t)n * nrhs, ls = nblk_ * NB * NB, ts = (size_t)NB * (nrhs > n ? nrhs : n);
+    double* Lf = (double*)((char*)A + al((size_t)B * n * n * 8));     // L^-1, full lower-triangular matrix
+    double* Tb = (double*)((char*)Lf + al((size_t)B * n * n * 8));    // products of the inversion levels
+    double* R = (double*)((char*)Tb + al((size_t)B * n * n * 8));
+    double* R2 = (double*)((char*)R + al((size_t)B * n * nrhs * 8));
+    int* info = (int*)((char*)R2 + al((size_t)B * n * nrhs * 8));
+    const size_t as = (size_t)n * n, fs = (size_t)n * nrhs;
     if (hipMemsetAsync(info, 0, 64, s) != hipSuccess) return gim_check_launch("gp_solve memset");
+    if (hipMemsetAsync(Lf, 0, (size_t)B * as * 8, s) != hipSuccess) return gim_check_launch("gp_solve memset");
     for (int b = 0; b < B; ++b) {
         hipLaunchKernelGGL(to_f64_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, s, K + (size_t)b * n * ldk, A + b * as, n, n, ldk, n);
         hipLaunchKernelGGL(to_f64_kernel, dim3((unsigned)(((size_t)n * nrhs + 255) / 256)), dim3(256), 0, s, F + (size_t)b * fs, R + b * fs, n, nrhs, nrhs, nrhs);
     }
-    // ---- A = L L^T (lower triangle of A overwritten by L) ----
+    // ---- A = L L^T (lower triangle of A overwritten by L); the inverses of the diagonal blocks land on the diagonal of Lf ----
     for (int k0 = 0; k0 < n; k0 += NB) {
         const int nb = n - k0 < NB ? n - k0 : NB;
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(B), dim3(64), 0, s, A, n, k0, nb, as, info, Li, ls);
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(B), dim3(64), 0, s, A, n, k0, nb, as, info, Lf, as, n);
         const int m = n - k0 - nb;
         if (m <= 0) break;
         const int tiles = (m + NB - 1) / NB;
         const size_t off = (size_t)(k0 + nb) * n;
-        const double* li = Li + (size_t)(k0 / NB) * NB * NB;
+        const double* li = Lf + (size_t)k0 * n + k0;
         // panel: P <- P L_kk^-T  = P (Linv)^T : Aop = P rows, Bop[k][c] = Linv[c][k]   (in place: one 64-column tile per row tile)
-        hipLaunchKernelGGL(gemm_set_kernel, dim3(1, tiles, B), dim3(256), 0, s, A + off + k0, n, A + off + k0, n, 0, li, NB, 1, m, nb, nb, as, as, ls);
+        hipLaunchKernelGGL(gemm_set_kernel, dim3(1, tiles, B), dim3(256), 0, s, A + off + k0, n, A + off + k0, n, 0, li, n, 1, m, nb, nb, as, as, as);
         // trailing[i][j] -= sum_k P[i][k] P[j][k]
         hipLaunchKernelGGL(gemm_sub_kernel, dim3(tiles, tiles, B), dim3(256), 0, s, A + off + k0 + nb, n, A + off + k0, n, 0,
                            A + off + k0, n, 1, m, m, nb, 1, as, as, as);
     }
-    // ---- L Y = F ----
+    // ---- L^-1 by doubling: inv([[A, 0], [C, D]]) = [[A^-1, 0], [-D^-1 C A^-1, D^-1]].  Every level is two batched GEMMs over
+    // all block pairs (6 levels for n = 2304) instead of the 2 x n/64 dependent small launches of blocked substitution. ----
+    for (int sz = NB; sz < n; sz *= 2) {
+        const int npair = (n + 2 * sz - 1) / (2 * sz);
+        const int last_r1 = (npair - 1) * 2 * sz + sz;                  // first row of the last pair's second half
+        const int mlast = last_r1 < n ? (n - last_r1 < sz ? n - last_r1 : sz) : 0;
+        GemmArgs g{};
+        // T = D^-1 C:  D^-1 = Lf[r1:r2, r1:r2] (lower), C = L[r1:r2, r0:r1]
+        g.C = Tb; g.ldc = sz; g.psC = (size_t)sz * sz; g.bsC = as;
+        g.A = Lf + (size_t)sz * n + sz; g.lda = n; g.ta = 0; g.psA = (size_t)2 * sz * n + 2 * sz; g.bsA = as;
+        g.B = A + (size_t)sz * n; g.ldb = n; g.tb = 0; g.psB = (size_t)2 * sz * n + 2 * sz; g.bsB = as;
+        g.M = sz; g.Mlast = mlast; g.N = sz; g.K = sz; g.Klast = mlast; g.tri = 1; g.npair = npair; g.sign = 1.0;
+        launch_gemm(s, B, g);
+        // Lf[r1:r2, r0:r1] = -T A^-1:  A^-1 = Lf[r0:r1, r0:r1] (lower)
+        GemmArgs h{};
+        h.C = Lf + (size_t)sz * n; h.ldc = n; h.psC = (size_t)2 * sz * n + 2 * sz; h.bsC = as;
+        h.A = Tb; h.lda = sz; h.ta = 0; h.psA = (size_t)sz * sz; h.bsA = as;
+        h.B = Lf; h.ldb = n; h.tb = 0; h.psB = (size_t)2 * sz * n + 2 * sz; h.bsB = as;
+        h.M = sz; h.Mlast = mlast; h.N = sz; h.K = sz; h.Klast = sz; h.tri = 3; h.npair = npair; h.sign = -1.0;
+        launch_gemm(s, B, h);
+    }
+    // ---- Y = L^-1 F, X = L^-T Y: two triangular GEMMs ----
+    {
+        GemmArgs g{};
+        g.C = R2; g.ldc = nrhs; g.bsC = fs; g.A = Lf; g.lda = n; g.ta = 0; g.bsA = as; g.B = R; g.ldb = nrhs; g.tb = 0; g.bsB = fs;
+        g.M = n; g.Mlast = n; g.N = nrhs; g.K = n; g.Klast = n; g.tri = 1; g.npair = 1; g.sign = 1.0;
+        launch_gemm(s, B, g);
+        GemmArgs h = g;
+        h.C = R; h.B = R2; h.ta = 1; h.tri = 2;
+        launch_gemm(s, B, h);
+    }
     const int ctiles = (nrhs + NB - 1) / NB;
-    for (int k0 = 0; k0 < n; k0 += NB) {
-        const int nb = n - k0 < NB ? n - k0 : NB;
-        const double* li = Li + (size_t)(k0 / NB) * NB * NB;
-        // Y_k = Linv F_k
-        // in place: every workgroup stages its whole 64 x 64 column tile of F_k in LDS before it stores
-        hipLaunchKernelGGL(gemm_set_kernel, dim3(ctiles, 1, B), dim3(256), 0, s, R + (size_t)k0 * nrhs, nrhs, li, NB, 0, R + (size_t)k0 * nrhs, nrhs, 0, nb, nrhs, nb, fs, ls, fs);
-        const int m = n - k0 - nb;
-        if (m <= 0) break;
-        hipLaunchKernelGGL(gemm_sub_kernel, dim3(ctiles, (m + NB - 1) / NB, B), dim3(256), 0, s, R + (size_t)(k0 + nb) * nrhs, nrhs,
-                           A + (size_t)(k0 + nb) * n + k0, n, 0, R + (size_t)k0 * nrhs, nrhs, 0, m, nrhs, nb, 0, fs, as, fs);
-    }
-    // ---- L^T X = Y ----
-    const int nblk = (n + NB - 1) / NB;
-    for (int kb = nblk - 1; kb >= 0; --kb) {
-        const int k0 = kb * NB, nb = n - k0 < NB ? n - k0 : NB;
-        const double* li = Li + (size_t)kb * NB * NB;
-        // X_k = Linv^T Y_k : Aop[i][k] = Linv[k][i]
-        hipLaunchKernelGGL(gemm_set_kernel, dim3(ctiles, 1, B), dim3(256), 0, s, R + (size_t)k0 * nrhs, nrhs, li, NB, 1, R + (size_t)k0 * nrhs, nrhs, 0, nb, nrhs, nb, fs, ls, fs);
-        if (k0 == 0) break;
-        hipLaunchKernelGGL(gemm_sub_kernel, dim3(ctiles, (k0 + NB - 1) / NB, B), dim3(256), 0, s, R, nrhs,
-                           A + (size_t)k0 * n, n, 1, R + (size_t)k0 * nrhs, nrhs, 0, k0, nrhs, nb, 0, fs, as, fs);
-    }
+    (void)ctiles;
     hipLaunchKernelGGL(store_xt_kernel, dim3((npad + 63) / 64, (nrhs + 63) / 64, B), dim3(256), 0, s, R, Xt, n, nrhs, npad);
     return gim_check_launch("gp_solve");
 }

@@ -46,7 +46,15 @@ __global__ void __launch_bounds__(64) potrf_diag_kernel(double* __restrict__ A, 
     __shared__ double Rinv[NB];
     double* a = A + blockIdx.x * bstride;
     const int lane = threadIdx.x;
-    for (int r = 0; r < NB; ++r) T[r][lane] = (r < nb && lane <= r) ? a[(size_t)(k0 + r) * n + k0 + lane] : 0.0;
+    // all loads of a half block are in flight before the first LDS write (a rolled load -> store loop: 64 dependent round trips)
+#pragma unroll 1
+    for (int h = 0; h < NB; h += 32) {
+        double tmp[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) tmp[r] = (h + r < nb && lane <= h + r) ? a[(size_t)(k0 + h + r) * n + k0 + lane] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) T[h + r][lane] = tmp[r];
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const int i = lane;
 #pragma unroll 1

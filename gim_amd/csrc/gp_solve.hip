@@ -1,11 +1,13 @@
 // GP posterior mean of the gim_dkm path (networks/dkm/models/dkm.py:340-370):  mu = K_xy (K_yy + sigma I)^-1 f.
 //
 // The reference inverts the n x n kernel matrix (n = 2352 at 672x896) with torch.linalg.inv (LU, fp32) and multiplies.
-// K_yy + sigma I is symmetric positive definite (exp-cosine kernel + 0.1 I), so here the system is SOLVED:
-// blocked right-looking Cholesky A = L L^T and two blocked triangular solves with the 256 right-hand sides, all in
-// fp64 (condition number up to ~2e4: an fp32 factorisation and the reference's fp32 LU agree to ~1e-3 only; fp64
-// puts this side's error far below the reference's own).  The n^3/3 flops are plain fp64 FMAs in 64 x 64 LDS tiles;
-// the cost is dominated by the ~260 small dependent launches (n/64 panel steps), a few ms per call.
+// K_yy + sigma I is symmetric positive definite (exp-cosine kernel + 0.1 I), so here the system is SOLVED, all in fp64
+// (condition number up to ~2e4: an fp32 factorisation and the reference's fp32 LU agree to ~1e-3 only; fp64 puts this
+// side's error far below the reference's own):
+//   1. blocked right-looking Cholesky A = L L^T -- n/64 dependent steps (diagonal block factored and inverted by one wave,
+//      panel and trailing update as 64-wide fp64 GEMM tiles): the serial part, ~3.5 ms at n = 2304;
+//   2. L^-1 completed from the inverted diagonal blocks by recursive doubling (two batched GEMMs per level);
+//   3. X = L^-T (L^-1 F) as two triangular GEMMs with the 256 / 512 right-hand sides.
 //
 //   gp_solve(K [B][n][ldk] fp32 (K_yy with sigma already on the diagonal), F [B][n][nrhs] fp32)
 //        -> Xt [B][nrhs][npad] fp32 = ((K)^-1 F)^T, zero padded to npad: the [N][K] "weight" layout the igemm takes
@@ -414,8 +416,6 @@ extern "C" int gim_gp_solve(const float* K, const float* F, float* Xt, void* ws,
         h.C = R; h.B = R2; h.ta = 1; h.tri = 2;
         launch_gemm(s, B, h);
     }
-    const int ctiles = (nrhs + NB - 1) / NB;
-    (void)ctiles;
     hipLaunchKernelGGL(store_xt_kernel, dim3((npad + 63) / 64, (nrhs + 63) / 64, B), dim3(256), 0, s, R, Xt, n, nrhs, npad);
     return gim_check_launch("gp_solve");
 }

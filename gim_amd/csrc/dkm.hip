@@ -680,28 +680,37 @@ __device__ __forceinline__ float4 round_half4(float4 v) {
     return make_float4((float)(_Float16)v.x, (float)(_Float16)v.y, (float)(_Float16)v.z, (float)(_Float16)v.w);
 }
 
+// One block = 64 query points; its 4 waves split the j range (chunks of 64 points, chunk c -> wave c % 4), each staging its
+// chunk in its own LDS slice (wave-local: no block barrier in the loop), partial sums combined in a fixed order.  The first
+// version ran 256 queries per block with the whole block walking all j: 79 blocks for 20 000 samples -- a quarter of the CUs,
+// one wave per SIMD, 1.6 ms per call; exp via v_exp_f32 (relative error ~1e-6 on a sum of 20 000 terms).
 __global__ void __launch_bounds__(256) kde_kernel(const float* __restrict__ x, float* __restrict__ density, int n, float inv2s2, int half) {
-    __shared__ float4 tile[256];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float4 tile[4][64];
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
     float4 xi = i < n ? *(const float4*)(x + (size_t)i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (half) xi = round_half4(xi);
+    const float c = -inv2s2 * 1.4426950408889634f;      // exp(-d2 * inv2s2) = exp2(d2 * c)
     float acc = 0.f;
-    for (int j0 = 0; j0 < n; j0 += 256) {
-        const int j = j0 + threadIdx.x;
+    for (int j0 = wv * 64; j0 < n; j0 += 256) {
+        const int j = j0 + lane;
         float4 xj = j < n ? *(const float4*)(x + (size_t)j * 4) : make_float4(1e18f, 1e18f, 1e18f, 1e18f);
         if (half && j < n) xj = round_half4(xj);
-        tile[threadIdx.x] = xj;
-        __syncthreads();
-        const int m = min(256, n - j0);
+        tile[wv][lane] = xj;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local LDS hand-off
+        const int m = min(64, n - j0);
+#pragma unroll 8
         for (int k = 0; k < m; ++k) {
-            const float4 v = tile[k];
+            const float4 v = tile[wv][k];
             const float dx = xi.x - v.x, dy = xi.y - v.y, dz = xi.z - v.z, dw = xi.w - v.w;
-            const float dist = sqrtf((dx * dx + dy * dy) + (dz * dz + dw * dw));   // torch.cdist, then ** 2
-            acc += expf(-(dist * dist) * inv2s2);
+            acc += __builtin_amdgcn_exp2f(((dx * dx + dy * dy) + (dz * dz + dw * dw)) * c);
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all reads done before the slice is overwritten
     }
-    if (i < n) density[i] = acc;
+    part[wv][lane] = acc;
+    __syncthreads();
+    if (wv == 0 && i < n) density[i] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 }  // namespace
@@ -888,7 +897,7 @@ extern "C" int gim_dkm_black_mask(const float* im, uint8_t* mask, int h, int w, 
 extern "C" int gim_kde(const float* x, float* density, int n, float std, gim_stream_t stream) {
     GIM_REQUIRE(x && density && n > 0 && std != 0.f, "kde: bad args");
     // std < 0: coordinates rounded to fp16 first (RoMa evaluates its KDE on x.half(), roma.py:1018-1023)
-    hipLaunchKernelGGL(kde_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, density, n, 1.0f / (2.0f * std * std), std < 0.f ? 1 : 0);
+    hipLaunchKernelGGL(kde_kernel, dim3((n + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, density, n, 1.0f / (2.0f * std * std), std < 0.f ? 1 : 0);
     return gim_check_launch("kde");
 }
 

@@ -10,7 +10,9 @@ from .._lib import GimHipError
 @torch.no_grad()
 def gim_lightglue_inference(detector, model, data):
     """Mutates `data` like the reference: adds hw0_i, hw1_i, mkpts0_f, mkpts1_f, m_bids, mconf.  Needs image0,
-    image1 ([B,1,H,W] gray), resize0/1 ([B,2] (h, w)), scale0/1 ([B,2]); color0/1 only provide hw*_i."""
+    image1 ([B,1,H,W] gray), scale0/1 ([B,2]) and either resize0/1 ([B,2] (h, w), the ZEB adapter, lightning.py:161-193) or
+    image_size0/1 ([B,2] (w, h), demo.py:485-511 -- the matcher flips whichever it gets, lightglue.py:414-415);
+    color0/1 only provide hw*_i."""
     img0, img1 = data["image0"], data["image1"]
     if not img0.is_cuda:
         raise GimHipError("gim_lightglue_inference needs device tensors: there is no CPU fallback")
@@ -24,7 +26,9 @@ def gim_lightglue_inference(detector, model, data):
         pred["descriptors0"], pred["descriptors1"] = both["descriptors"][:B], both["descriptors"][B:]
     else:
         for s, img in (("0", img0), ("1", img1)):
-            out = detector({"image": img, "image_size": data["resize" + s][:, [1, 0]]})
+            # lightning.py:166-173 passes image_size = resize[:, [1, 0]]; demo.py:490-497 passes none (the detector ignores it, quirk A-10)
+            extra = {"image_size": data["resize" + s][:, [1, 0]]} if ("resize" + s) in data else {}
+            out = detector({"image": img, **extra})
             pred["keypoints" + s], pred["descriptors" + s] = out["keypoints"], out["descriptors"]
     scale0 = data["scale0"].to(device=dev, dtype=torch.float32).contiguous()
     scale1 = data["scale1"].to(device=dev, dtype=torch.float32).contiguous()

@@ -422,9 +422,11 @@ static int lga_run_stats(const gim_lg_assign_args* a, LgaWs& w, LgaGeom& g, hipS
     g.inv_sqrt_d = 1.0f / sqrtf((float)a->C);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)lga_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_SMEM);
-        hipFuncSetAttribute((const void*)lga_best_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_SMEM);
-        hipFuncSetAttribute((const void*)lga_best_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_SMEM);
+        const void* kerns[3] = {(const void*)lga_stats_kernel, (const void*)lga_best_kernel<0>, (const void*)lga_best_kernel<1>};
+        for (const void* k : kerns) {
+            const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_SMEM);
+            if (e != hipSuccess) { gim_set_error("lg_assign: hipFuncSetAttribute: %s", hipGetErrorString(e)); return GIM_ERR_LAUNCH; }
+        }
         attr_set = true;
     }
     hipLaunchKernelGGL(lga_ktab_kernel, dim3(1), dim3(256), 0, s, w.ktab, a->C);

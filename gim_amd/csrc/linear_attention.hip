@@ -357,8 +357,9 @@ extern "C" int gim_linear_attention_kv(const void* k, const void* v, const uint8
         const int smem = 2 * 64 * 128 * (bf ? 2 : 4);
         static bool attr = false;
         if (!attr) {
-            hipFuncSetAttribute((const void*)la_kv_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 128 * 2);
-            hipFuncSetAttribute((const void*)la_kv_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 128 * 4);
+            hipError_t e = hipFuncSetAttribute((const void*)la_kv_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 128 * 2);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)la_kv_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 128 * 4);
+            if (e != hipSuccess) { gim_set_error("linear_attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return GIM_ERR_LAUNCH; }
             attr = true;
         }
         const dim3 g2((unsigned)nb, (unsigned)nc, 2u);

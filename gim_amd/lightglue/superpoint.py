@@ -21,8 +21,8 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .._lib import ACT_NONE, ACT_RELU, GIM_BF16, GIM_F32, GimHipError
-from ..packing import cstore, pack_conv, torch_dtype
+from .._lib import ACT_RELU, GIM_BF16, GIM_F32, GimHipError
+from ..packing import pack_conv, torch_dtype
 
 
 class SuperPoint(nn.Module):

@@ -5,8 +5,6 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gim_amd import ops
 from gim_amd.loftr import LoFTR, get_cfg_defaults, lower_config
-from gim_amd.packing import torch_dtype
-from gim_amd._lib import GIM_BF16
 
 torch.manual_seed(0)
 cfg = lower_config(get_cfg_defaults())["loftr"]; cfg["precision"] = "bf16"

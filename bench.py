@@ -1,21 +1,34 @@
-"""gim_loftr throughput bench on MI355X (driver contract: see the repo prompt / DESIGN.md section 6).
+"""gim_loftr throughput bench on MI355X (driver contract: see DESIGN.md section 6).
 
     python bench.py                       # 1 GPU, BASELINE config 2: gim_loftr 640x480 bf16, batch 8 pairs
+    python bench.py --gpus 8              # spawns 8 ranks itself (re-exec under torch.distributed.run, 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W        # what the driver does
 
-A "step" = one LoFTR.forward (HIP path through the C ABI) over one batch of 8 synthetic 640x480 pairs that
-are already resident in HBM, including the match-count read-back the reference's contract has
-(coarse_matching.py:193).  Pairs shard embarrassingly across ranks (weak scaling: 8 pairs per rank per
-step); the only collective is one RCCL all-gather(v) of the packed matches at the end of the run.
-Rank 0 prints ONE JSON line.  `roofline` = all gim_conv2d_bn_act launches (the implicit-GEMM MFMA kernel:
-backbone convs + transformer linears, > 95 % of the step's FLOPs) timed live with HIP events on the launch
-stream in extra instrumented steps; `cpu_baseline` = the CPU oracle (a port of the reference's forward,
-pinned to it by golden vectors) timed on this host's cores on a bounded sample (1 pair).
+A "step" = one LoFTR.forward (HIP path through the C ABI) over one batch of 8 synthetic 640x480 pairs that are
+already resident in HBM, including the match-count read-back the reference's contract has
+(coarse_matching.py:193).  The workload is MATCH-RICH: seeded "trained-like" weights (BatchNorm statistics
+calibrated, residual branches damped) on textured image pairs of which ~45 % of the frame corresponds
+(tools/synth_loftr.py), so ~1500 coarse matches per pair -- the mean of the reference's own gim_loftr dumps
+ -- flow through fine gather / fine transformer / fine matching inside the timed region.  Nothing is
+injected into the forward: the matches come out of the images.
+Pairs shard embarrassingly across ranks (weak scaling: 8 pairs per rank per step); the only collective is one
+RCCL all-gather(v) of the packed matches at the end of the run.  Rank 0 prints ONE JSON line.
+
+`roofline`  = all gim_conv2d_bn_act launches (the implicit-GEMM MFMA kernel: backbone convs + transformer
+              linears, > 95 % of the step's FLOPs) timed live with HIP events on the launch stream in extra
+              instrumented steps;
+`cpu_baseline` = the CPU oracle (a port of the reference's forward, pinned to it by golden vectors) on this
+              host's cores, 1 pair, 1 warm-up + 3 timed forwards; the same oracle run yields
+`parity`    = index flip rate / max coordinate and confidence deviation of the benchmarked bf16 engine against
+              the fp32 oracle on that pair;
+`h2d_inclusive` = the same step with both image batches starting in pinned host memory.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,49 +41,120 @@ if ROOT not in sys.path:
 
 H, W = 480, 640
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense, MI355X_MICROARCH.md
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="pairs per rank per step")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--coarse-sim", default=None, choices=["fp32", "bf16"], help="override LoFTR config['coarse_sim']")
+    ap.add_argument("--frac", type=float, default=0.45, help="corresponding fraction of the frame (match count knob)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=1)
-    args = ap.parse_args()
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="CPU-only check of the multi-rank launch / timing / gather protocol (gloo, no model)")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: re-exec as N ranks (test.py:188-218 runs pl.Trainer(gpus=N,
+    strategy=DDP); here one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1)."""
+    if not args.selftest_launch:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} HIP device(s) visible")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def selftest_worker(args, rank, world):
+    """gloo/CPU ranks walking the exact launch -> barrier -> timed loop -> gather -> max-over-ranks -> one-line
+    protocol of the real bench with a stand-in step (no GPU, no model)."""
+    from gim_amd.runner import all_gather_matches, pack_matches
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world, args.gpus)
+    nb = args.batch
+
+    def step(s):
+        g = torch.Generator().manual_seed(1000 * rank + s)
+        m = 3 + rank
+        return {"mkpts0_f": torch.rand(m, 2, generator=g), "mkpts1_f": torch.rand(m, 2, generator=g),
+                "mconf": torch.rand(m, generator=g), "m_bids": torch.zeros(m, dtype=torch.int64)}
+
+    who = [None] * world
+    dist.all_gather_object(who, (rank, int(os.environ.get("LOCAL_RANK", "-1")), os.getpid()))
+    dist.barrier()
+    t0 = time.perf_counter()
+    rows = [pack_matches(step(s), [(s * world + rank) * nb] * 1) for s in range(args.steps)]
+    allrows = all_gather_matches(torch.cat(rows))
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "steps": args.steps, "matches": int(allrows.shape[0]),
+                          "expected_matches": args.steps * sum(3 + r for r in range(world)),
+                          "ranks": [w[0] for w in who], "local_ranks": [w[1] for w in who],
+                          "distinct_processes": len({w[2] for w in who}) == world, "ms_per_step": round(1e3 * float(t) / args.steps, 3)}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch(args, argv))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.selftest_launch:
+        return selftest_worker(args, rank, world)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback in the product path)"
+    assert torch.cuda.device_count() > local_rank, f"rank {rank}: LOCAL_RANK {local_rank} has no HIP device"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == world
 
     from gim_amd import ops
-    from gim_amd.loftr import LoFTR, get_cfg_defaults, lower_config
     from gim_amd.runner import all_gather_matches, pack_matches
+    from tools import synth_loftr as S
+    from tools.parity import parity_vs_oracle
 
-    # random-init weights of the gim_loftr architecture (no checkpoint ships with the reference)
-    torch.manual_seed(0)
-    cfg = lower_config(get_cfg_defaults())["loftr"]
-    cfg["precision"] = args.precision
-    model = LoFTR(cfg).eval()
-    sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    # seeded "trained-like" weights of the gim_loftr architecture (no checkpoint ships with the reference)
+    over = {"coarse_sim": args.coarse_sim} if args.coarse_sim else {}
+    model, sd_cpu = S.synthetic_model(args.precision, seed=0, **over)
     model = model.to(dev)
 
-    g = torch.Generator().manual_seed(1234 + rank)
     nb = args.batch
-    c0 = torch.rand(nb, 3, H, W, generator=g).to(dev)
-    c1 = torch.rand(nb, 3, H, W, generator=g).to(dev)
+    c0h, c1h = S.textured_pairs(nb, H, W, seed=1234 + rank, frac=args.frac)
+    c0, c1 = c0h.to(dev), c1h.to(dev)
 
-    def step():
-        d = {"image0": c0[:, :1], "image1": c1[:, :1], "color0": c0, "color1": c1}
+    def step(a=None, b=None):
+        a = c0 if a is None else a
+        b = c1 if b is None else b
+        d = {"image0": a[:, :1], "image1": b[:, :1], "color0": a, "color1": b}
         model(d)
         return d
 
@@ -80,7 +164,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for w_ in range(args.warmup):  # the COMPLETE step, incl. match packing (torch loads its kernels lazily)
+    for w_ in range(max(2, args.warmup)):  # the COMPLETE step, incl. match packing; the 2nd call captures the HIP graph
         pack_matches(step(), list(range(nb)))
     all_gather_matches(torch.zeros(1, 6, device=dev))
     sync_all()
@@ -99,6 +183,8 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    d_last = d
+    solo = rank == 0 and world == 1  # the extra measurements below only run in single-GPU jobs
 
     # ---- live roofline of the dominant kernel (instrumented steps outside the timed region) --------
     roof = None
@@ -124,52 +210,67 @@ def main():
         # HBM bytes per launch from the TCC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected in
         # separate rocprofv3 --pmc passes of the same workload by tools/pmc_traffic.sh and committed under profiles/
         traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if args.precision == "bf16" and nb == 8 and os.path.exists(tj):
-            traffic = round(json.load(open(tj))["traffic_bytes_per_launch"])
+        if args.precision == "bf16" and nb == 8 and os.path.exists(TRAFFIC_JSON):
+            traffic = round(json.load(open(TRAFFIC_JSON))["traffic_bytes_per_launch"])
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
-                "kernel": "igemm_kernel (gim_conv2d_bn_act)", "launches_per_step": nlaunch // 2,
+                "kernel": "igemm_persistent_kernel (gim_conv2d_bn_act)", "launches_per_step": nlaunch // 2,
                 "avg_launch_us": round(1e3 * tot_ms / nlaunch, 2),
                 "gflop_per_launch": round(tot_fl / nlaunch / 1e9, 3),
                 "kernel_ms_per_step": round(tot_ms / 2, 3),
                 "top_layers_ms_tflops": [[k, round(v[0] / 2, 3), round(v[1] / (v[0] * 1e-3) / 1e12, 1)] for k, v in top]}
 
-    # ---- the same step with a realistically loaded fine level -----------------------------------------
-    # Random weights give ~1 match per pair.  Replace the coarse features in front of coarse matching by
-    # planted-correspondence features (f1 = permuted f0 + noise) so that ~1500 matches per pair
-    # (the mean of the reference's gim_loftr dumps) flow through fine gather / fine transformer / fine matching.
-    realistic = None
-    if rank == 0 and world == 1:  # single-GPU runs only: in a multi-rank job every rank leaves together after the timed region
-        gp = torch.Generator().manual_seed(7)
-        L, C = (H // 8) * (W // 8), 256
-        pf0 = torch.randn(nb, L, C, generator=gp) * 2.0
-        perm = torch.stack([torch.randperm(L, generator=gp) for _ in range(nb)])
-        pf1 = torch.gather(pf0, 1, perm[:, :, None].expand(-1, -1, C)) + 0.2 * torch.randn(nb, L, C, generator=gp)
-        keep = torch.rand(nb, L, generator=gp) < 0.41  # thin the planted set to ~1500 surviving matches per pair
-        pf1 = torch.where(keep[:, :, None], pf1, torch.randn(nb, L, C, generator=gp) * 2.0)
-        graph_was = model.use_graph
-        model._graphs.clear()
-        model.bench_override_coarse = (pf0.to(dev), pf1.to(dev))
+    # ---- the same step with the images starting in (pinned) host memory: PCIe-inclusive rate -------------
+    h2d = None
+    if solo:
+        p0, p1 = c0h.pin_memory(), c1h.pin_memory()
+        for _ in range(2):
+            step(p0.to(dev, non_blocking=True), p1.to(dev, non_blocking=True))
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        n_h = 10
+        for _ in range(n_h):
+            step(p0.to(dev, non_blocking=True), p1.to(dev, non_blocking=True))
+        torch.cuda.synchronize()
+        th = (time.perf_counter() - th) / n_h
+        h2d = {"pairs_per_s": round(nb / th, 2), "ms_per_step": round(1e3 * th, 3),
+               "note": f"{2 * c0h.numel() * 4 / 1e6:.0f} MB of fp32 NCHW images per step copied from pinned host memory "
+                       "on the compute stream (no overlap with the previous step)"}
+
+    # ---- the fine level idle (random-init weights, uniform-noise images: what round 1 reported) ----------
+    idle = None
+    if solo:
+        from gim_amd.loftr import LoFTR, get_cfg_defaults, lower_config
+        torch.manual_seed(0)
+        cfg = lower_config(get_cfg_defaults())["loftr"]
+        cfg["precision"] = args.precision
+        cfg.update(over)
+        m0 = LoFTR(cfg).eval().to(dev)
+        g = torch.Generator().manual_seed(1234)
+        u0, u1 = torch.rand(nb, 3, H, W, generator=g).to(dev), torch.rand(nb, 3, H, W, generator=g).to(dev)
+
+        def idle_step():
+            dd = {"image0": u0[:, :1], "image1": u1[:, :1], "color0": u0, "color1": u1}
+            m0(dd)
+            return dd
+
         for _ in range(3):
-            d = step()
+            dd = idle_step()
         torch.cuda.synchronize()
-        tr = time.perf_counter()
+        ti = time.perf_counter()
         for _ in range(10):
-            d = step()
+            dd = idle_step()
         torch.cuda.synchronize()
-        tr = (time.perf_counter() - tr) / 10
-        realistic = {"matches_per_pair": round(d["b_ids"].numel() / nb, 1), "ms_per_step": round(1e3 * tr, 3),
-                     "pairs_per_s": round(nb / tr, 2),
-                     "note": "coarse features replaced by planted correspondences in front of coarse matching; "
-                             "backbone / transformers / fine level run in full"}
-        model.bench_override_coarse = None
-        model._graphs.clear()
-        model.use_graph = graph_was
+        ti = (time.perf_counter() - ti) / 10
+        idle = {"pairs_per_s": round(nb / ti, 2), "ms_per_step": round(1e3 * ti, 3),
+                "matches_per_pair": round(dd["b_ids"].numel() / nb, 2),
+                "note": "random-init weights + uniform-noise images: ~1 match per pair, fine level idle (round-1 headline)"}
+        del m0, u0, u1
+        torch.cuda.empty_cache()
 
     # ---- secondary workload (reported, not the metric): gim_lightglue at the same resolution / batch ---------
     lightglue = None
-    if rank == 0 and world == 1 and not os.environ.get("GIM_BENCH_SKIP_LIGHTGLUE"):
+    if solo and not os.environ.get("GIM_BENCH_SKIP_LIGHTGLUE"):
         from gim_amd.lightglue import LightGlue, SuperPoint, gim_lightglue_inference
         torch.manual_seed(0)  # random-init weights of the reference architecture (no checkpoint in the container)
         det = SuperPoint({"max_num_keypoints": 2048, "force_num_keypoints": True, "detection_threshold": 0.0,
@@ -199,12 +300,12 @@ def main():
                                  "(9 layers) + adapter, random-init weights", "pairs_per_s": round(nb / tl, 2),
                      "ms_per_step": round(1e3 * tl, 3), "dtype": args.precision,
                      "achieved_tflops": round(nb / tl * 334e9 / 1e12, 1),
-                     "note": "algorithmic 334 GFLOP/pair (SURVEY 8d); kernel split in profiles/r01_lightglue_*"}
+                     "note": "algorithmic 334 GFLOP/pair (SURVEY 8d)"}
         del det, lgm
 
     # ---- secondary workloads: the two dense matchers at the reference's own configurations (one pair per call) ----
     dense = {}
-    if rank == 0 and world == 1 and not os.environ.get("GIM_BENCH_SKIP_DENSE"):
+    if solo and not os.environ.get("GIM_BENCH_SKIP_DENSE"):
         gg = torch.Generator().manual_seed(1)
         base = torch.nn.functional.interpolate(torch.rand(1, 3, 60, 80, generator=gg), size=(480, 640), mode="bicubic").clamp(0.05, 1)
         im0 = base.to(dev)
@@ -259,18 +360,23 @@ def main():
             m.upsample_res = (1152, 1536)
             return m
 
-        def build_roma():
-            from gim_amd.roma import RoMa, random_dinov2_weights
-            return RoMa([672], precision=args.precision, dinov2_weights=random_dinov2_weights(dev))
+        def build_roma(size):
+            def f():
+                from gim_amd.roma import RoMa, random_dinov2_weights
+                return RoMa([size], precision=args.precision, dinov2_weights=random_dinov2_weights(dev))
+            return f
 
         dense_bench("gim_dkm", build_dkm, "gim_dkm match() + sample(5000), 672x896 -> upsampling pass 1152x1536, one pair per call, "
                     "random-init weights (trainer/lightning.py:29-37 configuration)", batch=4)
-        dense_bench("gim_roma", build_roma, "gim_roma match() + sample(5000), 672x672 -> upsampling pass 1344x1344, one pair per call, "
+        dense_bench("gim_roma", build_roma(672), "gim_roma match() + sample(5000), 672x672 -> upsampling pass 1344x1344, one pair per call, "
                     "random-init weights incl. a synthetic DINOv2 ViT-L/14 (RoMa(img_size=[672]), trainer/lightning.py:38-41)")
+        dense_bench("gim_roma_560", build_roma(560), "gim_roma match() + sample(5000), 560x560 -> upsampling pass 1120x1120 (BASELINE config 4 "
+                    "resolution, RoMa(img_size=[560])), one pair per call per GPU, random-init weights")
 
-    # ---- CPU baseline: the oracle on this host's cores, bounded sample ------------------------------
+    # ---- CPU baseline: the oracle on this host's cores, bounded sample; parity of the benchmarked engine ----
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    parity = None
+    if solo and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import loftr_oracle as O
         # torch's CPU kernels oversubscribe badly on a 256-thread host (119.9 s per pair with all hardware threads): use at
@@ -278,14 +384,28 @@ def main():
         ncore = min(os.cpu_count() or 1, int(os.environ.get("GIM_CPU_THREADS", "64")))
         torch.set_num_threads(ncore)
         n = args.cpu_pairs
-        cc0, cc1 = c0[:n].cpu(), c1[:n].cpu()
-        tc = time.perf_counter()
-        with torch.no_grad():
-            O.loftr_forward(sd_cpu, {"image0": cc0[:, :1], "image1": cc1[:, :1], "color0": cc0, "color1": cc1})
-        tc = time.perf_counter() - tc
+        cc0, cc1 = c0h[:n], c1h[:n]
+
+        def cpu_forward():
+            with torch.no_grad():
+                return O.loftr_forward(sd_cpu, {"image0": cc0[:, :1], "image1": cc1[:, :1], "color0": cc0, "color1": cc1})
+
+        n_timed = int(os.environ.get("GIM_CPU_REPEATS", "3"))
+        cpu_forward()  # warm-up
+        tcs = []
+        for _ in range(n_timed):
+            tc = time.perf_counter()
+            ref = cpu_forward()
+            tcs.append(time.perf_counter() - tc)
+        tc = sum(tcs) / len(tcs)
         cpu = {"value": round(n / tc, 5), "unit": "pairs/s", "cores": ncore, "kind": "port",
-               "sample": f"{n} pair(s) 640x480 fp32, one un-warmed forward of oracle/loftr_oracle.py "
-                         f"(torch CPU, {ncore} threads), {tc:.1f} s"}
+               "sample": f"{n} pair(s) 640x480 fp32 (pair 0 of the benchmarked batch), oracle/loftr_oracle.py on torch CPU with "
+                         f"{ncore} threads, 1 warm-up + {n_timed} timed forwards, {tc:.2f} s each "
+                         f"(min {min(tcs):.2f}, max {max(tcs):.2f})"}
+        if n == 1:
+            parity = parity_vs_oracle(d_last, ref, 0)
+            parity["note"] = (f"pair 0 of the timed batch: {args.precision} engine (coarse_sim={model.coarse_sim}) vs the fp32 CPU "
+                              "oracle; flip_rate = |engine matches XOR oracle matches| / |oracle matches|")
 
     if rank == 0 and os.environ.get("GIM_BENCH_DEBUG"):
         print("per-step ms:", [round(1e3 * (b - a), 2) for a, b in zip([t0] + tstep[:-1], tstep)], file=sys.stderr)
@@ -296,16 +416,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"fine_stage_note": "random-init weights give ~1 match/pair, so the fine level is nearly idle here; "
-                                          "measured separately with synthetic matches (tools/bench_fine.py, "
-                                          "profiles/r01_fine_stage.txt): +1.2 / +3.1 / +7.9 ms per batch at 500 / "
-                                          "1500 / 4000 matches per pair",
-                       "workload": f"gim_loftr {W}x{H}, batch {nb} pairs per GPU per step, random-init weights, "
-                                   f"uniform-noise images (device resident), outputs incl. match count read back",
-                       "pairs_per_step": world * nb, "matches_per_pair": round(n_matches / max(1, pairs), 2),
+            "config": {"workload": f"gim_loftr {W}x{H}, batch {nb} pairs per GPU per step, seeded trained-like weights "
+                                   f"(calibrated BatchNorm statistics), textured image pairs with {args.frac:.2f} of the frame "
+                                   "in correspondence (device resident), fine level loaded, outputs incl. match count read back",
+                       "pairs_per_step": world * nb, "matches_per_pair": round(n_matches / max(1, pairs), 1),
+                       "coarse_sim": model.coarse_sim,
                        "parallelism": f"pairs sharded over {world} GPU(s), no collective per step",
                        "hip_graph": bool(model.use_graph)},
-            "roofline": roof, "cpu_baseline": cpu, "realistic_fine": realistic,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "h2d_inclusive": h2d, "fine_idle": idle,
             "secondary_workloads": {"gim_lightglue": lightglue, **dense},
         }
         print(json.dumps(out), flush=True)

@@ -64,7 +64,7 @@ inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t carve(CmWs& w, char* base, int N, int L, int S, int C) {
     w.ntL = (L + BM - 1) / BM;
     w.ntS = (S + BN - 1) / BN;
-    w.capc = 4 * L + 64;
+    w.capc = 20 * L + 64;  // < 1/thr entries of a row can exceed thr (sum_j softmax_j <= 1); validate() enforces thr >= 0.05
     // pre-candidate capacity; GIM_CM_PRECAND_PER_ROW (default 16) exists so that tests can force the
     // overflow -> recompute fallback
     static const int per_row = [] { const char* e = getenv("GIM_CM_PRECAND_PER_ROW"); int v = e ? atoi(e) : 16; return v < 0 ? 0 : v; }();
@@ -463,7 +463,7 @@ __global__ void cm_emit_kernel(const CmWs w, const EmitArgs e) {
     if (idx == 0) {
         int s = 0;
         for (int k = 0; k < e.N; ++k) s += e.count[1 + k];
-        e.count[0] = s;
+        e.count[0] = s < e.cap ? s : e.cap;  // the host sizes its views by count[0]: never beyond the output capacity
     }
     if (idx >= (size_t)e.N * e.L) return;
     const int n = (int)(idx / e.L), i = (int)(idx - (size_t)n * e.L);
@@ -493,7 +493,8 @@ int validate(const gim_coarse_args& a) {
     GIM_REQUIRE(a.ldf == 0 || (a.ldf >= a.C && a.ldf % (a.feat_dtype == GIM_BF16 ? 8 : 4) == 0), "coarse_match: ldf=%d", a.ldf);
     GIM_REQUIRE(a.h0c * a.w0c == a.L && a.h1c * a.w1c == a.S, "coarse_match: hw0_c/hw1_c do not match L/S");
     GIM_REQUIRE((int64_t)a.L * (a.ldf ? a.ldf : a.C) * 4 < (int64_t)0xFFFFFFF0ll && (int64_t)a.S * (a.ldf ? a.ldf : a.C) * 4 < (int64_t)0xFFFFFFF0ll, "coarse_match: feature map too large");
-    GIM_REQUIRE(a.temperature > 0.f && a.thr > 0.f, "coarse_match: temperature and thr must be positive");
+    GIM_REQUIRE(a.temperature > 0.f, "coarse_match: temperature must be positive");
+    GIM_REQUIRE(a.thr >= 0.05f, "coarse_match: thr=%g below 0.05 (the candidate buffers hold 20 entries per row = 1/0.05; gim_loftr uses 0.2)", (double)a.thr);
     GIM_REQUIRE((a.mask0 == nullptr) == (a.mask1 == nullptr), "coarse_match: mask0 and mask1 must be given together");
     return GIM_OK;
 }
@@ -517,8 +518,8 @@ static int cm_prepare(const gim_coarse_args& a, CmWs& w, CmGeom& g) {
     g.feat0 = a.feat0; g.feat1 = a.feat1; g.bf16 = a.feat_dtype == GIM_BF16; g.ldf = a.ldf ? a.ldf : a.C; g.mask0 = a.mask0; g.mask1 = a.mask1; g.N = a.N; g.L = a.L; g.S = a.S; g.C = a.C;
     g.inv_c = 1.0f / (float)a.C; g.temperature = a.temperature; g.thr = a.thr;
     g.inv_ct = 1.0f / ((float)a.C * a.temperature);
-    static bool attr = false;
-    if (!attr) {
+    static GimPerDevice attr;
+    if (attr.needed()) {
         int rc = set_smem(cm_stats_kernel<false>);
         if (rc == GIM_OK) rc = set_smem(cm_stats_kernel<true>);
         if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<0, false>);
@@ -526,7 +527,7 @@ static int cm_prepare(const gim_coarse_args& a, CmWs& w, CmGeom& g) {
         if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<0, true>);
         if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<1, true>);
         if (rc != GIM_OK) return rc;
-        attr = true;
+        attr.done();
     }
     return GIM_OK;
 }

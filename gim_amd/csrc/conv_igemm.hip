@@ -452,14 +452,14 @@ template <int BM, int BN, int WM, int WN, bool BF16, bool OUT_BF16, bool HAS_RES
 int launch_persistent(const gim_conv_args& a, hipStream_t stream) {
     constexpr int smem = 2 * (BM + BN) * KTB;
     auto kern = igemm_persistent_kernel<BM, BN, WM, WN, BF16, OUT_BF16, HAS_RES>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static GimPerDevice attr_done;
+    if (attr_done.needed()) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) {
             gim_set_error("hipFuncSetAttribute(%d B LDS): %s", smem, hipGetErrorString(e));
             return GIM_ERR_LAUNCH;
         }
-        attr_done = true;
+        attr_done.done();
     }
     const int M = a.B * a.Ho * a.Wo;
     const int mtiles = (M + BM - 1) / BM, ntiles = a.npad / BN;
@@ -478,14 +478,14 @@ int launch_ring3(const gim_conv_args& a, hipStream_t stream) {
     const int nkt = a.kpad * es / KTB;
     const int smem = 3 * (256 + 128) * KTB + (nkt + 2) * 8 * 4;
     auto kern = igemm_ring3_kernel<BF16, HAS_RES>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static GimPerDevice attr_done;
+    if (attr_done.needed()) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             gim_set_error("hipFuncSetAttribute(160 KiB LDS): %s", hipGetErrorString(e));
             return GIM_ERR_LAUNCH;
         }
-        attr_done = true;
+        attr_done.done();
     }
     const int M = a.B * a.Ho * a.Wo;
     const int mtiles = (M + 255) / 256, ntiles = a.npad / 128;
@@ -553,14 +553,14 @@ int launch_igemm(const gim_conv_args& a, hipStream_t stream) {
     constexpr int stage = 2 * (BM + BN) * KTB, ctile = BM * (BN + 4) * 4;
     constexpr int smem = stage > ctile ? stage : ctile;
     auto kern = igemm_kernel<BM, BN, WM, WN, BF16, LDSDMA>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static GimPerDevice attr_done;
+    if (attr_done.needed()) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) {
             gim_set_error("hipFuncSetAttribute(%d B LDS): %s", smem, hipGetErrorString(e));
             return GIM_ERR_LAUNCH;
         }
-        attr_done = true;
+        attr_done.done();
     }
     const int M = a.B * a.Ho * a.Wo;
     const int mtiles = (M + BM - 1) / BM, ntiles = a.npad / BN;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/gim_hip.h"
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
@@ -20,6 +21,17 @@ int gim_check_launch(const char* what);
             return GIM_ERR_INVALID;                  \
         }                                            \
     } while (0)
+
+// ---- one-time per-DEVICE kernel attribute setup ------------------------------------------------
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device property: a process that drives several GPUs must
+// set it on each of them.  `GimPerDevice flag;  if (flag.needed()) { ...set attributes...; flag.done(); }`
+// (one bit per device ordinal; racing threads at worst set the attribute twice, which is harmless).
+struct GimPerDevice {
+    std::atomic<unsigned long long> mask[4] = {};
+    static int dev() { int d = 0; (void)hipGetDevice(&d); return d & 255; }
+    bool needed() const { const int d = dev(); return !((mask[d >> 6].load(std::memory_order_acquire) >> (d & 63)) & 1ull); }
+    void done() { const int d = dev(); mask[d >> 6].fetch_or(1ull << (d & 63), std::memory_order_release); }
+};
 
 // ---- bf16 <-> f32 (round to nearest even, like torch's .to(bfloat16)) ------------------------
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) {

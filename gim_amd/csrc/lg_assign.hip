@@ -420,14 +420,14 @@ static int lga_run_stats(const gim_lg_assign_args* a, LgaWs& w, LgaGeom& g, hipS
     carve(w, (char*)a->ws, a->B, a->M, a->N, a->C);
     g.md0 = a->md0; g.md1 = a->md1; g.B = a->B; g.M = a->M; g.N = a->N; g.C = a->C;
     g.inv_sqrt_d = 1.0f / sqrtf((float)a->C);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static GimPerDevice attr_set;
+    if (attr_set.needed()) {
         const void* kerns[3] = {(const void*)lga_stats_kernel, (const void*)lga_best_kernel<0>, (const void*)lga_best_kernel<1>};
         for (const void* k : kerns) {
             const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_SMEM);
             if (e != hipSuccess) { gim_set_error("lg_assign: hipFuncSetAttribute: %s", hipGetErrorString(e)); return GIM_ERR_LAUNCH; }
         }
-        attr_set = true;
+        attr_set.done();
     }
     hipLaunchKernelGGL(lga_ktab_kernel, dim3(1), dim3(256), 0, s, w.ktab, a->C);
     hipLaunchKernelGGL(lga_prep_kernel, dim3((a->B * a->M + 3) / 4), dim3(256), 0, s, a->desc0, a->match_w, a->match_b, w.ls0, w.lsn0, w.best0, a->B * a->M, a->ld_desc);

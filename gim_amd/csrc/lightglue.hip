@@ -358,13 +358,13 @@ int launch_sdpa(const SdpaArgs& a, hipStream_t s) {
     constexpr int ES = BF16 ? 2 : 4;
     constexpr int smem = 2 * (64 * D * ES + D * 64 * ES);
     auto kern = sdpa_kernel<BF16, OUT_BF16, D>;
-    static bool attr = false;
-    if (!attr) {
+    static GimPerDevice attr;
+    if (attr.needed()) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
             gim_set_error("sdpa: hipFuncSetAttribute(%d B LDS) failed", smem);
             return GIM_ERR_LAUNCH;
         }
-        attr = true;
+        attr.done();
     }
     const dim3 grid((a.L + 127) / 128, a.H, a.nb), blk(256);
     hipLaunchKernelGGL(kern, grid, blk, smem, s, a);

@@ -355,12 +355,12 @@ extern "C" int gim_linear_attention_kv(const void* k, const void* v, const uint8
     if (mfma_path) {
         // coarse level: fp32-MFMA kernel, 4 heads of a 128-row chunk per workgroup
         const int smem = 2 * 64 * 128 * (bf ? 2 : 4);
-        static bool attr = false;
-        if (!attr) {
+        static GimPerDevice attr;
+        if (attr.needed()) {
             hipError_t e = hipFuncSetAttribute((const void*)la_kv_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 128 * 2);
             if (e == hipSuccess) e = hipFuncSetAttribute((const void*)la_kv_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 128 * 4);
             if (e != hipSuccess) { gim_set_error("linear_attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return GIM_ERR_LAUNCH; }
-            attr = true;
+            attr.done();
         }
         const dim3 g2((unsigned)nb, (unsigned)nc, 2u);
         if (bf) hipLaunchKernelGGL(la_kv_mfma_kernel<true>, g2, dim3(256), smem, s, k, v, kv_mask, part, S, ldk, ldv, nc);

@@ -16,8 +16,15 @@ fallback: without the HIP library the import fails, without a GPU tensor the cal
 Precision modes (`config['precision']`, default env GIM_PRECISION or 'bf16'):
   'fp32'  fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32 products/accumulate) -- the parity mode;
   'bf16'  bf16 operands / fp32 accumulate for the backbone and the transformer GEMMs -- the throughput
-          mode.  Coarse matching always runs on fp32 features with fp32 MFMA (index exactness).
+          mode.  The token residual stream stays fp32 and coarse matching reads those fp32 tokens.
+
+Coarse similarity (`config['coarse_sim']`, default env GIM_COARSE_SIM or 'fp32'):
+  'fp32'  similarity of the fp32 tokens with fp32-exact products (the default in BOTH precision modes: on the
+          same features the mutual-NN indices equal the reference's fp32 arithmetic);
+  'bf16'  bf16 mode only: similarity of the bf16 operand copy of the tokens on the bf16 MFMA (faster, not
+          index-exact against fp32 features: an explicit, reported switch).
 """
+import collections
 import math
 import os
 
@@ -163,8 +170,9 @@ class LoFTR(nn.Module):
         if config["fine_concat_coarse_feat"]:
             raise NotImplementedError("fine_concat_coarse_feat=True is not used by gim_loftr and is not built")
         self.precision = _precision_from(config)
-        # bf16 mode: similarity of coarse matching on the bf16 token copy (bf16 MFMA) unless asked to keep the fp32 tokens
-        self.coarse_sim_fp32 = bool(config.get("coarse_sim_fp32", False)) or os.environ.get("GIM_COARSE_SIM_FP32", "0") == "1"
+        self.coarse_sim = (config.get("coarse_sim") or os.environ.get("GIM_COARSE_SIM") or "fp32").lower()
+        if self.coarse_sim not in ("fp32", "bf16"):
+            raise ValueError(f"coarse_sim must be 'fp32' or 'bf16', got {self.coarse_sim!r}")
         self.backbone = _ResNetFPN_8_2(config["resnetfpn"])
         self.loftr_coarse = _LocalFeatureTransformer(config["coarse"])
         self.loftr_fine = _LocalFeatureTransformer(config["fine"])
@@ -174,13 +182,13 @@ class LoFTR(nn.Module):
         self._packed_key = None
         self._pe_cache = {}
         self.debug = None  # set to a dict to capture stage outputs (tests): coarse/fine maps, token features
-        # bench-only hook: (feat_c0, feat_c1) fp32 [N,L,C] device tensors that REPLACE the transformer output in
-        # front of coarse matching, to load the fine level with a realistic number of matches when the weights
-        # are random (bench.py "realistic_fine").  Never set by product code.
-        self.bench_override_coarse = None
-        # HIP-graph replay of the shape-static part of the forward (env GIM_GRAPH=0 disables)
+        # HIP-graph replay of the shape-static part of the forward (env GIM_GRAPH=0 disables).  A shape is captured
+        # the second time it is seen (its first call runs eagerly and doubles as the warm-up), and at most
+        # GIM_GRAPH_CACHE (default 4) graphs -- each owns its static inputs and activation pool -- are kept, LRU.
         self.use_graph = os.environ.get("GIM_GRAPH", "1") != "0"
-        self._graphs = {}
+        self.graph_cache_size = max(1, int(os.environ.get("GIM_GRAPH_CACHE", "4")))
+        self._graphs = collections.OrderedDict()
+        self._seen = collections.OrderedDict()
         self._generation = 0
         if config.get("weight") is not None:
             self.load_state_dict(torch.load(config["weight"], map_location="cpu"))
@@ -402,14 +410,9 @@ class LoFTR(nn.Module):
         # 3. coarse matching (coarse_matching.py:88-259), fused
         mc = cfg["match_coarse"]
         scale = color0.shape[2] / hw0_c[0]
-        if self.bench_override_coarse is not None:
-            T.X32[r0].copy_(self.bench_override_coarse[0].reshape(-1, C))
-            T.X32[r1].copy_(self.bench_override_coarse[1].reshape(-1, C))
-            T.CAT[r0, :C].copy_(self.bench_override_coarse[0].reshape(-1, C))
-            T.CAT[r1, :C].copy_(self.bench_override_coarse[1].reshape(-1, C))
-        if dt == GIM_BF16 and not self.coarse_sim_fp32:
-            # the operand-dtype copy of the final tokens (written by the last LayerNorm for the next GEMM) feeds the
-            # similarity: bf16 MFMA with fp32 accumulation, the same arithmetic as every other matrix op of this mode
+        if dt == GIM_BF16 and self.coarse_sim == "bf16":
+            # opt-in: the operand-dtype copy of the final tokens (written by the last LayerNorm for the next GEMM)
+            # feeds the similarity -- bf16 MFMA with fp32 accumulation, not index-exact against the fp32 tokens
             fc0 = T.CAT[r0].view(bs, L, 2 * C)[:, :, :C]
             fc1 = T.CAT[r1].view(bs, S, 2 * C)[:, :, :C]
         else:
@@ -420,27 +423,29 @@ class LoFTR(nn.Module):
         return {"c0": c0, "c1": c1, "f0": f0, "f1": f1, "cr": cr,
                 "feat_c0": T.X32[r0].view(bs, L, C), "feat_c1": T.X32[r1].view(bs, S, C)}
 
-    def _coarse_stage_graphed(self, color0, color1, scale0, scale1, mask0=None, mask1=None):
+    def _graph_key(self, color0, color1, scale0, mask0):
+        return (tuple(color0.shape), tuple(color1.shape), scale0 is not None, mask0 is not None, self.precision,
+                self.coarse_sim, str(color0.device))
+
+    def _coarse_stage_graphed(self, key, color0, color1, scale0, scale1, mask0=None, mask1=None):
         """HIP-graph replay of `_coarse_stage` (one graph per input shape / precision).  ~300 kernel launches
         collapse into one graph launch; inputs are copied into the graph's static buffers."""
-        key = (tuple(color0.shape), tuple(color1.shape), scale0 is not None, mask0 is not None, self.precision,
-               str(color0.device))
         ent = self._graphs.get(key)
         if ent is None:
-            self._prepack(color0.device)
-            for hw in (color0.shape[2:], color1.shape[2:]):
-                self._pos_encoding(self.config["coarse"]["d_model"], hw[0] // 8, hw[1] // 8, color0.device)
             sin = [color0.clone(), color1.clone(),
                    scale0.clone().float() if scale0 is not None else None,
                    scale1.clone().float() if scale1 is not None else None,
                    mask0.clone() if mask0 is not None else None, mask1.clone() if mask1 is not None else None]
-            self._coarse_stage(*sin)  # warm-up: one-time hipFuncSetAttribute calls, allocator pools
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             # thread_local: other threads (e.g. RCCL's watchdog in multi-GPU runs) may issue HIP calls meanwhile
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 out = self._coarse_stage(*sin)
+            while len(self._graphs) >= self.graph_cache_size:  # LRU eviction frees that graph's pool
+                self._graphs.popitem(last=False)
             ent = self._graphs[key] = (graph, sin, out)
+        else:
+            self._graphs.move_to_end(key)
         graph, sin, out = ent
         sin[0].copy_(color0)
         sin[1].copy_(color1)
@@ -485,15 +490,26 @@ class LoFTR(nn.Module):
         data.update({"bs": data["image0"].size(0),
                      "hw0_i": data["image0"].shape[2:], "hw1_i": data["image1"].shape[2:]})
         bs = data["bs"]
-        graphed = self.use_graph and self.debug is None
-        if graphed:
-            try:
-                st = self._coarse_stage_graphed(color0, color1, scale0, scale1, mask0, mask1)
-            except Exception as e:  # capture unsupported in this environment: same kernels, eager launches
-                import warnings
-                warnings.warn(f"gim_amd: HIP graph capture failed ({e!r}); falling back to eager kernel launches")
-                self.use_graph = graphed = False
-                self._graphs.clear()
+        graphed = False
+        if self.use_graph and self.debug is None:
+            key = self._graph_key(color0, color1, scale0, mask0)
+            if key in self._graphs or self._seen.get(key, 0) >= 1:
+                try:
+                    st = self._coarse_stage_graphed(key, color0, color1, scale0, scale1, mask0, mask1)
+                    graphed = True
+                except RuntimeError as e:
+                    # only a failed *capture* (HIP graphs unsupported in this environment) lands here: input errors
+                    # (ValueError / GimHipError from argument checks) were raised by this shape's eager first call
+                    if key in self._graphs or "capture" not in str(e).lower():
+                        raise
+                    import warnings
+                    warnings.warn(f"gim_amd: HIP graph capture failed ({e!r}); using eager kernel launches")
+                    self.use_graph = False
+                    self._graphs.clear()
+            else:
+                self._seen[key] = self._seen.get(key, 0) + 1
+                while len(self._seen) > 64:
+                    self._seen.popitem(last=False)
         if not graphed:
             st = self._coarse_stage(color0, color1, scale0, scale1, mask0, mask1)
         c0, c1, f0, f1, cr = st["c0"], st["c1"], st["f0"], st["f1"], st["cr"]

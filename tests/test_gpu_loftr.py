@@ -230,6 +230,11 @@ def test_fp32_end_to_end_masked(oracle_sd, graph):
     c1 = c1 * torch.nn.functional.interpolate(m1[:, None].float(), scale_factor=8)
     d = _data(c0, c1, "cuda:0", mask0=m0, mask1=m1)
     m(d)
+    if graph:  # a shape is captured the second time it is seen; the third call replays
+        for _ in range(2):
+            d = _data(c0, c1, "cuda:0", mask0=m0, mask1=m1)
+            m(d)
+        assert len(m._graphs) == 1
     with torch.no_grad():
         ref = O.loftr_forward(oracle_sd, _data(c0, c1, mask0=m0, mask1=m1))
     for k in ("b_ids", "i_ids", "j_ids"):

@@ -1,0 +1,146 @@
+"""Parity of the BENCHMARKED gim_loftr configuration (640x480, the BASELINE config-2 size) against the CPU oracle on
+match-rich synthetic pairs (tools/synth_loftr.py: calibrated "trained-like" weights + textured pairs, ~1400 coarse
+matches per pair come out of the images -- nothing is injected into the forward).
+
+  * fp32 mode, one 640x480 pair: match set exact (any flip must be marginal in the oracle's own decision, i.e. within
+    1e-3 of the threshold / of a mutual-NN tie), coordinates / confidences within 1e-4 (north_star's bar);
+  * bf16 mode (the mode bench.py times), batch 8: index flip rate and coordinate deviation against the fp32 oracle,
+    with stated bounds -- bf16 operand rounding in the backbone / transformer moves confidences by ~0.02 on average,
+    so matches whose confidence sits near thr = 0.2 flip; measured 1.7-2.6 % (both coarse_sim settings);
+  * fine level with >= 500 matches: fine transformer output (a8) and fine matching (a9) against the oracle's
+    `local_feature_transformer(sd, "loftr_fine", ...)` / `fine_matching` on the same windows.
+"""
+import pytest
+import torch
+
+import loftr_oracle as O
+from tools import synth_loftr as S
+from tools.parity import flip_margins, parity_vs_oracle
+
+pytestmark = pytest.mark.gpu
+
+H, W = 480, 640
+
+
+def _data(c0, c1, dev=None):
+    d = {"image0": c0[:, :1], "image1": c1[:, :1], "color0": c0, "color1": c1}
+    return {k: v.to(dev) for k, v in d.items()} if dev is not None else d
+
+
+@pytest.fixture(scope="module")
+def synth():
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    model, sd = S.synthetic_model("fp32")
+    return model.to("cuda:0"), sd
+
+
+@pytest.fixture(scope="module")
+def pairs():
+    return S.textured_pairs(8, H, W, seed=1234, frac=0.45)
+
+
+@pytest.fixture(scope="module")
+def oracle_two_pairs(synth, pairs):
+    _, sd = synth
+    c0, c1 = pairs
+    with torch.no_grad():
+        return O.loftr_forward(sd, _data(c0[:2], c1[:2]))
+
+
+def test_fp32_640x480_exact_vs_oracle(synth, pairs, oracle_two_pairs):
+    model, _ = synth
+    model.set_precision("fp32")
+    c0, c1 = pairs
+    ref = oracle_two_pairs
+    d = _data(c0[:2], c1[:2], "cuda:0")
+    model(d)
+    torch.cuda.synchronize()
+    assert ref["b_ids"].numel() >= 2000  # match-rich: ~1400 per pair
+    for b in range(2):
+        p = parity_vs_oracle(d, ref, b, b)
+        print("fp32 640x480 pair", b, p)
+        flips = flip_margins(d, ref, b, b)
+        # exact, except where the oracle's own decision is a coin toss at fp32 resolution
+        assert all(f[4] < 1e-3 or f[5] < 1e-3 for f in flips), flips
+        assert len(flips) <= 2, flips
+        assert p["max_abs_dmconf"] <= 1e-4, p
+        assert p["max_abs_dmkpts1_px"] <= 1e-4 and p["max_abs_dmkpts0_px"] == 0.0, p
+        assert p["max_abs_dexpec_f"] <= 1e-4, p
+    if not any(flip_margins(d, ref, b, b) for b in range(2)):  # then order and every index are identical as well
+        for k in ("b_ids", "i_ids", "j_ids"):
+            assert torch.equal(d[k].cpu(), ref[k]), k
+
+
+@pytest.mark.parametrize("coarse_sim", ["fp32", "bf16"])
+def test_bf16_batch8_flip_rate_vs_oracle(synth, pairs, oracle_two_pairs, coarse_sim):
+    """The benchmarked mode.  Bounds: flip rate <= 5 %, mean |d mkpts1_f| <= 0.02 px, max <= 1 px, on the common
+    matches; measured 1.7-2.6 %, 0.006 px, 0.33 px (profiles/r02_parity_probe.txt)."""
+    model, _ = synth
+    model.set_precision("bf16")
+    model.coarse_sim = coarse_sim
+    c0, c1 = pairs
+    try:
+        for _ in range(3):  # eager, capture, replay: the replayed graph is what bench.py times
+            d = _data(c0, c1, "cuda:0")
+            model(d)
+        torch.cuda.synchronize()
+        assert len(model._graphs) == 1
+        assert d["b_ids"].numel() >= 8 * 1000
+        for b in range(2):
+            p = parity_vs_oracle(d, oracle_two_pairs, b, b)
+            print("bf16 batch-8 coarse_sim", coarse_sim, "pair", b, p)
+            assert p["flip_rate"] <= 0.05, p
+            assert p["mean_abs_dmkpts1_px"] <= 0.02 and p["max_abs_dmkpts1_px"] <= 1.0, p
+            assert p["mean_abs_dmconf"] <= 0.05, p
+    finally:
+        model.coarse_sim = "fp32"
+        model.set_precision("fp32")
+
+
+def test_graph_replay_is_bitwise_eager(synth, pairs):
+    model, _ = synth
+    model.set_precision("bf16")
+    c0, c1 = pairs
+    outs = []
+    try:
+        for _ in range(3):
+            d = _data(c0[:4], c1[:4], "cuda:0")
+            model(d)
+            outs.append({k: d[k].clone() for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts1_f", "expec_f")})
+        torch.cuda.synchronize()
+        for k, v in outs[0].items():  # call 1 ran eagerly, call 3 replayed the captured graph
+            assert torch.equal(v, outs[2][k]), k
+    finally:
+        model.set_precision("fp32")
+
+
+def test_fine_level_match_rich_vs_oracle(synth):
+    """a8 / a9 with >= 500 matches (the fine transformer was only checked on <= 4 matches)."""
+    from gim_amd import ops
+    model, sd = synth
+    model.set_precision("fp32")
+    c0, c1 = S.textured_pairs(2, 256, 320, seed=5, frac=1.0)
+    model.debug = {}
+    try:
+        d = _data(c0, c1, "cuda:0")
+        model(d)
+        torch.cuda.synchronize()
+        dbg = model.debug
+    finally:
+        model.debug = None
+    M = d["b_ids"].numel()
+    assert M >= 500, M
+    b_ids, i_ids, j_ids = d["b_ids"].cpu(), d["i_ids"].cpu(), d["j_ids"].cpu()
+    # the engine's own fine maps -> the oracle's window extraction + fine transformer + fine matching
+    f0 = ops.nhwc_to_nchw(dbg["f0"].contiguous(), 128).cpu()
+    f1 = ops.nhwc_to_nchw(dbg["f1"].contiguous(), 128).cpu()
+    with torch.no_grad():
+        w0, w1 = O.fine_preprocess(f0, f1, b_ids, i_ids, j_ids, (32, 40), (128, 160), 5)
+        t0, t1 = O.local_feature_transformer(sd, "loftr_fine", w0, w1, 8, 1)
+        fm = O.fine_matching(t0, t1, d["mkpts0_c"].cpu(), d["mkpts1_c"].cpu(), b_ids, M, (256, 320), (128, 160))
+    for got, ref, name in ((dbg["fine0"], t0, "fine0"), (dbg["fine1"], t1, "fine1")):
+        err = (got.cpu() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 1e-4, (name, err)
+    assert (d["expec_f"].cpu() - fm["expec_f"]).abs().max() < 1e-4
+    assert (d["mkpts1_f"].cpu() - fm["mkpts1_f"]).abs().max() < 1e-4
+    assert fm["expec_f"][:, :2].abs().max() > 0.05  # the sub-pixel refinement is not degenerate

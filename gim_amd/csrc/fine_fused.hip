@@ -1,0 +1,464 @@
+// Fused fine level of gim_loftr (bf16 operand mode) for gfx950: ONE kernel per forward instead of
+// gather -> 21 GEMM / attention / LayerNorm launches -> fine_match, and no activation ever leaves the CU.
+//
+// Replaces, per coarse match (reference file:line):
+//   networks/loftr/submodules/fine_preprocess.py:40-47   the two 5x5x128 windows (only the M matched ones)
+//   networks/loftr/submodules/transformer.py:35-58,80-101 LocalFeatureTransformer(['self','cross'], d=128, 8 heads)
+//   networks/loftr/submodules/attentions.py:20-47        LinearAttention on 25-token sequences
+//   networks/loftr/utils/fine_matching.py:43-74          centre-row correlation, softmax, DSNT expectation, std
+//
+// One 256-thread workgroup owns G = 4 matches.  A match is one 32-row MFMA fragment (25 window tokens + 7 zero rows),
+// so both sides are [128 rows x 128 channels] bf16 operand tiles that live in LDS for the whole kernel:
+//
+//   LDS  X0, X1   operand copies of the two token streams          2 x 32 KiB
+//        T1, T2   temporaries (K^T / Q / LN1(msg)   and   V^T / msg / hidden half)   2 x 32 KiB
+//        scratch  per-match K sums, LayerNorm partial sums          6 KiB
+//   VGPR          the fp32 master copy of both token streams (residual adds stay fp32, as in the unfused path)
+//
+// Every matrix product is [128 rows] x [128 out] x K (128 or 256) on v_mfma_f32_32x32x16_bf16; wave w owns output
+// columns 32w..32w+31 for all 128 rows, so each weight element is fetched once per workgroup -- straight from L2 into
+// registers in a pre-packed fragment order (16 B per lane, 1 KiB per wave instruction), never through LDS.
+// The 256-wide MLP hidden layer is produced and consumed in two 128-column halves (the second GEMM accumulates over
+// them), so it never needs its own 64 KiB.
+//
+// Linear attention on the matrix cores (per match = per wave, per 32-channel group = 2 heads):
+//   K and V are produced TRANSPOSED ([channel][token], operands swapped in the MFMA) with the 7 padding tokens zeroed;
+//   KV = K^T V is one 32x32 fragment per channel group (contraction over the 32 token slots), masked to its two 16x16
+//   head blocks; msg = Q KV consumes that accumulator directly as the next MFMA's operand -- the contraction order of
+//   the second product is permuted to the accumulator layout (Q is read as two 8-byte pieces per lane), so the fragment
+//   never moves between lanes.  Z = 1 / (Q . sum_s K + eps) on the VALU.  (v / S ... * S of attentions.py:41,45
+//   cancels and is dropped.)
+//
+// Numerics: bf16 operands, fp32 accumulation, fp32 residual stream, fp32 LayerNorm / softmax statistics -- the same
+// rounding points as the unfused bf16 path (q, k, v, msg, LN outputs and hidden activations are bf16 there too).
+#include "gim_common.h"
+
+namespace {
+
+constexpr int C = 128;             // fine d_model
+constexpr int ROWB = C * 2;        // bytes of one activation row (bf16)
+constexpr int BUF = 128 * ROWB;    // 32 KiB: 128 rows x 128 channels
+constexpr int WW = 25, G = 4, NH = 8;
+constexpr int OFF_X0 = 0, OFF_X1 = BUF, OFF_T1 = 2 * BUF, OFF_T2 = 3 * BUF, OFF_SCR = 4 * BUF;
+constexpr int SCR_KSUM = 0, SCR_STAT = G * C * 4, SCR_BYTES = SCR_STAT + 128 * 4 * 8;
+constexpr int SMEM = 4 * BUF + SCR_BYTES;
+constexpr int FIN_LD = 132;        // floats per row of the final fp32 image-1 tokens (bank-conflict-free float4 rows)
+static_assert(G * WW * FIN_LD * 4 <= 2 * BUF, "final image-1 tokens must fit in X0|X1");
+
+// weight stream of one layer, in 16-byte units (uint4): [Wq | Wk | Wv | Wm | W0a | W0b | W2a | W2b]
+constexpr int U128 = 128 * 128 * 2 / 16, U256 = 128 * 256 * 2 / 16;
+constexpr int W_Q = 0, W_K = U128, W_V = 2 * U128, W_M = 3 * U128, W_0A = 4 * U128, W_0B = W_0A + U256,
+              W_2A = W_0B + U256, W_2B = W_2A + U128, W_LAYER = W_2B + U128;
+
+struct FineArgs {
+    const unsigned short* f0;   // fine maps, NHWC bf16
+    const unsigned short* f1;
+    const int64_t *b_ids, *i_ids, *j_ids;
+    const float* mkpts1_c;
+    const float* scale1;
+    const uint4* wts;           // 2 layers x W_LAYER
+    const float* ln;            // 2 layers x [g1 | b1 | g2 | b2] x 128
+    float* expec_f;
+    float* mkpts1_f;
+    float* dbg0;                // optional [M, 25, 128] fp32 dumps of the transformer output (tests)
+    float* dbg1;
+    int M, hf0, wf0, hf1, wf1, ldf, w0c, w1c, stride;
+    float fscale, eps;
+    int has_scale0;
+};
+
+struct Lane {
+    int lane, l31, lh, w, sw;   // sw = l31 & 15: the XOR swizzle key of this lane's row
+};
+
+__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v + 1.f : __expf(v); }
+
+// acc[j] (+)= act rows [32j .. 32j+31] x weight fragment stream.  NKS k16-steps; steps >= 8 read the second operand
+// buffer (the [x | msg] concatenation of transformer.py:55 is two LDS tiles, never materialised).
+template <int NKS, bool SWAP>
+__device__ __forceinline__ void gemm128(const char* a0, const char* a1, const uint4* __restrict__ wf, f32x16_t (&acc)[4], const Lane& L) {
+    constexpr int PF = 8;  // weight fragments in flight (8 x 16 B per lane)
+#pragma unroll
+    for (int k0 = 0; k0 < NKS; k0 += PF) {
+        bf16x8_t wr[PF];
+#pragma unroll
+        for (int ks = 0; ks < PF; ++ks) wr[ks] = __builtin_bit_cast(bf16x8_t, wf[(k0 + ks) * 64 + L.lane]);
+#pragma unroll
+        for (int ks = 0; ks < PF; ++ks) {
+            const char* ab = (k0 + ks < 8 ? a0 : a1) + L.l31 * ROWB + (((2 * ((k0 + ks) & 7) + L.lh) ^ L.sw) << 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x8_t a = *(const bf16x8_t*)(ab + j * 32 * ROWB);
+                if constexpr (SWAP) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wr[ks], acc[j], 0, 0, 0);
+                else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[ks], a, acc[j], 0, 0, 0);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void zero4(f32x16_t (&acc)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+}
+
+// accumulators in row orientation (lane = token row 32j + l31, channels 32w + 8rg + 4lh + e) -> bf16 rows in LDS
+template <int ACT>  // 0 none, 1 relu, 2 elu+1
+__device__ __forceinline__ void store_rows(char* buf, const f32x16_t (&acc)[4], const Lane& L) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = acc[j][rg * 4 + e];
+                v[e] = ACT == 1 ? fmaxf(x, 0.f) : (ACT == 2 ? elu1(x) : x);
+            }
+            *(uint2*)(buf + (32 * j + L.l31) * ROWB + (((4 * L.w + rg) ^ L.sw) << 4) + L.lh * 8) =
+                make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
+        }
+}
+
+// accumulators in swapped orientation (lane = channel 32w + l31, tokens 32j + 8rg + 4lh + e) -> [channel][token] in LDS,
+// padding tokens (>= 25 of each match) written as exact zeros
+template <int ACT>
+__device__ __forceinline__ void store_transposed(char* buf, const f32x16_t (&acc)[4], const Lane& L) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = acc[j][rg * 4 + e];
+                v[e] = (8 * rg + 4 * L.lh + e < WW) ? (ACT == 2 ? elu1(x) : x) : 0.f;
+            }
+            *(uint2*)(buf + (32 * L.w + L.l31) * ROWB + (((4 * j + rg) ^ L.sw) << 4) + L.lh * 8) =
+                make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
+        }
+}
+
+// LayerNorm over the 128 channels of every row, in accumulator layout (the 4 waves hold 32 channels each).
+// Contains one workgroup barrier.  transformer.py:53,57 (nn.LayerNorm, biased variance, eps 1e-5).
+__device__ __forceinline__ void layernorm_rows(f32x16_t (&acc)[4], const float* __restrict__ gamma, const float* __restrict__ beta,
+                                               float2* stat, float eps, const Lane& L) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s += acc[j][r]; q = fmaf(acc[j][r], acc[j][r], q); }
+        s += __shfl_xor(s, 32, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (L.lh == 0) stat[(32 * j + L.l31) * 4 + L.w] = make_float2(s, q);
+    }
+    __syncthreads();
+    float g[16], b[16];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const float4 gg = *(const float4*)(gamma + 32 * L.w + 8 * rg + 4 * L.lh);
+        const float4 bb = *(const float4*)(beta + 32 * L.w + 8 * rg + 4 * L.lh);
+        g[rg * 4] = gg.x; g[rg * 4 + 1] = gg.y; g[rg * 4 + 2] = gg.z; g[rg * 4 + 3] = gg.w;
+        b[rg * 4] = bb.x; b[rg * 4 + 1] = bb.y; b[rg * 4 + 2] = bb.z; b[rg * 4 + 3] = bb.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 p0 = *(const float4*)(stat + (32 * j + L.l31) * 4), p1 = *(const float4*)(stat + (32 * j + L.l31) * 4 + 2);
+        const float s = (p0.x + p0.z) + (p1.x + p1.z), q = (p0.y + p0.w) + (p1.y + p1.w);
+        const float mean = s * (1.0f / C);
+        const float var = fmaxf(q * (1.0f / C) - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + eps);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] - mean) * rstd * g[r] + b[r];
+    }
+}
+
+// LoFTREncoderLayer.forward(x = side XS, source = side SS) (transformer.py:35-58) for the workgroup's 4 matches.
+// xm: fp32 master of side XS in accumulator layout.  Ends with a barrier (X[XS] rewritten).
+__device__ __forceinline__ void encoder_layer(char* smem, char* bx, const char* bs, const uint4* __restrict__ wl, const float* __restrict__ ln,
+                                              f32x16_t (&xm)[4], float eps, const Lane& L) {
+    char* T1 = smem + OFF_T1;
+    char* T2 = smem + OFF_T2;
+    float* ksum = (float*)(smem + OFF_SCR + SCR_KSUM);
+    float2* stat = (float2*)(smem + OFF_SCR + SCR_STAT);
+    f32x16_t acc[4];
+    // ---- K^T = elu1(S Wk)^T -> T1,  V^T = (S Wv)^T -> T2 ------------------------------------------------------
+    zero4(acc);
+    gemm128<8, true>(bs, bs, wl + W_K + L.w * 8 * 64, acc, L);
+    store_transposed<2>(T1, acc, L);
+    zero4(acc);
+    gemm128<8, true>(bs, bs, wl + W_V + L.w * 8 * 64, acc, L);
+    store_transposed<0>(T2, acc, L);
+    __syncthreads();
+    // ---- wave w = match w: K sums, KV = K^T V per 32-channel group (2 heads), masked, packed as the next operand
+    {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int ch = L.lane + 64 * hh;
+            float s = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const uint4 u = *(const uint4*)(T1 + ch * ROWB + (((4 * L.w + sl) ^ (ch & 15)) << 4));
+                const unsigned uu[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) s += __uint_as_float(uu[t] << 16) + __uint_as_float(uu[t] & 0xffff0000u);
+            }
+            ksum[L.w * C + ch] = s;
+        }
+    }
+    bf16x8_t kvp[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f32x16_t kv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) kv[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int off = (32 * i + L.l31) * ROWB + (((4 * L.w + 2 * ks + L.lh) ^ L.sw) << 4);
+            const bf16x8_t a = *(const bf16x8_t*)(T1 + off), b = *(const bf16x8_t*)(T2 + off);
+            kv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, kv, 0, 0, 0);  // lane: v-channel l31, k-channels 8rg+4lh+e
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bool keep = (L.l31 >> 4) == ks;  // same head: k-channels 16ks.. with v-channels 16ks..
+            unsigned p[4];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int rg = 2 * ks + h2;
+                p[h2 * 2] = keep ? cvt_pk_bf16(kv[rg * 4], kv[rg * 4 + 1]) : 0u;
+                p[h2 * 2 + 1] = keep ? cvt_pk_bf16(kv[rg * 4 + 2], kv[rg * 4 + 3]) : 0u;
+            }
+            kvp[i][ks] = __builtin_bit_cast(bf16x8_t, make_uint4(p[0], p[1], p[2], p[3]));
+        }
+    }
+    __syncthreads();  // every wave is done with K^T / V^T
+    // ---- Q = elu1(X Wq) -> T1 (row layout) -----------------------------------------------------------------------
+    zero4(acc);
+    gemm128<8, false>(bx, bx, wl + W_Q + L.w * 8 * 64, acc, L);
+    store_rows<2>(T1, acc, L);
+    __syncthreads();
+    // ---- wave w = match w: Z = 1 / (Q . Ksum + eps) per head, msg = (Q KV) Z -> T2 rows of this match ---------------
+    {
+        const int row = 32 * L.w + L.l31;
+        float zlo[4], zhi[4];   // Z of heads 0..3 / 4..7 for this lane's token
+#pragma unroll
+        for (int hq = 0; hq < 4; ++hq) {  // this lane: heads 4lh .. 4lh+3; the partner lane (xor 32) has the others
+            const int h = 4 * L.lh + hq;
+            float d = 0.f;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const uint4 u = *(const uint4*)(T1 + row * ROWB + (((2 * h + half) ^ L.sw) << 4));
+                const float4 k0 = *(const float4*)(ksum + L.w * C + 16 * h + 8 * half), k1 = *(const float4*)(ksum + L.w * C + 16 * h + 8 * half + 4);
+                d = fmaf(__uint_as_float(u.x << 16), k0.x, d); d = fmaf(__uint_as_float(u.x & 0xffff0000u), k0.y, d);
+                d = fmaf(__uint_as_float(u.y << 16), k0.z, d); d = fmaf(__uint_as_float(u.y & 0xffff0000u), k0.w, d);
+                d = fmaf(__uint_as_float(u.z << 16), k1.x, d); d = fmaf(__uint_as_float(u.z & 0xffff0000u), k1.y, d);
+                d = fmaf(__uint_as_float(u.w << 16), k1.z, d); d = fmaf(__uint_as_float(u.w & 0xffff0000u), k1.w, d);
+            }
+            const float zz = 1.0f / (d + 1e-6f);
+            const float other = __shfl_xor(zz, 32, 64);
+            zlo[hq] = L.lh == 0 ? zz : other;
+            zhi[hq] = L.lh == 0 ? other : zz;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x16_t o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                // contraction order follows the KV accumulator: position p <-> k-channel 16ks + 8(p/4) + 4lh + p%4
+                const uint2 lo = *(const uint2*)(T1 + row * ROWB + (((4 * i + 2 * ks) ^ L.sw) << 4) + L.lh * 8);
+                const uint2 hi = *(const uint2*)(T1 + row * ROWB + (((4 * i + 2 * ks + 1) ^ L.sw) << 4) + L.lh * 8);
+                const bf16x8_t qf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kvp[i][ks], qf, o, 0, 0, 0);  // lane: token l31, v-channels 8rg+4lh+e
+            }
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float zz = (2 * i + (rg >> 1)) < 4 ? zlo[(2 * i + (rg >> 1)) & 3] : zhi[(2 * i + (rg >> 1)) & 3];
+                *(uint2*)(T2 + row * ROWB + (((4 * i + rg) ^ L.sw) << 4) + L.lh * 8) =
+                    make_uint2(cvt_pk_bf16(o[rg * 4] * zz, o[rg * 4 + 1] * zz), cvt_pk_bf16(o[rg * 4 + 2] * zz, o[rg * 4 + 3] * zz));
+            }
+        }
+    }
+    __syncthreads();
+    // ---- merge + norm1 -> T1 (transformer.py:52-53) ----------------------------------------------------------------
+    zero4(acc);
+    gemm128<8, false>(T2, T2, wl + W_M + L.w * 8 * 64, acc, L);
+    layernorm_rows(acc, ln, ln + C, stat, eps, L);   // barrier inside: every wave is done reading Q (T1) and msg (T2)
+    store_rows<0>(T1, acc, L);
+    __syncthreads();
+    // ---- mlp: relu([x | msg] W0) W2, hidden layer in two 128-column halves (transformer.py:55-56) -------------------
+    f32x16_t out[4];
+    zero4(out);
+    zero4(acc);
+    gemm128<16, false>(bx, T1, wl + W_0A + L.w * 16 * 64, acc, L);
+    store_rows<1>(T2, acc, L);
+    __syncthreads();
+    gemm128<8, false>(T2, T2, wl + W_2A + L.w * 8 * 64, out, L);
+    zero4(acc);
+    gemm128<16, false>(bx, T1, wl + W_0B + L.w * 16 * 64, acc, L);
+    __syncthreads();  // first hidden half consumed by every wave
+    store_rows<1>(T2, acc, L);
+    __syncthreads();
+    gemm128<8, false>(T2, T2, wl + W_2B + L.w * 8 * 64, out, L);
+    // ---- norm2, residual add in fp32, new operand copy of x (transformer.py:57-58) ------------------------------------
+    layernorm_rows(out, ln + 2 * C, ln + 3 * C, stat, eps, L);  // barrier inside: every wave is done reading X[XS]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xm[j][r] += out[j][r];
+    store_rows<0>(bx, xm, L);
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256, 1) fine_fused_kernel(const FineArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Lane L;
+    L.lane = threadIdx.x & 63;
+    L.l31 = L.lane & 31;
+    L.lh = L.lane >> 5;
+    L.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    L.sw = L.l31 & 15;
+    const int m_base = blockIdx.x * G;
+    // ---- gather: 2 sides x 4 matches x 32 token slots x 256 B (fine_preprocess.py:40-47; border -> zeros like F.unfold padding)
+    {
+        const int t = threadIdx.x, slot = t & 15;
+#pragma unroll 4
+        for (int pass = 0; pass < 16; ++pass) {
+            const int r = pass * 16 + (t >> 4);   // 0..255
+            const int side = r >> 7, rr = r & 127, mm = rr >> 5, tok = rr & 31;
+            const int m = m_base + mm;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (tok < WW && m < a.M) {
+                const int b = (int)a.b_ids[m];
+                const int cell = (int)(side ? a.j_ids[m] : a.i_ids[m]);
+                const int wc = side ? a.w1c : a.w0c, hf = side ? a.hf1 : a.hf0, wf = side ? a.wf1 : a.wf0;
+                const int cy = cell / wc, cx = cell - cy * wc;
+                const int y = cy * a.stride - 2 + tok / 5, x = cx * a.stride - 2 + tok % 5;
+                if (y >= 0 && y < hf && x >= 0 && x < wf)
+                    v = *(const uint4*)((side ? a.f1 : a.f0) + (((size_t)b * hf + y) * wf + x) * a.ldf + slot * 8);
+            }
+            *(uint4*)(smem + (side ? OFF_X1 : OFF_X0) + rr * ROWB + ((slot ^ (rr & 15)) << 4)) = v;
+        }
+    }
+    __syncthreads();
+    // fp32 masters in accumulator layout
+    f32x16_t xm0[4], xm1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int off = (32 * j + L.l31) * ROWB + (((4 * L.w + rg) ^ L.sw) << 4) + L.lh * 8;
+            const uint2 u0 = *(const uint2*)(smem + OFF_X0 + off), u1 = *(const uint2*)(smem + OFF_X1 + off);
+            xm0[j][rg * 4] = __uint_as_float(u0.x << 16); xm0[j][rg * 4 + 1] = __uint_as_float(u0.x & 0xffff0000u);
+            xm0[j][rg * 4 + 2] = __uint_as_float(u0.y << 16); xm0[j][rg * 4 + 3] = __uint_as_float(u0.y & 0xffff0000u);
+            xm1[j][rg * 4] = __uint_as_float(u1.x << 16); xm1[j][rg * 4 + 1] = __uint_as_float(u1.x & 0xffff0000u);
+            xm1[j][rg * 4 + 2] = __uint_as_float(u1.y << 16); xm1[j][rg * 4 + 3] = __uint_as_float(u1.y & 0xffff0000u);
+        }
+    char* X0 = smem + OFF_X0;
+    char* X1 = smem + OFF_X1;
+    // layer 0 'self' (transformer.py:91-93), layer 1 'cross': feat0 first, feat1 against the UPDATED feat0 (:94-96)
+#pragma unroll 1
+    for (int layer = 0; layer < 2; ++layer) {
+        const uint4* wl = a.wts + (size_t)layer * W_LAYER;
+        const float* ln = a.ln + layer * 4 * C;
+        encoder_layer(smem, X0, layer == 0 ? X0 : X1, wl, ln, xm0, a.eps, L);
+        encoder_layer(smem, X1, layer == 0 ? X1 : X0, wl, ln, xm1, a.eps, L);
+    }
+
+    // ---- optional dumps of the transformer output (tests), straight from the fp32 masters --------------------------
+    if (a.dbg0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m_base + j;
+            if (m < a.M && L.l31 < WW) {
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const size_t o = ((size_t)m * WW + L.l31) * C + 32 * L.w + 8 * rg + 4 * L.lh;
+                    *(float4*)(a.dbg0 + o) = make_float4(xm0[j][rg * 4], xm0[j][rg * 4 + 1], xm0[j][rg * 4 + 2], xm0[j][rg * 4 + 3]);
+                    *(float4*)(a.dbg1 + o) = make_float4(xm1[j][rg * 4], xm1[j][rg * 4 + 1], xm1[j][rg * 4 + 2], xm1[j][rg * 4 + 3]);
+                }
+            }
+        }
+    }
+    // ---- fine matching (fine_matching.py:43-74): fp32 tokens of image 1 + the centre token of image 0 -> LDS -------
+    float* fin1 = (float*)(smem + OFF_X0);   // [4 x 25][FIN_LD]  (the operand tiles are dead: last layer ended with a barrier)
+    float* fin0 = (float*)(smem + OFF_T1);   // [4][128]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int ch = 32 * L.w + 8 * rg + 4 * L.lh;
+            if (L.l31 < WW)
+                *(float4*)(fin1 + (j * WW + L.l31) * FIN_LD + ch) = make_float4(xm1[j][rg * 4], xm1[j][rg * 4 + 1], xm1[j][rg * 4 + 2], xm1[j][rg * 4 + 3]);
+            if (L.l31 == WW / 2)
+                *(float4*)(fin0 + j * C + ch) = make_float4(xm0[j][rg * 4], xm0[j][rg * 4 + 1], xm0[j][rg * 4 + 2], xm0[j][rg * 4 + 3]);
+        }
+    __syncthreads();
+    const int m = m_base + L.w;
+    if (m >= a.M) return;
+    float s = -INFINITY;
+    if (L.lane < WW) {
+        const float* kr = fin1 + (L.w * WW + L.lane) * FIN_LD;
+        const float* q = fin0 + L.w * C;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < C; c += 4) {
+            const float4 x = *(const float4*)(q + c), y = *(const float4*)(kr + c);
+            acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc);
+            acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+        }
+        s = (1.0f / sqrtf((float)C)) * acc;  // softmax_temp * sim_matrix
+    }
+    const float mx = wave_max(s);
+    const float e = L.lane < WW ? expf(s - mx) : 0.f;
+    const float heat = e / wave_sum(e);
+    const float gx = L.lane < WW ? -1.0f + 0.5f * (float)(L.lane % 5) : 0.f;   // create_meshgrid(5, 5, normalized): {-1,-.5,0,.5,1}
+    const float gy = L.lane < WW ? -1.0f + 0.5f * (float)(L.lane / 5) : 0.f;
+    const float cx = wave_sum(gx * heat), cy = wave_sum(gy * heat);
+    const float vx = wave_sum(gx * gx * heat) - cx * cx, vy = wave_sum(gy * gy * heat) - cy * cy;
+    if (L.lane == 0) {
+        const float sd = sqrtf(fmaxf(vx, 1e-10f)) + sqrtf(fmaxf(vy, 1e-10f));
+        a.expec_f[3 * m + 0] = cx; a.expec_f[3 * m + 1] = cy; a.expec_f[3 * m + 2] = sd;
+        float s1x = a.fscale, s1y = a.fscale;
+        if (a.has_scale0) {  // quirk preserved: keyed on scale0, multiplies scale1 (fine_matching.py:68)
+            const int b = (int)a.b_ids[m];
+            s1x = a.fscale * a.scale1[2 * b + 0];
+            s1y = a.fscale * a.scale1[2 * b + 1];
+        }
+        a.mkpts1_f[2 * m + 0] = a.mkpts1_c[2 * m + 0] + cx * 2.0f * s1x;   // W // 2 = 2
+        a.mkpts1_f[2 * m + 1] = a.mkpts1_c[2 * m + 1] + cy * 2.0f * s1y;
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t gim_fine_fused_weight_bytes(void) { return (int64_t)2 * W_LAYER * 16; }
+
+extern "C" int gim_fine_fused(const void* feat_f0, const void* feat_f1, const int64_t* b_ids, const int64_t* i_ids,
+                              const int64_t* j_ids, const float* mkpts1_c, const float* scale1, const void* weights,
+                              const float* ln_params, float* expec_f, float* mkpts1_f, float* dbg_fine0, float* dbg_fine1,
+                              int M, int hf0, int wf0, int hf1, int wf1, int C_, int ldf, int w0c, int w1c, int stride, int W,
+                              float scale, float ln_eps, int has_scale0, gim_stream_t stream) {
+    if (M == 0) return GIM_OK;
+    GIM_REQUIRE(feat_f0 && feat_f1 && b_ids && i_ids && j_ids && mkpts1_c && weights && ln_params && expec_f && mkpts1_f, "fine_fused: NULL pointer");
+    GIM_REQUIRE(C_ == C && W == 5, "fine_fused: built for d_model 128 / 5x5 windows (got C=%d W=%d)", C_, W);
+    GIM_REQUIRE(M > 0 && hf0 > 0 && wf0 > 0 && hf1 > 0 && wf1 > 0 && stride > 0 && ldf >= C && ldf % 8 == 0, "fine_fused: bad geometry");
+    GIM_REQUIRE((dbg_fine0 == nullptr) == (dbg_fine1 == nullptr), "fine_fused: give both debug outputs or none");
+    GIM_REQUIRE(!has_scale0 || scale1, "fine_fused: scale1 required when has_scale0");
+    static GimPerDevice attr;
+    if (attr.needed()) {
+        hipError_t e = hipFuncSetAttribute((const void*)fine_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) { gim_set_error("fine_fused: hipFuncSetAttribute(%d B LDS): %s", SMEM, hipGetErrorString(e)); return GIM_ERR_LAUNCH; }
+        attr.done();
+    }
+    FineArgs a;
+    a.f0 = (const unsigned short*)feat_f0; a.f1 = (const unsigned short*)feat_f1;
+    a.b_ids = b_ids; a.i_ids = i_ids; a.j_ids = j_ids; a.mkpts1_c = mkpts1_c; a.scale1 = scale1;
+    a.wts = (const uint4*)weights; a.ln = ln_params; a.expec_f = expec_f; a.mkpts1_f = mkpts1_f; a.dbg0 = dbg_fine0; a.dbg1 = dbg_fine1;
+    a.M = M; a.hf0 = hf0; a.wf0 = wf0; a.hf1 = hf1; a.wf1 = wf1; a.ldf = ldf; a.w0c = w0c; a.w1c = w1c; a.stride = stride;
+    a.fscale = scale; a.eps = ln_eps; a.has_scale0 = has_scale0;
+    hipLaunchKernelGGL(fine_fused_kernel, dim3((unsigned)((M + G - 1) / G)), dim3(256), SMEM, (hipStream_t)stream, a);
+    return gim_check_launch("fine_fused");
+}

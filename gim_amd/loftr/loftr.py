@@ -33,7 +33,7 @@ import torch.nn as nn
 
 from .. import ops
 from .._lib import ACT_ELU1, ACT_LEAKY, ACT_NONE, ACT_RELU, GIM_BF16, GIM_F32, GimHipError
-from ..packing import cstore, pack_conv, torch_dtype
+from ..packing import cstore, pack_conv, pack_fine_fused, torch_dtype
 
 
 # --------------------------------------------------------------------------------------------------
@@ -178,6 +178,9 @@ class LoFTR(nn.Module):
         self.loftr_fine = _LocalFeatureTransformer(config["fine"])
         self.W = config["fine_window_size"]
         self.use_lds_dma = os.environ.get("GIM_LDS_DMA", "1") != "0"
+        # bf16 mode: the whole fine level (gather + 2-layer transformer + fine matching) as ONE kernel (fine_fused.hip);
+        # GIM_FINE_FUSED=0 keeps the unfused launch sequence (the only fine path of the fp32 parity mode)
+        self.fine_fused = os.environ.get("GIM_FINE_FUSED", "1") != "0"
         self._packed = None
         self._packed_key = None
         self._pe_cache = {}
@@ -262,6 +265,9 @@ class LoFTR(nn.Module):
                     ln = getattr(layer, nm)
                     P[p + nm] = (ln.weight.detach().float().to(device).contiguous(),
                                  ln.bias.detach().float().to(device).contiguous(), ln.eps)
+        fl = self.loftr_fine
+        if dt == GIM_BF16 and fl.d_model == 128 and fl.nhead == 8 and fl.layer_names == ["self", "cross"] and self.W == 5:
+            P["fine_fused"] = pack_fine_fused(fl.layers, device) + (fl.layers[0].norm1.eps,)
         self._packed, self._packed_key = P, key
         return P
 
@@ -541,15 +547,30 @@ class LoFTR(nn.Module):
             data.update({"expec_f": torch.empty(0, 3, device=dev),
                          "mkpts0_f": data["mkpts0_c"], "mkpts1_f": data["mkpts1_c"]})
             return
+        expec_f, mkpts1_f, fine0, fine1 = self._fine_level(f0, f1, b_ids, i_ids, j_ids, mkpts1_c, scale1, "scale0" in data,
+                                                           hw0_c, hw1_c, data["hw0_i"], self.fine_fused)
+        if self.debug is not None:
+            self.debug.update({"fine0": fine0, "fine1": fine1})
+        data.update({"expec_f": expec_f, "mkpts0_f": data["mkpts0_c"], "mkpts1_f": mkpts1_f})
+
+    def _fine_level(self, f0, f1, b_ids, i_ids, j_ids, mkpts1_c, scale1, has_s0, hw0_c, hw1_c, hw0_i, fused):
+        """FinePreprocess + loftr_fine + FineMatching (loftr.py:84-91) for M > 0 matches on the NHWC fine maps f0 / f1.
+        Returns (expec_f, mkpts1_f, fine0, fine1); fine0/fine1 = fp32 [M, WW, C] transformer outputs (None unless
+        self.debug is set on the fused path)."""
+        dev = f0.device
+        dt = GIM_BF16 if self.precision == "bf16" else GIM_F32
+        M, W, WW, Cf = b_ids.numel(), self.W, self.W * self.W, self.config["fine"]["d_model"]
         P = self._prepack(dev)
+        hw0_f, hw1_f = f0.shape[1:3], f1.shape[1:3]
         stride = hw0_f[0] // hw0_c[0]
-        F = self._TfBuffers(2 * M * WW, Cf, tdt, dev)
+        fscale = hw0_i[0] / hw0_f[0]
+        if fused and "fine_fused" in P and f0.dtype == torch.bfloat16:
+            wts, lnp, eps = P["fine_fused"]
+            return ops.fine_fused(f0, f1, b_ids, i_ids, j_ids, mkpts1_c, scale1 if has_s0 else None, wts, lnp, M,
+                                  hw0_c[1], hw1_c[1], stride, W, fscale, eps, has_s0, debug=self.debug is not None)
+        F = self._TfBuffers(2 * M * WW, Cf, torch_dtype(dt), dev)
         ops.fine_gather(f0, f1, b_ids, i_ids, j_ids, M, hw0_c[1], hw1_c[1], stride, W, F.X32, F.CAT[:, :Cf])
         self._transformer(P, "f", self.loftr_fine, F, M, WW, M, WW)
-        if self.debug is not None:
-            self.debug.update({"fine0": F.X32[:M * WW].view(M, WW, Cf), "fine1": F.X32[M * WW:].view(M, WW, Cf)})
-        fscale = data["hw0_i"][0] / hw0_f[0]
-        has_s0 = "scale0" in data
         expec_f, mkpts1_f = ops.fine_match(F.X32[:M * WW], F.X32[M * WW:], mkpts1_c, b_ids,
                                            scale1 if has_s0 else None, M, WW, fscale, has_s0)
-        data.update({"expec_f": expec_f, "mkpts0_f": data["mkpts0_c"], "mkpts1_f": mkpts1_f})
+        return expec_f, mkpts1_f, F.X32[:M * WW].view(M, WW, Cf), F.X32[M * WW:].view(M, WW, Cf)

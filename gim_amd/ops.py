@@ -261,6 +261,26 @@ def fine_match(f0, f1, mkpts1_c, b_ids, scale1, M, WW, scale, has_scale0):
     return expec, mk1
 
 
+def fine_fused(feat_f0, feat_f1, b_ids, i_ids, j_ids, mkpts1_c, scale1, weights, ln_params, M, w0c, w1c, stride, W,
+               scale, ln_eps, has_scale0, debug=False):
+    """Whole fine level in one launch (bf16 fine maps).  Returns (expec_f [M,3], mkpts1_f [M,2], fine0, fine1) where
+    fine0/fine1 are fp32 [M, W*W, C] dumps of the transformer output when `debug`, else None."""
+    _req_cuda(feat_f0, feat_f1, b_ids, mkpts1_c, weights, ln_params)
+    assert feat_f0.dtype == torch.bfloat16 and feat_f0.is_contiguous() and feat_f1.is_contiguous()
+    _, hf0, wf0, C = feat_f0.shape
+    _, hf1, wf1, _ = feat_f1.shape
+    dev = feat_f0.device
+    expec = torch.empty(M, 3, dtype=torch.float32, device=dev)
+    mk1 = torch.empty(M, 2, dtype=torch.float32, device=dev)
+    d0 = torch.empty(M, W * W, C, dtype=torch.float32, device=dev) if debug else None
+    d1 = torch.empty(M, W * W, C, dtype=torch.float32, device=dev) if debug else None
+    assert weights.numel() * weights.element_size() == lib.gim_fine_fused_weight_bytes()
+    check(lib.gim_fine_fused(_p(feat_f0), _p(feat_f1), _p(b_ids), _p(i_ids), _p(j_ids), _p(mkpts1_c), _p(scale1),
+                             _p(weights), _p(ln_params), _p(expec), _p(mk1), _p(d0), _p(d1), M, hf0, wf0, hf1, wf1, C, C,
+                             w0c, w1c, stride, W, scale, ln_eps, 1 if has_scale0 else 0, _stream()), "gim_fine_fused")
+    return expec, mk1, d0, d1
+
+
 # ---- gim_lightglue: SuperPoint glue -----------------------------------------------------------------------
 def maxpool2x2(x):
     """x [B,H,W,C] NHWC -> new [B,H/2,W/2,C]"""

@@ -107,3 +107,30 @@ def pack_conv(weight, bn, dtype, device, stride=1, pad=0, cin_pad=None, bias=Non
     p.n_store = cstore(cout, dtype)
     p.npad, p.kpad, p.dtype = npad, kpad, dtype
     return p
+
+
+def _frag_order(w):
+    """[128 out][K] fp32 -> MFMA fragment order [wave = out/32][k16 step][lane = (k/8 % 2)*32 + out%32][8] (flat)."""
+    n, k = w.shape
+    assert n == 128 and k % 16 == 0
+    return w.reshape(4, 32, k // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
+
+
+def pack_fine_fused(layers, device):
+    """Weights of the 2-layer fine LocalFeatureTransformer for gim_fine_fused (see include/gim_hip.h): one bf16 stream
+    [Wq | Wk | Wv | Wmerge | mlp.0[:128] | mlp.0[128:] | mlp.2[:, :128] | mlp.2[:, 128:]] per layer in fragment order,
+    plus the fp32 LayerNorm parameters [g1 | b1 | g2 | b2] per layer.  `layers`: modules with q_proj/k_proj/v_proj/merge/
+    mlp/norm1/norm2 (transformer.py:8-33)."""
+    ws, lns = [], []
+    for layer in layers:
+        f = lambda t: t.detach().float().cpu()  # noqa: E731
+        m0, m2 = f(layer.mlp[0].weight), f(layer.mlp[2].weight)
+        assert m0.shape == (256, 256) and m2.shape == (128, 256)
+        for blk in (f(layer.q_proj.weight), f(layer.k_proj.weight), f(layer.v_proj.weight), f(layer.merge.weight),
+                    m0[:128], m0[128:], m2[:, :128], m2[:, 128:]):
+            ws.append(_frag_order(blk.contiguous()))
+        lns += [f(layer.norm1.weight), f(layer.norm1.bias), f(layer.norm2.weight), f(layer.norm2.bias)]
+        assert abs(layer.norm1.eps - layer.norm2.eps) == 0
+    w = torch.cat(ws).to(device).to(torch.bfloat16).contiguous()
+    assert w.numel() * 2 == _lib.lib.gim_fine_fused_weight_bytes()
+    return w, torch.cat(lns).to(device).contiguous()

@@ -170,6 +170,20 @@ int gim_fine_gather(const void* feat_f0, const void* feat_f1, const int64_t* b_i
 int gim_fine_match(const float* f0, const float* f1, const float* mkpts1_c, const int64_t* b_ids,
                    const float* scale1, float* expec_f, float* mkpts1_f, int M, int WW, int C, int ld,
                    float scale, int has_scale0, gim_stream_t stream);
+/* The whole fine level in ONE kernel (bf16 operand mode, d_model 128, 5x5 windows, layer_names ['self','cross']):
+ * window gather (fine_preprocess.py:40-47) + LocalFeatureTransformer (transformer.py:35-58,80-101, LinearAttention
+ * attentions.py:20-47) + FineMatching (fine_matching.py:43-74); 4 matches per workgroup, activations never leave the CU.
+ * feat_f0/feat_f1: NHWC bf16 fine maps (row stride ldf).  `weights`: gim_fine_fused_weight_bytes() bytes, bf16, per layer
+ * [Wq | Wk | Wv | Wmerge | mlp.0 rows 0..127 | mlp.0 rows 128..255 | mlp.2 cols 0..127 | mlp.2 cols 128..255], each block
+ * [128 out][K] re-ordered to MFMA fragment order [wave = out/32][k16 step][lane = (k/8 % 2)*32 + out%32][8] (host side:
+ * gim_amd/packing.py::pack_fine_fused).  ln_params: per layer [norm1.weight | norm1.bias | norm2.weight | norm2.bias] fp32.
+ * dbg_fine0/dbg_fine1: NULL or fp32 [M, 25, 128] dumps of the transformer output (tests). */
+int64_t gim_fine_fused_weight_bytes(void);
+int gim_fine_fused(const void* feat_f0, const void* feat_f1, const int64_t* b_ids, const int64_t* i_ids,
+                   const int64_t* j_ids, const float* mkpts1_c, const float* scale1, const void* weights,
+                   const float* ln_params, float* expec_f, float* mkpts1_f, float* dbg_fine0, float* dbg_fine1,
+                   int M, int hf0, int wf0, int hf1, int wf1, int C, int ldf, int w0c, int w1c, int stride, int W,
+                   float scale, float ln_eps, int has_scale0, gim_stream_t stream);
 
 
 /* ======================================================================================================

@@ -17,7 +17,7 @@ for r in csv.DictReader(open(f[0])):
     k = r['Kernel_Name'][:60]
     acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in acc.items():
-    if not any(t in k for t in ("igemm", "cm_stats", "sdpa", "la_")): continue
+    if not any(t in k for t in ("igemm", "cm_stats", "sdpa", "la_", "fine_fused", "tok_")): continue
     print(k)
     for c, v in d.items(): print(f"   {c:28s} avg {sum(v)/len(v):14.1f}  (n={len(v)})")
 PY

@@ -7,19 +7,20 @@
 //   networks/loftr/submodules/attentions.py:20-47        LinearAttention on 25-token sequences
 //   networks/loftr/utils/fine_matching.py:43-74          centre-row correlation, softmax, DSNT expectation, std
 //
-// One 256-thread workgroup owns G = 4 matches.  A match is one 32-row MFMA fragment (25 window tokens + 7 zero rows),
+// One 512-thread workgroup (8 waves, 2 per SIMD: one wave's epilogue VALU overlaps its partner's MFMAs) owns G = 4 matches.  A match is one 32-row MFMA fragment (25 window tokens + 7 zero rows),
 // so both sides are [128 rows x 128 channels] bf16 operand tiles that live in LDS for the whole kernel:
 //
 //   LDS  X0, X1   operand copies of the two token streams          2 x 32 KiB
-//        T1, T2   temporaries (K^T / Q / LN1(msg)   and   V^T / msg / hidden half)   2 x 32 KiB
+//        T1, T2   temporaries (K^T / Q / LN1(msg) / hidden 128..255   and   V^T / msg / hidden 0..127)   2 x 32 KiB
 //        scratch  per-match K sums, LayerNorm partial sums          6 KiB
-//   VGPR          the fp32 master copy of both token streams (residual adds stay fp32, as in the unfused path)
+//        LO       low halves (x - bf16(x), as bf16) of the token stream that is not being updated   25 KiB
+//   VGPR          the fp32 master copy of the token stream being updated (residual adds stay fp32, as in the unfused
+//                 path); the other stream is parked as bf16 hi (its operand tile) + bf16 lo (LO): 2^-17 relative
 //
-// Every matrix product is [128 rows] x [128 out] x K (128 or 256) on v_mfma_f32_32x32x16_bf16; wave w owns output
-// columns 32w..32w+31 for all 128 rows, so each weight element is fetched once per workgroup -- straight from L2 into
-// registers in a pre-packed fragment order (16 B per lane, 1 KiB per wave instruction), never through LDS.
-// The 256-wide MLP hidden layer is produced and consumed in two 128-column halves (the second GEMM accumulates over
-// them), so it never needs its own 64 KiB.
+// Every matrix product is [128 rows] x [128 out] x K (128 or 256) on v_mfma_f32_32x32x16_bf16; wave (wm, wn) owns rows
+// 64wm.. x output columns 32wn..32wn+31.  Weights go straight from L2 into registers in a pre-packed fragment order (16 B
+// per lane, 1 KiB per wave instruction), never through LDS, and are requested one 8-fragment unit ahead of their use.
+// The 256-wide MLP hidden layer lives in the two temporaries (its second half replaces LN1(msg) once that is consumed).
 //
 // Linear attention on the matrix cores (per match = per wave, per 32-channel group = 2 heads):
 //   K and V are produced TRANSPOSED ([channel][token], operands swapped in the MFMA) with the 7 padding tokens zeroed;
@@ -32,6 +33,7 @@
 // Numerics: bf16 operands, fp32 accumulation, fp32 residual stream, fp32 LayerNorm / softmax statistics -- the same
 // rounding points as the unfused bf16 path (q, k, v, msg, LN outputs and hidden activations are bf16 there too).
 #include "gim_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -41,9 +43,11 @@ constexpr int BUF = 128 * ROWB;    // 32 KiB: 128 rows x 128 channels
 constexpr int WW = 25, G = 4, NH = 8;
 constexpr int OFF_X0 = 0, OFF_X1 = BUF, OFF_T1 = 2 * BUF, OFF_T2 = 3 * BUF, OFF_SCR = 4 * BUF;
 constexpr int SCR_KSUM = 0, SCR_STAT = G * C * 4, SCR_BYTES = SCR_STAT + 128 * 4 * 8;
-constexpr int SMEM = 4 * BUF + SCR_BYTES;
+constexpr int OFF_LO = 4 * BUF + SCR_BYTES;   // parked low halves of one fp32 token stream: [4 x 25 valid rows][128] bf16
+constexpr int SMEM = OFF_LO + G * 25 * ROWB;
+static_assert(SMEM <= 160 * 1024, "LDS budget");
 constexpr int FIN_LD = 132;        // floats per row of the final fp32 image-1 tokens (bank-conflict-free float4 rows)
-static_assert(G * WW * FIN_LD * 4 <= 2 * BUF, "final image-1 tokens must fit in X0|X1");
+static_assert(G * WW * FIN_LD * 4 <= 2 * BUF, "final image-1 tokens must fit in T1|T2");
 
 // weight stream of one layer, in 16-byte units (uint4): [Wq | Wk | Wv | Wm | W0a | W0b | W2a | W2b]
 constexpr int U128 = 128 * 128 * 2 / 16, U256 = 128 * 256 * 2 / 16;
@@ -65,49 +69,79 @@ struct FineArgs {
     int M, hf0, wf0, hf1, wf1, ldf, w0c, w1c, stride;
     float fscale, eps;
     int has_scale0;
+    int dbg_stage;
 };
 
 struct Lane {
-    int lane, l31, lh, w, sw;   // sw = l31 & 15: the XOR swizzle key of this lane's row
+    int lane, l31, lh, wm, wn, sw;   // wave (wm, wn) owns rows 64wm..64wm+63 (matches 2wm, 2wm+1) x columns 32wn..32wn+31;
+                                     // sw = l31 & 15: the XOR swizzle key of this lane's row
+    // byte offsets inside a 32 KiB tile that every access is "one of these + a compile-time constant" of (the XOR swizzle
+    // cannot be folded into an instruction offset; without the tables the compiler materialises and hoists one address
+    // register per (buffer, row fragment, k step) and spills a hundred of them)
+#ifdef FF_DEBUG_STAGES
+    int dbg_stage, dbg_call, dbg_m_base, dbg_M; float* dbg_out;
+#endif
+    int a8[8];    // MFMA operand rows: (64wm + l31) * 256 + (((2ks + lh) ^ sw) << 4)
+    int st4[4];   // accumulator-layout 8-byte pieces: (64wm + l31) * 256 + (((4wn + rg) ^ sw) << 4) + 8lh
+    __device__ __forceinline__ void tables(int key) {   // key = sw, passed through an opaque asm so that the tables (and
+#pragma unroll                                           // everything derived from them) are rebuilt per call, not kept alive
+        for (int ks = 0; ks < 8; ++ks) a8[ks] = (64 * wm + l31) * ROWB + (((2 * ks + lh) ^ key) << 4);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) st4[rg] = (64 * wm + l31) * ROWB + (((4 * wn + rg) ^ key) << 4) + lh * 8;
+    }
 };
 
-__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v + 1.f : __expf(v); }
+struct W8 { bf16x8_t f[8];           // 8 weight fragments (one 128-deep K range of this wave's 32 output columns)
+#ifdef FF_NOPREFETCH
+            const uint4* p;
+#endif
+};
 
-// acc[j] (+)= act rows [32j .. 32j+31] x weight fragment stream.  NKS k16-steps; steps >= 8 read the second operand
-// buffer (the [x | msg] concatenation of transformer.py:55 is two LDS tiles, never materialised).
-template <int NKS, bool SWAP>
-__device__ __forceinline__ void gemm128(const char* a0, const char* a1, const uint4* __restrict__ wf, f32x16_t (&acc)[4], const Lane& L) {
-    constexpr int PF = 8;  // weight fragments in flight (8 x 16 B per lane)
+__device__ __forceinline__ float elu1(float v) { return fmaxf(v, 0.f) + __expf(fminf(v, 0.f)); }   // elu(v) + 1
+
+// issue the 8 fragment loads of one weight unit (1 KiB per wave instruction, straight from L2); consumed one unit later
+__device__ __forceinline__ void wload(W8& w, const uint4* __restrict__ p, const Lane& L) {
+#ifdef FF_NOPREFETCH
+    w.p = p; return;
+#endif
 #pragma unroll
-    for (int k0 = 0; k0 < NKS; k0 += PF) {
-        bf16x8_t wr[PF];
+    for (int ks = 0; ks < 8; ++ks) w.f[ks] = __builtin_bit_cast(bf16x8_t, p[ks * 64 + L.lane]);
+    __builtin_amdgcn_sched_barrier(0);   // keep the requests here: hoisted above the MFMAs they would need a second register set
+}
+
+// acc[j] (+)= rows [64wm + 32j ..] of the LDS operand tile `a` (128 channels = 8 k16 steps) x this wave's 8 fragments
+template <bool SWAP, bool FIRST>
+__device__ __forceinline__ void mma8(const char* a, const W8& w, f32x16_t (&acc)[2], const Lane& L) {
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (FIRST) {
 #pragma unroll
-        for (int ks = 0; ks < PF; ++ks) wr[ks] = __builtin_bit_cast(bf16x8_t, wf[(k0 + ks) * 64 + L.lane]);
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int ks = 0; ks < PF; ++ks) {
-            const char* ab = (k0 + ks < 8 ? a0 : a1) + L.l31 * ROWB + (((2 * ((k0 + ks) & 7) + L.lh) ^ L.sw) << 4);
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bf16x8_t a = *(const bf16x8_t*)(ab + j * 32 * ROWB);
-                if constexpr (SWAP) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wr[ks], acc[j], 0, 0, 0);
-                else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[ks], a, acc[j], 0, 0, 0);
-            }
+    for (int ks = 0; ks < 8; ++ks) {
+        const char* ab = a + L.a8[ks];
+#ifdef FF_NOPREFETCH
+        const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, w.p[ks * 64 + L.lane]);
+#else
+        const bf16x8_t wf = w.f[ks];
+#endif
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bf16x8_t v = *(const bf16x8_t*)(ab + j * 32 * ROWB);
+            if constexpr (SWAP) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v, wf, acc[j], 0, 0, 0);
+            else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, v, acc[j], 0, 0, 0);
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
 }
 
-__device__ __forceinline__ void zero4(f32x16_t (&acc)[4]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-}
-
-// accumulators in row orientation (lane = token row 32j + l31, channels 32w + 8rg + 4lh + e) -> bf16 rows in LDS
+// accumulators in row orientation (lane = token row 64wm + 32j + l31, channels 32wn + 8rg + 4lh + e) -> bf16 rows in LDS
 template <int ACT>  // 0 none, 1 relu, 2 elu+1
-__device__ __forceinline__ void store_rows(char* buf, const f32x16_t (&acc)[4], const Lane& L) {
+__device__ __forceinline__ void store_rows(char* buf, const f32x16_t (&acc)[2], const Lane& L) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             float v[4];
@@ -116,17 +150,16 @@ __device__ __forceinline__ void store_rows(char* buf, const f32x16_t (&acc)[4], 
                 const float x = acc[j][rg * 4 + e];
                 v[e] = ACT == 1 ? fmaxf(x, 0.f) : (ACT == 2 ? elu1(x) : x);
             }
-            *(uint2*)(buf + (32 * j + L.l31) * ROWB + (((4 * L.w + rg) ^ L.sw) << 4) + L.lh * 8) =
-                make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
+            *(uint2*)(buf + L.st4[rg] + j * 32 * ROWB) = make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
         }
 }
 
-// accumulators in swapped orientation (lane = channel 32w + l31, tokens 32j + 8rg + 4lh + e) -> [channel][token] in LDS,
-// padding tokens (>= 25 of each match) written as exact zeros
+// accumulators in swapped orientation (lane = channel 32wn + l31, tokens of match 2wm + j: 8rg + 4lh + e) -> [channel][token]
+// in LDS, padding tokens (>= 25 of each match) written as exact zeros
 template <int ACT>
-__device__ __forceinline__ void store_transposed(char* buf, const f32x16_t (&acc)[4], const Lane& L) {
+__device__ __forceinline__ void store_transposed(char* buf, const f32x16_t (&acc)[2], const Lane& L) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             float v[4];
@@ -135,87 +168,160 @@ __device__ __forceinline__ void store_transposed(char* buf, const f32x16_t (&acc
                 const float x = acc[j][rg * 4 + e];
                 v[e] = (8 * rg + 4 * L.lh + e < WW) ? (ACT == 2 ? elu1(x) : x) : 0.f;
             }
-            *(uint2*)(buf + (32 * L.w + L.l31) * ROWB + (((4 * j + rg) ^ L.sw) << 4) + L.lh * 8) =
+            *(uint2*)(buf + (32 * L.wn + L.l31) * ROWB + (((4 * (2 * L.wm + j) + rg) ^ L.sw) << 4) + L.lh * 8) =
                 make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
         }
 }
 
-// LayerNorm over the 128 channels of every row, in accumulator layout (the 4 waves hold 32 channels each).
+// LayerNorm over the 128 channels of every row, in accumulator layout (the 4 waves of a row half hold 32 channels each).
 // Contains one workgroup barrier.  transformer.py:53,57 (nn.LayerNorm, biased variance, eps 1e-5).
-__device__ __forceinline__ void layernorm_rows(f32x16_t (&acc)[4], const float* __restrict__ gamma, const float* __restrict__ beta,
+__device__ __forceinline__ void layernorm_rows(f32x16_t (&acc)[2], const float* __restrict__ gamma, const float* __restrict__ beta,
                                                float2* stat, float eps, const Lane& L) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2; ++j) {
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s += acc[j][r]; q = fmaf(acc[j][r], acc[j][r], q); }
         s += __shfl_xor(s, 32, 64);
         q += __shfl_xor(q, 32, 64);
-        if (L.lh == 0) stat[(32 * j + L.l31) * 4 + L.w] = make_float2(s, q);
+        if (L.lh == 0) stat[(64 * L.wm + 32 * j + L.l31) * 4 + L.wn] = make_float2(s, q);
     }
-    __syncthreads();
     float g[16], b[16];
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-        const float4 gg = *(const float4*)(gamma + 32 * L.w + 8 * rg + 4 * L.lh);
-        const float4 bb = *(const float4*)(beta + 32 * L.w + 8 * rg + 4 * L.lh);
+        const float4 gg = *(const float4*)(gamma + 32 * L.wn + 8 * rg + 4 * L.lh);
+        const float4 bb = *(const float4*)(beta + 32 * L.wn + 8 * rg + 4 * L.lh);
         g[rg * 4] = gg.x; g[rg * 4 + 1] = gg.y; g[rg * 4 + 2] = gg.z; g[rg * 4 + 3] = gg.w;
         b[rg * 4] = bb.x; b[rg * 4 + 1] = bb.y; b[rg * 4 + 2] = bb.z; b[rg * 4 + 3] = bb.w;
     }
+    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float4 p0 = *(const float4*)(stat + (32 * j + L.l31) * 4), p1 = *(const float4*)(stat + (32 * j + L.l31) * 4 + 2);
+    for (int j = 0; j < 2; ++j) {
+        const float4 p0 = *(const float4*)(stat + (64 * L.wm + 32 * j + L.l31) * 4), p1 = *(const float4*)(stat + (64 * L.wm + 32 * j + L.l31) * 4 + 2);
         const float s = (p0.x + p0.z) + (p1.x + p1.z), q = (p0.y + p0.w) + (p1.y + p1.w);
         const float mean = s * (1.0f / C);
         const float var = fmaxf(q * (1.0f / C) - mean * mean, 0.f);
         const float rstd = rsqrtf(var + eps);
+        const float nm = -mean * rstd;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] - mean) * rstd * g[r] + b[r];
+        for (int r = 0; r < 16; ++r) acc[j][r] = fmaf(fmaf(acc[j][r], rstd, nm), g[r], b[r]);
     }
 }
 
-// LoFTREncoderLayer.forward(x = side XS, source = side SS) (transformer.py:35-58) for the workgroup's 4 matches.
-// xm: fp32 master of side XS in accumulator layout.  Ends with a barrier (X[XS] rewritten).
-__device__ __forceinline__ void encoder_layer(char* smem, char* bx, const char* bs, const uint4* __restrict__ wl, const float* __restrict__ ln,
-                                              f32x16_t (&xm)[4], float eps, const Lane& L) {
+// fp32 master of a token stream in accumulator layout <- its bf16 operand tile (+ the parked low halves)
+template <bool WITH_LO>
+__device__ __forceinline__ void load_master(f32x16_t (&xm)[2], const char* xb, const char* lo, const Lane& L) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const uint2 u = *(const uint2*)(xb + L.st4[rg] + j * 32 * ROWB);
+            xm[j][rg * 4] = __uint_as_float(u.x << 16); xm[j][rg * 4 + 1] = __uint_as_float(u.x & 0xffff0000u);
+            xm[j][rg * 4 + 2] = __uint_as_float(u.y << 16); xm[j][rg * 4 + 3] = __uint_as_float(u.y & 0xffff0000u);
+            if constexpr (WITH_LO) {
+                if (L.l31 < WW) {
+                    const int cr = (2 * L.wm + j) * WW + L.l31;
+                    const uint2 v = *(const uint2*)(lo + cr * ROWB + (((4 * L.wn + rg) ^ (cr & 15)) << 4) + L.lh * 8);
+                    xm[j][rg * 4] += __uint_as_float(v.x << 16); xm[j][rg * 4 + 1] += __uint_as_float(v.x & 0xffff0000u);
+                    xm[j][rg * 4 + 2] += __uint_as_float(v.y << 16); xm[j][rg * 4 + 3] += __uint_as_float(v.y & 0xffff0000u);
+                }
+            }
+        }
+}
+
+// low halves x - bf16(x) of a master, packed as bf16 (the high halves are the operand tile store_rows wrote)
+__device__ __forceinline__ void pack_lo(uint2 (&lo)[2][4], const f32x16_t (&xm)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const unsigned h0 = cvt_pk_bf16(xm[j][rg * 4], xm[j][rg * 4 + 1]), h1 = cvt_pk_bf16(xm[j][rg * 4 + 2], xm[j][rg * 4 + 3]);
+            lo[j][rg] = make_uint2(cvt_pk_bf16(xm[j][rg * 4] - __uint_as_float(h0 << 16), xm[j][rg * 4 + 1] - __uint_as_float(h0 & 0xffff0000u)),
+                                   cvt_pk_bf16(xm[j][rg * 4 + 2] - __uint_as_float(h1 << 16), xm[j][rg * 4 + 3] - __uint_as_float(h1 & 0xffff0000u)));
+        }
+}
+__device__ __forceinline__ void store_lo(char* lob, const uint2 (&lo)[2][4], const Lane& L) {
+    if (L.l31 < WW) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int cr = (2 * L.wm + j) * WW + L.l31;
+                *(uint2*)(lob + cr * ROWB + (((4 * L.wn + rg) ^ (cr & 15)) << 4) + L.lh * 8) = lo[j][rg];
+            }
+    }
+}
+
+#ifdef FF_DEBUG_STAGES
+#define FF_STAGE(ID, BUFPTR, TRANSPOSED)                                                                              \
+    if (L.dbg_stage == L.dbg_call * 10 + (ID)) {                                                                                          \
+        __syncthreads();                                                                                              \
+        for (int e = threadIdx.x; e < 128 * 128; e += 512) {                                                          \
+            const int r = e >> 7, c = e & 127;                                                                        \
+            const int row = (TRANSPOSED) ? c : r, col = (TRANSPOSED) ? r : c; /* tile[row][col] */                    \
+            const unsigned short hv = *(const unsigned short*)((BUFPTR) + row * ROWB + ((((col >> 3)) ^ (row & 15)) << 4) + (col & 7) * 2); \
+            const int tokrow = (TRANSPOSED) ? col : row, ch = (TRANSPOSED) ? row : col;                               \
+            const int mq = tokrow >> 5, tok = tokrow & 31;                                                            \
+            if (tok < WW && L.dbg_m_base + mq < L.dbg_M) L.dbg_out[((size_t)(L.dbg_m_base + mq) * WW + tok) * C + ch] = __uint_as_float(((unsigned)hv) << 16); \
+        }                                                                                                             \
+        L.dbg_stage = -1;                                                                                             \
+    }
+#else
+#define FF_STAGE(ID, BUFPTR, TRANSPOSED)
+#endif
+
+// LoFTREncoderLayer.forward(x, source) (transformer.py:35-58) for the workgroup's 4 matches.  bx / bs: LDS operand tiles of
+// x / source; xm: fp32 master of x in accumulator layout.  The 8 fragments of the NEXT weight unit are requested into `w` right
+// behind the MFMAs of the current one, so the fetch runs under the epilogue / barrier (on entry `w` holds this call's Wk, on exit
+// `wnext`, the next call's Wk).  Ends with a barrier.
+__device__ __forceinline__ void encoder_layer(char* smem, char* bx, const char* bs, const uint4* __restrict__ wl, const uint4* __restrict__ wnext,
+                                              const float* __restrict__ ln, f32x16_t (&xm)[2], W8& w, float eps, Lane& L) {
+    {
+        int key = L.sw;
+        asm volatile("" : "+v"(key));   // opaque: address tables are per call (see Lane)
+        L.sw = key;
+        L.tables(key);
+    }
     char* T1 = smem + OFF_T1;
     char* T2 = smem + OFF_T2;
     float* ksum = (float*)(smem + OFF_SCR + SCR_KSUM);
     float2* stat = (float2*)(smem + OFF_SCR + SCR_STAT);
-    f32x16_t acc[4];
+    const uint4* w128 = wl + L.wn * 8 * 64;    // this wave's stream inside a [128 x 128] unit
+    const uint4* w256 = wl + L.wn * 16 * 64;   // ... inside a [128 x 256] unit (two consecutive 8-fragment halves)
+    f32x16_t acc[2];
     // ---- K^T = elu1(S Wk)^T -> T1,  V^T = (S Wv)^T -> T2 ------------------------------------------------------
-    zero4(acc);
-    gemm128<8, true>(bs, bs, wl + W_K + L.w * 8 * 64, acc, L);
+    mma8<true, true>(bs, w, acc, L);
+    wload(w, w128 + W_V, L);
     store_transposed<2>(T1, acc, L);
-    zero4(acc);
-    gemm128<8, true>(bs, bs, wl + W_V + L.w * 8 * 64, acc, L);
+    mma8<true, true>(bs, w, acc, L);
+    wload(w, w128 + W_Q, L);
     store_transposed<0>(T2, acc, L);
     __syncthreads();
-    // ---- wave w = match w: K sums, KV = K^T V per 32-channel group (2 heads), masked, packed as the next operand
+    FF_STAGE(1, T1, true)
+    FF_STAGE(2, T2, true)
+    // ---- two waves per match (mm), two 32-channel groups (= 4 heads) each: K sums, KV = K^T V masked to the head blocks
+    const int mm = 2 * L.wm + (L.wn >> 1), ig0 = 2 * (L.wn & 1);
     {
+        const int ch = 64 * (L.wn & 1) + L.lane;
+        float s = 0.f;
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int ch = L.lane + 64 * hh;
-            float s = 0.f;
+        for (int sl = 0; sl < 4; ++sl) {
+            const uint4 u = *(const uint4*)(T1 + ch * ROWB + (((4 * mm + sl) ^ (ch & 15)) << 4));
+            const unsigned uu[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-            for (int sl = 0; sl < 4; ++sl) {
-                const uint4 u = *(const uint4*)(T1 + ch * ROWB + (((4 * L.w + sl) ^ (ch & 15)) << 4));
-                const unsigned uu[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-                for (int t = 0; t < 4; ++t) s += __uint_as_float(uu[t] << 16) + __uint_as_float(uu[t] & 0xffff0000u);
-            }
-            ksum[L.w * C + ch] = s;
+            for (int t = 0; t < 4; ++t) s += __uint_as_float(uu[t] << 16) + __uint_as_float(uu[t] & 0xffff0000u);
         }
+        ksum[mm * C + ch] = s;
     }
-    bf16x8_t kvp[4][2];
+    bf16x8_t kvp[2][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int ii = 0; ii < 2; ++ii) {
         f32x16_t kv;
 #pragma unroll
         for (int r = 0; r < 16; ++r) kv[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int off = (32 * i + L.l31) * ROWB + (((4 * L.w + 2 * ks + L.lh) ^ L.sw) << 4);
+            const int off = (32 * (ig0 + ii) + L.l31) * ROWB + (((4 * mm + 2 * ks + L.lh) ^ L.sw) << 4);
             const bf16x8_t a = *(const bf16x8_t*)(T1 + off), b = *(const bf16x8_t*)(T2 + off);
             kv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, kv, 0, 0, 0);  // lane: v-channel l31, k-channels 8rg+4lh+e
         }
@@ -229,27 +335,28 @@ __device__ __forceinline__ void encoder_layer(char* smem, char* bx, const char* 
                 p[h2 * 2] = keep ? cvt_pk_bf16(kv[rg * 4], kv[rg * 4 + 1]) : 0u;
                 p[h2 * 2 + 1] = keep ? cvt_pk_bf16(kv[rg * 4 + 2], kv[rg * 4 + 3]) : 0u;
             }
-            kvp[i][ks] = __builtin_bit_cast(bf16x8_t, make_uint4(p[0], p[1], p[2], p[3]));
+            kvp[ii][ks] = __builtin_bit_cast(bf16x8_t, make_uint4(p[0], p[1], p[2], p[3]));
         }
     }
     __syncthreads();  // every wave is done with K^T / V^T
     // ---- Q = elu1(X Wq) -> T1 (row layout) -----------------------------------------------------------------------
-    zero4(acc);
-    gemm128<8, false>(bx, bx, wl + W_Q + L.w * 8 * 64, acc, L);
+    mma8<false, true>(bx, w, acc, L);
+    wload(w, w128 + W_M, L);
     store_rows<2>(T1, acc, L);
     __syncthreads();
-    // ---- wave w = match w: Z = 1 / (Q . Ksum + eps) per head, msg = (Q KV) Z -> T2 rows of this match ---------------
+    FF_STAGE(3, T1, false)
+    // ---- Z = 1 / (Q . Ksum + eps) for this wave's 4 heads, msg = (Q KV) Z -> T2 rows of match mm ---------------------
     {
-        const int row = 32 * L.w + L.l31;
-        float zlo[4], zhi[4];   // Z of heads 0..3 / 4..7 for this lane's token
+        const int row = 32 * mm + L.l31, hb = 4 * (L.wn & 1);
+        float zq[4];   // Z of heads hb .. hb+3 for this lane's token
 #pragma unroll
-        for (int hq = 0; hq < 4; ++hq) {  // this lane: heads 4lh .. 4lh+3; the partner lane (xor 32) has the others
-            const int h = 4 * L.lh + hq;
+        for (int hq = 0; hq < 2; ++hq) {  // this lane: heads hb + 2lh + {0,1}; the partner lane (xor 32) has the other two
+            const int h = hb + 2 * L.lh + hq;
             float d = 0.f;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const uint4 u = *(const uint4*)(T1 + row * ROWB + (((2 * h + half) ^ L.sw) << 4));
-                const float4 k0 = *(const float4*)(ksum + L.w * C + 16 * h + 8 * half), k1 = *(const float4*)(ksum + L.w * C + 16 * h + 8 * half + 4);
+                const float4 k0 = *(const float4*)(ksum + mm * C + 16 * h + 8 * half), k1 = *(const float4*)(ksum + mm * C + 16 * h + 8 * half + 4);
                 d = fmaf(__uint_as_float(u.x << 16), k0.x, d); d = fmaf(__uint_as_float(u.x & 0xffff0000u), k0.y, d);
                 d = fmaf(__uint_as_float(u.y << 16), k0.z, d); d = fmaf(__uint_as_float(u.y & 0xffff0000u), k0.w, d);
                 d = fmaf(__uint_as_float(u.z << 16), k1.x, d); d = fmaf(__uint_as_float(u.z & 0xffff0000u), k1.y, d);
@@ -257,11 +364,12 @@ __device__ __forceinline__ void encoder_layer(char* smem, char* bx, const char* 
             }
             const float zz = 1.0f / (d + 1e-6f);
             const float other = __shfl_xor(zz, 32, 64);
-            zlo[hq] = L.lh == 0 ? zz : other;
-            zhi[hq] = L.lh == 0 ? other : zz;
+            zq[hq] = L.lh == 0 ? zz : other;
+            zq[2 + hq] = L.lh == 0 ? other : zz;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = ig0 + ii;
             f32x16_t o;
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[r] = 0.f;
@@ -271,62 +379,82 @@ __device__ __forceinline__ void encoder_layer(char* smem, char* bx, const char* 
                 const uint2 lo = *(const uint2*)(T1 + row * ROWB + (((4 * i + 2 * ks) ^ L.sw) << 4) + L.lh * 8);
                 const uint2 hi = *(const uint2*)(T1 + row * ROWB + (((4 * i + 2 * ks + 1) ^ L.sw) << 4) + L.lh * 8);
                 const bf16x8_t qf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
-                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kvp[i][ks], qf, o, 0, 0, 0);  // lane: token l31, v-channels 8rg+4lh+e
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kvp[ii][ks], qf, o, 0, 0, 0);  // lane: token l31, v-channels 8rg+4lh+e
             }
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const float zz = (2 * i + (rg >> 1)) < 4 ? zlo[(2 * i + (rg >> 1)) & 3] : zhi[(2 * i + (rg >> 1)) & 3];
+                const float zz = zq[2 * ii + (rg >> 1)];
                 *(uint2*)(T2 + row * ROWB + (((4 * i + rg) ^ L.sw) << 4) + L.lh * 8) =
                     make_uint2(cvt_pk_bf16(o[rg * 4] * zz, o[rg * 4 + 1] * zz), cvt_pk_bf16(o[rg * 4 + 2] * zz, o[rg * 4 + 3] * zz));
             }
         }
     }
     __syncthreads();
+    FF_STAGE(4, T2, false)
     // ---- merge + norm1 -> T1 (transformer.py:52-53) ----------------------------------------------------------------
-    zero4(acc);
-    gemm128<8, false>(T2, T2, wl + W_M + L.w * 8 * 64, acc, L);
+    mma8<false, true>(T2, w, acc, L);
+    wload(w, w256 + W_0A, L);
     layernorm_rows(acc, ln, ln + C, stat, eps, L);   // barrier inside: every wave is done reading Q (T1) and msg (T2)
     store_rows<0>(T1, acc, L);
     __syncthreads();
-    // ---- mlp: relu([x | msg] W0) W2, hidden layer in two 128-column halves (transformer.py:55-56) -------------------
-    f32x16_t out[4];
-    zero4(out);
-    zero4(acc);
-    gemm128<16, false>(bx, T1, wl + W_0A + L.w * 16 * 64, acc, L);
+    FF_STAGE(5, T1, false)
+    // ---- mlp: relu([x | msg] W0) W2 (transformer.py:55-56): hidden columns 0..127 -> T2, 128..255 -> T1 (LN1(msg) is dead
+    // once both halves have read it), then ONE accumulation over both -- a single accumulator set is live at a time
+    mma8<false, true>(bx, w, acc, L);
+    wload(w, w256 + W_0A + 8 * 64, L);
+    mma8<false, false>(T1, w, acc, L);
+    wload(w, w256 + W_0B, L);
     store_rows<1>(T2, acc, L);
+    mma8<false, true>(bx, w, acc, L);
+    wload(w, w256 + W_0B + 8 * 64, L);
+    mma8<false, false>(T1, w, acc, L);
+    wload(w, w128 + W_2A, L);
+    __syncthreads();  // LN1(msg) consumed by every wave
+    FF_STAGE(6, T2, false)
+    store_rows<1>(T1, acc, L);
     __syncthreads();
-    gemm128<8, false>(T2, T2, wl + W_2A + L.w * 8 * 64, out, L);
-    zero4(acc);
-    gemm128<16, false>(bx, T1, wl + W_0B + L.w * 16 * 64, acc, L);
-    __syncthreads();  // first hidden half consumed by every wave
-    store_rows<1>(T2, acc, L);
-    __syncthreads();
-    gemm128<8, false>(T2, T2, wl + W_2B + L.w * 8 * 64, out, L);
+    FF_STAGE(7, T1, false)
+    f32x16_t out[2];
+    mma8<false, true>(T2, w, out, L);
+    wload(w, w128 + W_2B, L);
+    mma8<false, false>(T1, w, out, L);
+    wload(w, wnext + L.wn * 8 * 64, L);   // the next call's Wk
     // ---- norm2, residual add in fp32, new operand copy of x (transformer.py:57-58) ------------------------------------
-    layernorm_rows(out, ln + 2 * C, ln + 3 * C, stat, eps, L);  // barrier inside: every wave is done reading X[XS]
+    layernorm_rows(out, ln + 2 * C, ln + 3 * C, stat, eps, L);  // barrier inside: every wave is done reading X
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) xm[j][r] += out[j][r];
     store_rows<0>(bx, xm, L);
     __syncthreads();
+    FF_STAGE(8, bx, false)
+#ifdef FF_DEBUG_STAGES
+    L.dbg_call++;
+#endif
 }
 
-__global__ void __launch_bounds__(256, 1) fine_fused_kernel(const FineArgs a) {
+__global__ void __launch_bounds__(512, 2) fine_fused_kernel(const FineArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lane L;
     L.lane = threadIdx.x & 63;
     L.l31 = L.lane & 31;
     L.lh = L.lane >> 5;
-    L.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    L.wm = wave >> 2;
+    L.wn = wave & 3;
     L.sw = L.l31 & 15;
     const int m_base = blockIdx.x * G;
+#ifdef FF_DEBUG_STAGES
+    L.dbg_stage = a.dbg_stage; L.dbg_call = 0; L.dbg_m_base = m_base; L.dbg_M = a.M; L.dbg_out = a.dbg0;
+#endif
+    W8 w;
+    wload(w, a.wts + W_K + L.wn * 8 * 64, L);   // layer 0, Wk: in flight during the gather
     // ---- gather: 2 sides x 4 matches x 32 token slots x 256 B (fine_preprocess.py:40-47; border -> zeros like F.unfold padding)
     {
         const int t = threadIdx.x, slot = t & 15;
 #pragma unroll 4
-        for (int pass = 0; pass < 16; ++pass) {
-            const int r = pass * 16 + (t >> 4);   // 0..255
+        for (int pass = 0; pass < 8; ++pass) {
+            const int r = pass * 32 + (t >> 4);   // 0..255
             const int side = r >> 7, rr = r & 127, mm = rr >> 5, tok = rr & 31;
             const int m = m_base + mm;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -343,65 +471,70 @@ __global__ void __launch_bounds__(256, 1) fine_fused_kernel(const FineArgs a) {
         }
     }
     __syncthreads();
-    // fp32 masters in accumulator layout
-    f32x16_t xm0[4], xm1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const int off = (32 * j + L.l31) * ROWB + (((4 * L.w + rg) ^ L.sw) << 4) + L.lh * 8;
-            const uint2 u0 = *(const uint2*)(smem + OFF_X0 + off), u1 = *(const uint2*)(smem + OFF_X1 + off);
-            xm0[j][rg * 4] = __uint_as_float(u0.x << 16); xm0[j][rg * 4 + 1] = __uint_as_float(u0.x & 0xffff0000u);
-            xm0[j][rg * 4 + 2] = __uint_as_float(u0.y << 16); xm0[j][rg * 4 + 3] = __uint_as_float(u0.y & 0xffff0000u);
-            xm1[j][rg * 4] = __uint_as_float(u1.x << 16); xm1[j][rg * 4 + 1] = __uint_as_float(u1.x & 0xffff0000u);
-            xm1[j][rg * 4 + 2] = __uint_as_float(u1.y << 16); xm1[j][rg * 4 + 3] = __uint_as_float(u1.y & 0xffff0000u);
-        }
     char* X0 = smem + OFF_X0;
     char* X1 = smem + OFF_X1;
+    char* LO = smem + OFF_LO;
+    float* fin1 = (float*)(smem + OFF_T1);   // [4 x 25][FIN_LD] final fp32 tokens of image 1 (over the dead temporaries T1 | T2)
+    // final centre tokens of image 0, 512 B per match: parked in padding rows 25, 26 of the match's X0 block -- the last call only
+    // READS X0 (as the source), and whatever its padding rows hold is replaced by exact zeros in K^T / V^T (store_transposed)
+    auto fin0 = [&](int mq) { return (float*)(smem + OFF_X0 + (32 * mq + WW) * ROWB); };
+    f32x16_t xm[2];   // fp32 master of the stream being updated
+    L.tables(L.sw);
+    load_master<false>(xm, X0, LO, L);
     // layer 0 'self' (transformer.py:91-93), layer 1 'cross': feat0 first, feat1 against the UPDATED feat0 (:94-96)
 #pragma unroll 1
     for (int layer = 0; layer < 2; ++layer) {
         const uint4* wl = a.wts + (size_t)layer * W_LAYER;
+        const uint4* wk_next_layer = a.wts + (size_t)(layer == 0 ? W_LAYER : 0) + W_K;   // (after layer 1: a harmless re-fetch)
         const float* ln = a.ln + layer * 4 * C;
-        encoder_layer(smem, X0, layer == 0 ? X0 : X1, wl, ln, xm0, a.eps, L);
-        encoder_layer(smem, X1, layer == 0 ? X1 : X0, wl, ln, xm1, a.eps, L);
-    }
-
-    // ---- optional dumps of the transformer output (tests), straight from the fp32 masters --------------------------
-    if (a.dbg0) {
+        encoder_layer(smem, X0, layer == 0 ? X0 : X1, wl, wl + W_K, ln, xm, w, a.eps, L);        // stream 0
+        if (layer == 0) {
+            uint2 lo[2][4];
+            pack_lo(lo, xm);
+            store_lo(LO, lo, L);                      // LO = low halves of stream 0
+            load_master<false>(xm, X1, LO, L);        // stream 1 is still exactly its bf16 tile
+        } else {
+            // stream 0 is final: centre tokens for the fine matching, optional dump; then un-park stream 1
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m_base + j;
-            if (m < a.M && L.l31 < WW) {
+            for (int j = 0; j < 2; ++j) {
+                const int mq = 2 * L.wm + j, m = m_base + mq;
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
-                    const size_t o = ((size_t)m * WW + L.l31) * C + 32 * L.w + 8 * rg + 4 * L.lh;
-                    *(float4*)(a.dbg0 + o) = make_float4(xm0[j][rg * 4], xm0[j][rg * 4 + 1], xm0[j][rg * 4 + 2], xm0[j][rg * 4 + 3]);
-                    *(float4*)(a.dbg1 + o) = make_float4(xm1[j][rg * 4], xm1[j][rg * 4 + 1], xm1[j][rg * 4 + 2], xm1[j][rg * 4 + 3]);
+                    const int ch = 32 * L.wn + 8 * rg + 4 * L.lh;
+                    const float4 v = make_float4(xm[j][rg * 4], xm[j][rg * 4 + 1], xm[j][rg * 4 + 2], xm[j][rg * 4 + 3]);
+                    if (L.l31 == WW / 2) *(float4*)(fin0(mq) + ch) = v;
+                    if (a.dbg0 && a.dbg_stage == 0 && m < a.M && L.l31 < WW) *(float4*)(a.dbg0 + ((size_t)m * WW + L.l31) * C + ch) = v;
                 }
             }
+            load_master<true>(xm, X1, LO, L);
+        }
+        encoder_layer(smem, X1, layer == 0 ? X1 : X0, wl, wk_next_layer, ln, xm, w, a.eps, L);   // stream 1
+        if (layer == 0) {
+            uint2 lo[2][4];
+            pack_lo(lo, xm);                          // low halves of stream 1 ...
+            load_master<true>(xm, X0, LO, L);         // ... swap places with those of stream 0 (lane-private LDS words)
+            store_lo(LO, lo, L);
         }
     }
-    // ---- fine matching (fine_matching.py:43-74): fp32 tokens of image 1 + the centre token of image 0 -> LDS -------
-    float* fin1 = (float*)(smem + OFF_X0);   // [4 x 25][FIN_LD]  (the operand tiles are dead: last layer ended with a barrier)
-    float* fin0 = (float*)(smem + OFF_T1);   // [4][128]
+    // ---- stream 1 is final: optional dump, fp32 tokens -> LDS for the fine matching (fine_matching.py:43-74) ---------------
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 2; ++j) {
+        const int mq = 2 * L.wm + j, m = m_base + mq;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-            const int ch = 32 * L.w + 8 * rg + 4 * L.lh;
-            if (L.l31 < WW)
-                *(float4*)(fin1 + (j * WW + L.l31) * FIN_LD + ch) = make_float4(xm1[j][rg * 4], xm1[j][rg * 4 + 1], xm1[j][rg * 4 + 2], xm1[j][rg * 4 + 3]);
-            if (L.l31 == WW / 2)
-                *(float4*)(fin0 + j * C + ch) = make_float4(xm0[j][rg * 4], xm0[j][rg * 4 + 1], xm0[j][rg * 4 + 2], xm0[j][rg * 4 + 3]);
+            const int ch = 32 * L.wn + 8 * rg + 4 * L.lh;
+            const float4 v = make_float4(xm[j][rg * 4], xm[j][rg * 4 + 1], xm[j][rg * 4 + 2], xm[j][rg * 4 + 3]);
+            if (L.l31 < WW) *(float4*)(fin1 + (mq * WW + L.l31) * FIN_LD + ch) = v;   // T1 / T2 are dead: the last call ended with a barrier
+            if (a.dbg1 && m < a.M && L.l31 < WW) *(float4*)(a.dbg1 + ((size_t)m * WW + L.l31) * C + ch) = v;
         }
+    }
     __syncthreads();
-    const int m = m_base + L.w;
-    if (m >= a.M) return;
+    const int m = m_base + wave;
+    if (wave >= G || m >= a.M) return;
     float s = -INFINITY;
     if (L.lane < WW) {
-        const float* kr = fin1 + (L.w * WW + L.lane) * FIN_LD;
-        const float* q = fin0 + L.w * C;
+        const float* kr = fin1 + (wave * WW + L.lane) * FIN_LD;
+        const float* q = fin0(wave);
         float acc = 0.f;
 #pragma unroll 8
         for (int c = 0; c < C; c += 4) {
@@ -459,6 +592,10 @@ extern "C" int gim_fine_fused(const void* feat_f0, const void* feat_f1, const in
     a.wts = (const uint4*)weights; a.ln = ln_params; a.expec_f = expec_f; a.mkpts1_f = mkpts1_f; a.dbg0 = dbg_fine0; a.dbg1 = dbg_fine1;
     a.M = M; a.hf0 = hf0; a.wf0 = wf0; a.hf1 = hf1; a.wf1 = wf1; a.ldf = ldf; a.w0c = w0c; a.w1c = w1c; a.stride = stride;
     a.fscale = scale; a.eps = ln_eps; a.has_scale0 = has_scale0;
-    hipLaunchKernelGGL(fine_fused_kernel, dim3((unsigned)((M + G - 1) / G)), dim3(256), SMEM, (hipStream_t)stream, a);
+    a.dbg_stage = 0;
+#ifdef FF_DEBUG_STAGES
+    if (const char* e = getenv("GIM_FF_STAGE")) a.dbg_stage = atoi(e);
+#endif
+    hipLaunchKernelGGL(fine_fused_kernel, dim3((unsigned)((M + G - 1) / G)), dim3(512), SMEM, (hipStream_t)stream, a);
     return gim_check_launch("fine_fused");
 }

@@ -43,11 +43,15 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
 }
-// two fp32 -> packed bf16x2 (lo in bits 0-15), round to nearest even: one gfx950 instruction
+// two fp32 -> packed bf16x2 (lo in bits 0-15), round to nearest even: one gfx950 instruction (v_cvt_pk_bf16_f32).
+// Written as a vector conversion, NOT as inline asm: the hazard recogniser does not look inside asm statements, and an asm
+// v_cvt_pk right behind the v_mfma that produces its operands reads the accumulator before the matrix pipe has written
+// it back (measured in fine_fused.hip: wrong even heads in one of two inlined copies of the same code).
+typedef __bf16 gim_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float gim_f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    const gim_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, gim_bf16x2_t));
 }
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return cvt_pk_bf16(lo, hi); }
 

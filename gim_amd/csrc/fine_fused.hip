@@ -7,22 +7,26 @@
 //   networks/loftr/submodules/attentions.py:20-47        LinearAttention on 25-token sequences
 //   networks/loftr/utils/fine_matching.py:43-74          centre-row correlation, softmax, DSNT expectation, std
 //
-// One 512-thread workgroup (8 waves, 2 per SIMD: one wave's epilogue VALU overlaps its partner's MFMAs) owns G = 4 matches.  A match is one 32-row MFMA fragment (25 window tokens + 7 zero rows),
-// so both sides are [128 rows x 128 channels] bf16 operand tiles that live in LDS for the whole kernel:
+// One 256-thread workgroup owns G = 2 matches and two workgroups are resident per CU (2 waves per SIMD): one workgroup's
+// epilogue VALU / LDS latencies / barrier waits overlap the other's MFMAs, and since hardware barriers are per workgroup the two
+// never wait for each other (measured: 8 waves x 4 matches in ONE workgroup 1.02 ms, 2 x (4 waves x 2 matches) 0.89 ms at 12 000
+// matches).  A match is one 32-row MFMA fragment (25 window tokens + 7 zero rows), so each token stream is a [64 rows x 128
+// channels] bf16 operand tile that lives in LDS for the whole kernel:
 //
-//   LDS  X0, X1   operand copies of the two token streams          2 x 32 KiB
-//        T1, T2   temporaries (K^T / Q / LN1(msg) / hidden 128..255   and   V^T / msg / hidden 0..127)   2 x 32 KiB
-//        scratch  per-match K sums, LayerNorm partial sums          6 KiB
-//        LO       low halves (x - bf16(x), as bf16) of the token stream that is not being updated   25 KiB
+//   LDS  X0, X1   operand copies of the two token streams                                              2 x 16 KiB
+//        T1, T2   temporaries (K^T / Q / LN1(msg) / hidden 128..255   and   V^T / msg / hidden 0..127)  2 x 16 KiB
+//        scratch  per-match K sums, LayerNorm partial sums                                              3 KiB
+//        LO       low halves (x - bf16(x), as bf16) of the token stream that is not being updated       12.5 KiB
 //   VGPR          the fp32 master copy of the token stream being updated (residual adds stay fp32, as in the unfused
 //                 path); the other stream is parked as bf16 hi (its operand tile) + bf16 lo (LO): 2^-17 relative
 //
-// Every matrix product is [128 rows] x [128 out] x K (128 or 256) on v_mfma_f32_32x32x16_bf16; wave (wm, wn) owns rows
-// 64wm.. x output columns 32wn..32wn+31.  Weights go straight from L2 into registers in a pre-packed fragment order (16 B
-// per lane, 1 KiB per wave instruction), never through LDS, and are requested one 8-fragment unit ahead of their use.
+// Every matrix product is [64 rows] x [128 out] x K (128 or 256) on v_mfma_f32_32x32x16_bf16; wave wn owns output columns
+// 32wn..32wn+31 for all rows, so a workgroup fetches each weight element once -- straight from L2 into registers in a pre-packed
+// fragment order (16 B per lane, 1 KiB per wave instruction), never through LDS, requested one 8-fragment unit ahead of its use
+// (behind the MFMAs of the previous unit, so the fetch runs under that unit's epilogue: -8 % time).
 // The 256-wide MLP hidden layer lives in the two temporaries (its second half replaces LN1(msg) once that is consumed).
 //
-// Linear attention on the matrix cores (per match = per wave, per 32-channel group = 2 heads):
+// Linear attention on the matrix cores (two waves per match, two 32-channel groups = 4 heads each):
 //   K and V are produced TRANSPOSED ([channel][token], operands swapped in the MFMA) with the 7 padding tokens zeroed;
 //   KV = K^T V is one 32x32 fragment per channel group (contraction over the 32 token slots), masked to its two 16x16
 //   head blocks; msg = Q KV consumes that accumulator directly as the next MFMA's operand -- the contraction order of
@@ -39,13 +43,17 @@ namespace {
 
 constexpr int C = 128;             // fine d_model
 constexpr int ROWB = C * 2;        // bytes of one activation row (bf16)
-constexpr int BUF = 128 * ROWB;    // 32 KiB: 128 rows x 128 channels
-constexpr int WW = 25, G = 4, NH = 8;
+constexpr int WW = 25, G = 2, NH = 8;   // G matches per workgroup
+constexpr int ROWS = 32 * G;        // token rows of one stream (a match = one 32-row MFMA fragment)
+constexpr int BUF = ROWS * ROWB;    // 16 KiB: 64 rows x 128 channels
+constexpr int TROWB = ROWS * 2;     // bytes of one row of a TRANSPOSED tile [128 channels][64 token slots] (8 x 16 B, XOR key (ch >> 1) & 7:
+                                    // two 128-byte rows share a 256-byte bank row, so the key skips the channel's low bit)
+static_assert(G == 2, "tile addressing below is written for 2 matches (64 rows) per workgroup");
 constexpr int OFF_X0 = 0, OFF_X1 = BUF, OFF_T1 = 2 * BUF, OFF_T2 = 3 * BUF, OFF_SCR = 4 * BUF;
-constexpr int SCR_KSUM = 0, SCR_STAT = G * C * 4, SCR_BYTES = SCR_STAT + 128 * 4 * 8;
+constexpr int SCR_KSUM = 0, SCR_STAT = G * C * 4, SCR_BYTES = SCR_STAT + ROWS * 4 * 8;
 constexpr int OFF_LO = 4 * BUF + SCR_BYTES;   // parked low halves of one fp32 token stream: [4 x 25 valid rows][128] bf16
 constexpr int SMEM = OFF_LO + G * 25 * ROWB;
-static_assert(SMEM <= 160 * 1024, "LDS budget");
+static_assert(2 * SMEM <= 160 * 1024, "LDS budget: two workgroups per CU");
 constexpr int FIN_LD = 132;        // floats per row of the final fp32 image-1 tokens (bank-conflict-free float4 rows)
 static_assert(G * WW * FIN_LD * 4 <= 2 * BUF, "final image-1 tokens must fit in T1|T2");
 
@@ -72,8 +80,14 @@ struct FineArgs {
     int dbg_stage;
 };
 
+#ifdef FF_NOSYNC   // timing experiment only (results are wrong): how much of the kernel is barrier waiting
+#define FF_SYNC() do { } while (0)
+#else
+#define FF_SYNC() __syncthreads()
+#endif
+
 struct Lane {
-    int lane, l31, lh, wm, wn, sw;   // wave (wm, wn) owns rows 64wm..64wm+63 (matches 2wm, 2wm+1) x columns 32wn..32wn+31;
+    int lane, l31, lh, wn, sw, tsw;  // wave wn owns all 64 rows (both matches) x columns 32wn..32wn+31;  tsw = (l31 >> 1) & 7: key of transposed tiles
                                      // sw = l31 & 15: the XOR swizzle key of this lane's row
     // byte offsets inside a 32 KiB tile that every access is "one of these + a compile-time constant" of (the XOR swizzle
     // cannot be folded into an instruction offset; without the tables the compiler materialises and hoists one address
@@ -81,13 +95,13 @@ struct Lane {
 #ifdef FF_DEBUG_STAGES
     int dbg_stage, dbg_call, dbg_m_base, dbg_M; float* dbg_out;
 #endif
-    int a8[8];    // MFMA operand rows: (64wm + l31) * 256 + (((2ks + lh) ^ sw) << 4)
-    int st4[4];   // accumulator-layout 8-byte pieces: (64wm + l31) * 256 + (((4wn + rg) ^ sw) << 4) + 8lh
+    int a8[8];    // MFMA operand rows: l31 * 256 + (((2ks + lh) ^ sw) << 4)
+    int st4[4];   // accumulator-layout 8-byte pieces: l31 * 256 + (((4wn + rg) ^ sw) << 4) + 8lh
     __device__ __forceinline__ void tables(int key) {   // key = sw, passed through an opaque asm so that the tables (and
 #pragma unroll                                           // everything derived from them) are rebuilt per call, not kept alive
-        for (int ks = 0; ks < 8; ++ks) a8[ks] = (64 * wm + l31) * ROWB + (((2 * ks + lh) ^ key) << 4);
+        for (int ks = 0; ks < 8; ++ks) a8[ks] = l31 * ROWB + (((2 * ks + lh) ^ key) << 4);
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) st4[rg] = (64 * wm + l31) * ROWB + (((4 * wn + rg) ^ key) << 4) + lh * 8;
+        for (int rg = 0; rg < 4; ++rg) st4[rg] = l31 * ROWB + (((4 * wn + rg) ^ key) << 4) + lh * 8;
     }
 };
 
@@ -109,7 +123,7 @@ __device__ __forceinline__ void wload(W8& w, const uint4* __restrict__ p, const 
     __builtin_amdgcn_sched_barrier(0);   // keep the requests here: hoisted above the MFMAs they would need a second register set
 }
 
-// acc[j] (+)= rows [64wm + 32j ..] of the LDS operand tile `a` (128 channels = 8 k16 steps) x this wave's 8 fragments
+// acc[j] (+)= rows [32j ..] of the LDS operand tile `a` (128 channels = 8 k16 steps) x this wave's 8 fragments
 template <bool SWAP, bool FIRST>
 __device__ __forceinline__ void mma8(const char* a, const W8& w, f32x16_t (&acc)[2], const Lane& L) {
     __builtin_amdgcn_sched_barrier(0);
@@ -137,7 +151,7 @@ __device__ __forceinline__ void mma8(const char* a, const W8& w, f32x16_t (&acc)
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// accumulators in row orientation (lane = token row 64wm + 32j + l31, channels 32wn + 8rg + 4lh + e) -> bf16 rows in LDS
+// accumulators in row orientation (lane = token row 32j + l31, channels 32wn + 8rg + 4lh + e) -> bf16 rows in LDS
 template <int ACT>  // 0 none, 1 relu, 2 elu+1
 __device__ __forceinline__ void store_rows(char* buf, const f32x16_t (&acc)[2], const Lane& L) {
 #pragma unroll
@@ -154,7 +168,7 @@ __device__ __forceinline__ void store_rows(char* buf, const f32x16_t (&acc)[2], 
         }
 }
 
-// accumulators in swapped orientation (lane = channel 32wn + l31, tokens of match 2wm + j: 8rg + 4lh + e) -> [channel][token]
+// accumulators in swapped orientation (lane = channel 32wn + l31, tokens of match j: 8rg + 4lh + e) -> [channel][token]
 // in LDS, padding tokens (>= 25 of each match) written as exact zeros
 template <int ACT>
 __device__ __forceinline__ void store_transposed(char* buf, const f32x16_t (&acc)[2], const Lane& L) {
@@ -168,12 +182,12 @@ __device__ __forceinline__ void store_transposed(char* buf, const f32x16_t (&acc
                 const float x = acc[j][rg * 4 + e];
                 v[e] = (8 * rg + 4 * L.lh + e < WW) ? (ACT == 2 ? elu1(x) : x) : 0.f;
             }
-            *(uint2*)(buf + (32 * L.wn + L.l31) * ROWB + (((4 * (2 * L.wm + j) + rg) ^ L.sw) << 4) + L.lh * 8) =
+            *(uint2*)(buf + (32 * L.wn + L.l31) * TROWB + (((4 * j + rg) ^ L.tsw) << 4) + L.lh * 8) =
                 make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
         }
 }
 
-// LayerNorm over the 128 channels of every row, in accumulator layout (the 4 waves of a row half hold 32 channels each).
+// LayerNorm over the 128 channels of every row, in accumulator layout (the 4 waves hold 32 channels each).
 // Contains one workgroup barrier.  transformer.py:53,57 (nn.LayerNorm, biased variance, eps 1e-5).
 __device__ __forceinline__ void layernorm_rows(f32x16_t (&acc)[2], const float* __restrict__ gamma, const float* __restrict__ beta,
                                                float2* stat, float eps, const Lane& L) {
@@ -184,7 +198,7 @@ __device__ __forceinline__ void layernorm_rows(f32x16_t (&acc)[2], const float* 
         for (int r = 0; r < 16; ++r) { s += acc[j][r]; q = fmaf(acc[j][r], acc[j][r], q); }
         s += __shfl_xor(s, 32, 64);
         q += __shfl_xor(q, 32, 64);
-        if (L.lh == 0) stat[(64 * L.wm + 32 * j + L.l31) * 4 + L.wn] = make_float2(s, q);
+        if (L.lh == 0) stat[(32 * j + L.l31) * 4 + L.wn] = make_float2(s, q);
     }
     float g[16], b[16];
 #pragma unroll
@@ -194,10 +208,10 @@ __device__ __forceinline__ void layernorm_rows(f32x16_t (&acc)[2], const float* 
         g[rg * 4] = gg.x; g[rg * 4 + 1] = gg.y; g[rg * 4 + 2] = gg.z; g[rg * 4 + 3] = gg.w;
         b[rg * 4] = bb.x; b[rg * 4 + 1] = bb.y; b[rg * 4 + 2] = bb.z; b[rg * 4 + 3] = bb.w;
     }
-    __syncthreads();
+    FF_SYNC();
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const float4 p0 = *(const float4*)(stat + (64 * L.wm + 32 * j + L.l31) * 4), p1 = *(const float4*)(stat + (64 * L.wm + 32 * j + L.l31) * 4 + 2);
+        const float4 p0 = *(const float4*)(stat + (32 * j + L.l31) * 4), p1 = *(const float4*)(stat + (32 * j + L.l31) * 4 + 2);
         const float s = (p0.x + p0.z) + (p1.x + p1.z), q = (p0.y + p0.w) + (p1.y + p1.w);
         const float mean = s * (1.0f / C);
         const float var = fmaxf(q * (1.0f / C) - mean * mean, 0.f);
@@ -220,7 +234,7 @@ __device__ __forceinline__ void load_master(f32x16_t (&xm)[2], const char* xb, c
             xm[j][rg * 4 + 2] = __uint_as_float(u.y << 16); xm[j][rg * 4 + 3] = __uint_as_float(u.y & 0xffff0000u);
             if constexpr (WITH_LO) {
                 if (L.l31 < WW) {
-                    const int cr = (2 * L.wm + j) * WW + L.l31;
+                    const int cr = j * WW + L.l31;
                     const uint2 v = *(const uint2*)(lo + cr * ROWB + (((4 * L.wn + rg) ^ (cr & 15)) << 4) + L.lh * 8);
                     xm[j][rg * 4] += __uint_as_float(v.x << 16); xm[j][rg * 4 + 1] += __uint_as_float(v.x & 0xffff0000u);
                     xm[j][rg * 4 + 2] += __uint_as_float(v.y << 16); xm[j][rg * 4 + 3] += __uint_as_float(v.y & 0xffff0000u);
@@ -246,7 +260,7 @@ __device__ __forceinline__ void store_lo(char* lob, const uint2 (&lo)[2][4], con
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const int cr = (2 * L.wm + j) * WW + L.l31;
+                const int cr = j * WW + L.l31;
                 *(uint2*)(lob + cr * ROWB + (((4 * L.wn + rg) ^ (cr & 15)) << 4) + L.lh * 8) = lo[j][rg];
             }
     }
@@ -255,11 +269,12 @@ __device__ __forceinline__ void store_lo(char* lob, const uint2 (&lo)[2][4], con
 #ifdef FF_DEBUG_STAGES
 #define FF_STAGE(ID, BUFPTR, TRANSPOSED)                                                                              \
     if (L.dbg_stage == L.dbg_call * 10 + (ID)) {                                                                                          \
-        __syncthreads();                                                                                              \
-        for (int e = threadIdx.x; e < 128 * 128; e += 512) {                                                          \
-            const int r = e >> 7, c = e & 127;                                                                        \
+        FF_SYNC();                                                                                              \
+        for (int e = threadIdx.x; e < ROWS * 128; e += 256) {                                                         \
+            const int r = e >> 7, c = e & 127;   /* r: token slot, c: channel */                                      \
             const int row = (TRANSPOSED) ? c : r, col = (TRANSPOSED) ? r : c; /* tile[row][col] */                    \
-            const unsigned short hv = *(const unsigned short*)((BUFPTR) + row * ROWB + ((((col >> 3)) ^ (row & 15)) << 4) + (col & 7) * 2); \
+            const unsigned short hv = (TRANSPOSED) ? *(const unsigned short*)((BUFPTR) + row * TROWB + ((((col >> 3)) ^ ((row >> 1) & 7)) << 4) + (col & 7) * 2) \
+                                                   : *(const unsigned short*)((BUFPTR) + row * ROWB + ((((col >> 3)) ^ (row & 15)) << 4) + (col & 7) * 2); \
             const int tokrow = (TRANSPOSED) ? col : row, ch = (TRANSPOSED) ? row : col;                               \
             const int mq = tokrow >> 5, tok = tokrow & 31;                                                            \
             if (tok < WW && L.dbg_m_base + mq < L.dbg_M) L.dbg_out[((size_t)(L.dbg_m_base + mq) * WW + tok) * C + ch] = __uint_as_float(((unsigned)hv) << 16); \
@@ -270,7 +285,7 @@ __device__ __forceinline__ void store_lo(char* lob, const uint2 (&lo)[2][4], con
 #define FF_STAGE(ID, BUFPTR, TRANSPOSED)
 #endif
 
-// LoFTREncoderLayer.forward(x, source) (transformer.py:35-58) for the workgroup's 4 matches.  bx / bs: LDS operand tiles of
+// LoFTREncoderLayer.forward(x, source) (transformer.py:35-58) for the workgroup's 2 matches.  bx / bs: LDS operand tiles of
 // x / source; xm: fp32 master of x in accumulator layout.  The 8 fragments of the NEXT weight unit are requested into `w` right
 // behind the MFMAs of the current one, so the fetch runs under the epilogue / barrier (on entry `w` holds this call's Wk, on exit
 // `wnext`, the next call's Wk).  Ends with a barrier.
@@ -296,17 +311,17 @@ __device__ __forceinline__ void encoder_layer(char* smem, char* bx, const char* 
     mma8<true, true>(bs, w, acc, L);
     wload(w, w128 + W_Q, L);
     store_transposed<0>(T2, acc, L);
-    __syncthreads();
+    FF_SYNC();
     FF_STAGE(1, T1, true)
     FF_STAGE(2, T2, true)
     // ---- two waves per match (mm), two 32-channel groups (= 4 heads) each: K sums, KV = K^T V masked to the head blocks
-    const int mm = 2 * L.wm + (L.wn >> 1), ig0 = 2 * (L.wn & 1);
+    const int mm = L.wn >> 1, ig0 = 2 * (L.wn & 1);
     {
         const int ch = 64 * (L.wn & 1) + L.lane;
         float s = 0.f;
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {
-            const uint4 u = *(const uint4*)(T1 + ch * ROWB + (((4 * mm + sl) ^ (ch & 15)) << 4));
+            const uint4 u = *(const uint4*)(T1 + ch * TROWB + (((4 * mm + sl) ^ ((ch >> 1) & 7)) << 4));
             const unsigned uu[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
             for (int t = 0; t < 4; ++t) s += __uint_as_float(uu[t] << 16) + __uint_as_float(uu[t] & 0xffff0000u);
@@ -321,7 +336,7 @@ __device__ __forceinline__ void encoder_layer(char* smem, char* bx, const char* 
         for (int r = 0; r < 16; ++r) kv[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int off = (32 * (ig0 + ii) + L.l31) * ROWB + (((4 * mm + 2 * ks + L.lh) ^ L.sw) << 4);
+            const int off = (32 * (ig0 + ii) + L.l31) * TROWB + (((4 * mm + 2 * ks + L.lh) ^ L.tsw) << 4);
             const bf16x8_t a = *(const bf16x8_t*)(T1 + off), b = *(const bf16x8_t*)(T2 + off);
             kv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, kv, 0, 0, 0);  // lane: v-channel l31, k-channels 8rg+4lh+e
         }
@@ -338,12 +353,12 @@ __device__ __forceinline__ void encoder_layer(char* smem, char* bx, const char* 
             kvp[ii][ks] = __builtin_bit_cast(bf16x8_t, make_uint4(p[0], p[1], p[2], p[3]));
         }
     }
-    __syncthreads();  // every wave is done with K^T / V^T
+    FF_SYNC();  // every wave is done with K^T / V^T
     // ---- Q = elu1(X Wq) -> T1 (row layout) -----------------------------------------------------------------------
     mma8<false, true>(bx, w, acc, L);
     wload(w, w128 + W_M, L);
     store_rows<2>(T1, acc, L);
-    __syncthreads();
+    FF_SYNC();
     FF_STAGE(3, T1, false)
     // ---- Z = 1 / (Q . Ksum + eps) for this wave's 4 heads, msg = (Q KV) Z -> T2 rows of match mm ---------------------
     {
@@ -389,14 +404,14 @@ __device__ __forceinline__ void encoder_layer(char* smem, char* bx, const char* 
             }
         }
     }
-    __syncthreads();
+    FF_SYNC();
     FF_STAGE(4, T2, false)
     // ---- merge + norm1 -> T1 (transformer.py:52-53) ----------------------------------------------------------------
     mma8<false, true>(T2, w, acc, L);
     wload(w, w256 + W_0A, L);
     layernorm_rows(acc, ln, ln + C, stat, eps, L);   // barrier inside: every wave is done reading Q (T1) and msg (T2)
     store_rows<0>(T1, acc, L);
-    __syncthreads();
+    FF_SYNC();
     FF_STAGE(5, T1, false)
     // ---- mlp: relu([x | msg] W0) W2 (transformer.py:55-56): hidden columns 0..127 -> T2, 128..255 -> T1 (LN1(msg) is dead
     // once both halves have read it), then ONE accumulation over both -- a single accumulator set is live at a time
@@ -409,10 +424,10 @@ __device__ __forceinline__ void encoder_layer(char* smem, char* bx, const char* 
     wload(w, w256 + W_0B + 8 * 64, L);
     mma8<false, false>(T1, w, acc, L);
     wload(w, w128 + W_2A, L);
-    __syncthreads();  // LN1(msg) consumed by every wave
+    FF_SYNC();  // LN1(msg) consumed by every wave
     FF_STAGE(6, T2, false)
     store_rows<1>(T1, acc, L);
-    __syncthreads();
+    FF_SYNC();
     FF_STAGE(7, T1, false)
     f32x16_t out[2];
     mma8<false, true>(T2, w, out, L);
@@ -426,23 +441,23 @@ __device__ __forceinline__ void encoder_layer(char* smem, char* bx, const char* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) xm[j][r] += out[j][r];
     store_rows<0>(bx, xm, L);
-    __syncthreads();
+    FF_SYNC();
     FF_STAGE(8, bx, false)
 #ifdef FF_DEBUG_STAGES
     L.dbg_call++;
 #endif
 }
 
-__global__ void __launch_bounds__(512, 2) fine_fused_kernel(const FineArgs a) {
+__global__ void __launch_bounds__(256, 2) fine_fused_kernel(const FineArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lane L;
     L.lane = threadIdx.x & 63;
     L.l31 = L.lane & 31;
     L.lh = L.lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    L.wm = wave >> 2;
-    L.wn = wave & 3;
+    L.wn = wave;
     L.sw = L.l31 & 15;
+    L.tsw = (L.l31 >> 1) & 7;
     const int m_base = blockIdx.x * G;
 #ifdef FF_DEBUG_STAGES
     L.dbg_stage = a.dbg_stage; L.dbg_call = 0; L.dbg_m_base = m_base; L.dbg_M = a.M; L.dbg_out = a.dbg0;
@@ -453,9 +468,9 @@ __global__ void __launch_bounds__(512, 2) fine_fused_kernel(const FineArgs a) {
     {
         const int t = threadIdx.x, slot = t & 15;
 #pragma unroll 4
-        for (int pass = 0; pass < 8; ++pass) {
-            const int r = pass * 32 + (t >> 4);   // 0..255
-            const int side = r >> 7, rr = r & 127, mm = rr >> 5, tok = rr & 31;
+        for (int pass = 0; pass < 2 * ROWS / 16; ++pass) {
+            const int r = pass * 16 + (t >> 4);   // 0..127
+            const int side = r >> 6, rr = r & 63, mm = rr >> 5, tok = rr & 31;
             const int m = m_base + mm;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (tok < WW && m < a.M) {
@@ -470,7 +485,7 @@ __global__ void __launch_bounds__(512, 2) fine_fused_kernel(const FineArgs a) {
             *(uint4*)(smem + (side ? OFF_X1 : OFF_X0) + rr * ROWB + ((slot ^ (rr & 15)) << 4)) = v;
         }
     }
-    __syncthreads();
+    FF_SYNC();
     char* X0 = smem + OFF_X0;
     char* X1 = smem + OFF_X1;
     char* LO = smem + OFF_LO;
@@ -497,7 +512,7 @@ __global__ void __launch_bounds__(512, 2) fine_fused_kernel(const FineArgs a) {
             // stream 0 is final: centre tokens for the fine matching, optional dump; then un-park stream 1
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int mq = 2 * L.wm + j, m = m_base + mq;
+                const int mq = j, m = m_base + mq;
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
                     const int ch = 32 * L.wn + 8 * rg + 4 * L.lh;
@@ -519,7 +534,7 @@ __global__ void __launch_bounds__(512, 2) fine_fused_kernel(const FineArgs a) {
     // ---- stream 1 is final: optional dump, fp32 tokens -> LDS for the fine matching (fine_matching.py:43-74) ---------------
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int mq = 2 * L.wm + j, m = m_base + mq;
+        const int mq = j, m = m_base + mq;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             const int ch = 32 * L.wn + 8 * rg + 4 * L.lh;
@@ -528,7 +543,7 @@ __global__ void __launch_bounds__(512, 2) fine_fused_kernel(const FineArgs a) {
             if (a.dbg1 && m < a.M && L.l31 < WW) *(float4*)(a.dbg1 + ((size_t)m * WW + L.l31) * C + ch) = v;
         }
     }
-    __syncthreads();
+    FF_SYNC();
     const int m = m_base + wave;
     if (wave >= G || m >= a.M) return;
     float s = -INFINITY;
@@ -596,6 +611,6 @@ extern "C" int gim_fine_fused(const void* feat_f0, const void* feat_f1, const in
 #ifdef FF_DEBUG_STAGES
     if (const char* e = getenv("GIM_FF_STAGE")) a.dbg_stage = atoi(e);
 #endif
-    hipLaunchKernelGGL(fine_fused_kernel, dim3((unsigned)((M + G - 1) / G)), dim3(512), SMEM, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(fine_fused_kernel, dim3((unsigned)((M + G - 1) / G)), dim3(256), SMEM, (hipStream_t)stream, a);
     return gim_check_launch("fine_fused");
 }

@@ -172,7 +172,7 @@ int gim_fine_match(const float* f0, const float* f1, const float* mkpts1_c, cons
                    float scale, int has_scale0, gim_stream_t stream);
 /* The whole fine level in ONE kernel (bf16 operand mode, d_model 128, 5x5 windows, layer_names ['self','cross']):
  * window gather (fine_preprocess.py:40-47) + LocalFeatureTransformer (transformer.py:35-58,80-101, LinearAttention
- * attentions.py:20-47) + FineMatching (fine_matching.py:43-74); 4 matches per workgroup, activations never leave the CU.
+ * attentions.py:20-47) + FineMatching (fine_matching.py:43-74); 2 matches per workgroup, activations never leave the CU.
  * feat_f0/feat_f1: NHWC bf16 fine maps (row stride ldf).  `weights`: gim_fine_fused_weight_bytes() bytes, bf16, per layer
  * [Wq | Wk | Wv | Wmerge | mlp.0 rows 0..127 | mlp.0 rows 128..255 | mlp.2 cols 0..127 | mlp.2 cols 128..255], each block
  * [128 out][K] re-ordered to MFMA fragment order [wave = out/32][k16 step][lane = (k/8 % 2)*32 + out%32][8] (host side:

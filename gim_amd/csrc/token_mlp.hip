@@ -1,0 +1,299 @@
+// Fused token-wise tail of a LoFTREncoderLayer for the coarse level (d_model 256, bf16 operand mode) on gfx950:
+//
+//     msg  = norm1(merge(attention output))                                 transformer.py:52-53
+//     msg  = norm2(mlp.2(relu(mlp.0(cat[x, msg]))))                          transformer.py:55-57
+//     x   += msg                                                             transformer.py:58
+//
+// ONE launch instead of merge GEMM -> LayerNorm -> mlp.0 GEMM -> mlp.2 GEMM -> LayerNorm+residual, and none of the five
+// intermediate row buffers (merge output, norm1 output, 512-wide hidden layer, mlp.2 output) touches HBM.  Everything after
+// the attention is row-local, so a 256-thread workgroup owns 64 token rows from the attention output to the updated stream:
+//
+//   LDS   A   [64 rows][256] bf16   attention output, later norm1(msg)        32 KiB
+//         X   [64 rows][256] bf16   operand copy of x (the other half of cat)  32 KiB
+//         H   [64 rows][128] bf16   one quarter of the hidden layer             16 KiB   (+ LayerNorm partial sums while it is idle)
+//   two workgroups per CU (80 KiB each): one's epilogues / barrier waits run under the other's MFMAs.
+//
+// The 512-wide hidden layer is produced and consumed in four 128-column quarters: relu([x | msg] W0[q]) -> H -> out += H W2[:, q];
+// `out` (64 x 256 fp32) stays in the accumulators of the 4 waves (64 columns each) across the quarters.
+// Weights stream from L2 straight into registers in a per-wave fragment order fixed at pack time (gim_amd/packing.py::
+// pack_token_mlp): 28 units of 8 fragments per wave = 896 KiB per workgroup, each unit requested right behind the MFMAs of the
+// previous one.  v_mfma_f32_32x32x16_bf16, fp32 accumulate; LayerNorm statistics and the residual stream are fp32
+// (x32 is read, updated and written once, through an LDS transposition so that every global access is a full 256-byte row
+// segment); the operand copy of the new x is written as bf16.
+#include "gim_common.h"
+
+namespace {
+
+constexpr int C = 256;
+constexpr int ROWS = 64;
+constexpr int ROWB = C * 2;          // bytes of one row of the A / X tiles
+constexpr int HROWB = 128 * 2;       // bytes of one row of the hidden-quarter tile
+constexpr int OFF_A = 0, OFF_X = ROWS * ROWB, OFF_H = 2 * ROWS * ROWB;
+constexpr int SMEM = OFF_H + ROWS * HROWB;   // 80 KiB
+static_assert(2 * SMEM <= 160 * 1024, "two workgroups per CU");
+constexpr int UNITS_PER_WAVE = 4 + 4 * (4 + 2);
+constexpr int UNIT_U4 = 8 * 64;      // uint4 per unit (8 fragments x 64 lanes x 16 B)
+
+struct Args {
+    const unsigned short* msg;   // [R][ldm] bf16 attention output
+    unsigned short* xb;          // [R][ldxb] bf16 operand copy of x (in: x, out: x + msg)
+    float* x32;                  // [R][ldx32] fp32 residual stream (in / out)
+    const uint4* wts;            // 4 waves x 28 units x 8 fragments
+    const float* ln;             // [g1 | b1 | g2 | b2] x 256
+    int R, ldm, ldxb, ldx32;
+    float eps;
+};
+
+struct W8 { bf16x8_t f[8]; };
+
+struct Lane {
+    int lane, l31, lh, w, sw;
+    int a8[8];    // l31 * 512 + (((2ks + lh) ^ sw) << 4), ks = 0..7: first 128 channels of an A / X row (+ 256 B for the next 128)
+    int h8[8];    // l31 * 256 + (((2ks + lh) ^ sw) << 4): hidden-quarter rows
+    __device__ __forceinline__ void tables(int key) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            a8[ks] = l31 * ROWB + (((2 * ks + lh) ^ key) << 4);
+            h8[ks] = l31 * HROWB + (((2 * ks + lh) ^ key) << 4);
+        }
+    }
+};
+
+__device__ __forceinline__ void wload(W8& w, const uint4* __restrict__ p, int lane) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w.f[i] = __builtin_bit_cast(bf16x8_t, p[i * 64 + lane]);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// unit of a 64-column product (merge, mlp.2): 4 k16 steps x 2 column fragments; acc[nf][j] += W-frag x rows 32j..
+// `tile` + tab[ks] (+ koff bytes) addresses the operand rows
+template <bool FIRST>
+__device__ __forceinline__ void mma_n64(const char* tile, const int (&tab)[8], int ks0, int jstride, const W8& w, f32x16_t (&acc)[2][2]) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const char* ab = tile + tab[ks0 + k];
+        const bf16x8_t v0 = *(const bf16x8_t*)(ab), v1 = *(const bf16x8_t*)(ab + jstride);
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+            if (FIRST && k == 0) {
+                f32x16_t z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                acc[nf][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[2 * k + nf], v0, z, 0, 0, 0);
+                acc[nf][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[2 * k + nf], v1, z, 0, 0, 0);
+            } else {
+                acc[nf][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[2 * k + nf], v0, acc[nf][0], 0, 0, 0);
+                acc[nf][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[2 * k + nf], v1, acc[nf][1], 0, 0, 0);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// unit of a 32-column product (one hidden quarter): 8 k16 steps x 1 column fragment
+template <bool FIRST>
+__device__ __forceinline__ void mma_n32(const char* tile, const int (&tab)[8], const W8& w, f32x16_t (&acc)[2]) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const char* ab = tile + tab[k];
+        const bf16x8_t v0 = *(const bf16x8_t*)(ab), v1 = *(const bf16x8_t*)(ab + 32 * ROWB);
+        if (FIRST && k == 0) {
+            f32x16_t z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[k], v0, z, 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[k], v1, z, 0, 0, 0);
+        } else {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[k], v0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[k], v1, acc[1], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// LayerNorm over the 256 channels of every row, in accumulator layout (wave w holds channels 64w..64w+63 of all 64 rows:
+// acc[nf][j][4rg + e] = channel 64w + 32nf + 8rg + 4lh + e of row 32j + l31).  One workgroup barrier inside.
+__device__ __forceinline__ void layernorm_rows(f32x16_t (&acc)[2][2], const float* __restrict__ gamma, const float* __restrict__ beta,
+                                               float2* stat, float eps, const Lane& L) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s += acc[nf][j][r]; q = fmaf(acc[nf][j][r], acc[nf][j][r], q); }
+        s += __shfl_xor(s, 32, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (L.lh == 0) stat[(32 * j + L.l31) * 4 + L.w] = make_float2(s, q);
+    }
+    __syncthreads();
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float4 p0 = *(const float4*)(stat + (32 * j + L.l31) * 4), p1 = *(const float4*)(stat + (32 * j + L.l31) * 4 + 2);
+        const float s = (p0.x + p0.z) + (p1.x + p1.z), q = (p0.y + p0.w) + (p1.y + p1.w);
+        mean[j] = s * (1.0f / C);
+        rstd[j] = rsqrtf(fmaxf(q * (1.0f / C) - mean[j] * mean[j], 0.f) + eps);
+    }
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const float4 g = *(const float4*)(gamma + 64 * L.w + 32 * nf + 8 * rg + 4 * L.lh);
+            const float4 b = *(const float4*)(beta + 64 * L.w + 32 * nf + 8 * rg + 4 * L.lh);
+            const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[nf][j][rg * 4 + e] = fmaf(fmaf(acc[nf][j][rg * 4 + e], rstd[j], -mean[j] * rstd[j]), gg[e], bb[e]);
+        }
+}
+
+__global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Lane L;
+    L.lane = threadIdx.x & 63;
+    L.l31 = L.lane & 31;
+    L.lh = L.lane >> 5;
+    L.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    L.sw = L.l31 & 15;
+    L.tables(L.sw);
+    const int r0 = blockIdx.x * ROWS;
+    char* A = smem + OFF_A;
+    char* X = smem + OFF_X;
+    char* H = smem + OFF_H;
+    float2* stat = (float2*)H;   // [64 rows][4 waves] partial (sum, sum of squares): H is idle whenever a LayerNorm runs
+    const uint4* wp = a.wts + (size_t)L.w * UNITS_PER_WAVE * UNIT_U4;
+    W8 w;
+    wload(w, wp, L.lane);   // merge, unit 0: in flight during the tile loads
+    // ---- A <- attention output rows, X <- operand copy of x (512 B rows: 32 lanes x 16 B, 8 rows per pass) ----------
+    {
+        const int t = threadIdx.x, slot = t & 31;
+#pragma unroll 4
+        for (int pass = 0; pass < ROWS / 8; ++pass) {
+            const int row = pass * 8 + (t >> 5), m = r0 + row;
+            uint4 va = make_uint4(0u, 0u, 0u, 0u), vx = va;
+            if (m < a.R) {
+                va = *(const uint4*)(a.msg + (size_t)m * a.ldm + slot * 8);
+                vx = *(const uint4*)(a.xb + (size_t)m * a.ldxb + slot * 8);
+            }
+            const int off = row * ROWB + ((slot ^ (row & 15)) << 4);   // XOR on the low 4 slot bits: conflict-free b128 rows
+            *(uint4*)(A + off) = va;
+            *(uint4*)(X + off) = vx;
+        }
+    }
+    __syncthreads();
+    // ---- merge: [64 x 256] x W_merge^T, this wave's 64 output channels (transformer.py:52) ----------------------------
+    f32x16_t acc[2][2];
+    int u = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {          // 4 units x 4 k16 steps = K 256
+        ++u;
+        const char* tile = A + (q >> 1) * 256;   // k16 steps 0..7 -> first 256 B of the row, 8..15 -> second
+        if (q == 0) mma_n64<true>(tile, L.a8, 0, 32 * ROWB, w, acc);
+        else mma_n64<false>(tile, L.a8, (q & 1) * 4, 32 * ROWB, w, acc);
+        wload(w, wp + (size_t)u * UNIT_U4, L.lane);
+    }
+    // ---- norm1 -> A (the attention output is consumed: barrier inside the LayerNorm) ---------------------------------
+    layernorm_rows(acc, a.ln, a.ln + C, stat, a.eps, L);
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+                *(uint2*)(A + (32 * j + L.l31) * ROWB + (((8 * L.w + 4 * nf + rg) ^ L.sw) << 4) + L.lh * 8) =
+                    make_uint2(cvt_pk_bf16(acc[nf][j][rg * 4], acc[nf][j][rg * 4 + 1]), cvt_pk_bf16(acc[nf][j][rg * 4 + 2], acc[nf][j][rg * 4 + 3]));
+    __syncthreads();
+    // ---- mlp: four hidden quarters (transformer.py:55-56) --------------------------------------------------------------
+    f32x16_t out[2][2];
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[nf][j][r] = 0.f;
+#pragma unroll 1
+    for (int hq = 0; hq < 4; ++hq) {
+        f32x16_t hid[2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {      // K = 512: [x | msg], 4 units of 8 k16 steps
+            ++u;
+            const char* tile = (q < 2 ? X : A) + (q & 1) * 256;
+            if (q == 0) mma_n32<true>(tile, L.a8, w, hid);
+            else mma_n32<false>(tile, L.a8, w, hid);
+            wload(w, wp + (size_t)u * UNIT_U4, L.lane);
+        }
+        if (hq > 0) __syncthreads();       // every wave is done reading the previous quarter
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+                *(uint2*)(H + (32 * j + L.l31) * HROWB + (((4 * L.w + rg) ^ L.sw) << 4) + L.lh * 8) =
+                    make_uint2(cvt_pk_bf16(fmaxf(hid[j][rg * 4], 0.f), fmaxf(hid[j][rg * 4 + 1], 0.f)),
+                               cvt_pk_bf16(fmaxf(hid[j][rg * 4 + 2], 0.f), fmaxf(hid[j][rg * 4 + 3], 0.f)));
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {      // out += H x W2[:, quarter]: K = 128, 2 units of 4 k16 steps
+            ++u;
+            mma_n64<false>(H, L.h8, q * 4, 32 * HROWB, w, out);
+            if (u < UNITS_PER_WAVE) wload(w, wp + (size_t)u * UNIT_U4, L.lane);
+        }
+    }
+    __syncthreads();   // H is consumed: its space serves the LayerNorm partial sums
+    // ---- norm2 (transformer.py:57); residual add + stores through a wave-private LDS transposition --------------------
+    layernorm_rows(out, a.ln + 2 * C, a.ln + 3 * C, stat, a.eps, L);   // barrier inside: A and X are dead from here on
+    float* tr = (float*)(smem + L.w * 16384);   // this wave's [64 rows][64 channels] fp32, 16-byte slots XOR-swizzled by row
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int row = 32 * j + L.l31;
+                *(float4*)((char*)tr + row * 256 + (((8 * nf + 2 * rg + L.lh) ^ (row & 15)) << 4)) =
+                    make_float4(out[nf][j][rg * 4], out[nf][j][rg * 4 + 1], out[nf][j][rg * 4 + 2], out[nf][j][rg * 4 + 3]);
+            }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave reads below: LDS executes a wave's accesses in order
+    {
+        const int slot = L.lane & 15, rsub = L.lane >> 4;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 4 + rsub, m = r0 + row;
+            const float4 v = *(const float4*)((char*)tr + row * 256 + ((slot ^ (row & 15)) << 4));
+            if (m < a.R) {
+                float* xp = a.x32 + (size_t)m * a.ldx32 + 64 * L.w + 4 * slot;
+                float4 x = *(const float4*)xp;
+                x.x += v.x; x.y += v.y; x.z += v.z; x.w += v.w;   // x + message
+                *(float4*)xp = x;
+                *(uint2*)(a.xb + (size_t)m * a.ldxb + 64 * L.w + 4 * slot) = make_uint2(cvt_pk_bf16(x.x, x.y), cvt_pk_bf16(x.z, x.w));
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t gim_token_mlp_weight_bytes(void) { return (int64_t)4 * UNITS_PER_WAVE * UNIT_U4 * 16; }
+
+extern "C" int gim_token_mlp(const void* msg, void* xb, float* x32, const void* weights, const float* ln_params, int R, int C_,
+                             int ldm, int ldxb, int ldx32, float ln_eps, gim_stream_t stream) {
+    if (R == 0) return GIM_OK;
+    GIM_REQUIRE(msg && xb && x32 && weights && ln_params, "token_mlp: NULL pointer");
+    GIM_REQUIRE(C_ == C, "token_mlp: built for d_model 256 (got %d)", C_);
+    GIM_REQUIRE(R > 0 && ldm >= C && ldxb >= C && ldx32 >= C && ldm % 8 == 0 && ldxb % 8 == 0 && ldx32 % 4 == 0, "token_mlp: bad strides");
+    static GimPerDevice attr;
+    if (attr.needed()) {
+        hipError_t e = hipFuncSetAttribute((const void*)token_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) { gim_set_error("token_mlp: hipFuncSetAttribute(%d B LDS): %s", SMEM, hipGetErrorString(e)); return GIM_ERR_LAUNCH; }
+        attr.done();
+    }
+    Args a;
+    a.msg = (const unsigned short*)msg; a.xb = (unsigned short*)xb; a.x32 = x32; a.wts = (const uint4*)weights; a.ln = ln_params;
+    a.R = R; a.ldm = ldm; a.ldxb = ldxb; a.ldx32 = ldx32; a.eps = ln_eps;
+    hipLaunchKernelGGL(token_mlp_kernel, dim3((unsigned)((R + ROWS - 1) / ROWS)), dim3(256), SMEM, (hipStream_t)stream, a);
+    return gim_check_launch("token_mlp");
+}

@@ -33,7 +33,7 @@ import torch.nn as nn
 
 from .. import ops
 from .._lib import ACT_ELU1, ACT_LEAKY, ACT_NONE, ACT_RELU, GIM_BF16, GIM_F32, GimHipError
-from ..packing import cstore, pack_conv, pack_fine_fused, torch_dtype
+from ..packing import cstore, pack_conv, pack_fine_fused, pack_token_mlp, torch_dtype
 
 
 # --------------------------------------------------------------------------------------------------
@@ -181,6 +181,9 @@ class LoFTR(nn.Module):
         # bf16 mode: the whole fine level (gather + 2-layer transformer + fine matching) as ONE kernel (fine_fused.hip);
         # GIM_FINE_FUSED=0 keeps the unfused launch sequence (the only fine path of the fp32 parity mode)
         self.fine_fused = os.environ.get("GIM_FINE_FUSED", "1") != "0"
+        # bf16 mode, d_model 256: merge -> norm1 -> mlp -> norm2 -> residual of every coarse encoder layer as ONE kernel
+        # (token_mlp.hip); GIM_TOKEN_FUSED=0 keeps the five separate launches
+        self.token_fused = os.environ.get("GIM_TOKEN_FUSED", "1") != "0"
         self._packed = None
         self._packed_key = None
         self._pe_cache = {}
@@ -265,6 +268,9 @@ class LoFTR(nn.Module):
                     ln = getattr(layer, nm)
                     P[p + nm] = (ln.weight.detach().float().to(device).contiguous(),
                                  ln.bias.detach().float().to(device).contiguous(), ln.eps)
+        if dt == GIM_BF16 and self.loftr_coarse.d_model == 256:
+            for li, layer in enumerate(self.loftr_coarse.layers):
+                P[f"c{li}.tok"] = pack_token_mlp(layer, device)
         fl = self.loftr_fine
         if dt == GIM_BF16 and fl.d_model == 128 and fl.nhead == 8 and fl.layer_names == ["self", "cross"] and self.W == 5:
             P["fine_fused"] = pack_fine_fused(fl.layers, device) + (fl.layers[0].norm1.eps,)
@@ -356,6 +362,10 @@ class LoFTR(nn.Module):
         km = T.MASK[ss] if T.MASK is not None else None
         T.ws = ops.linear_attention(T.QKV[xs, :C], T.QKV[ss, C:2 * C], T.QKV[ss, 2 * C:], T.MSG[xs], nb, L, nb, S, H,
                                     T.ws, qm, km)
+        if self.token_fused and (p + "tok") in P:
+            wts, lnp, eps = P[p + "tok"]
+            ops.token_mlp(T.MSG[xs], T.CAT[xs, :C], T.X32[xs], wts, lnp, eps)   # x += norm2(mlp(cat[x, norm1(merge(msg))]))
+            return
         ops.linear(T.MSG[xs], P[p + "merge"], T.MRG[xs], ACT_NONE, dma)
         g1, b1, e1 = P[p + "norm1"]
         ops.layernorm_residual(T.MRG[xs], g1, b1, None, None, T.CAT[xs, C:], e1)

@@ -261,6 +261,16 @@ def fine_match(f0, f1, mkpts1_c, b_ids, scale1, M, WW, scale, has_scale0):
     return expec, mk1
 
 
+def token_mlp(msg, xb, x32, weights, ln_params, eps):
+    """x += norm2(mlp.2(relu(mlp.0(cat[x, norm1(merge(msg))])))) on row views: msg [R, >=256] bf16, xb [R, >=256] bf16 (operand copy
+    of x, updated in place), x32 [R, >=256] fp32 (updated in place)."""
+    _req_cuda(msg, xb, x32, weights, ln_params)
+    assert msg.dtype == torch.bfloat16 and xb.dtype == torch.bfloat16 and x32.dtype == torch.float32
+    assert msg.stride(1) == 1 and xb.stride(1) == 1 and x32.stride(1) == 1 and msg.shape[0] == xb.shape[0] == x32.shape[0]
+    check(lib.gim_token_mlp(_p(msg), _p(xb), _p(x32), _p(weights), _p(ln_params), msg.shape[0], 256, msg.stride(0), xb.stride(0),
+                            x32.stride(0), eps, _stream()), "gim_token_mlp")
+
+
 def fine_fused(feat_f0, feat_f1, b_ids, i_ids, j_ids, mkpts1_c, scale1, weights, ln_params, M, w0c, w1c, stride, W,
                scale, ln_eps, has_scale0, debug=False):
     """Whole fine level in one launch (bf16 fine maps).  Returns (expec_f [M,3], mkpts1_f [M,2], fine0, fine1) where

@@ -134,3 +134,38 @@ def pack_fine_fused(layers, device):
     w = torch.cat(ws).to(device).to(torch.bfloat16).contiguous()
     assert w.numel() * 2 == _lib.lib.gim_fine_fused_weight_bytes()
     return w, torch.cat(lns).to(device).contiguous()
+
+
+def _frag(w, n0, k0):
+    """MFMA fragment W[n0:n0+32, k0:k0+16] in lane order: lane = (k/8 % 2) * 32 + n -> 8 consecutive k."""
+    return w[n0:n0 + 32, k0:k0 + 16].reshape(32, 2, 8).permute(1, 0, 2).reshape(-1)
+
+
+def pack_token_mlp(layer, device):
+    """Weights of one coarse LoFTREncoderLayer's token-wise tail for gim_token_mlp: per wave w (output columns 64w.. of merge / mlp.2,
+    hidden columns 32w.. of every 128-column quarter) the fragments in the order the kernel consumes them:
+      merge:   4 units x (4 k16 steps x 2 column fragments)
+      quarter hq = 0..3:  mlp.0 rows 128hq + 32w..: 4 units x 8 k16 steps (K = [x | msg]);  mlp.2 cols 128hq..: 2 units x (4 k16 x 2)
+    Returns (bf16 weight stream, fp32 [norm1.weight | norm1.bias | norm2.weight | norm2.bias], eps)."""
+    f = lambda t: t.detach().float().cpu()  # noqa: E731
+    wm, w0, w2 = f(layer.merge.weight), f(layer.mlp[0].weight), f(layer.mlp[2].weight)
+    assert wm.shape == (256, 256) and w0.shape == (512, 512) and w2.shape == (256, 512)
+    out = []
+    for w in range(4):
+        for q in range(4):
+            for k in range(4):
+                for nf in range(2):
+                    out.append(_frag(wm, 64 * w + 32 * nf, 16 * (4 * q + k)))
+        for hq in range(4):
+            for q in range(4):
+                for k in range(8):
+                    out.append(_frag(w0, 128 * hq + 32 * w, 16 * (8 * q + k)))
+            for q in range(2):
+                for k in range(4):
+                    for nf in range(2):
+                        out.append(_frag(w2, 64 * w + 32 * nf, 128 * hq + 16 * (4 * q + k)))
+    wts = torch.cat(out).to(device).to(torch.bfloat16).contiguous()
+    assert wts.numel() * 2 == _lib.lib.gim_token_mlp_weight_bytes()
+    ln = torch.cat([f(layer.norm1.weight), f(layer.norm1.bias), f(layer.norm2.weight), f(layer.norm2.bias)]).to(device).contiguous()
+    assert layer.norm1.eps == layer.norm2.eps
+    return wts, ln, layer.norm1.eps

@@ -155,6 +155,16 @@ int gim_coarse_match(const gim_coarse_args* a, gim_stream_t stream);
  * needs the workspace of the preceding gim_coarse_match call (row/column softmax statistics). */
 int gim_coarse_conf_matrix(const gim_coarse_args* a, float* conf, gim_stream_t stream);
 
+/* Token-wise tail of a LoFTREncoderLayer in ONE kernel (bf16 operand mode, d_model 256; transformer.py:52-58):
+ *     x += norm2(mlp.2(relu(mlp.0(cat[x, norm1(merge(msg))]))))
+ * msg: [R][ldm] bf16 attention output; xb: [R][ldxb] bf16 operand copy of x (read, then overwritten with the new x);
+ * x32: [R][ldx32] fp32 residual stream (read-modify-write).  `weights`: gim_token_mlp_weight_bytes() bytes of bf16 in the
+ * per-wave fragment order of gim_amd/packing.py::pack_token_mlp; ln_params: [norm1.weight | norm1.bias | norm2.weight |
+ * norm2.bias] fp32.  64 rows per workgroup; none of the intermediate row buffers exists in memory. */
+int64_t gim_token_mlp_weight_bytes(void);
+int gim_token_mlp(const void* msg, void* xb, float* x32, const void* weights, const float* ln_params, int R, int C,
+                  int ldm, int ldxb, int ldx32, float ln_eps, gim_stream_t stream);
+
 /* --------------------------------------------------------------------------------------------
  * Fine level.  gim_fine_gather = F.unfold(k=W,stride,pad=W/2) + [b_ids,i_ids] pick
  * (submodules/fine_preprocess.py:40-47) without materialising the unfold: windows of image0 go to

@@ -1,0 +1,85 @@
+"""gim_token_mlp (merge -> norm1 -> mlp.0 -> relu -> mlp.2 -> norm2 -> residual of a coarse LoFTREncoderLayer in one kernel,
+transformer.py:52-58) against a plain torch fp32 restatement with the kernel's rounding points (bf16 operands, fp32 accumulation)
+and against the unfused launch sequence, incl. a row count that is not a multiple of the 64-row workgroup tile and strided
+row views (the operand copy of x lives in the [x | msg] concat buffer)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _layer(seed):
+    from gim_amd.loftr.loftr import _EncoderLayer
+    torch.manual_seed(seed)
+    layer = _EncoderLayer(256, 8)
+    with torch.no_grad():
+        for p in layer.parameters():
+            if p.dim() > 1:
+                torch.nn.init.xavier_uniform_(p)
+        for ln in (layer.norm1, layer.norm2):
+            ln.weight.copy_(0.75 + 0.5 * torch.rand(256))
+            ln.bias.copy_(0.1 * torch.randn(256))
+    return layer
+
+
+def _reference(layer, msg, x32):
+    bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    m = bf(msg) @ bf(layer.merge.weight).T
+    m = bf(F.layer_norm(m, (256,), layer.norm1.weight, layer.norm1.bias, layer.norm1.eps))
+    h = bf(F.relu(torch.cat([bf(x32), m], 1) @ bf(layer.mlp[0].weight).T))
+    o = h @ bf(layer.mlp[2].weight).T
+    return x32 + F.layer_norm(o, (256,), layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
+
+
+@pytest.mark.parametrize("R", [64, 200, 4800 * 2 + 7])
+def test_token_mlp_matches_reference(R):
+    from gim_amd import ops
+    from gim_amd.packing import pack_token_mlp
+    layer = _layer(R)
+    g = torch.Generator().manual_seed(R)
+    msg = (0.5 * torch.randn(R, 256, generator=g)).to(torch.bfloat16)
+    x32 = torch.randn(R, 256, generator=g) * 2.0
+    with torch.no_grad():
+        ref = _reference(layer, msg.float(), x32)
+    wts, ln, eps = pack_token_mlp(layer, "cuda")
+    cat = torch.zeros(R, 512, dtype=torch.bfloat16, device="cuda")      # [x | msg] buffer of the engine: x in the left half
+    cat[:, :256] = x32.cuda().to(torch.bfloat16)
+    cat[:, 256:] = 7.0                                                   # must stay untouched
+    xd = x32.cuda().clone()
+    ops.token_mlp(msg.cuda(), cat[:, :256], xd, wts, ln, eps)
+    torch.cuda.synchronize()
+    got = xd.cpu()
+    err = (got - ref).abs()
+    assert err.max() < 3e-2 and err.mean() < 2e-3, (err.max().item(), err.mean().item())
+    assert torch.equal(cat[:, :256].cpu(), got.to(torch.bfloat16))       # operand copy of the new x
+    assert bool((cat[:, 256:] == 7.0).all())
+
+
+def test_coarse_transformer_fused_vs_unfused_vs_oracle():
+    """8 coarse layers with and without the fused tail on the same tokens; both against the fp32 oracle."""
+    import loftr_oracle as O
+    from tools import synth_loftr as S
+    model, sd = S.synthetic_model("bf16")
+    model = model.cuda()
+    c0, c1 = S.textured_pairs(2, 96, 128, seed=2)
+    outs = {}
+    for fused in (True, False):
+        model.token_fused = fused
+        model.debug = {}
+        d = {"image0": c0[:, :1].cuda(), "image1": c1[:, :1].cuda(), "color0": c0.cuda(), "color1": c1.cuda()}
+        model(d)
+        outs[fused] = (model.debug["feat_c0"].float().cpu(), model.debug["feat_c1"].float().cpu())
+        model.debug = None
+    model.token_fused = True
+    with torch.no_grad():
+        fc, _ = O.backbone(sd, torch.cat([c0, c1], 0))
+        pe = O.position_encoding(256, 12, 16)
+        t = (fc + pe).flatten(2).transpose(1, 2)
+        r0, r1 = O.local_feature_transformer(sd, "loftr_coarse", t[:2], t[2:], 8, 4)
+    scale = r0.abs().max().item()
+    for k, ref in ((0, r0), (1, r1)):
+        ef = (outs[True][k] - ref).abs().mean().item() / scale
+        eu = (outs[False][k] - ref).abs().mean().item() / scale
+        assert ef < 1.5 * eu + 1e-3, (k, ef, eu)     # the fused tail is no further from the oracle than the unfused one
+        assert (outs[True][k] - outs[False][k]).abs().mean().item() / scale < 2 * eu + 1e-3

@@ -406,6 +406,13 @@ def main():
             parity = parity_vs_oracle(d_last, ref, 0)
             parity["note"] = (f"pair 0 of the timed batch: {args.precision} engine (coarse_sim={model.coarse_sim}) vs the fp32 CPU "
                               "oracle; flip_rate = |engine matches XOR oracle matches| / |oracle matches|")
+            if args.precision == "bf16":   # the same batch with the other similarity setting: is the operand rounding visible?
+                was = model.coarse_sim
+                model.coarse_sim = "fp32" if was == "bf16" else "bf16"
+                alt = parity_vs_oracle(step(), ref, 0)
+                parity["other_coarse_sim"] = {"coarse_sim": model.coarse_sim, "flip_rate": alt["flip_rate"],
+                                              "mean_abs_dmconf": alt.get("mean_abs_dmconf"), "mean_abs_dmkpts1_px": alt.get("mean_abs_dmkpts1_px")}
+                model.coarse_sim = was
 
     if rank == 0 and os.environ.get("GIM_BENCH_DEBUG"):
         print("per-step ms:", [round(1e3 * (b - a), 2) for a, b in zip([t0] + tstep[:-1], tstep)], file=sys.stderr)

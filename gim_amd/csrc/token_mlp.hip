@@ -4,6 +4,8 @@
 //     msg  = norm2(mlp.2(relu(mlp.0(cat[x, msg]))))                          transformer.py:55-57
 //     x   += msg                                                             transformer.py:58
 //
+// Optionally the attention's apply step runs in the prologue (msg = (Q KV) Z S from the query rows and the [32 x 32] per-head
+// state, attentions.py:44-45), so the attention output never exists in memory either.
 // ONE launch instead of merge GEMM -> LayerNorm -> mlp.0 GEMM -> mlp.2 GEMM -> LayerNorm+residual, and none of the five
 // intermediate row buffers (merge output, norm1 output, 512-wide hidden layer, mlp.2 output) touches HBM.  Everything after
 // the attention is row-local, so a 256-thread workgroup owns 64 token rows from the attention output to the updated stream:
@@ -35,7 +37,12 @@ constexpr int UNITS_PER_WAVE = 4 + 4 * (4 + 2);
 constexpr int UNIT_U4 = 8 * 64;      // uint4 per unit (8 fragments x 64 lanes x 16 B)
 
 struct Args {
-    const unsigned short* msg;   // [R][ldm] bf16 attention output
+    const float* kv;             // NULL: `msg` is the attention output.  Else: [nb][8][32*32 + 32] fp32 KV / Ksum state of the linear
+                                 // attention (gim_linear_attention_kv) and `msg` holds the elu+1 QUERY rows: the apply step runs here
+    const unsigned char* qmask;  // optional [R] padding mask of the query rows (attentions.py:36)
+    int L;                       // rows per sequence (kv != NULL: must be a multiple of 64, rows of a tile share one sequence)
+    float slen;                  // source length S (values were divided by it, attentions.py:41,45)
+    const unsigned short* msg;   // [R][ldm] bf16 attention output (or queries, see kv)
     unsigned short* xb;          // [R][ldxb] bf16 operand copy of x (in: x, out: x + msg)
     float* x32;                  // [R][ldx32] fp32 residual stream (in / out)
     const uint4* wts;            // 4 waves x 28 units x 8 fragments
@@ -186,6 +193,57 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
         }
     }
     __syncthreads();
+    if (a.kv) {
+        // ---- linear-attention apply (attentions.py:44-45), in place on A: this wave owns heads 2w, 2w+1 = channels 64w..64w+63, and
+        // nothing else reads or writes those columns.  msg[row, 32h + v] = S * Z[row,h] * sum_d Q[row, 32h + d] KV[h][d][v]  on the
+        // bf16 MFMA (KV rounded to bf16), Z = 1 / (Q . Ksum + eps) in fp32.
+        const float* kvb = a.kv + (size_t)(r0 / a.L) * 8 * (32 * 32 + 32);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int h = 2 * L.w + hh;
+            const float* KV = kvb + h * (32 * 32 + 32);
+            bf16x8_t kf[2];
+            float ksum[2][8];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float t[8];
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    t[p] = KV[(16 * ks + 8 * L.lh + p) * 32 + L.l31];          // A operand: m = v (l31), k = d
+                    ksum[ks][p] = KV[32 * 32 + 16 * ks + 8 * L.lh + p];
+                }
+                kf[ks] = __builtin_bit_cast(bf16x8_t, make_uint4(cvt_pk_bf16(t[0], t[1]), cvt_pk_bf16(t[2], t[3]), cvt_pk_bf16(t[4], t[5]), cvt_pk_bf16(t[6], t[7])));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16_t o;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] = 0.f;
+                float z = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int k16 = 2 * h + ks;   // k16 step of the 256-channel row
+                    const uint4 q = *(const uint4*)(A + (k16 >> 3) * 256 + L.a8[k16 & 7] + j * 32 * ROWB);
+                    const unsigned qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        z = fmaf(__uint_as_float(qq[p] << 16), ksum[ks][2 * p], z);
+                        z = fmaf(__uint_as_float(qq[p] & 0xffff0000u), ksum[ks][2 * p + 1], z);
+                    }
+                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], __builtin_bit_cast(bf16x8_t, q), o, 0, 0, 0);
+                }
+                z += __shfl_xor(z, 32, 64);
+                const int m = r0 + 32 * j + L.l31;
+                const bool valid = !a.qmask || (m < a.R && a.qmask[m]);
+                const float sc = valid ? a.slen * __builtin_amdgcn_rcpf(z + 1e-6f) : 0.f;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    *(uint2*)(A + (32 * j + L.l31) * ROWB + (((4 * h + rg) ^ L.sw) << 4) + L.lh * 8) =
+                        make_uint2(cvt_pk_bf16(o[rg * 4] * sc, o[rg * 4 + 1] * sc), cvt_pk_bf16(o[rg * 4 + 2] * sc, o[rg * 4 + 3] * sc));
+            }
+        }
+        __syncthreads();
+    }
     // ---- merge: [64 x 256] x W_merge^T, this wave's 64 output channels (transformer.py:52) ----------------------------
     f32x16_t acc[2][2];
     int u = 0;
@@ -279,12 +337,14 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
 
 extern "C" int64_t gim_token_mlp_weight_bytes(void) { return (int64_t)4 * UNITS_PER_WAVE * UNIT_U4 * 16; }
 
-extern "C" int gim_token_mlp(const void* msg, void* xb, float* x32, const void* weights, const float* ln_params, int R, int C_,
-                             int ldm, int ldxb, int ldx32, float ln_eps, gim_stream_t stream) {
+extern "C" int gim_token_mlp(const void* msg, void* xb, float* x32, const void* weights, const float* ln_params, const float* kv,
+                             const uint8_t* q_mask, int R, int C_, int L, int S, int ldm, int ldxb, int ldx32, float ln_eps,
+                             gim_stream_t stream) {
     if (R == 0) return GIM_OK;
     GIM_REQUIRE(msg && xb && x32 && weights && ln_params, "token_mlp: NULL pointer");
     GIM_REQUIRE(C_ == C, "token_mlp: built for d_model 256 (got %d)", C_);
     GIM_REQUIRE(R > 0 && ldm >= C && ldxb >= C && ldx32 >= C && ldm % 8 == 0 && ldxb % 8 == 0 && ldx32 % 4 == 0, "token_mlp: bad strides");
+    GIM_REQUIRE(!kv || (L > 0 && L % ROWS == 0 && R % L == 0 && S > 0), "token_mlp: fused attention apply needs L %% 64 == 0 and R %% L == 0 (L=%d R=%d)", L, R);
     static GimPerDevice attr;
     if (attr.needed()) {
         hipError_t e = hipFuncSetAttribute((const void*)token_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -292,6 +352,7 @@ extern "C" int gim_token_mlp(const void* msg, void* xb, float* x32, const void* 
         attr.done();
     }
     Args a;
+    a.kv = kv; a.qmask = q_mask; a.L = L > 0 ? L : R; a.slen = (float)S;
     a.msg = (const unsigned short*)msg; a.xb = (unsigned short*)xb; a.x32 = x32; a.wts = (const uint4*)weights; a.ln = ln_params;
     a.R = R; a.ldm = ldm; a.ldxb = ldxb; a.ldx32 = ldx32; a.eps = ln_eps;
     hipLaunchKernelGGL(token_mlp_kernel, dim3((unsigned)((R + ROWS - 1) / ROWS)), dim3(256), SMEM, (hipStream_t)stream, a);

@@ -18,11 +18,14 @@ Precision modes (`config['precision']`, default env GIM_PRECISION or 'bf16'):
   'bf16'  bf16 operands / fp32 accumulate for the backbone and the transformer GEMMs -- the throughput
           mode.  The token residual stream stays fp32 and coarse matching reads those fp32 tokens.
 
-Coarse similarity (`config['coarse_sim']`, default env GIM_COARSE_SIM or 'fp32'):
-  'fp32'  similarity of the fp32 tokens with fp32-exact products (the default in BOTH precision modes: on the
-          same features the mutual-NN indices equal the reference's fp32 arithmetic);
-  'bf16'  bf16 mode only: similarity of the bf16 operand copy of the tokens on the bf16 MFMA (faster, not
-          index-exact against fp32 features: an explicit, reported switch).
+Coarse similarity (`config['coarse_sim']`, env GIM_COARSE_SIM; default = the precision mode):
+  'fp32'  similarity of the fp32 tokens with fp32-exact products: on the same features the mutual-NN indices equal the
+          reference's fp32 arithmetic.  Always used by the fp32 mode; selectable in bf16 mode.
+  'bf16'  (bf16 mode only, its default) similarity of the bf16 operand copy of the tokens on the bf16 MFMA.  Measured on
+          match-rich 640x480 pairs against the fp32 oracle (profiles/r02_parity_probe.txt, tests/test_gpu_loftr_fullsize.py):
+          index flip rate 1.7-2.5 % with EITHER setting -- the flips come from the bf16 backbone / transformer, the
+          similarity's operand rounding adds nothing measurable -- at 0.47 instead of 1.17 ms per batch of 8.
+          bench.py reports the flip rate of both settings next to the throughput.
 """
 import collections
 import math
@@ -170,7 +173,7 @@ class LoFTR(nn.Module):
         if config["fine_concat_coarse_feat"]:
             raise NotImplementedError("fine_concat_coarse_feat=True is not used by gim_loftr and is not built")
         self.precision = _precision_from(config)
-        self.coarse_sim = (config.get("coarse_sim") or os.environ.get("GIM_COARSE_SIM") or "fp32").lower()
+        self.coarse_sim = (config.get("coarse_sim") or os.environ.get("GIM_COARSE_SIM") or self.precision).lower()
         if self.coarse_sim not in ("fp32", "bf16"):
             raise ValueError(f"coarse_sim must be 'fp32' or 'bf16', got {self.coarse_sim!r}")
         self.backbone = _ResNetFPN_8_2(config["resnetfpn"])
@@ -216,9 +219,10 @@ class LoFTR(nn.Module):
             self._graphs.clear()
         return super()._apply(fn, *a, **k)
 
-    def set_precision(self, precision):
+    def set_precision(self, precision, coarse_sim=None):
         assert precision in ("bf16", "fp32")
         self.precision = precision
+        self.coarse_sim = coarse_sim or precision
         self._packed = None
         self._graphs.clear()
         return self
@@ -360,9 +364,16 @@ class LoFTR(nn.Module):
             ops.linear(s_t, P[p + "kv"], T.QKV[ss, C:], ACT_ELU1, dma, act_cols=C)
         qm = T.MASK[xs] if T.MASK is not None else None  # x_mask / source_mask (transformer.py:50, attentions.py:35-39)
         km = T.MASK[ss] if T.MASK is not None else None
+        fused = self.token_fused and (p + "tok") in P
+        if fused and L % 64 == 0 and H == 8 and C == 256:
+            # KV / Ksum state of the source, then ONE kernel: attention apply + merge + norm1 + mlp + norm2 + residual
+            wts, lnp, eps = P[p + "tok"]
+            T.ws, _ = ops.linear_attention_state(T.QKV[ss, C:2 * C], T.QKV[ss, 2 * C:], nb, S, H, T.ws, km)
+            ops.token_mlp(T.QKV[xs, :C], T.CAT[xs, :C], T.X32[xs], wts, lnp, eps, kv=T.ws, L=L, S=S, q_mask=qm)
+            return
         T.ws = ops.linear_attention(T.QKV[xs, :C], T.QKV[ss, C:2 * C], T.QKV[ss, 2 * C:], T.MSG[xs], nb, L, nb, S, H,
                                     T.ws, qm, km)
-        if self.token_fused and (p + "tok") in P:
+        if fused:
             wts, lnp, eps = P[p + "tok"]
             ops.token_mlp(T.MSG[xs], T.CAT[xs, :C], T.X32[xs], wts, lnp, eps)   # x += norm2(mlp(cat[x, norm1(merge(msg))]))
             return

@@ -261,14 +261,28 @@ def fine_match(f0, f1, mkpts1_c, b_ids, scale1, M, WW, scale, has_scale0):
     return expec, mk1
 
 
-def token_mlp(msg, xb, x32, weights, ln_params, eps):
+def token_mlp(msg, xb, x32, weights, ln_params, eps, kv=None, L=0, S=0, q_mask=None):
     """x += norm2(mlp.2(relu(mlp.0(cat[x, norm1(merge(msg))])))) on row views: msg [R, >=256] bf16, xb [R, >=256] bf16 (operand copy
-    of x, updated in place), x32 [R, >=256] fp32 (updated in place)."""
-    _req_cuda(msg, xb, x32, weights, ln_params)
+    of x, updated in place), x32 [R, >=256] fp32 (updated in place).  With `kv` (the fp32 state of linear_attention_state) the
+    attention's apply step is fused in front: `msg` then holds the elu+1 query rows of R / L sequences, S = source length."""
+    _req_cuda(msg, xb, x32, weights, ln_params, kv, q_mask)
     assert msg.dtype == torch.bfloat16 and xb.dtype == torch.bfloat16 and x32.dtype == torch.float32
     assert msg.stride(1) == 1 and xb.stride(1) == 1 and x32.stride(1) == 1 and msg.shape[0] == xb.shape[0] == x32.shape[0]
-    check(lib.gim_token_mlp(_p(msg), _p(xb), _p(x32), _p(weights), _p(ln_params), msg.shape[0], 256, msg.stride(0), xb.stride(0),
-                            x32.stride(0), eps, _stream()), "gim_token_mlp")
+    check(lib.gim_token_mlp(_p(msg), _p(xb), _p(x32), _p(weights), _p(ln_params), _p(kv), _p(q_mask), msg.shape[0], 256, L, S,
+                            msg.stride(0), xb.stride(0), x32.stride(0), eps, _stream()), "gim_token_mlp")
+
+
+def linear_attention_state(k, v, nb_kv, S, H, ws=None, kv_mask=None):
+    """First half of linear_attention: KV / Ksum state of nb_kv sequences of S rows -> (fp32 state view [nb_kv*H*(D*D+D)], ws).
+    The state sits behind the per-chunk partials in the workspace when S spans several chunks (gim_linear_attention_kv)."""
+    _req_cuda(k, v, kv_mask)
+    D = k.shape[1] // H
+    need = lib.gim_linear_attention_ws_bytes(nb_kv, S, H, D)
+    if ws is None or ws.numel() * ws.element_size() < need:
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=k.device)
+    check(lib.gim_linear_attention_kv(_p(k), _p(v), _p(kv_mask), _p(ws), nb_kv, S, H, D, k.stride(0), v.stride(0),
+                                      gim_dtype(k), _stream()), "gim_linear_attention_kv")
+    return ws, need
 
 
 def fine_fused(feat_f0, feat_f1, b_ids, i_ids, j_ids, mkpts1_c, scale1, weights, ln_params, M, w0c, w1c, stride, W,

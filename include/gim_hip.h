@@ -160,10 +160,14 @@ int gim_coarse_conf_matrix(const gim_coarse_args* a, float* conf, gim_stream_t s
  * msg: [R][ldm] bf16 attention output; xb: [R][ldxb] bf16 operand copy of x (read, then overwritten with the new x);
  * x32: [R][ldx32] fp32 residual stream (read-modify-write).  `weights`: gim_token_mlp_weight_bytes() bytes of bf16 in the
  * per-wave fragment order of gim_amd/packing.py::pack_token_mlp; ln_params: [norm1.weight | norm1.bias | norm2.weight |
- * norm2.bias] fp32.  64 rows per workgroup; none of the intermediate row buffers exists in memory. */
+ * norm2.bias] fp32.  64 rows per workgroup; none of the intermediate row buffers exists in memory.
+ * kv != NULL fuses the apply step of the linear attention (attentions.py:44-45) in front: `msg` then holds the elu+1 QUERY rows,
+ * kv the [nb][8][32*32 + 32] fp32 state written by gim_linear_attention_kv (nb = R / L sequences of L rows, L % 64 == 0), S the
+ * source length, q_mask an optional [R] padding mask. */
 int64_t gim_token_mlp_weight_bytes(void);
-int gim_token_mlp(const void* msg, void* xb, float* x32, const void* weights, const float* ln_params, int R, int C,
-                  int ldm, int ldxb, int ldx32, float ln_eps, gim_stream_t stream);
+int gim_token_mlp(const void* msg, void* xb, float* x32, const void* weights, const float* ln_params, const float* kv,
+                  const uint8_t* q_mask, int R, int C, int L, int S, int ldm, int ldxb, int ldx32, float ln_eps,
+                  gim_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * Fine level.  gim_fine_gather = F.unfold(k=W,stride,pad=W/2) + [b_ids,i_ids] pick

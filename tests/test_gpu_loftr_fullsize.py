@@ -76,8 +76,7 @@ def test_bf16_batch8_flip_rate_vs_oracle(synth, pairs, oracle_two_pairs, coarse_
     """The benchmarked mode.  Bounds: flip rate <= 5 %, mean |d mkpts1_f| <= 0.02 px, max <= 1 px, on the common
     matches; measured 1.7-2.6 %, 0.006 px, 0.33 px (profiles/r02_parity_probe.txt)."""
     model, _ = synth
-    model.set_precision("bf16")
-    model.coarse_sim = coarse_sim
+    model.set_precision("bf16", coarse_sim)
     c0, c1 = pairs
     try:
         for _ in range(3):  # eager, capture, replay: the replayed graph is what bench.py times
@@ -93,7 +92,6 @@ def test_bf16_batch8_flip_rate_vs_oracle(synth, pairs, oracle_two_pairs, coarse_
             assert p["mean_abs_dmkpts1_px"] <= 0.02 and p["max_abs_dmkpts1_px"] <= 1.0, p
             assert p["mean_abs_dmconf"] <= 0.05, p
     finally:
-        model.coarse_sim = "fp32"
         model.set_precision("fp32")
 
 

@@ -83,3 +83,56 @@ def test_coarse_transformer_fused_vs_unfused_vs_oracle():
         eu = (outs[False][k] - ref).abs().mean().item() / scale
         assert ef < 1.5 * eu + 1e-3, (k, ef, eu)     # the fused tail is no further from the oracle than the unfused one
         assert (outs[True][k] - outs[False][k]).abs().mean().item() / scale < 2 * eu + 1e-3
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_token_mlp_with_fused_attention_apply(masked):
+    """kv != NULL: queries in, the apply step of the linear attention (attentions.py:44-45) runs in the kernel's prologue; against the
+    two-launch sequence (gim_linear_attention + gim_token_mlp) and the torch restatement, with and without padding masks."""
+    from gim_amd import ops
+    from gim_amd.packing import pack_token_mlp
+    import loftr_oracle as O
+    nb, L, S, H, C = 3, 128, 192, 8, 256
+    layer = _layer(5)
+    g = torch.Generator().manual_seed(5)
+    bf = lambda t: t.to(torch.bfloat16)  # noqa: E731
+    q = bf(torch.nn.functional.elu(torch.randn(nb * L, C, generator=g)) + 1)
+    k = bf(torch.nn.functional.elu(torch.randn(nb * S, C, generator=g)) + 1)
+    v = bf(torch.randn(nb * S, C, generator=g))
+    x32 = torch.randn(nb * L, C, generator=g) * 2.0
+    qm = km = None
+    if masked:
+        qm = (torch.rand(nb * L, generator=g) > 0.2).to(torch.uint8)
+        km = (torch.rand(nb * S, generator=g) > 0.2).to(torch.uint8)
+    wts, ln, eps = pack_token_mlp(layer, "cuda")
+    dev = "cuda"
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    qmd, kmd = (qm.to(dev), km.to(dev)) if masked else (None, None)
+    # reference sequence: attention output, then the unfused-prologue kernel
+    msg = torch.empty(nb * L, C, dtype=torch.bfloat16, device=dev)
+    ops.linear_attention(qd, kd, vd, msg, nb, L, nb, S, H, None, qmd, kmd)
+    xb_a = x32.to(dev).to(torch.bfloat16).contiguous()
+    xa = x32.to(dev).clone()
+    ops.token_mlp(msg, xb_a, xa, wts, ln, eps)
+    # fused
+    ws, _ = ops.linear_attention_state(kd, vd, nb, S, H, None, kmd)
+    xb_b = x32.to(dev).to(torch.bfloat16).contiguous()
+    xbf = x32.to(dev).clone()
+    ops.token_mlp(qd, xb_b, xbf, wts, ln, eps, kv=ws, L=L, S=S, q_mask=qmd)
+    torch.cuda.synchronize()
+    err = (xbf - xa).abs()
+    assert err.max() < 5e-2 and err.mean() < 3e-3, (err.max().item(), err.mean().item())
+    # torch restatement of the whole thing
+    with torch.no_grad():
+        m = O.linear_attention(torch.zeros(0), torch.zeros(0), torch.zeros(0)) if False else None
+        Q, K, V = q.float().view(nb, L, H, 32), k.float().view(nb, S, H, 32), v.float().view(nb, S, H, 32)
+        if masked:
+            Q = Q * qm.view(nb, L, 1, 1)
+            K = K * km.view(nb, S, 1, 1)
+            V = V * km.view(nb, S, 1, 1)
+        KV = torch.einsum("nshd,nshv->nhdv", K, V / S)
+        Z = 1 / (torch.einsum("nlhd,nhd->nlh", Q, K.sum(1)) + 1e-6)
+        att = (torch.einsum("nlhd,nhdv,nlh->nlhv", Q, KV, Z) * S).reshape(nb * L, C)
+        ref = _reference(layer, att, x32)
+    err = (xbf.cpu() - ref).abs()
+    assert err.max() < 5e-2 and err.mean() < 3e-3, (err.max().item(), err.mean().item())

@@ -26,8 +26,7 @@ q = torch.quantile(ref["mconf"], torch.tensor([0.05, 0.25, 0.5, 0.75]))
 print("oracle mconf quantiles", [round(float(x), 3) for x in q])
 model = model.cuda()
 for prec, sim in (("fp32", "fp32"), ("bf16", "fp32"), ("bf16", "bf16")):
-    model.set_precision(prec)
-    model.coarse_sim = sim
+    model.set_precision(prec, sim)
     for use_graph in (False,):
         model.use_graph = use_graph
         d = {"image0": c0[:, :1].cuda(), "image1": c1[:, :1].cuda(), "color0": c0.cuda(), "color1": c1.cuda()}

@@ -18,15 +18,27 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"{root}/gpurun_out/pmc_{c}/**/*counter_collection.csv", recursive=True)
     if not f:
         print("missing", c, open(f"{root}/gpurun_out/pmc_{c}/log.txt").read()[-1500:]); sys.exit(1)
-    tot, n = 0.0, 0
+    tot, n, allk = 0.0, 0, collections.defaultdict(float)
     for r in csv.DictReader(open(f[0])):
-        if "igemm" in r["Kernel_Name"] and r["Counter_Name"] == c:
+        if r["Counter_Name"] != c:
+            continue
+        nm = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+        allk[nm.split("<")[0].split("(")[0][-48:]] += float(r["Counter_Value"])
+        if "igemm" in r["Kernel_Name"]:
             tot += float(r["Counter_Value"]); n += 1
     res[c] = (tot, n)
+    res[c + "_all"] = allk
 nl = res["FETCH_SIZE"][1]
 fetch_b = res["FETCH_SIZE"][0] * 1024 * 2.0   # gfx950 correction (see header)
 write_b = res["WRITE_SIZE"][0] * 1024
-out = {"workload": "gim_loftr 640x480 batch 8 bf16, 3 forwards, eager launches", "igemm_launches": nl,
+NF = 3  # forwards in the run (tools/prof_forward.py 3)
+per_kernel = {}
+for k in set(res["FETCH_SIZE_all"]) | set(res["WRITE_SIZE_all"]):
+    per_kernel[k] = round((res["FETCH_SIZE_all"].get(k, 0.0) * 2048 + res["WRITE_SIZE_all"].get(k, 0.0) * 1024) / NF / 1e9, 3)
+out = {"workload": "gim_loftr 640x480 batch 8 bf16, match-rich synthetic pairs (bench.py workload), 3 forwards, eager launches", "igemm_launches": nl,
+       "total_gb_per_forward_all_kernels": round(sum(per_kernel.values()), 2),
+       "igemm_gb_per_forward": round((fetch_b + write_b) / NF / 1e9, 2),
+       "gb_per_forward_by_kernel": dict(sorted(per_kernel.items(), key=lambda kv: -kv[1])[:12]),
        "fetch_bytes_per_launch": fetch_b / nl, "write_bytes_per_launch": write_b / res["WRITE_SIZE"][1],
        "traffic_bytes_per_launch": fetch_b / nl + write_b / res["WRITE_SIZE"][1],
        "fetch_correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 counts 64 B per 128-B request)",

@@ -1,13 +1,15 @@
-"""N plain forwards of gim_loftr (batch 8, 640x480, bf16) for rocprofv3 --kernel-trace --stats."""
+"""N plain forwards of the benchmarked gim_loftr workload (batch 8, 640x480, bf16, match-rich synthetic pairs: tools/synth_loftr.py)
+for rocprofv3 --kernel-trace / --pmc runs."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gim_amd.loftr import LoFTR, get_cfg_defaults, lower_config
+from tools import synth_loftr as S
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-torch.manual_seed(0)
-cfg = lower_config(get_cfg_defaults())["loftr"]; cfg["precision"] = "bf16"
-m = LoFTR(cfg).eval().cuda()
-g = torch.Generator().manual_seed(1234)
-c0 = torch.rand(8, 3, 480, 640, generator=g).cuda(); c1 = torch.rand(8, 3, 480, 640, generator=g).cuda()
+m, _ = S.synthetic_model("bf16")
+m = m.cuda()
+c0, c1 = S.textured_pairs(8, 480, 640, seed=1234, frac=0.45)
+c0, c1 = c0.cuda(), c1.cuda()
 for _ in range(n):
-    m({"image0": c0[:, :1], "image1": c1[:, :1], "color0": c0, "color1": c1})
+    d = {"image0": c0[:, :1], "image1": c1[:, :1], "color0": c0, "color1": c1}
+    m(d)
 torch.cuda.synchronize()
+print("matches per pair", d["b_ids"].numel() / 8)

@@ -71,6 +71,7 @@ PROTOTYPES = {
     "gim_coarse_conf_matrix": (c_int, [ctypes.POINTER(CoarseArgs), c_void_p, c_void_p]),
     "gim_fine_gather": (c_int, [c_void_p] * 7 + [c_int] * 14 + [c_void_p]),
     "gim_fine_match": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_float, c_int, c_void_p]),
+    "gim_bneck64_fused": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p]),
     "gim_token_mlp_weight_bytes": (c_int64, []),
     "gim_token_mlp": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_float, c_void_p]),
     "gim_fine_fused_weight_bytes": (c_int64, []),

@@ -36,7 +36,7 @@ import torch.nn as nn
 
 from .. import ops
 from .._lib import ACT_ELU1, ACT_LEAKY, ACT_NONE, ACT_RELU, GIM_BF16, GIM_F32, GimHipError
-from ..packing import cstore, pack_conv, pack_fine_fused, pack_token_mlp, torch_dtype
+from ..packing import cstore, pack_bneck, pack_conv, pack_fine_fused, pack_token_mlp, torch_dtype
 
 
 # --------------------------------------------------------------------------------------------------
@@ -187,6 +187,9 @@ class LoFTR(nn.Module):
         # bf16 mode, d_model 256: merge -> norm1 -> mlp -> norm2 -> residual of every coarse encoder layer as ONE kernel
         # (token_mlp.hip); GIM_TOKEN_FUSED=0 keeps the five separate launches
         self.token_fused = os.environ.get("GIM_TOKEN_FUSED", "1") != "0"
+        # bf16 mode, layer1 (planes 64): conv2 -> conv3 (+identity) -> the next block's conv1 chained through registers
+        # (bneck_fused.hip); GIM_BNECK_FUSED=0 keeps one implicit-GEMM launch per convolution
+        self.bneck_fused = os.environ.get("GIM_BNECK_FUSED", "1") != "0"
         self._packed = None
         self._packed_key = None
         self._pe_cache = {}
@@ -249,6 +252,10 @@ class LoFTR(nn.Module):
                 if blk.downsample is not None:
                     P[p + "ds"] = pack_conv(blk.downsample[0].weight, self._bn(blk.downsample[1]), dt, device,
                                             stride=blk.stride)
+        if dt == GIM_BF16:
+            l1 = list(enc.layer1)
+            for bi, blk in enumerate(l1):   # the last block's trailing conv1 is layer2's first one (256 -> 128, same resolution)
+                P[f"l1.{bi}.fused"] = pack_bneck(blk, l1[bi + 1] if bi + 1 < len(l1) else enc.layer2[0], device)
         bb = self.backbone
         P["l3o"] = pack_conv(bb.layer3_outconv.weight, None, dt, device)
         P["l2o"] = pack_conv(bb.layer2_outconv.weight, None, dt, device)
@@ -317,13 +324,20 @@ class LoFTR(nn.Module):
         dma = self.use_lds_dma
         x = ops.conv2d(x, P["stem"], ACT_RELU, lds_dma=dma)
         feats = []
+        o = None   # conv1 output of the upcoming block when the previous fused kernel already produced it
         for li, nblk in ((1, 3), (2, 4), (3, 6)):
+            fuse = li == 1 and self.bneck_fused and "l1.0.fused" in P and x.shape[1] % 8 == 0 and x.shape[2] % 32 == 0
             for bi in range(nblk):
                 p = f"l{li}.{bi}."
-                o = ops.conv2d(x, P[p + "c1"], ACT_RELU, lds_dma=dma)
-                o = ops.conv2d(o, P[p + "c2"], ACT_RELU, lds_dma=dma)
+                if o is None:
+                    o = ops.conv2d(x, P[p + "c1"], ACT_RELU, lds_dma=dma)
                 idn = ops.conv2d(x, P[p + "ds"], ACT_NONE, lds_dma=dma) if (p + "ds") in P else x
+                if fuse:   # conv2 -> conv3 + identity -> the next conv1 (of this layer, or layer2's first), one kernel
+                    x, o = ops.bneck64(o, idn, P[p + "fused"], True)
+                    continue
+                o = ops.conv2d(o, P[p + "c2"], ACT_RELU, lds_dma=dma)
                 x = ops.conv2d(o, P[p + "c3"], ACT_RELU, res=idn, lds_dma=dma)
+                o = None
             feats.append(x)
         x1, x2, x3 = feats
         x3_out = ops.conv2d(x3, P["l3o"], lds_dma=dma)

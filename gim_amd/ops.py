@@ -261,6 +261,22 @@ def fine_match(f0, f1, mkpts1_c, b_ids, scale1, M, WW, scale, has_scale0):
     return expec, mk1
 
 
+def bneck64(t1, res, pk, want_next):
+    """Fused Bottleneck tail (+ the next conv1): t1 [B,H,W,64] bf16, res [B,H,W,256] bf16 -> (x' [B,H,W,256], t1' [B,H,W,N1] or None).
+    pk = packing.pack_bneck(...); N1 = 64 (next block of the layer) or 128 (the next layer's first conv1) from the packed weights."""
+    _req_cuda(t1, res)
+    assert t1.dtype == torch.bfloat16 and res.dtype == torch.bfloat16 and t1.is_contiguous() and res.is_contiguous()
+    B, H, W, _ = t1.shape
+    w2, w3, w1n, b2, b3, b1n = pk
+    n1 = w1n.shape[0] if (want_next and w1n is not None) else 0
+    assert not want_next or n1 in (64, 128)
+    xo = torch.empty(B, H, W, 256, dtype=torch.bfloat16, device=t1.device)
+    t1n = torch.empty(B, H, W, n1, dtype=torch.bfloat16, device=t1.device) if n1 else None
+    check(lib.gim_bneck64_fused(_p(t1), _p(res), _p(xo), _p(t1n), _p(w2), _p(w3), _p(w1n if n1 else None), _p(b2), _p(b3),
+                                _p(b1n if n1 else None), B, H, W, n1, _stream()), "gim_bneck64_fused")
+    return xo, t1n
+
+
 def token_mlp(msg, xb, x32, weights, ln_params, eps, kv=None, L=0, S=0, q_mask=None):
     """x += norm2(mlp.2(relu(mlp.0(cat[x, norm1(merge(msg))])))) on row views: msg [R, >=256] bf16, xb [R, >=256] bf16 (operand copy
     of x, updated in place), x32 [R, >=256] fp32 (updated in place).  With `kv` (the fp32 state of linear_attention_state) the

@@ -169,3 +169,32 @@ def pack_token_mlp(layer, device):
     ln = torch.cat([f(layer.norm1.weight), f(layer.norm1.bias), f(layer.norm2.weight), f(layer.norm2.bias)]).to(device).contiguous()
     assert layer.norm1.eps == layer.norm2.eps
     return wts, ln, layer.norm1.eps
+
+
+def _acc_order(k):
+    """Column permutation that brings a weight's K axis into MFMA accumulator order: position 16s + 8lh + p of the packed row holds
+    input channel 32(s >> 1) + 16(s & 1) + 8(p >> 2) + 4lh + (p & 3) -- what lane-half lh of a 32x32 accumulator fragment holds
+    for k16 step s after two v_cvt_pk per quad (csrc/bneck_fused.hip)."""
+    q = torch.arange(k)
+    s_, lh, p = q // 16, (q // 8) % 2, q % 8
+    return 32 * (s_ // 2) + 16 * (s_ % 2) + 8 * (p // 4) + 4 * lh + (p % 4)
+
+
+def pack_bneck(blk, nxt, device):
+    """gim_bneck64_fused operands of Bottleneck `blk` (conv2/bn2, conv3/bn3) and, if given, the next block's conv1/bn1:
+    (w2 [64][576] bf16 K=(ky,kx,c), w3 [256][64] bf16 K in accumulator order, w1n [64 or 128][256] bf16 or None, b2, b3, b1n fp32)."""
+    bn = lambda m: (m.weight, m.bias, m.running_mean, m.running_var, m.eps)  # noqa: E731
+    w2, b2 = fold_bn(blk.conv2.weight, bn(blk.bn2))
+    w3, b3 = fold_bn(blk.conv3.weight, bn(blk.bn3))
+    assert tuple(w2.shape) == (64, 64, 3, 3) and tuple(w3.shape) == (256, 64, 1, 1) and blk.conv2.stride == (1, 1)
+    to = lambda t: t.to(device).to(torch.bfloat16).contiguous()  # noqa: E731
+    w2p = to(w2.permute(0, 2, 3, 1).reshape(64, 576).cpu())
+    w3p = to(w3.reshape(256, 64).cpu()[:, _acc_order(64)])
+    w1p = b1 = None
+    if nxt is not None:
+        w1, b1 = fold_bn(nxt.conv1.weight, bn(nxt.bn1))
+        n1 = w1.shape[0]
+        assert tuple(w1.shape) == (n1, 256, 1, 1) and n1 in (64, 128)
+        w1p = to(w1.reshape(n1, 256).cpu()[:, _acc_order(256)])
+        b1 = b1.float().to(device).contiguous()
+    return w2p, w3p, w1p, b2.float().to(device).contiguous(), b3.float().to(device).contiguous(), b1

@@ -155,6 +155,17 @@ int gim_coarse_match(const gim_coarse_args* a, gim_stream_t stream);
  * needs the workspace of the preceding gim_coarse_match call (row/column softmax statistics). */
 int gim_coarse_conf_matrix(const gim_coarse_args* a, float* conf, gim_stream_t stream);
 
+/* Tail of a ResNet Bottleneck (planes 64) fused with the head of the next block (resnet.py:109-126), one kernel:
+ *     x' = relu(bn3(conv3(relu(bn2(conv2_3x3(t1))))) + identity);   t1' = relu(bn1'(conv1'(x')))   (optional)
+ * t1: [B,H,W,64] bf16 (the block's conv1 output), res: [B,H,W,256] bf16 identity / downsample branch, x_out: [B,H,W,256],
+ * t1_next: [B,H,W,n_next] or NULL (n_next = 64: the next block of the layer; 128: the next layer's first conv1; 0: none).
+ * Weights bf16 with eval-BN folded in (biases fp32): w2 [64][576] with K = (ky, kx, c);
+ * w3 [256][64] and w1n [n_next][256] with K permuted to the MFMA accumulator layout (gim_amd/packing.py::pack_bneck) -- the three
+ * products are chained through registers.  H % 8 == 0, W % 32 == 0. */
+int gim_bneck64_fused(const void* t1, const void* res, void* x_out, void* t1_next, const void* w2, const void* w3,
+                      const void* w1n, const float* b2, const float* b3, const float* b1n, int B, int H, int W,
+                      int n_next, gim_stream_t stream);
+
 /* Token-wise tail of a LoFTREncoderLayer in ONE kernel (bf16 operand mode, d_model 256; transformer.py:52-58):
  *     x += norm2(mlp.2(relu(mlp.0(cat[x, norm1(merge(msg))]))))
  * msg: [R][ldm] bf16 attention output; xb: [R][ldxb] bf16 operand copy of x (read, then overwritten with the new x);

@@ -191,12 +191,19 @@ def main():
     if rank == 0:
         graph_was, model.use_graph = model.use_graph, False  # events need eager launches
         step()
-        ops.PROFILE = []
+        ops.PROFILE, ops.PROFILE_FUSED = [], []
         for _ in range(2):
             step()
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
+        fprof, ops.PROFILE_FUSED = ops.PROFILE_FUSED, None
         model.use_graph = graph_was
+        fam = {}
+        for e0, e1, f, name in fprof:
+            ms, fl, n = fam.get(name, (0.0, 0.0, 0))
+            fam[name] = (ms + e0.elapsed_time(e1), fl + f, n + 1)
+        fused = {k: {"launches_per_step": v[2] // 2, "ms_per_step": round(v[0] / 2, 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1)}
+                 for k, v in fam.items()}
         tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in prof)
         tot_fl = sum(f for _, _, f, _ in prof)
         nlaunch = len(prof)
@@ -218,6 +225,7 @@ def main():
                 "avg_launch_us": round(1e3 * tot_ms / nlaunch, 2),
                 "gflop_per_launch": round(tot_fl / nlaunch / 1e9, 3),
                 "kernel_ms_per_step": round(tot_ms / 2, 3),
+                "fused_kernels": fused,   # the hand-fused kernels that took work OUT of the implicit-GEMM kernel (same live HIP-event timing)
                 "top_layers_ms_tflops": [[k, round(v[0] / 2, 3), round(v[1] / (v[0] * 1e-3) / 1e12, 1)] for k, v in top]}
 
     # ---- the same step with the images starting in (pinned) host memory: PCIe-inclusive rate -------------

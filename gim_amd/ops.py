@@ -15,10 +15,31 @@ _DT = {torch.float32: GIM_F32, torch.bfloat16: GIM_BF16}
 # When set to a list, every gim_conv2d_bn_act launch is bracketed by HIP events recorded on the launch
 # stream and (start, end, algorithmic_flops, label) is appended -- bench.py's live roofline measurement.
 PROFILE = None
+PROFILE_FUSED = None
 
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Timed:
+    """bench.py's live measurement of the fused kernels: HIP events on the launch stream around one C-ABI call, appended to
+    PROFILE_FUSED as (start, end, algorithmic_flops, kernel family) when that list is set."""
+
+    def __init__(self, family, flops):
+        self.family, self.flops = family, flops
+
+    def __enter__(self):
+        if PROFILE_FUSED is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE_FUSED is not None:
+            self.e1.record()
+            PROFILE_FUSED.append((self.e0, self.e1, self.flops, self.family))
+        return False
 
 
 def _p(t):
@@ -272,8 +293,9 @@ def bneck64(t1, res, pk, want_next):
     assert not want_next or n1 in (64, 128)
     xo = torch.empty(B, H, W, 256, dtype=torch.bfloat16, device=t1.device)
     t1n = torch.empty(B, H, W, n1, dtype=torch.bfloat16, device=t1.device) if n1 else None
-    check(lib.gim_bneck64_fused(_p(t1), _p(res), _p(xo), _p(t1n), _p(w2), _p(w3), _p(w1n if n1 else None), _p(b2), _p(b3),
-                                _p(b1n if n1 else None), B, H, W, n1, _stream()), "gim_bneck64_fused")
+    with _Timed("bneck64_fused", 2.0 * B * H * W * (576 * 64 + 64 * 256 + 256 * n1)):
+        check(lib.gim_bneck64_fused(_p(t1), _p(res), _p(xo), _p(t1n), _p(w2), _p(w3), _p(w1n if n1 else None), _p(b2), _p(b3),
+                                    _p(b1n if n1 else None), B, H, W, n1, _stream()), "gim_bneck64_fused")
     return xo, t1n
 
 
@@ -284,8 +306,9 @@ def token_mlp(msg, xb, x32, weights, ln_params, eps, kv=None, L=0, S=0, q_mask=N
     _req_cuda(msg, xb, x32, weights, ln_params, kv, q_mask)
     assert msg.dtype == torch.bfloat16 and xb.dtype == torch.bfloat16 and x32.dtype == torch.float32
     assert msg.stride(1) == 1 and xb.stride(1) == 1 and x32.stride(1) == 1 and msg.shape[0] == xb.shape[0] == x32.shape[0]
-    check(lib.gim_token_mlp(_p(msg), _p(xb), _p(x32), _p(weights), _p(ln_params), _p(kv), _p(q_mask), msg.shape[0], 256, L, S,
-                            msg.stride(0), xb.stride(0), x32.stride(0), eps, _stream()), "gim_token_mlp")
+    with _Timed("token_mlp", 2.0 * msg.shape[0] * (256 * 256 + 512 * 512 + 512 * 256 + (32 * 256 if kv is not None else 0))):
+        check(lib.gim_token_mlp(_p(msg), _p(xb), _p(x32), _p(weights), _p(ln_params), _p(kv), _p(q_mask), msg.shape[0], 256, L, S,
+                                msg.stride(0), xb.stride(0), x32.stride(0), eps, _stream()), "gim_token_mlp")
 
 
 def linear_attention_state(k, v, nb_kv, S, H, ws=None, kv_mask=None):
@@ -315,9 +338,10 @@ def fine_fused(feat_f0, feat_f1, b_ids, i_ids, j_ids, mkpts1_c, scale1, weights,
     d0 = torch.empty(M, W * W, C, dtype=torch.float32, device=dev) if debug else None
     d1 = torch.empty(M, W * W, C, dtype=torch.float32, device=dev) if debug else None
     assert weights.numel() * weights.element_size() == lib.gim_fine_fused_weight_bytes()
-    check(lib.gim_fine_fused(_p(feat_f0), _p(feat_f1), _p(b_ids), _p(i_ids), _p(j_ids), _p(mkpts1_c), _p(scale1),
-                             _p(weights), _p(ln_params), _p(expec), _p(mk1), _p(d0), _p(d1), M, hf0, wf0, hf1, wf1, C, C,
-                             w0c, w1c, stride, W, scale, ln_eps, 1 if has_scale0 else 0, _stream()), "gim_fine_fused")
+    with _Timed("fine_fused", 33.6e6 * M):   # 33.6 MFLOP per match
+        check(lib.gim_fine_fused(_p(feat_f0), _p(feat_f1), _p(b_ids), _p(i_ids), _p(j_ids), _p(mkpts1_c), _p(scale1),
+                                 _p(weights), _p(ln_params), _p(expec), _p(mk1), _p(d0), _p(d1), M, hf0, wf0, hf1, wf1, C, C,
+                                 w0c, w1c, stride, W, scale, ln_eps, 1 if has_scale0 else 0, _stream()), "gim_fine_fused")
     return expec, mk1, d0, d1
 
 

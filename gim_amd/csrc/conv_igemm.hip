@@ -158,7 +158,7 @@ struct Epilogue {
         const int lane = threadIdx.x & 63;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         l31 = lane & 31; lh = lane >> 5;
-        wm = wave / WN; wn = wave - wm * WN;
+        G::wave_mn(wave, wm, wn);
         rrow = lane / LPR; rslot = lane % LPR;
     }
 
@@ -312,7 +312,11 @@ __device__ __forceinline__ gim::MainloopArgs mainloop_args(const gim_conv_args& 
 // while slab s is on the MFMAs, the LDS-DMA of slab s+1 (possibly the first slab of the *next* tile) and
 // the residual rows of the current tile are already in flight, and the stores of the previous tile's
 // epilogue drain in the background.
-template <int BM, int BN, int WM, int WN, bool BF16, bool OUT_BF16, bool HAS_RES>
+template <int N> struct IntC { static constexpr int value = N; };
+
+// SKIP: waves whose last 32-channel fragment lies entirely beyond N run a K loop without it (a second copy of the loop,
+// selected per tile by a wave-uniform branch; see Igemm::mma)
+template <int BM, int BN, int WM, int WN, bool BF16, bool OUT_BF16, bool HAS_RES, bool SKIP = false>
 __global__ void __launch_bounds__(WM * WN * 64, 2)  // 2 waves per SIMD: 2 x 4-wave or 1 x 8-wave workgroup per CU
 igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntiles, const int M) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -344,20 +348,29 @@ igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntile
         const int m0n = (int)(tile_n / ntiles) * BM, n0n = (int)(tile_n % ntiles) * BN;
         if (has_next) gn.decode(ml, m0n, n0n);
         // ---- K loop: only MFMAs touch the accumulators in here ------------------------------------------
-        for (int kt = 0; kt < nkt; ++kt) {
-            const bool last = kt + 1 == nkt;
-            int k2 = kt + 2;
-            if (k2 >= nkt) k2 -= nkt;
-            if (k2 >= nkt) k2 = 0;  // nkt == 1
-            const int e_n2 = a.ktab[G::ktab_index(k2)];
-            if (!last) g.stage_issue(ml, smem, buf ^ 1, kt + 1, e_nxt);
-            else if (has_next) gn.stage_issue(ml, smem, buf ^ 1, 0, e_nxt);  // first slab of the next tile
-            if (last) epi.prefetch_res(a, rres, m0, n0, M);
-            G::compute(smem, buf, acc);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            buf ^= 1;
-            e_nxt = e_n2;
+        auto kloop = [&](auto live) __attribute__((always_inline)) {
+            for (int kt = 0; kt < nkt; ++kt) {
+                const bool last = kt + 1 == nkt;
+                int k2 = kt + 2;
+                if (k2 >= nkt) k2 -= nkt;
+                if (k2 >= nkt) k2 = 0;  // nkt == 1
+                const int e_n2 = a.ktab[G::ktab_index(k2)];
+                if (!last) g.stage_issue(ml, smem, buf ^ 1, kt + 1, e_nxt);
+                else if (has_next) gn.stage_issue(ml, smem, buf ^ 1, 0, e_nxt);  // first slab of the next tile
+                if (last) epi.prefetch_res(a, rres, m0, n0, M);
+                G::template compute<decltype(live)::value>(smem, buf, acc);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                buf ^= 1;
+                e_nxt = e_n2;
+            }
+        };
+        if constexpr (SKIP && G::TN > 1) {
+            // the wave's last channel fragment holds only padding channels (wave-uniform)
+            if (n0 + epi.wn * G::WTN + (G::TN - 1) * 32 >= a.N) kloop(IntC<G::TN - 1>());
+            else kloop(IntC<G::TN>());
+        } else {
+            kloop(IntC<G::TN>());
         }
         epi.run(a, acc, rres, smem + (buf ^ 1) * G::STAGE, m0, n0, M);  // buf ^ 1: the stage just consumed
         epi.init_acc(a, acc, n0n < a.npad ? n0n : 0);
@@ -366,6 +379,7 @@ igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntile
         __syncthreads();  // the transposition tile lives in a stage buffer the next slab's DMA will overwrite
     }
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // Deep-prefetch variant for the MFMA-bound layers: 8 waves (4 x 2), 256 x 128 tile, THREE LDS stages of
@@ -448,10 +462,10 @@ igemm_ring3_kernel(const gim_conv_args a, const int mtiles, const int ntiles, co
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool BF16, bool OUT_BF16, bool HAS_RES>
+template <int BM, int BN, int WM, int WN, bool BF16, bool OUT_BF16, bool HAS_RES, bool SKIP = false>
 int launch_persistent(const gim_conv_args& a, hipStream_t stream) {
     constexpr int smem = 2 * (BM + BN) * KTB;
-    auto kern = igemm_persistent_kernel<BM, BN, WM, WN, BF16, OUT_BF16, HAS_RES>;
+    auto kern = igemm_persistent_kernel<BM, BN, WM, WN, BF16, OUT_BF16, HAS_RES, SKIP>;
     static GimPerDevice attr_done;
     if (attr_done.needed()) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -508,6 +522,7 @@ static int big_mode() {
     return mode;
 }
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static int skip_mode() { static const int v = env_int("GIM_IGEMM_SKIP", 1); return v; }
 static int big_min_tiles() { static const int v = env_int("GIM_IGEMM_BIG_MIN_TILES", 512); return v; }
 static int big_min_nkt() { static const int v = env_int("GIM_IGEMM_BIG_MIN_NKT", 4); return v; }
 
@@ -536,7 +551,12 @@ int dispatch_persistent(const gim_conv_args& a, hipStream_t s) {
         const int bmode = big_mode();
         if (a.npad % 256 == 0 && a.out_dtype == GIM_BF16 && !a.res &&
             (bmode == 2 || (bmode == 1 && nkt >= big_min_nkt() && ((M + 255) / 256) * (a.npad / 256) >= big_min_tiles())))
+        {
+            // N <= 224 (the FPN's 196-channel layers): the second column half's last fragment is pure padding
+            const bool skip = a.N <= a.npad - 32 && skip_mode();
+            if (skip) return launch_persistent<256, 256, 4, 2, BF16, true, false, true>(a, s);
             return launch_persistent<256, 256, 4, 2, BF16, true, false>(a, s);
+        }
         // (a 512 x 128 tile with 128 x 64 wave tiles for the N = 128 layers measured slower than 128 x 128: 875 vs 716 us
         //  on 196->128 3x3 -- not built)
         const int mode = ring3_mode();

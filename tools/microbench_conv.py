@@ -23,6 +23,7 @@ ap.add_argument("--act", default="relu")
 ap.add_argument("--dma", type=int, default=1)
 ap.add_argument("--precision", default="bf16")
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--ldx", type=int, default=0, help="pixel stride of the input in elements (default: cin_pad)")
 ap.add_argument("--copy", type=int, default=0, help="also time a plain device copy of the output tensor")
 a = ap.parse_args()
 dt = _lib.GIM_BF16 if a.precision == "bf16" else _lib.GIM_F32
@@ -35,6 +36,16 @@ Ho = (a.H + 2 * (a.k // 2) - a.k) // a.stride + 1
 Wo = (a.W + 2 * (a.k // 2) - a.k) // a.stride + 1
 res = torch.randn(a.B, Ho, Wo, pk.n_store, generator=g).to(torch_dtype(dt)).to(dev) if a.res else None
 act = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "leaky": ops.ACT_LEAKY}[a.act]
+if a.ldx:
+    xf = torch.zeros(a.B, a.H, a.W, a.ldx, dtype=x.dtype, device=dev)
+    xf[..., :pk.cin_pad] = x
+    xr = xf.view(-1, a.ldx)[:, :pk.cin_pad]
+    yb = torch.empty(a.B, Ho, Wo, pk.n_store, dtype=x.dtype, device=dev)
+    _conv = ops.conv2d
+    def conv2d(x_, pk_, act_, res=None, lds_dma=True):
+        ops.conv_rows(xr, pk_, (a.B, a.H, a.W, Ho, Wo), yb.view(-1, pk_.n_store), act_, res.view(-1, res.shape[-1]) if res is not None else None, 0, lds_dma)
+        return yb
+    ops.conv2d = conv2d
 for _ in range(3):
     y = ops.conv2d(x, pk, act, res=res, lds_dma=bool(a.dma))
 torch.cuda.synchronize()

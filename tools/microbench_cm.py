@@ -16,6 +16,8 @@ if planted:
 else:
     f1 = torch.randn(N, L, C, generator=g) * sigma
 f0, f1 = f0.cuda(), f1.cuda()
+if "--bf16" in sys.argv:
+    f0, f1 = f0.bfloat16(), f1.bfloat16()
 for _ in range(3):
     r = ops.coarse_match(f0, f1, (60, 80), (60, 80), 8.0, 0.1, thr)
 torch.cuda.synchronize()

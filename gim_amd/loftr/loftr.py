@@ -563,27 +563,28 @@ class LoFTR(nn.Module):
 
         M = int(cr.count[0].item())  # the one host sync the reference also has (torch.where, :193)
         self._generation += 1
+        data.update({"conf_matrix": LazyConfMatrix(cr, self, self._generation if graphed else None)})
+        W = self.W
+        data.update({"W": W})
+        # 4./5. fine level (fine_preprocess.py:29-47, transformer on [M,25,128], fine_matching.py:15-74): enqueued first, straight
+        # from the coarse stage's buffers, so that the GPU is not left idle while the host hands out the match lists below
+        fine = None
+        if M > 0:
+            fine = self._fine_level(f0, f1, cr.b_ids[:M], cr.i_ids[:M], cr.j_ids[:M], cr.mkpts1_c[:M], scale1, "scale0" in data,
+                                    hw0_c, hw1_c, data["hw0_i"], self.fine_fused)
         # graph replays reuse their output buffers: hand out private copies of the (small) match lists
         own = (lambda t: t.clone()) if graphed else (lambda t: t)
         b_ids, i_ids, j_ids = own(cr.b_ids[:M]), own(cr.i_ids[:M]), own(cr.j_ids[:M])
         mkpts0_c, mkpts1_c, mconf = own(cr.mkpts0_c[:M]), own(cr.mkpts1_c[:M]), own(cr.mconf[:M])
-        data.update({"conf_matrix": LazyConfMatrix(cr, self, self._generation if graphed else None)})
         data.update({"b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids,
                      "gt_mask": torch.zeros(M, dtype=torch.bool, device=dev),  # mconf == 0 never holds (> thr)
                      "m_bids": b_ids.clone(),
                      "mkpts0_c": mkpts0_c, "mkpts1_c": mkpts1_c, "mconf": mconf})
-
-        # 4./5. fine level (fine_preprocess.py:29-47, transformer on [M,25,128], fine_matching.py:15-74)
-        W = self.W
-        data.update({"W": W})
-        WW = W * W
-        Cf = cfg["fine"]["d_model"]
-        if M == 0:
+        if fine is None:
             data.update({"expec_f": torch.empty(0, 3, device=dev),
                          "mkpts0_f": data["mkpts0_c"], "mkpts1_f": data["mkpts1_c"]})
             return
-        expec_f, mkpts1_f, fine0, fine1 = self._fine_level(f0, f1, b_ids, i_ids, j_ids, mkpts1_c, scale1, "scale0" in data,
-                                                           hw0_c, hw1_c, data["hw0_i"], self.fine_fused)
+        expec_f, mkpts1_f, fine0, fine1 = fine
         if self.debug is not None:
             self.debug.update({"fine0": fine0, "fine1": fine1})
         data.update({"expec_f": expec_f, "mkpts0_f": data["mkpts0_c"], "mkpts1_f": mkpts1_f})

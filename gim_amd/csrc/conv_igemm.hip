@@ -382,6 +382,128 @@ igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntile
 
 
 // ------------------------------------------------------------------------------------------------
+// Ping-pong variant of the 256 x 256 / 8-wave tile (bf16, bf16 output, no residual) -- EXPERIMENTAL, GIM_IGEMM_PP=1.
+//
+// In the kernel above the two waves of a SIMD (w and w + 4) leave every slab barrier together: both first issue their eight
+// LDS-DMA instructions, then both compete for the MFMA pipe, then both wait for the DMA to land -- the pipe is busy 50 % of
+// the time.  Here the waves form two groups, G0 = waves 0-3 and G1 = waves 4-7 (one of each on every SIMD), that run the
+// same program ONE BARRIER APART.  The program alternates memory phases and MFMA phases,
+//      m0: ds_read K step 0 | c0: 8 MFMAs | m1: ds_read K steps 1-3 | c1: 24 MFMAs
+// each closed by a raw s_barrier, so that while one group reads LDS the other one owns the MFMA pipe:
+//      interval   4s        4s+1      4s+2      4s+3
+//      G0         m0(s)     c0(s)     m1(s)     c1(s)
+//      G1         c1(s-1)   m0(s)     c0(s)     m1(s)
+// Slab s + 1 goes into the stage slab s - 1 occupied (its last reader, G1's m1(s-1), has waited lgkmcnt(0) before the barrier
+// that closes 4s-1) and is first read at 4s+4.  Its eight LDS-DMA instructions per wave are SPREAD over the phases -- eight in
+// one phase beside the partner's MFMAs cost ~250 cycles each (measured: 1786 us on the 196->196 3x3 layer): G0 issues 3 + 3 + 2 in m0 / c0 / m1 (intervals 4s ..
+// 4s+2), G1 4 + 4 in m0 / c0 (4s+1, 4s+2); every wave waits vmcnt(0) for its own pieces before the barrier that closes 4s+3
+// (G0 at the end of c1, G1 at the end of m1).  The epilogue of a tile is one more phase.
+// Measured: exactly as fast as the plain kernel (1154 vs 1144 us on 196->196 3x3, 1457 vs 1452 us on 256->256 3x3 at M = 1.2 M)
+// -- two very different schedules, one speed: the schedule is not what bounds this tile.  Kept (off) as the starting point for
+// a half-tile-stage version; tests force it through GIM_IGEMM_PP=2.
+__device__ __forceinline__ void pp_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ void __launch_bounds__(512, 2)
+igemm_pp_kernel(const gim_conv_args a, const int mtiles, const int ntiles, const int M) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 256, BN = 256;
+    typedef gim::Igemm<BM, BN, 4, 2, true, true> G;
+    typedef Epilogue<G, true, false> E;
+    static_assert(G::NPIECE == 8, "piece schedule below assumes 8 LDS-DMA instructions per wave and slab");
+    int* ktl = (int*)(smem + 2 * G::STAGE);
+
+    unsigned first, step, end;
+    tile_list((unsigned)(mtiles * ntiles), first, step, end);
+    if (first >= end) return;
+    const gim::MainloopArgs ml = mainloop_args(a, M, G::ES);
+    const int nkt = a.kpad * G::ES / KTB;
+    for (int i = threadIdx.x; i < (nkt + 2) * 8; i += 512) ktl[i] = a.ktab[i];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    pp_barrier();
+
+    E epi;
+    G g, gn;
+    typename G::Acc acc;
+    typename E::Res rres;
+    const int grp = epi.wave >> 2;  // wave-uniform
+    int m0 = (int)(first / ntiles) * BM, n0 = (int)(first % ntiles) * BN;
+    epi.init_acc(a, acc, n0);
+    g.decode(ml, m0, n0);
+    {   // prologue: slab 0 of the first tile -> stage 0
+        const typename G::Tap tap = G::tap_decode(ml, ktl[G::ktab_index(0)]);
+#pragma unroll
+        for (int p = 0; p < G::NPIECE; ++p) g.issue_piece(ml, smem, 0, 0, tap, p);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pp_barrier();
+    }
+    if (grp) pp_barrier();  // G1 runs one barrier behind G0 from here on
+    int st = 0;             // stage of the slab being computed
+
+    for (unsigned tile = first; tile < end; tile += step) {
+        const unsigned tile_n = tile + step;
+        const bool has_next = tile_n < end;
+        const int m0n = (int)(tile_n / ntiles) * BM, n0n = (int)(tile_n % ntiles) * BN;
+        gn = g;  // without a next tile the staging cursor re-reads this tile's first slab into the free stage (unread)
+        if (has_next) gn.decode(ml, m0n, n0n);
+        auto kloop = [&](auto live) __attribute__((always_inline)) {
+            constexpr int LIVE = decltype(live)::value;
+            for (int kt = 0; kt < nkt; ++kt) {
+                const bool last = kt + 1 == nkt;
+                if (last) g = gn;  // the cursor moves on to the next tile's first slab
+                const int kt_issue = last ? 0 : kt + 1;
+                const typename G::FragAddr fr = G::frag_addr(smem, st);
+                const typename G::Tap tap = G::tap_decode(ml, ktl[G::ktab_index(kt_issue)]);
+                auto pieces = [&](const int p0, const int p1) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int p = 0; p < G::NPIECE; ++p)
+                        if (p >= p0 && p < p1) g.issue_piece(ml, smem, st ^ 1, kt_issue, tap, p);
+                };
+                // ---- m0 ------------------------------------------------------------------------------------------
+                typename G::template Frags<LIVE> f0;
+                G::template load_frags<LIVE>(fr, 0, f0);
+                if (grp) pieces(0, 4); else pieces(0, 3);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                pp_barrier();
+                // ---- c0 ------------------------------------------------------------------------------------------
+                G::template mma<LIVE>(acc, f0);
+                if (grp) pieces(4, 8); else pieces(3, 6);
+                pp_barrier();
+                // ---- m1 ------------------------------------------------------------------------------------------
+                typename G::template Frags<LIVE> f1, f2, f3;
+                G::template load_frags<LIVE>(fr, 1, f1);
+                G::template load_frags<LIVE>(fr, 2, f2);
+                G::template load_frags<LIVE>(fr, 3, f3);
+                if (!grp) pieces(6, 8);
+                if (grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                pp_barrier();
+                // ---- c1 ------------------------------------------------------------------------------------------
+                G::template mma<LIVE>(acc, f1);
+                G::template mma<LIVE>(acc, f2);
+                G::template mma<LIVE>(acc, f3);
+                if (!grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                pp_barrier();
+                st ^= 1;
+            }
+        };
+        kloop(IntC<G::TN>());  // (no fragment skipping here: the two-copy K loop spills in this kernel)
+        // ---- epilogue phase: st ^ 1 is the stage the tile's last slab was read from -----------------------------------
+        epi.run(a, acc, rres, smem + (st ^ 1) * G::STAGE, m0, n0, M);
+        epi.init_acc(a, acc, n0n < a.npad ? n0n : 0);
+        m0 = m0n; n0 = n0n;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pp_barrier();
+    }
+    if (!grp) pp_barrier();  // G0 meets G1's extra barrier
+}
+
+// ------------------------------------------------------------------------------------------------
 // Deep-prefetch variant for the MFMA-bound layers: 8 waves (4 x 2), 256 x 128 tile, THREE LDS stages of
 // 48 KiB (one workgroup per CU).  With two stages the DMA of slab s+1 has only one compute phase (~1000
 // cycles) to land -- less than the loaded L2/HBM latency -- and both resident workgroups stall together
@@ -486,6 +608,30 @@ int launch_persistent(const gim_conv_args& a, hipStream_t stream) {
     return gim_check_launch("igemm_persistent_kernel");
 }
 
+int launch_pp(const gim_conv_args& a, hipStream_t stream) {
+    const int nkt = a.kpad * 2 / KTB;
+    const int smem = 2 * (256 + 256) * KTB + (nkt + 2) * 8 * 4;
+    if (smem > 160 * 1024) return launch_persistent<256, 256, 4, 2, true, true, false>(a, stream);
+    auto kern = igemm_pp_kernel;
+    static GimPerDevice attr_done;
+    if (attr_done.needed()) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            gim_set_error("hipFuncSetAttribute(160 KiB LDS): %s", hipGetErrorString(e));
+            return GIM_ERR_LAUNCH;
+        }
+        attr_done.done();
+    }
+    const int M = a.B * a.Ho * a.Wo;
+    const int mtiles = (M + 255) / 256, ntiles = a.npad / 256;
+    const int T = mtiles * ntiles;
+    constexpr int RESIDENT = 256;  // one workgroup per CU
+    const int rounds = (T + RESIDENT - 1) / RESIDENT;
+    const int grid = (T + rounds - 1) / rounds;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, a, mtiles, ntiles, M);
+    return gim_check_launch("igemm_pp_kernel");
+}
+
 template <bool BF16, bool HAS_RES>
 int launch_ring3(const gim_conv_args& a, hipStream_t stream) {
     const int es = BF16 ? 2 : 4;
@@ -523,6 +669,9 @@ static int big_mode() {
 }
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static int skip_mode() { static const int v = env_int("GIM_IGEMM_SKIP", 1); return v; }
+// GIM_IGEMM_PP: ping-pong variant of the 256 x 256 tile: 0 = never (default), 1 = for K loops of at least GIM_IGEMM_PP_MIN_NKT slabs, 2 = always
+static int pp_mode() { static const int v = env_int("GIM_IGEMM_PP", 0); return v; }
+static int pp_min_nkt() { static const int v = env_int("GIM_IGEMM_PP_MIN_NKT", 8); return v; }
 static int big_min_tiles() { static const int v = env_int("GIM_IGEMM_BIG_MIN_TILES", 512); return v; }
 static int big_min_nkt() { static const int v = env_int("GIM_IGEMM_BIG_MIN_NKT", 4); return v; }
 
@@ -554,6 +703,10 @@ int dispatch_persistent(const gim_conv_args& a, hipStream_t s) {
         {
             // N <= 224 (the FPN's 196-channel layers): the second column half's last fragment is pure padding
             const bool skip = a.N <= a.npad - 32 && skip_mode();
+            if constexpr (BF16) {
+                if (pp_mode() == 2 || (pp_mode() == 1 && nkt >= pp_min_nkt()))
+                    return launch_pp(a, s);
+            }
             if (skip) return launch_persistent<256, 256, 4, 2, BF16, true, false, true>(a, s);
             return launch_persistent<256, 256, 4, 2, BF16, true, false>(a, s);
         }

@@ -112,6 +112,35 @@ struct Igemm {
         }
     }
 
+    // ---- the same staging, one DMA instruction ("piece") at a time -------------------------------------------------
+    // (the ping-pong kernel spreads the pieces over its phases)
+    static constexpr int NPIECE = PA + PB;
+    struct Tap { unsigned tapoff; int dy, dx; };
+    static __device__ __forceinline__ Tap tap_decode(const MainloopArgs& a, int e) {
+        Tap t;
+        const int c = e & 0xffff;
+        t.dx = (e >> 16) & 0xff;
+        int dy = (e >> 24) & 0xff;
+        t.dy = dy == 255 ? (1 << 28) : dy;
+        t.tapoff = ((unsigned)(t.dy * a.W + t.dx) * (unsigned)a.ldx + (unsigned)c) * ES;
+        return t;
+    }
+    __device__ __forceinline__ void issue_piece(const MainloopArgs& a, char* smem, int buf, int kt, const Tap& t, int p) const {
+        static_assert(LDSDMA, "piece-wise staging is LDS-DMA only");
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        char* sA = smem + buf * STAGE;
+        if (p < PA) {
+            const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+            const bool ok = ((unsigned)(iy0[p] + t.dy) < (unsigned)a.H) & ((unsigned)(ix0[p] + t.dx) < (unsigned)a.W);
+            const unsigned voff = ok ? rowoff[p] + t.tapoff : a.x_bytes;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(sA + (p * RPP + wave * 8) * KTB), 16, voff, 0, 0, 0);
+        } else {
+            const int i = p - PA;
+            const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.w_bytes, 0x00020000);
+            const unsigned voff = wrow + (unsigned)(i * RPP) * (unsigned)a.ldw * ES + (unsigned)kt * KTB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(sA + A_BYTES + (i * RPP + wave * 8) * KTB), 16, voff, 0, 0, 0);
+        }
+    }
     // register-staging path only: write the fetched slab into LDS stage `buf`
     __device__ __forceinline__ void stage_write(char* smem, int buf) {
         if constexpr (!LDSDMA) {

@@ -632,6 +632,215 @@ int launch_pp(const gim_conv_args& a, hipStream_t stream) {
     return gim_check_launch("igemm_pp_kernel");
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with a HALO tile as the pixel operand (bf16 in / out, no residual).
+//
+// The implicit GEMM above stages every (tap, 64-channel) K slab of the pixel operand separately: the nine taps of a 3x3 conv
+// fetch the same input pixels nine times from L2 into LDS, and the PMC / variant experiments show the tile bound by
+// what it stages per MFMA, not by its schedule.  Here a workgroup owns an 8 x 32 patch of output pixels of one image: per
+// 64-channel chunk it stages the (8+2) x (32+2) halo of input pixels ONCE (340 rows x 128 B = 43 LDS-DMA pieces instead of
+// 9 x 32) and the nine taps read their fragments from it at shifted rows -- row(py, px, dy, dx) = (py + dy) * 34 + px + dx.
+// The XOR swizzle ((row >> 1) & 7 on the 16-byte slot) stays conflict-free for ANY row offset: a ds_read_b128 lane group
+// covers 16 rows whose low four bits are all different, shifted or not.  The weight operand streams as before, one
+// [BN][64] slab per K step of four 16-channel sub-steps; K order is (chunk, tap, channel) for the full chunks and
+// (tap, channel) for the last, narrower one (Cin = 196: three chunks + nine 16-channel sub-steps packed four to a slab), a
+// small per-slab table in LDS tells every sub-step its row shift and its channel offset inside the halo row.
+constexpr int HTH = 8, HTW = 32, HW2 = HTW + 2, HROWS = (HTH + 2) * HW2;  // 340 halo rows
+constexpr int HPIECES = (HROWS + 7) / 8;                                 // 43 LDS-DMA pieces of 8 rows
+constexpr int HA_BYTES = HPIECES * 8 * KTB;                              // 44032 B per halo buffer
+constexpr int HNPA = (HPIECES + 7) / 8;                                  // pieces per wave (6)
+
+template <int TN>  // wave tile: 64 pixels x TN * 32 channels; BN = 2 * TN * 32
+__global__ void __launch_bounds__(512, 2)
+conv3x3_halo_kernel(const gim_conv_args a, const int tiles_x, const int tiles_y, const int ntiles, const int nslab) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 256, BN = 2 * TN * 32, PB = BN / 64;
+    typedef gim::Igemm<BM, BN, 4, 2, true, true> G;
+    typedef Epilogue<G, true, false> E;
+    char* const sAh = smem;                    // [2][HA_BYTES]
+    char* const sBb = smem + 2 * HA_BYTES;     // [2][BN * KTB]
+    int* const tab = (int*)(sBb + 2 * BN * KTB);
+
+    unsigned first, step, end;
+    tile_list((unsigned)(tiles_x * tiles_y * a.B * ntiles), first, step, end);
+    if (first >= end) return;
+    for (int i = threadIdx.x; i < nslab * 8; i += 512) tab[i] = a.ktab[i];
+
+    const int t = threadIdx.x, lane = t & 63;
+    E epi;  // wave, wm, wn, l31, lh, rrow, rslot
+    const int wave = epi.wave;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)((unsigned)a.npad * (unsigned)a.kpad * 2u), 0x00020000);
+
+    // ---- per-thread staging coordinates ---------------------------------------------------------------------------------
+    unsigned offA[HNPA];   // byte offset of (pixel, channel group) of this thread's slot in piece i, 0xFFFFFFFF = outside the image
+    int gch[HNPA];         // first channel (within the chunk) of that slot
+    auto decode = [&](const unsigned tile) {
+        const int mt = (int)(tile / (unsigned)ntiles);
+        const int tx = mt % tiles_x, ty = (mt / tiles_x) % tiles_y, b = mt / (tiles_x * tiles_y);
+        const int x0 = tx * HTW, y0 = ty * HTH;
+#pragma unroll
+        for (int i = 0; i < HNPA; ++i) {
+            const int q = wave + 8 * i, r = 8 * q + (lane >> 3);
+            const int hy = r / HW2, hx = r - hy * HW2;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = (q < HPIECES) & (r < HROWS) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
+            const int g = (lane & 7) ^ ((r >> 1) & 7);
+            gch[i] = g * 8;
+            offA[i] = ok ? ((unsigned)((b * a.H + y) * a.W + x) * (unsigned)a.ldx + (unsigned)(g * 8)) * 2u : 0xFFFFFFFFu;
+        }
+    };
+    const int cin_pad = a.res_mod;  // halo mode: the channel count of x rows that holds data (cin_pad <= ldx); no residual here
+    auto issue_A = [&](const int c0, const int ab) {  // halo of channels [c0, c0 + 64) -> sAh[ab]
+#pragma unroll
+        for (int i = 0; i < HNPA; ++i) {
+            const int q = wave + 8 * i;
+            if (q < HPIECES) {
+                const bool ok = (offA[i] != 0xFFFFFFFFu) & (c0 + gch[i] < cin_pad);
+                const unsigned voff = ok ? offA[i] + (unsigned)c0 * 2u : (unsigned)a.x_bytes;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(sAh + ab * HA_BYTES + q * 8 * KTB), 16, voff, 0, 0, 0);
+            }
+        }
+    };
+    const int srow = t >> 3, sgrp = (t & 7) ^ ((srow >> 1) & 7);
+    auto issue_B = [&](const int n0, const int slab, const int bb) {  // weight slab -> sBb[bb]
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const unsigned voff = ((unsigned)(n0 + i * 64 + srow) * (unsigned)a.kpad + (unsigned)(slab * 64 + sgrp * 8)) * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(sBb + bb * BN * KTB + (i * 64 + wave * 8) * KTB), 16, voff, 0, 0, 0);
+        }
+    };
+
+    typename G::Acc acc;
+    unsigned tile = first;
+    int n0 = (int)(tile % (unsigned)ntiles) * BN;
+    epi.init_acc(a, acc, n0);
+    decode(tile);
+    issue_A(0, 0);
+    issue_B(n0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // fragment addressing
+    const int lswz = (epi.l31 >> 1) & 7;
+    const int rb0 = (2 * epi.wm) * HW2 + epi.l31;  // halo row of the wave's first pixel row at tap (0, 0)
+    int ab = 0, bb = 0;
+
+    for (; tile < end; tile += step) {
+        const unsigned tile_n = tile + step;
+        const bool has_next = tile_n < end;
+        const int n0n = has_next ? (int)(tile_n % (unsigned)ntiles) * BN : n0;
+        const int mt = (int)(tile / (unsigned)ntiles);
+        auto kloop = [&](auto live) __attribute__((always_inline)) {
+        constexpr int LIVE = decltype(live)::value;
+        for (int s = 0; s < nslab; ++s) {
+            const int* te = tab + s * 8;
+            const int flags = __builtin_amdgcn_readfirstlane(te[1]);
+            const bool last = s + 1 == nslab;
+            // ---- prefetch: next weight slab, and (at the first slab of a chunk) the next halo -------------------------------
+            if (!last) issue_B(n0, s + 1, bb ^ 1);
+            else if (has_next) issue_B(n0n, 0, bb ^ 1);
+            if (flags & 1) {
+                const int cnext = __builtin_amdgcn_readfirstlane(te[6]);  // channel base of the next chunk, -1: the tile's last chunk
+                if (cnext >= 0) issue_A(cnext, ab ^ 1);
+                else if (has_next) { decode(tile_n); issue_A(0, ab ^ 1); }
+            }
+            // ---- MFMAs of this slab ---------------------------------------------------------------------------------------
+            const char* sA = sAh + ab * HA_BYTES;
+            const char* sB = sBb + bb * BN * KTB + (epi.wn * G::WTN + epi.l31) * KTB;
+            auto load = [&](const int ks, typename G::template Frags<LIVE>& f) __attribute__((always_inline)) {
+                const int e = __builtin_amdgcn_readfirstlane(te[2 + ks]);  // row shift | channel sub-step << 8
+                const int shift = e & 0xff, ksc = (e >> 8) & 0xff;
+#pragma unroll
+                for (int j = 0; j < G::TM; ++j) {
+                    const int row = rb0 + j * HW2 + shift;
+                    f.a[j] = *(const bf16x8_t*)(sA + row * KTB + ((((2 * ksc + epi.lh) ^ (row >> 1)) & 7) << 4));
+                }
+                const int so = ((2 * ks + epi.lh) ^ lswz) << 4;
+#pragma unroll
+                for (int i = 0; i < LIVE; ++i) f.b[i] = *(const bf16x8_t*)(sB + i * 32 * KTB + so);
+            };
+            // (unused sub-steps of the last slab carry zero weights: no branch in here)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {  // (loading step ks + 1 ahead of the MFMAs of step ks by hand compiles to the same schedule)
+                typename G::template Frags<LIVE> f;
+                load(ks, f);
+                G::template mma<LIVE>(acc, f);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            bb ^= 1;
+            if (flags & 2) ab ^= 1;  // last slab of its chunk
+        }
+        };
+        // (no fragment skipping here: a second copy of this K loop spills; layers with an all-padding fragment stay on the
+        // generic kernel, which skips it)
+        kloop(IntC<TN>());
+        // ---- epilogue: activation, bf16, per-wave transposition through the halo buffer just consumed (ab ^ 1), row stores ------
+        {
+            const int tx = mt % tiles_x, ty = (mt / tiles_x) % tiles_y, b = mt / (tiles_x * tiles_y);
+            const int x0 = tx * HTW, y0 = ty * HTH;
+            char* wl = (char*)sAh + (ab ^ 1) * HA_BYTES + wave * E::WAVE_BYTES;
+            const int act = a.act;
+#pragma unroll
+            for (int j = 0; j < G::TM; ++j) {
+                const int y = y0 + 2 * epi.wm + j;
+#pragma unroll
+                for (int nh = 0; nh < E::NH; ++nh) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[nh * 2 + i][j][r] = apply_act(acc[nh * 2 + i][j][r], act);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const f32x16_t& v = acc[nh * 2 + i][j];
+                            *(uint2*)(wl + epi.l31 * E::RB + (((i * 4 + rg) ^ (epi.l31 & 7)) << 4) + epi.lh * 8) =
+                                make_uint2(cvt_pk_bf16(v[rg * 4 + 0], v[rg * 4 + 1]), cvt_pk_bf16(v[rg * 4 + 2], v[rg * 4 + 3]));
+                        }
+                    const int ncol = n0 + epi.wn * G::WTN + nh * 64 + epi.rslot * 8;
+#pragma unroll
+                    for (int k = 0; k < E::NI; ++k) {
+                        const int row = k * E::RPI + epi.rrow, x = x0 + row;
+                        const uint4 o = *(const uint4*)(wl + row * E::RB + ((epi.rslot ^ (row & 7)) << 4));
+                        if (ncol < a.N && y < a.H && x < a.W)
+                            *(uint4*)((char*)a.y + ((size_t)((b * a.H + y) * a.W + x) * a.ldy + ncol) * 2) = o;
+                    }
+                }
+            }
+        }
+        epi.init_acc(a, acc, n0n);
+        n0 = n0n;
+        __syncthreads();  // the transposition tiles live in a halo buffer the next chunk's DMA will overwrite
+    }
+}
+
+template <int TN>
+int launch_halo(const gim_conv_args& a, hipStream_t stream) {
+    constexpr int BN = 2 * TN * 32;
+    const int nslab = a.kpad / 64;
+    const int smem = 2 * HA_BYTES + 2 * BN * KTB + nslab * 8 * 4;
+    GIM_REQUIRE(smem <= 160 * 1024, "conv3x3 halo: %d slabs do not fit the LDS table", nslab);
+    auto kern = conv3x3_halo_kernel<TN>;
+    static GimPerDevice attr_done;
+    if (attr_done.needed()) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            gim_set_error("hipFuncSetAttribute(160 KiB LDS): %s", hipGetErrorString(e));
+            return GIM_ERR_LAUNCH;
+        }
+        attr_done.done();
+    }
+    const int tiles_x = (a.W + HTW - 1) / HTW, tiles_y = (a.H + HTH - 1) / HTH, ntiles = a.npad / BN;
+    const int T = tiles_x * tiles_y * a.B * ntiles;
+    constexpr int RESIDENT = 256;  // one workgroup per CU
+    const int rounds = (T + RESIDENT - 1) / RESIDENT;
+    const int grid = (T + rounds - 1) / rounds;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, a, tiles_x, tiles_y, ntiles, nslab);
+    return gim_check_launch("conv3x3_halo_kernel");
+}
+
 template <bool BF16, bool HAS_RES>
 int launch_ring3(const gim_conv_args& a, hipStream_t stream) {
     const int es = BF16 ? 2 : 4;
@@ -767,6 +976,12 @@ extern "C" int gim_conv2d_bn_act(const gim_conv_args* ap, gim_stream_t stream) {
     GIM_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.Ho > 0 && a.Wo > 0 && a.stride > 0, "conv: bad geometry");
     GIM_REQUIRE((int64_t)a.B * a.Ho * a.Wo < (int64_t)0x7fffffff, "conv: too many output rows");
     hipStream_t s = (hipStream_t)stream;
+    if (a.use_lds_dma == 2) {  // 3x3 halo kernel: w / ktab / kpad describe the halo packing (gim_amd/packing.py::pack_halo)
+        GIM_REQUIRE(a.dtype == GIM_BF16 && a.out_dtype == GIM_BF16 && !a.res && a.stride == 1 && a.pad == 1 && a.H == a.Ho && a.W == a.Wo,
+                    "conv3x3 halo: bf16 in / out, stride 1, pad 1, no residual");
+        GIM_REQUIRE(a.npad % 128 == 0 && a.kpad % 64 == 0 && a.res_mod > 0 && a.res_mod <= a.ldx && a.act_cols == 0, "conv3x3 halo: bad packing");
+        return a.npad % 256 == 0 ? launch_halo<4>(a, s) : launch_halo<2>(a, s);
+    }
     if (a.dtype == GIM_BF16) return a.use_lds_dma ? dispatch_persistent<true>(a, s) : dispatch_tile<true, false>(a, s);
     return a.use_lds_dma ? dispatch_persistent<false>(a, s) : dispatch_tile<false, false>(a, s);
 }

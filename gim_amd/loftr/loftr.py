@@ -563,9 +563,6 @@ class LoFTR(nn.Module):
 
         M = int(cr.count[0].item())  # the one host sync the reference also has (torch.where, :193)
         self._generation += 1
-        data.update({"conf_matrix": LazyConfMatrix(cr, self, self._generation if graphed else None)})
-        W = self.W
-        data.update({"W": W})
         # 4./5. fine level (fine_preprocess.py:29-47, transformer on [M,25,128], fine_matching.py:15-74): enqueued first, straight
         # from the coarse stage's buffers, so that the GPU is not left idle while the host hands out the match lists below
         fine = None
@@ -576,10 +573,12 @@ class LoFTR(nn.Module):
         own = (lambda t: t.clone()) if graphed else (lambda t: t)
         b_ids, i_ids, j_ids = own(cr.b_ids[:M]), own(cr.i_ids[:M]), own(cr.j_ids[:M])
         mkpts0_c, mkpts1_c, mconf = own(cr.mkpts0_c[:M]), own(cr.mkpts1_c[:M]), own(cr.mconf[:M])
+        data.update({"conf_matrix": LazyConfMatrix(cr, self, self._generation if graphed else None)})   # key order = the reference's
         data.update({"b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids,
                      "gt_mask": torch.zeros(M, dtype=torch.bool, device=dev),  # mconf == 0 never holds (> thr)
                      "m_bids": b_ids.clone(),
                      "mkpts0_c": mkpts0_c, "mkpts1_c": mkpts1_c, "mconf": mconf})
+        data.update({"W": self.W})
         if fine is None:
             data.update({"expec_f": torch.empty(0, 3, device=dev),
                          "mkpts0_f": data["mkpts0_c"], "mkpts1_f": data["mkpts1_c"]})

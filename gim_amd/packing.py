@@ -43,7 +43,7 @@ def _round_up(x, m):
 class PackedConv:
     """One conv / linear layer in kernel layout."""
     __slots__ = ("w", "bias", "ktab", "kh", "kw", "stride", "pad", "cin", "cin_pad", "cout", "n_store",
-                 "npad", "kpad", "dtype")
+                 "npad", "kpad", "dtype", "halo")
 
     def __repr__(self):
         return (f"PackedConv({self.cin}->{self.cout} k{self.kh} s{self.stride} cin_pad={self.cin_pad} "
@@ -106,7 +106,59 @@ def pack_conv(weight, bn, dtype, device, stride=1, pad=0, cin_pad=None, bias=Non
     p.cin, p.cin_pad, p.cout = cin, cin_pad, cout
     p.n_store = cstore(cout, dtype)
     p.npad, p.kpad, p.dtype = npad, kpad, dtype
+    p.halo = None
+    if dtype == _lib.GIM_BF16 and kh == 3 and kw == 3 and stride == 1 and pad == 1:
+        p.halo = pack_halo(wp, cin_pad, device)
     return p
+
+
+HALO_W2 = 34  # halo row length of the 8 x 32-pixel patch (gim_amd/csrc/conv_igemm.hip: conv3x3_halo_kernel)
+
+
+def pack_halo(wp, cin_pad, device):
+    """Second packing of a 3x3 / stride-1 / pad-1 bf16 layer for the halo kernel.  wp: fp32 [npad, 3, 3, cin_pad] (BN folded,
+    zero padded).  Returns (w [npad128, nslab * 64] bf16, table int32 [nslab * 8], nslab).  K order: for every full 64-channel
+    chunk the nine taps (one slab each), then the remaining channels in 16-channel sub-steps, tap-major, four to a slab.
+    Table row per slab: [chunk, flags (1 = first slab of its chunk, 2 = last), 4 x (row shift | channel sub-step << 8),
+    channel base of the next chunk (-1: none, first slab only), unused]."""
+    npad = wp.shape[0]
+    npad = (npad + 127) // 128 * 128
+    nw, rem = cin_pad // 64, cin_pad % 64
+    nsub = (rem + 15) // 16
+    nchunk = nw + (1 if rem else 0)
+    cols, table = [], []
+    for c in range(nw):
+        for t in range(9):
+            dy, dx = t // 3, t % 3
+            cols.append(wp[:, dy, dx, c * 64:(c + 1) * 64])
+            sh = dy * HALO_W2 + dx
+            table.append([c, (1 if t == 0 else 0) | (2 if t == 8 else 0)] + [sh | (k << 8) for k in range(4)]
+                         + [((c + 1) * 64 if c + 1 < nchunk else -1) if t == 0 else 0, 0])
+    if rem:
+        steps = [(u // nsub, u % nsub) for u in range(9 * nsub)]
+        nsl = (len(steps) + 3) // 4
+        for q in range(nsl):
+            ent, blk = [], []
+            for k in range(4):
+                u = 4 * q + k
+                if u < len(steps):
+                    t, ksc = steps[u]
+                    dy, dx = t // 3, t % 3
+                    c0 = nw * 64 + ksc * 16
+                    w16 = torch.zeros(wp.shape[0], 16)
+                    n = max(0, min(16, cin_pad - c0))
+                    w16[:, :n] = wp[:, dy, dx, c0:c0 + n]
+                    blk.append(w16)
+                    ent.append((dy * HALO_W2 + dx) | (ksc << 8))
+                else:
+                    blk.append(torch.zeros(wp.shape[0], 16))
+                    ent.append(0)
+            cols.append(torch.cat(blk, 1))
+            table.append([nw, (1 if q == 0 else 0) | (2 if q == nsl - 1 else 0)] + ent + [-1 if q == 0 else 0, 0])
+    wk = torch.zeros(npad, len(cols) * 64)
+    wk[:wp.shape[0]] = torch.cat(cols, 1)
+    tab = torch.tensor(table, dtype=torch.int32).reshape(-1)
+    return wk.to(device).to(torch.bfloat16).contiguous(), tab.to(device), len(cols)
 
 
 def _frag_order(w):

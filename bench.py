@@ -221,7 +221,7 @@ def main():
             traffic = round(json.load(open(TRAFFIC_JSON))["traffic_bytes_per_launch"])
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
-                "kernel": "igemm_persistent_kernel (gim_conv2d_bn_act)", "launches_per_step": nlaunch // 2,
+                "kernel": "gim_conv2d_bn_act kernels (igemm_persistent_kernel + conv3x3_halo_kernel)", "launches_per_step": nlaunch // 2,
                 "avg_launch_us": round(1e3 * tot_ms / nlaunch, 2),
                 "gflop_per_launch": round(tot_fl / nlaunch / 1e9, 3),
                 "kernel_ms_per_step": round(tot_ms / 2, 3),

@@ -1,5 +1,5 @@
 #!/bin/bash
-# HBM traffic of the gim_conv2d_bn_act launches of one batch-8 forward, from the TCC memory-side counters.
+# HBM traffic of the gim_conv2d_bn_act launches (igemm_* and conv3x3_halo kernels) of one batch-8 forward, from the TCC memory-side counters.
 # Two separate rocprofv3 passes (FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2: they do not fit together), kernel-trace
 # only, eager launches (GIM_GRAPH=0).  Writes profiles/traffic_<tag>.json: per-launch average over the igemm kernels.
 # MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a
@@ -24,7 +24,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             continue
         nm = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
         allk[nm.split("<")[0].split("(")[0][-48:]] += float(r["Counter_Value"])
-        if "igemm" in r["Kernel_Name"]:
+        if "igemm" in r["Kernel_Name"] or "conv3x3_halo" in r["Kernel_Name"]:  # every kernel behind gim_conv2d_bn_act
             tot += float(r["Counter_Value"]); n += 1
     res[c] = (tot, n)
     res[c + "_all"] = allk

@@ -13,7 +13,7 @@ if not f:
     print('no stats csv'); print(open(out + '/log.txt').read()[-2000:]); sys.exit()
 rows = list(csv.DictReader(open(f[0])))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
-ig = [r for r in rows if 'igemm' in r['Name']]
+ig = [r for r in rows if 'igemm' in r['Name'] or 'conv3x3_halo' in r['Name']]  # every kernel behind gim_conv2d_bn_act
 ig_calls = sum(int(r['Calls']) for r in ig); ig_ns = sum(float(r['TotalDurationNs']) for r in ig)
 lines = [f"rocprofv3 --kernel-trace --stats -- python bench.py --steps {steps} --warmup 2 --no-cpu-baseline (GIM_BENCH_SKIP_DENSE=1 GIM_BENCH_SKIP_LIGHTGLUE=1)",
          f"total kernel time {tot/1e6:.3f} ms; igemm (gim_conv2d_bn_act) kernels: {ig_calls} launches, {ig_ns/1e6:.3f} ms, average {ig_ns/max(1,ig_calls)/1e3:.2f} us per launch"]

@@ -62,7 +62,7 @@ def read_images(path, max_resize, df, padding, image=None):
     if image is None:
         from PIL import Image
         image = np.asarray(Image.open(path).convert("RGB"))
-    t = torch.from_numpy(np.ascontiguousarray(image)).permute(2, 0, 1).float()          # [3,h,w], 0..255
+    t = torch.from_numpy(np.array(image)).permute(2, 0, 1).float()                       # [3,h,w], 0..255 (np.array: writable copy)
     g = (0.299 * t[0] + 0.587 * t[1] + 0.114 * t[2]).round()[None]                       # cv2.COLOR_RGB2GRAY
     w, h = image.shape[1], image.shape[0]
     w_new, h_new = get_resized_wh(w, h, max_resize) if max(w, h) > max_resize else (w, h)

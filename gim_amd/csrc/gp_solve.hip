@@ -232,14 +232,24 @@ struct GemmArgs {
     size_t bsC, bsA, bsB, psC, psA, psB;
 };
 
-// 128 x 64 block tile, 8 x 4 per thread (rows q*32 + ty*2 + {0,1}, columns h*32 + tx*2 + {0,1}: every ds_read_b128 of a
-// wave covers 256 contiguous bytes or is a broadcast), K in slabs of 32.  5.3 FMAs per LDS read -- the 4 x 4 version (2 FMAs
-// per read) was LDS-bound at 3.9 TFLOP/s on the n = 2304 triangular products.
+// 128 x 64 block tile on the fp64 MFMA (v_mfma_f64_16x16x4_f64: A lane l = A[l % 16][l / 16], B lane l = B[l / 16][l % 16],
+// D lane l, register r = D[4 r + l / 16][l % 16], r = 0..3 -- probed on the device, tools/probe_mfma_f64.hip): wave w owns rows [32 w, 32 w + 32) x all 64 columns = 2 x 4 MFMA tiles,
+// K in slabs of 32 = 8 MFMA steps, per step 6 ds_read_b64 feed 8 MFMAs.  Each operand keeps the orientation of its SOURCE
+// in LDS, so that the coalesced global rows are stored contiguously: [k][row] with rows padded by 16 doubles when the row
+// index is the contiguous source dimension (the two k rows a 32-lane read group touches sit 32 banks apart), [row][k] with a
+// stride of 34 doubles when k is (16 rows x 2 k land on 64 distinct banks).  Both the stores and the fragment reads are
+// conflict-free in both orientations; a single [k][row] image made the transposing stores 16-way conflicted.
+// The first version of this kernel was a VALU product, 8 x 4 per thread, 5.3 FMAs per LDS read: 6.5 TFLOP/s, 2.8 ms of a
+// gim_dkm match() (round 1).
+typedef double f64x4_t __attribute__((ext_vector_type(4)));
 constexpr int GBM = 128, GBN = 64, GKT = 32;
 
+constexpr int GSK = GBM + 16, GSKB = GBN + 16, GSR = GKT + 2;   // row strides: [k][row] images (A / B), [row][k] image
+
+template <bool TA, bool TB>
 __global__ void __launch_bounds__(256) gemm_f64_kernel(const GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) double As[GKT][GBM + 2];  // [k][i]
-    __shared__ __attribute__((aligned(16))) double Bs[GKT][GBN + 2];  // [k][c]
+    __shared__ __attribute__((aligned(16))) double As[TA ? GKT * GSK : GBM * GSR];   // TA: [k][i], else [i][k]
+    __shared__ __attribute__((aligned(16))) double Bs[TB ? GBN * GSR : GKT * GSKB];  // TB: [c][k], else [k][c]
     const int b = blockIdx.z / g.npair, p = blockIdx.z - b * g.npair;
     const int M = p == g.npair - 1 ? g.Mlast : g.M;
     const int K = p == g.npair - 1 ? g.Klast : g.K;
@@ -252,13 +262,19 @@ __global__ void __launch_bounds__(256) gemm_f64_kernel(const GemmArgs g) {
     if (g.tri == 1) ke = min(K, i0 + GBM);
     else if (g.tri == 2) kb = i0;
     else if (g.tri == 3) kb = c0;
-    const int ty = t >> 4, tx = t & 15;
-    double acc[8][4] = {};
-    for (int k0 = kb; k0 < ke; k0 += GKT) {
-        // coalesce along the contiguous source dimension; all loads of the slab are issued before the first LDS write (a
-        // rolled load -> wait -> store loop cost 24 dependent memory round trips per slab: 0.7 ms for the n = 2304 products)
-        double ra[GBM * GKT / 256], rb[GBN * GKT / 256];
-        if (g.ta) {
+    const int wave = t >> 6, lane = t & 63, l15 = lane & 15, lq = lane >> 4;
+    f64x4_t acc[2][4];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = (f64x4_t){0.0, 0.0, 0.0, 0.0};
+    // Software pipeline over the K slabs: the global loads of slab s + 1 are issued (into registers) before the MFMAs of slab s
+    // and written to LDS after them -- single-buffered, every slab exposed a full memory round trip (~1.5 us x 72 slabs per
+    // n = 2304 product, whatever the FMA rate: the MFMA version of the inner product alone gained 8 %).
+    // Loads coalesce along the contiguous source dimension.
+    double ra[GBM * GKT / 256], rb[GBN * GKT / 256];
+    auto fetch = [&](const int k0) {
+        if (TA) {
 #pragma unroll
             for (int j = 0; j < GBM * GKT / 256; ++j) {
                 const int e = t + 256 * j, k = e / GBM, i = e - k * GBM;
@@ -271,7 +287,7 @@ __global__ void __launch_bounds__(256) gemm_f64_kernel(const GemmArgs g) {
                 ra[j] = (k0 + k < ke && i0 + i < M) ? am[(size_t)(i0 + i) * g.lda + k0 + k] : 0.0;
             }
         }
-        if (g.tb) {
+        if (TB) {
 #pragma unroll
             for (int j = 0; j < GBN * GKT / 256; ++j) {
                 const int e = t + 256 * j, cc = e / GKT, k = e - cc * GKT;
@@ -284,41 +300,47 @@ __global__ void __launch_bounds__(256) gemm_f64_kernel(const GemmArgs g) {
                 rb[j] = (k0 + k < ke && c0 + cc < g.N) ? bm[(size_t)(k0 + k) * g.ldb + c0 + cc] : 0.0;
             }
         }
+    };
+    if (kb < ke) fetch(kb);
+    for (int k0 = kb; k0 < ke; k0 += GKT) {
 #pragma unroll
         for (int j = 0; j < GBM * GKT / 256; ++j) {
             const int e = t + 256 * j;
-            if (g.ta) { const int k = e / GBM; As[k][e - k * GBM] = ra[j]; } else { const int i = e / GKT; As[e - i * GKT][i] = ra[j]; }
+            if (TA) { const int k = e / GBM; As[k * GSK + e - k * GBM] = ra[j]; } else { const int i = e / GKT; As[i * GSR + e - i * GKT] = ra[j]; }
         }
 #pragma unroll
         for (int j = 0; j < GBN * GKT / 256; ++j) {
             const int e = t + 256 * j;
-            if (g.tb) { const int cc = e / GKT; Bs[e - cc * GKT][cc] = rb[j]; } else { const int k = e / GBN; Bs[k][e - k * GBN] = rb[j]; }
+            if (TB) { const int cc = e / GKT; Bs[cc * GSR + e - cc * GKT] = rb[j]; } else { const int k = e / GBN; Bs[k * GSKB + e - k * GBN] = rb[j]; }
         }
         __syncthreads();
-#pragma unroll 4
-        for (int k = 0; k < GKT; ++k) {
-            double av[8], bv[4];
+        if (k0 + GKT < ke) fetch(k0 + GKT);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { av[2 * q] = As[k][q * 32 + ty * 2]; av[2 * q + 1] = As[k][q * 32 + ty * 2 + 1]; }
+        for (int k4 = 0; k4 < GKT; k4 += 4) {
+            double av[2], bv[4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) { bv[2 * h] = Bs[k][h * 32 + tx * 2]; bv[2 * h + 1] = Bs[k][h * 32 + tx * 2 + 1]; }
+            for (int x = 0; x < 2; ++x) av[x] = TA ? As[(k4 + lq) * GSK + wave * 32 + x * 16 + l15] : As[(wave * 32 + x * 16 + l15) * GSR + k4 + lq];
 #pragma unroll
-            for (int x = 0; x < 8; ++x)
+            for (int y = 0; y < 4; ++y) bv[y] = TB ? Bs[(y * 16 + l15) * GSR + k4 + lq] : Bs[(k4 + lq) * GSKB + y * 16 + l15];
 #pragma unroll
-                for (int y = 0; y < 4; ++y) acc[x][y] = fma(av[x], bv[y], acc[x][y]);
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int x = 0; x < 8; ++x) {
-        const int i = i0 + (x >> 1) * 32 + ty * 2 + (x & 1);
-        if (i >= M) continue;
+    for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            const int cc = c0 + (y >> 1) * 32 + tx * 2 + (y & 1);
-            if (cc < g.N) c[(size_t)i * g.ldc + cc] = g.sign * acc[x][y];
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + wave * 32 + x * 16 + r * 4 + lq;
+            if (i >= M) continue;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                const int cc = c0 + y * 16 + l15;
+                if (cc < g.N) c[(size_t)i * g.ldc + cc] = g.sign * acc[x][y][r];
+            }
         }
-    }
 }
 
 // Xt[b][c][i] = (float) X[b][i][c], zero for i in [n, npad)
@@ -349,7 +371,10 @@ extern "C" int64_t gim_gp_solve_ws_bytes(int B, int n, int nrhs) {
 namespace {
 void launch_gemm(hipStream_t s, int B, const GemmArgs& g) {
     const int mt = ((g.M > g.Mlast ? g.M : g.Mlast) + GBM - 1) / GBM, nt = (g.N + GBN - 1) / GBN;
-    hipLaunchKernelGGL(gemm_f64_kernel, dim3(nt, mt, B * g.npair), dim3(256), 0, s, g);
+    if (g.ta && g.tb) hipLaunchKernelGGL((gemm_f64_kernel<true, true>), dim3(nt, mt, B * g.npair), dim3(256), 0, s, g);
+    else if (g.ta) hipLaunchKernelGGL((gemm_f64_kernel<true, false>), dim3(nt, mt, B * g.npair), dim3(256), 0, s, g);
+    else if (g.tb) hipLaunchKernelGGL((gemm_f64_kernel<false, true>), dim3(nt, mt, B * g.npair), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_f64_kernel<false, false>), dim3(nt, mt, B * g.npair), dim3(256), 0, s, g);
 }
 }  // namespace
 

@@ -16,6 +16,8 @@ import os
 
 import numpy as np
 
+_trapz = getattr(np, "trapezoid", None) or np.trapz   # np.trapz is deprecated since numpy 2.0
+
 DATASETS = ["GL3D", "BlendedMVS", "ETH3DI", "ETH3DO", "KITTI", "RobotcarWeather", "RobotcarSeason",
             "RobotcarNight", "Multi-FoV", "SceneNetRGBD", "ICL-NUIM", "GTA-SfM"]  # analysis.py:18-31
 HEADER = "identifiers covisible0 covisible1 R_errs t_errs t_errs2 Bef.Prec Bef.Num Aft.Prec Aft.Num"
@@ -37,7 +39,7 @@ def error_auc(errs0, errs1, thresholds=(5.0, 10.0, 20.0)):
         last_index = np.searchsorted(errors, thr)
         y = recall[:last_index] + [recall[last_index - 1]]
         x = errors[:last_index] + [thr]
-        out[thr] = float(np.trapz(y, x) / thr)
+        out[thr] = float(_trapz(y, x) / thr)
     return out
 
 

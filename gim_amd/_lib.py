@@ -24,6 +24,7 @@ class ConvArgs(ctypes.Structure):
         ("stride", c_int), ("pad", c_int), ("ldx", c_int), ("ldy", c_int), ("ldres", c_int),
         ("N", c_int), ("npad", c_int), ("kpad", c_int), ("act", c_int), ("act_cols", c_int), ("res_mod", c_int),
         ("dtype", c_int), ("out_dtype", c_int), ("res_dtype", c_int), ("use_lds_dma", c_int),
+        ("ups", c_void_p), ("ups_h", c_int), ("ups_w", c_int), ("ups_ld", c_int),
     ]
 
 
@@ -59,6 +60,7 @@ PROTOTYPES = {
     "gim_nchw_to_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "gim_nhwc_to_nchw": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "gim_conv2d_bn_act": (c_int, [ctypes.POINTER(ConvArgs), c_void_p]),
+    "gim_conv_ups_supported": (c_int, [ctypes.POINTER(ConvArgs)]),
     "gim_upsample2x_add": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "gim_posenc_add": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
     "gim_linear_attention_ws_bytes": (c_int64, [c_int] * 4),

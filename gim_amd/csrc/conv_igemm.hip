@@ -138,7 +138,7 @@ igemm_kernel(const gim_conv_args a, const int mtiles, const int ntiles, const in
 // extra LDS), so that residual loads and output stores are 16 bytes per lane with a whole 128/256-byte row
 // segment per 8/16 adjacent lanes.  Bias enters as the accumulator's initial value; activation kind,
 // bounds and dtypes are tile-uniform branches; bf16 rounding is one v_cvt_pk_bf16_f32 per pair.
-template <typename G, bool OUT_BF16, bool HAS_RES>
+template <typename G, bool OUT_BF16, bool HAS_RES, bool UPS = false>
 struct Epilogue {
     static constexpr int TM = G::TM, TN = G::TN, WTM = G::WTM, WTN = G::WTN, WN = G::WTN == 0 ? 1 : (G::B_BYTES / KTB) / G::WTN;
     static_assert(WTM % 32 == 0 && WTN % 64 == 0, "epilogue transposition works on 32 px x 64 ch passes of the wave tile");
@@ -267,11 +267,50 @@ struct Epilogue {
                                 make_float4(v[rg * 4 + 0], v[rg * 4 + 1], v[rg * 4 + 2], v[rg * 4 + 3]);
                         }
                     }
+                // UPS: y += bilinear x2 (align_corners=True) of a.ups, arithmetic of upsample2x_add_kernel (elementwise.hip) on
+                // the rounded conv output.  The 32 pixels of a pass lie in one image row (Wo % 32 == 0, checked at launch).
+                int ub = 0, uY = 0, uX0 = 0;
+                if constexpr (UPS) {
+                    const int mb = m0 + wm * WTM + j * 32;  // wave-uniform
+                    const int W2 = 2 * a.ups_w, H2 = 2 * a.ups_h;
+                    const int pr = mb / W2;
+                    uX0 = mb - pr * W2; ub = pr / H2; uY = pr - ub * H2;
+                }
 #pragma unroll
                 for (int k = 0; k < NI; ++k) {
                     const int row = k * RPI + rrow;
                     const int m = m0 + wm * WTM + j * 32 + row;
-                    const uint4 o = *(const uint4*)(wl + row * RB + ((rslot ^ (row & 7)) << 4));
+                    uint4 o = *(const uint4*)(wl + row * RB + ((rslot ^ (row & 7)) << 4));
+                    if constexpr (UPS && OUT_BF16) {
+                        if (ncol_ok && (full || m < M)) {
+                            const int h = a.ups_h, w = a.ups_w;
+                            const float sy = (float)(h - 1) / (float)(2 * h - 1), sx = (float)(w - 1) / (float)(2 * w - 1);
+                            const float fy = sy * uY, fx = sx * (uX0 + row);
+                            const int y0 = (int)fy, x0 = (int)fx;
+                            const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+                            const float ly1 = fy - y0, ly0 = 1.f - ly1, lx1 = fx - x0, lx0 = 1.f - lx1;
+                            const size_t base = (size_t)ub * h * w;
+                            const unsigned short* up = (const unsigned short*)a.ups + ncol;
+                            const uint4 qa = *(const uint4*)(up + (base + (size_t)y0 * w + x0) * a.ups_ld);
+                            const uint4 qb = *(const uint4*)(up + (base + (size_t)y0 * w + x1) * a.ups_ld);
+                            const uint4 qc = *(const uint4*)(up + (base + (size_t)y1 * w + x0) * a.ups_ld);
+                            const uint4 qd = *(const uint4*)(up + (base + (size_t)y1 * w + x1) * a.ups_ld);
+                            const unsigned ov[4] = {o.x, o.y, o.z, o.w}, av[4] = {qa.x, qa.y, qa.z, qa.w}, bv[4] = {qb.x, qb.y, qb.z, qb.w};
+                            const unsigned cv[4] = {qc.x, qc.y, qc.z, qc.w}, dv[4] = {qd.x, qd.y, qd.z, qd.w};
+                            unsigned rv[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float o0 = __uint_as_float(ov[e] << 16), o1 = __uint_as_float(ov[e] & 0xffff0000u);
+                                const float a0 = __uint_as_float(av[e] << 16), a1 = __uint_as_float(av[e] & 0xffff0000u);
+                                const float b0 = __uint_as_float(bv[e] << 16), b1 = __uint_as_float(bv[e] & 0xffff0000u);
+                                const float c0 = __uint_as_float(cv[e] << 16), c1 = __uint_as_float(cv[e] & 0xffff0000u);
+                                const float d0 = __uint_as_float(dv[e] << 16), d1 = __uint_as_float(dv[e] & 0xffff0000u);
+                                rv[e] = cvt_pk_bf16(o0 + (ly0 * (lx0 * a0 + lx1 * b0) + ly1 * (lx0 * c0 + lx1 * d0)),
+                                                    o1 + (ly0 * (lx0 * a1 + lx1 * b1) + ly1 * (lx0 * c1 + lx1 * d1)));
+                            }
+                            o = make_uint4(rv[0], rv[1], rv[2], rv[3]);
+                        }
+                    }
                     if (ncol_ok && (full || m < M)) *(uint4*)((char*)a.y + ((size_t)m * a.ldy + ncol) * OES) = o;
                 }
             }
@@ -316,12 +355,12 @@ template <int N> struct IntC { static constexpr int value = N; };
 
 // SKIP: waves whose last 32-channel fragment lies entirely beyond N run a K loop without it (a second copy of the loop,
 // selected per tile by a wave-uniform branch; see Igemm::mma)
-template <int BM, int BN, int WM, int WN, bool BF16, bool OUT_BF16, bool HAS_RES, bool SKIP = false>
+template <int BM, int BN, int WM, int WN, bool BF16, bool OUT_BF16, bool HAS_RES, bool SKIP = false, bool UPS = false>
 __global__ void __launch_bounds__(WM * WN * 64, 2)  // 2 waves per SIMD: 2 x 4-wave or 1 x 8-wave workgroup per CU
 igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntiles, const int M) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef gim::Igemm<BM, BN, WM, WN, BF16, true> G;
-    typedef Epilogue<G, OUT_BF16, HAS_RES> E;
+    typedef Epilogue<G, OUT_BF16, HAS_RES, UPS> E;
 
     unsigned first, step, end;
     tile_list((unsigned)(mtiles * ntiles), first, step, end);
@@ -584,10 +623,10 @@ igemm_ring3_kernel(const gim_conv_args a, const int mtiles, const int ntiles, co
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool BF16, bool OUT_BF16, bool HAS_RES, bool SKIP = false>
+template <int BM, int BN, int WM, int WN, bool BF16, bool OUT_BF16, bool HAS_RES, bool SKIP = false, bool UPS = false>
 int launch_persistent(const gim_conv_args& a, hipStream_t stream) {
     constexpr int smem = 2 * (BM + BN) * KTB;
-    auto kern = igemm_persistent_kernel<BM, BN, WM, WN, BF16, OUT_BF16, HAS_RES, SKIP>;
+    auto kern = igemm_persistent_kernel<BM, BN, WM, WN, BF16, OUT_BF16, HAS_RES, SKIP, UPS>;
     static GimPerDevice attr_done;
     if (attr_done.needed()) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -916,6 +955,10 @@ int dispatch_persistent(const gim_conv_args& a, hipStream_t s) {
                 if (pp_mode() == 2 || (pp_mode() == 1 && nkt >= pp_min_nkt()))
                     return launch_pp(a, s);
             }
+            if constexpr (BF16) {
+                if (a.ups) return skip ? launch_persistent<256, 256, 4, 2, true, true, false, true, true>(a, s)
+                                       : launch_persistent<256, 256, 4, 2, true, true, false, false, true>(a, s);
+            }
             if (skip) return launch_persistent<256, 256, 4, 2, BF16, true, false, true>(a, s);
             return launch_persistent<256, 256, 4, 2, BF16, true, false>(a, s);
         }
@@ -958,6 +1001,20 @@ int dispatch_tile(const gim_conv_args& a, hipStream_t s) {
 
 }  // namespace
 
+// a->ups is only built into the 256 x 256 / 8-wave bf16 tile: the launch must be one that dispatch_persistent sends there
+static bool ups_supported(const gim_conv_args& a) {
+    if (a.dtype != GIM_BF16 || a.out_dtype != GIM_BF16 || a.res || a.use_lds_dma != 1 || a.npad % 256 != 0) return false;
+    // output rows are (image, Y, X) with Y < 2 ups_h, X < 2 ups_w whatever geometry the launch states (a 1x1 conv is launched flat)
+    const long long Mo = (long long)a.B * a.Ho * a.Wo;
+    if (a.ups_h <= 0 || a.ups_w <= 0 || Mo % (4ll * a.ups_h * a.ups_w) != 0 || (2 * a.ups_w) % 32 != 0 || a.ups_ld % 8 != 0 || a.ups_ld < a.N) return false;
+    if (a.act_cols != 0 || big_mode() == 0 || pp_mode() != 0) return false;
+    const int nkt = a.kpad * 2 / KTB;
+    const long long M = (long long)a.B * a.Ho * a.Wo;
+    return big_mode() == 2 || (nkt >= big_min_nkt() && ((M + 255) / 256) * (a.npad / 256) >= big_min_tiles());
+}
+
+extern "C" int gim_conv_ups_supported(const gim_conv_args* ap) { return ap && ups_supported(*ap) ? 1 : 0; }
+
 extern "C" int gim_conv2d_bn_act(const gim_conv_args* ap, gim_stream_t stream) {
     GIM_REQUIRE(ap, "gim_conv2d_bn_act: NULL args");
     const gim_conv_args& a = *ap;
@@ -975,6 +1032,7 @@ extern "C" int gim_conv2d_bn_act(const gim_conv_args* ap, gim_stream_t stream) {
     GIM_REQUIRE(a.act_cols >= 0 && a.act_cols % 128 == 0, "conv: act_cols=%d must be a multiple of 128", a.act_cols);
     GIM_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.Ho > 0 && a.Wo > 0 && a.stride > 0, "conv: bad geometry");
     GIM_REQUIRE((int64_t)a.B * a.Ho * a.Wo < (int64_t)0x7fffffff, "conv: too many output rows");
+    GIM_REQUIRE(!a.ups || ups_supported(a), "conv: this launch cannot take the fused upsample-add (see gim_conv_ups_supported)");
     hipStream_t s = (hipStream_t)stream;
     if (a.use_lds_dma == 2) {  // 3x3 halo kernel: w / ktab / kpad describe the halo packing (gim_amd/packing.py::pack_halo)
         GIM_REQUIRE(a.dtype == GIM_BF16 && a.out_dtype == GIM_BF16 && !a.res && a.stride == 1 && a.pad == 1 && a.H == a.Ho && a.W == a.Wo,

@@ -341,11 +341,11 @@ class LoFTR(nn.Module):
             feats.append(x)
         x1, x2, x3 = feats
         x3_out = ops.conv2d(x3, P["l3o"], lds_dma=dma)
-        x2_out = ops.conv2d(x2, P["l2o"], lds_dma=dma)
-        ops.upsample2x_add(x3_out, x2_out)
+        # lateral 1x1 conv + F.interpolate(scale_factor=2, bilinear, align_corners=True) of the coarser level + add (resnet.py:
+        # 321-327): the upsample-add runs in the conv's epilogue when the launch takes it, else as a second pass over the output
+        x2_out = ops.conv2d(x2, P["l2o"], lds_dma=dma, ups=x3_out)
         x2_out = ops.conv2d(ops.conv2d(x2_out, P["l2o2a"], ACT_LEAKY, lds_dma=dma), P["l2o2b"], lds_dma=dma)
-        x1_out = ops.conv2d(x1, P["l1o"], lds_dma=dma)
-        ops.upsample2x_add(x2_out, x1_out)
+        x1_out = ops.conv2d(x1, P["l1o"], lds_dma=dma, ups=x2_out)
         x1_out = ops.conv2d(ops.conv2d(x1_out, P["l1o2a"], ACT_LEAKY, lds_dma=dma), P["l1o2b"], lds_dma=dma)
         return x3_out, x1_out
 

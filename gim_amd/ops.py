@@ -86,8 +86,10 @@ def nhwc_to_nchw(src, C):
 
 
 # ---- conv / linear --------------------------------------------------------------------------------
-def conv_rows(x, pk, geom, y, act=ACT_NONE, res=None, res_mod=0, lds_dma=True, act_cols=0):
-    """Generic launch.  x: 2-D row view [rows_in, ldx]; geom = (B, H, W, Ho, Wo); y: 2-D row view."""
+def conv_rows(x, pk, geom, y, act=ACT_NONE, res=None, res_mod=0, lds_dma=True, act_cols=0, ups=None):
+    """Generic launch.  x: 2-D row view [rows_in, ldx]; geom = (B, H, W, Ho, Wo); y: 2-D row view.  ups: half-resolution NHWC
+    tensor whose bilinear x2 upsampling is added in the epilogue, or a callable that performs that addition as a separate pass when
+    the launch cannot take it (returns True when it was fused)."""
     _req_cuda(x, y, res)
     B, H, W, Ho, Wo = geom
     a = _lib.ConvArgs()
@@ -108,19 +110,29 @@ def conv_rows(x, pk, geom, y, act=ACT_NONE, res=None, res_mod=0, lds_dma=True, a
     a.res_dtype = gim_dtype(res) if res is not None else GIM_F32
     a.use_lds_dma = 1 if lds_dma else 0
     assert y.shape[0] >= B * Ho * Wo and y.shape[1] >= pk.n_store
+    if ups is not None:
+        a.ups, a.ups_h, a.ups_w, a.ups_ld = ups.data_ptr(), ups.shape[1], ups.shape[2], ups.shape[3]
+        if not (UPS_FUSED and ups.dtype == torch.bfloat16 and lib.gim_conv_ups_supported(ctypes.byref(a))):
+            a.ups = None
+    fused_ups = ups is not None and a.ups is not None
     if PROFILE is None:
         check(lib.gim_conv2d_bn_act(ctypes.byref(a), _stream()), "gim_conv2d_bn_act")
-        return
+        return fused_ups
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     check(lib.gim_conv2d_bn_act(ctypes.byref(a), _stream()), "gim_conv2d_bn_act")
     e1.record()
     flops = 2.0 * B * Ho * Wo * pk.cout * pk.cin * pk.kh * pk.kw  # algorithmic: real channels, no padding
-    PROFILE.append((e0, e1, flops, f"{pk.cin}->{pk.cout} k{pk.kh}s{pk.stride} M={B * Ho * Wo}"))
+    PROFILE.append((e0, e1, flops, f"{pk.cin}->{pk.cout} k{pk.kh}s{pk.stride} M={B * Ho * Wo}" + (" +ups" if fused_ups else "")))
+    return fused_ups
 
 
-def conv2d(x, pk, act=ACT_NONE, res=None, out_dtype=None, lds_dma=True):
-    """x [B,H,W,cin_pad] NHWC -> new [B,Ho,Wo,n_store]"""
+UPS_FUSED = os.environ.get("GIM_UPS_FUSED", "1") != "0"   # FPN: bilinear x2 + add inside the lateral 1x1 conv's epilogue
+
+
+def conv2d(x, pk, act=ACT_NONE, res=None, out_dtype=None, lds_dma=True, ups=None):
+    """x [B,H,W,cin_pad] NHWC -> new [B,Ho,Wo,n_store].  ups: [B,Ho/2,Wo/2,n_store] -> y += bilinear_x2(ups) (align_corners=True):
+    in the conv's epilogue when the launch supports it, otherwise as a second pass (gim_upsample2x_add)."""
     B, H, W, cs = x.shape
     assert cs == pk.cin_pad, (cs, pk)
     Ho = (H + 2 * pk.pad - pk.kh) // pk.stride + 1
@@ -133,6 +145,11 @@ def conv2d(x, pk, act=ACT_NONE, res=None, out_dtype=None, lds_dma=True):
     if HALO and pk.halo is not None and res is None and lds_dma and x.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 \
             and _halo_pays(pk, B, H, W):
         conv3x3_halo(x, pk, y, act)
+        return y
+    if ups is not None:
+        assert ups.shape == (B, Ho // 2, Wo // 2, pk.n_store) and res is None
+        if not conv_rows(x.view(-1, cs), pk, geom, y.view(-1, pk.n_store), act, r, 0, lds_dma, ups=ups):
+            upsample2x_add(ups, y)
         return y
     conv_rows(x.view(-1, cs), pk, geom, y.view(-1, pk.n_store), act, r, 0, lds_dma)
     return y

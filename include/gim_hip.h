@@ -74,8 +74,16 @@ typedef struct gim_conv_args {
     int dtype;          /* dtype of x and w */
     int out_dtype;      /* dtype of y */
     int res_dtype;      /* dtype of res */
-    int use_lds_dma;    /* 1: buffer_load ... lds staging (default); 0: register staging */
+    int use_lds_dma;    /* 1: buffer_load ... lds staging (default); 0: register staging; 2: 3x3 halo kernel (w / ktab / kpad =
+                           the halo packing, res_mod = channels stored per input row) */
+    const void* ups;    /* NULL, or a half-resolution tensor [B, ups_h, ups_w, ups_ld] (dtype = out_dtype = bf16) whose bilinear x2
+                           upsampling (align_corners=True) is added to the (rounded) conv output in the epilogue: the FPN's
+                           `x2_out + F.interpolate(x3_out, scale_factor=2.)` (backbone/resnet.py:321-327) without a second pass
+                           over y.  Output rows = (image, Y < 2 ups_h, X < 2 ups_w); needs (2 ups_w) % 32 == 0 and a launch the 256 x 256 tile takes
+                           (1x1 conv, bf16, no residual, npad % 256 == 0, >= 4 K slabs, >= 512 tiles): gim_conv_ups_supported() */
+    int ups_h, ups_w, ups_ld;
 } gim_conv_args;
+int gim_conv_ups_supported(const gim_conv_args* a);   /* 1 if gim_conv2d_bn_act would take a->ups (set or not) for this launch */
 int gim_conv2d_bn_act(const gim_conv_args* a, gim_stream_t stream);
 
 /* y[m,:] += bilinear_upsample_2x(x)[m,:], align_corners=True (resnet.py:321,325: F.interpolate +

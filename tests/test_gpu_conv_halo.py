@@ -46,3 +46,38 @@ def test_conv3x3_halo_vs_reference(case):
     assert (got - y2.float().cpu())[..., :cout].abs().max().item() <= 1e-2 * scale  # generic path: same products, other K order
     if pk.n_store > cout:
         assert (got[..., cout:] == 0).all()                                        # pad channels stay exact zeros
+
+
+@pytest.mark.parametrize("case", [(2, 16, 64, 512, 256), (1, 24, 96, 256, 196), (2, 8, 32, 64, 256)],
+                         ids=["512to256", "256to196", "small_falls_back"])
+def test_conv1x1_fused_upsample_add(case):
+    """FPN lateral conv + bilinear x2 (align_corners=True) + add: epilogue-fused (gim_conv_args.ups) vs the two-pass path vs torch"""
+    from gim_amd import _lib, ops
+    from gim_amd.packing import cstore, pack_conv
+    B, H, W, cin, cout = case
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(cout, cin, 1, 1, generator=g) * (1.0 / cin) ** 0.5
+    pk = pack_conv(w, None, _lib.GIM_BF16, dev)
+    cs, ns = cstore(cin, _lib.GIM_BF16), pk.n_store
+    x = torch.zeros(B, H, W, cs); x[..., :cin] = torch.randn(B, H, W, cin, generator=g)
+    lo = torch.zeros(B, H // 2, W // 2, ns); lo[..., :cout] = torch.randn(B, H // 2, W // 2, cout, generator=g)
+    xb, lob = x.to(torch.bfloat16).to(dev), lo.to(torch.bfloat16).to(dev)
+    old_big = None
+    try:
+        ops.UPS_FUSED = True
+        y_f = ops.conv2d(xb, pk, ups=lob)
+        ops.UPS_FUSED = False
+        y_u = ops.conv2d(xb, pk, ups=lob)
+    finally:
+        ops.UPS_FUSED = True
+    torch.cuda.synchronize()
+    conv = F.conv2d(xb.float().cpu()[..., :cin].permute(0, 3, 1, 2), w.to(torch.bfloat16).float())
+    up = F.interpolate(lob.float().cpu()[..., :cout].permute(0, 3, 1, 2), scale_factor=2.0, mode="bilinear", align_corners=True)
+    ref = (conv.to(torch.bfloat16).float() + up).permute(0, 2, 3, 1)
+    scale = ref.abs().max().item()
+    for name, y in (("fused", y_f), ("two-pass", y_u)):
+        assert (y.float().cpu()[..., :cout] - ref).abs().max().item() <= 1e-2 * scale, name
+    # same arithmetic on the same rounded conv output: the two paths agree to bf16 rounding of an fp32 sum that may contract differently
+    assert (y_f.float() - y_u.float()).abs().max().item() <= 2e-2 * scale
+    assert ((y_f.float() - y_u.float()).abs() > 0).float().mean().item() < 0.02

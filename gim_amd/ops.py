@@ -177,10 +177,10 @@ def conv3x3_halo(x, pk, y, act=ACT_NONE):
     """x [B,H,W,cin_pad] bf16 -> y [B,H,W,n_store] bf16 through the halo-tile kernel (3x3, stride 1, pad 1, no residual)"""
     _req_cuda(x, y)
     B, H, W, cs = x.shape
-    w, tab, nslab = pk.halo
+    w, tab, nslab, bias = pk.halo
     a = _lib.ConvArgs()
     a.x, a.w, a.ktab = x.data_ptr(), w.data_ptr(), tab.data_ptr()
-    a.bias = pk.bias.data_ptr() if pk.bias is not None else None
+    a.bias = bias.data_ptr() if bias is not None else None
     a.res, a.y = None, y.data_ptr()
     a.x_bytes = ((B * H * W - 1) * cs + pk.cin_pad) * 2
     a.B, a.H, a.W, a.Ho, a.Wo = B, H, W, H, W

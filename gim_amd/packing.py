@@ -108,7 +108,12 @@ def pack_conv(weight, bn, dtype, device, stride=1, pad=0, cin_pad=None, bias=Non
     p.npad, p.kpad, p.dtype = npad, kpad, dtype
     p.halo = None
     if dtype == _lib.GIM_BF16 and kh == 3 and kw == 3 and stride == 1 and pad == 1:
-        p.halo = pack_halo(wp, cin_pad, device)
+        wh, tab, nslab = pack_halo(wp, cin_pad, device)
+        bh = p.bias
+        if bh is not None and wh.shape[0] > npad:      # the halo kernel's N tile is 128 wide: its bias reads cover wh.shape[0] entries
+            bh = torch.zeros(wh.shape[0], dtype=torch.float32, device=device)
+            bh[:npad] = p.bias
+        p.halo = (wh, tab, nslab, bh)
     return p
 
 

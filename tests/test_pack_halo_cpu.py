@@ -13,7 +13,7 @@ def test_pack_halo_table_reproduces_conv(cin, cout):
     g = torch.Generator().manual_seed(3)
     w = torch.randn(cout, cin, 3, 3, generator=g)
     pk = pack_conv(w, None, _lib.GIM_BF16, "cpu", stride=1, pad=1)
-    wh, tab, nslab = pk.halo
+    wh, tab, nslab, _ = pk.halo
     tab = tab.reshape(nslab, 8)
     cs = cstore(cin, _lib.GIM_BF16)
     H, W = 8, 32                                   # one patch

@@ -15,15 +15,19 @@ pytestmark = [pytest.mark.gpu,
 
 @pytest.fixture(autouse=True)
 def _numpy_inverse(monkeypatch):
-    """torch.linalg.inv on the CPU fails for the 2352 x 2352 GP matrix in this image's torch build ("Pivots given to lu_solve must
-    all be greater or equal to 1"; fine for the 80 ... 320-row matrices of the small-size tests): the oracle's fp32 LU inverse goes through numpy's LAPACK here"""
+    """torch.linalg.inv on the CPU can fail in this image's torch build ("Pivots given to lu_solve must all be greater or equal to
+    1": observed for the 2352 x 2352 GP matrix, and for smaller ones after torch.set_num_threads() had been called -- which is
+    why this file leaves the thread count alone): fall back to numpy's LAPACK for the oracle's fp32 LU inverse when it does"""
     import numpy as np
     real = torch.linalg.inv
 
     def inv(a):
-        if a.is_cuda or a.shape[-1] < 128:
+        try:
             return real(a)
-        return torch.from_numpy(np.linalg.inv(a.detach().numpy())).to(a.dtype)
+        except RuntimeError:
+            if a.is_cuda:
+                raise
+            return torch.from_numpy(np.linalg.inv(a.detach().numpy())).to(a.dtype)
     monkeypatch.setattr(torch.linalg, "inv", inv)
 
 
@@ -42,7 +46,6 @@ def _close(got, ref, tol, name, frac=0.999, mean_tol=None):
 def test_dkm_672x896_vs_oracle():
     import dkm_oracle as O
     from gim_amd.dkm import DKMv3
-    torch.set_num_threads(min(int(os.environ.get("GIM_ORACLE_THREADS", "16")), os.cpu_count() or 8))  # (torch CPU getrf fails at n = 2352 with 64 threads on this image)
     sd = O.make_state_dict(0)
     im0, im1 = O.seeded_pair(672, 896, 3)
     with torch.no_grad():
@@ -59,7 +62,6 @@ def test_roma_672_vs_oracle():
     import dkm_oracle as DO
     import roma_oracle as O
     from gim_amd.roma import RoMa
-    torch.set_num_threads(min(int(os.environ.get("GIM_ORACLE_THREADS", "16")), os.cpu_count() or 8))  # (torch CPU getrf fails at n = 2352 with 64 threads on this image)
     sd, dsd = O.make_state_dicts(0)
     im0, im1 = DO.seeded_pair(672, 672, 3)
     with torch.no_grad():

@@ -41,7 +41,9 @@ if ROOT not in sys.path:
 
 H, W = 480, 640
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense, MI355X_MICROARCH.md
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_traffic.json")
+if not os.path.exists(TRAFFIC_JSON):
+    TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
 def parse_args(argv=None):
@@ -75,7 +77,7 @@ def launch(args, argv):
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} HIP device(s) visible")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "8")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, (os.cpu_count() or 8) // max(1, args.gpus)))))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
     return subprocess.call(cmd, env=env)
@@ -136,9 +138,10 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         assert dist.get_world_size() == world
+        bind_rank_to_cores(local_rank, world)   # N ranks share one host: own core slice + thread cap per rank
 
     from gim_amd import ops
-    from gim_amd.runner import all_gather_matches, pack_matches
+    from gim_amd.runner import HostPairFeeder, all_gather_matches, bind_rank_to_cores, pack_matches
     from tools import synth_loftr as S
     from tools.parity import parity_vs_oracle
 
@@ -165,7 +168,7 @@ def main():
             torch.cuda.synchronize()
 
     for w_ in range(max(2, args.warmup)):  # the COMPLETE step, incl. match packing; the 2nd call captures the HIP graph
-        pack_matches(step(), list(range(nb)))
+        pack_matches(step(), 0)
     all_gather_matches(torch.zeros(1, 6, device=dev))
     sync_all()
     t0 = time.perf_counter()
@@ -173,7 +176,7 @@ def main():
     tstep = []
     for s in range(args.steps):
         d = step()
-        rows.append(pack_matches(d, [(s * world + rank) * nb + b for b in range(nb)]))
+        rows.append(pack_matches(d, (s * world + rank) * nb))   # consecutive pair ids of this batch, packed on the device
         tstep.append(time.perf_counter())
     allrows = all_gather_matches(torch.cat(rows))  # the one collective: matches, for reporting
     n_matches = int(allrows.shape[0])
@@ -229,21 +232,61 @@ def main():
                 "top_layers_ms_tflops": [[k, round(v[0] / 2, 3), round(v[1] / (v[0] * 1e-3) / 1e12, 1)] for k, v in top]}
 
     # ---- the same step with the images starting in (pinned) host memory: PCIe-inclusive rate -------------
+    # double-buffered staging on a copy stream (gim_amd.runner.HostPairFeeder): the transfer of step s + 1 overlaps step s
     h2d = None
     if solo:
         p0, p1 = c0h.pin_memory(), c1h.pin_memory()
+        feeder = HostPairFeeder(dev)
+
+        def h2d_run(n):
+            feeder.put([p0, p1])
+            for i in range(n):
+                a, b = feeder.get()
+                if i + 1 < n:
+                    feeder.put([p0, p1])
+                step(a, b)
+                feeder.done()
+            torch.cuda.synchronize()
+
+        h2d_run(3)
+        n_h = 10
+        th = time.perf_counter()
+        h2d_run(n_h)
+        th = (time.perf_counter() - th) / n_h
         for _ in range(2):
             step(p0.to(dev, non_blocking=True), p1.to(dev, non_blocking=True))
         torch.cuda.synchronize()
-        th = time.perf_counter()
-        n_h = 10
-        for _ in range(n_h):
+        ts = time.perf_counter()
+        for _ in range(5):
             step(p0.to(dev, non_blocking=True), p1.to(dev, non_blocking=True))
         torch.cuda.synchronize()
-        th = (time.perf_counter() - th) / n_h
+        ts = (time.perf_counter() - ts) / 5
         h2d = {"pairs_per_s": round(nb / th, 2), "ms_per_step": round(1e3 * th, 3),
-               "note": f"{2 * c0h.numel() * 4 / 1e6:.0f} MB of fp32 NCHW images per step copied from pinned host memory "
-                       "on the compute stream (no overlap with the previous step)"}
+               "serial_copy_ms_per_step": round(1e3 * ts, 3),
+               "note": f"{2 * c0h.numel() * 4 / 1e6:.0f} MB of fp32 NCHW images per step from pinned host memory, double-buffered on a "
+                       "copy stream so that the transfer of step s+1 overlaps the kernels of step s (incl. the first, exposed copy); "
+                       "serial_copy = the same copies issued on the compute stream (round 2's figure)"}
+
+    # ---- the parity mode on the same workload: precision='fp32' (exact fp32 MFMA products), the mode whose match indices equal
+    # the oracle's -- timed on the driver's line next to the bf16 headline -------------------
+    parity_mode = None
+    if solo and args.precision == "bf16" and not os.environ.get("GIM_BENCH_SKIP_PARITY_MODE"):
+        model.set_precision("fp32")
+        for _ in range(2):
+            d32 = step()
+        torch.cuda.synchronize()
+        n32 = 5
+        t32 = time.perf_counter()
+        for _ in range(n32):
+            d32 = step()
+        torch.cuda.synchronize()
+        t32 = (time.perf_counter() - t32) / n32
+        parity_mode = {"precision": "fp32", "pairs_per_s": round(nb / t32, 2), "ms_per_step": round(1e3 * t32, 3), "steps": n32,
+                       "matches_per_pair": round(d32["b_ids"].numel() / nb, 1),
+                       "note": "same workload and batch with every GEMM on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)"}
+        d32 = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in d32.items() if k != "conf_matrix"}
+        model.set_precision("bf16", args.coarse_sim)
+        torch.cuda.empty_cache()
 
     # ---- the fine level idle (random-init weights, uniform-noise images: what round 1 reported) ----------
     idle = None
@@ -407,6 +450,8 @@ def main():
             tcs.append(time.perf_counter() - tc)
         tc = sum(tcs) / len(tcs)
         cpu = {"value": round(n / tc, 5), "unit": "pairs/s", "cores": ncore, "kind": "port",
+               "port_of": "networks/loftr/loftr.py:43-91 LoFTR.forward -- oracle/loftr_oracle.py, pinned to the reference's own outputs "
+                          "(0.0 ... 4e-7 apart on every stage, tests/golden); /root/reference does not exist on the GPU box",
                "sample": f"{n} pair(s) 640x480 fp32 (pair 0 of the benchmarked batch), oracle/loftr_oracle.py on torch CPU with "
                          f"{ncore} threads, 1 warm-up + {n_timed} timed forwards, {tc:.2f} s each "
                          f"(min {min(tcs):.2f}, max {max(tcs):.2f})"}
@@ -421,6 +466,8 @@ def main():
                 parity["other_coarse_sim"] = {"coarse_sim": model.coarse_sim, "flip_rate": alt["flip_rate"],
                                               "mean_abs_dmconf": alt.get("mean_abs_dmconf"), "mean_abs_dmkpts1_px": alt.get("mean_abs_dmkpts1_px")}
                 model.coarse_sim = was
+            if parity_mode is not None:
+                parity_mode["parity"] = parity_vs_oracle(d32, ref, 0)
 
     if rank == 0 and os.environ.get("GIM_BENCH_DEBUG"):
         print("per-step ms:", [round(1e3 * (b - a), 2) for a, b in zip([t0] + tstep[:-1], tstep)], file=sys.stderr)
@@ -438,7 +485,7 @@ def main():
                        "coarse_sim": model.coarse_sim,
                        "parallelism": f"pairs sharded over {world} GPU(s), no collective per step",
                        "hip_graph": bool(model.use_graph)},
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "h2d_inclusive": h2d, "fine_idle": idle,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "parity_mode": parity_mode, "h2d_inclusive": h2d, "fine_idle": idle,
             "secondary_workloads": {"gim_lightglue": lightglue, **dense},
         }
         print(json.dumps(out), flush=True)

@@ -41,6 +41,12 @@ class CoarseArgs(ctypes.Structure):
     ]
 
 
+class CopySegs(ctypes.Structure):
+    """struct gim_copy_segs (include/gim_hip.h)."""
+    MAX = 12
+    _fields_ = [("src", c_void_p * 12), ("dst", c_void_p * 12), ("bytes", c_int64 * 12), ("n", c_int)]
+
+
 class LgAssignArgs(ctypes.Structure):
     """struct gim_lg_assign_args (include/gim_hip.h)."""
     _fields_ = [
@@ -78,6 +84,8 @@ PROTOTYPES = {
     "gim_token_mlp": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_float, c_void_p]),
     "gim_fine_fused_weight_bytes": (c_int64, []),
     "gim_fine_fused": (c_int, [c_void_p] * 13 + [c_int] * 11 + [c_float, c_float, c_int, c_void_p]),
+    "gim_copy_segments": (c_int, [ctypes.POINTER(CopySegs), c_void_p]),
+    "gim_pack_matches": (c_int, [c_void_p] * 5 + [c_int64, c_void_p, c_int, c_void_p]),
     # gim_lightglue path
     "gim_maxpool2x2": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "gim_sp_scores": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),

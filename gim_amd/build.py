@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgimhip.so")
 SOURCES = ["runtime.hip", "conv_igemm.hip", "elementwise.hip", "linear_attention.hip", "coarse_match.hip",
-           "fine_match.hip", "fine_fused.hip", "token_mlp.hip", "bneck_fused.hip", "superpoint.hip", "lightglue.hip", "lg_assign.hip", "dkm.hip", "gp_solve.hip", "sample.hip"]
+           "fine_match.hip", "fine_fused.hip", "token_mlp.hip", "bneck_fused.hip", "emit.hip", "superpoint.hip", "lightglue.hip", "lg_assign.hip", "dkm.hip", "gp_solve.hip", "sample.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"] + os.environ.get("GIM_HIPCC_EXTRA", "").split()
 
 

@@ -36,8 +36,14 @@ def read_image(path, grayscale=False):
     return np.asarray(im.convert("L" if grayscale else "RGB"))
 
 
-def preprocess(image, grayscale=False, resize_max=None, dfactor=8):
-    """demo.py:140-178 -> (float tensor [C,H',W'] in [0,1], scale (x, y) = original size / new size)"""
+def preprocess(image, grayscale=False, resize_max=None, dfactor=8, antialias=False):
+    """demo.py:140-178 -> (float tensor [C,H',W'] in [0,1], scale (x, y) = original size / new size).
+    Numerics vs the reference when a resize actually happens: (1) the divisible-by-8 resize is torchvision's `F.resize` on a
+    TENSOR = bilinear, align_corners=False; the reference pins torchvision 0.13.1 (environment.yaml), whose tensor path does
+    NOT antialias (`antialias=None`), hence the default here -- pass `antialias=True` to reproduce a torchvision >= 0.17
+    installation, where it became the default; (2) the `resize_max` downscale is cv2 INTER_AREA in the reference: `mode='area'`
+    (adaptive average pooling) equals it for integer factors only, non-integer factors differ in the fractional cell weights;
+    (3) `read_image` decodes with PIL instead of OpenCV (identical for PNG, +-1 grey level for JPEG)."""
     image = image.astype(np.float32, copy=False)
     size = image.shape[:2][::-1]
     t = torch.from_numpy(image[None] if grayscale else image.transpose(2, 0, 1)).float()
@@ -48,7 +54,7 @@ def preprocess(image, grayscale=False, resize_max=None, dfactor=8):
             t = F.interpolate(t[None], size=size_new[::-1], mode="area")[0]
     t = t / 255.0
     size_new = tuple(int(x // dfactor * dfactor) for x in t.shape[-2:])
-    t = F.interpolate(t[None], size=size_new, mode="bilinear", align_corners=False)[0]   # torchvision F.resize on a tensor
+    t = F.interpolate(t[None], size=size_new, mode="bilinear", align_corners=False, antialias=antialias)[0]   # F.resize on a tensor
     scale = np.array(size) / np.array(size_new)[::-1]
     return t, scale
 

@@ -212,22 +212,26 @@ class LoFTR(nn.Module):
                 state_dict[k.replace("model.", "", 1)] = state_dict.pop(k)
             if k.startswith("matcher."):
                 state_dict[k.replace("matcher.", "", 1)] = state_dict.pop(k)
-        self._packed = None
-        self._graphs.clear()
+        self._invalidate()
         return super().load_state_dict(state_dict, *args, **kwargs)
 
-    def _apply(self, fn, *a, **k):
+    def _invalidate(self):
+        """weights / device / precision changed: packed weights, captured graphs AND the seen-shape counters go (a stale
+        counter would send the next forward of a known shape straight into capture with nothing packed)"""
         self._packed = None
         if hasattr(self, "_graphs"):
             self._graphs.clear()
+            self._seen.clear()
+
+    def _apply(self, fn, *a, **k):
+        self._invalidate()
         return super()._apply(fn, *a, **k)
 
     def set_precision(self, precision, coarse_sim=None):
         assert precision in ("bf16", "fp32")
         self.precision = precision
         self.coarse_sim = coarse_sim or precision
-        self._packed = None
-        self._graphs.clear()
+        self._invalidate()
         return self
 
     # ---- weight pre-pack --------------------------------------------------------------------------
@@ -309,18 +313,22 @@ class LoFTR(nn.Module):
         return self._pe_cache[key]
 
     # ---- stages -------------------------------------------------------------------------------------
-    def _backbone(self, P, images, dt):
-        """images: list of [n_i,3,H,W] fp32 tensors sharing (H,W).  Returns (x3_out NHWC [B,h8,w8,256],
-        feat_f NHWC [B,h2,w2,128]) in the compute dtype.  (resnet.py:230-235, 306-329)"""
-        dev = images[0].device
+    def _to_nhwc(self, images, dt, out=None):
+        """list of [n_i,3,H,W] fp32 tensors sharing (H,W) -> one NHWC [sum n_i, H, W, cstore(3)] tensor of the compute dtype
+        (replaces torch.cat([color0, color1]), loftr.py:60).  `out`: an existing tensor to fill (the HIP graph's static input)."""
         H, W = images[0].shape[2:]
         B = sum(im.shape[0] for im in images)
-        tdt = torch_dtype(dt)
-        x = torch.empty(B, H, W, cstore(3, dt), dtype=tdt, device=dev)
+        if out is None:
+            out = torch.empty(B, H, W, cstore(3, dt), dtype=torch_dtype(dt), device=images[0].device)
         off = 0
-        for im in images:  # replaces torch.cat([color0, color1]) (loftr.py:60)
-            ops.nchw_to_nhwc(im.contiguous().float(), x, off)
+        for im in images:
+            ops.nchw_to_nhwc(im, out, off)
             off += im.shape[0]
+        return out
+
+    def _backbone(self, P, x, dt):
+        """x: NHWC [B,H,W,cstore(3)] images in the compute dtype.  Returns (x3_out NHWC [B,h8,w8,256], feat_f NHWC [B,h2,w2,128])
+        in the compute dtype.  (resnet.py:230-235, 306-329)"""
         dma = self.use_lds_dma
         x = ops.conv2d(x, P["stem"], ACT_RELU, lds_dma=dma)
         feats = []
@@ -418,23 +426,23 @@ class LoFTR(nn.Module):
                 self._encoder_layer(P, p, T, r1, r0, n1, S, L, H)
 
     # ---- forward (loftr.py:43-91) -------------------------------------------------------------------
-    def _coarse_stage(self, color0, color1, scale0, scale1, mask0=None, mask1=None):
-        """Everything up to and including coarse matching: a fixed launch sequence with no host sync and
+    def _coarse_stage(self, xs, bs, scale0, scale1, mask0=None, mask1=None):
+        """Everything from the NHWC images up to and including coarse matching: a fixed launch sequence with no host sync and
         no data-dependent shape, so it can be captured once per input shape into a HIP graph and replayed.
+        xs: [x_all] (both images of all pairs in one [2 bs, H, W, c] tensor: equal image shapes) or [x0, x1] (loftr.py:59-63).
         Returns a dict of device tensors (graph-owned when captured)."""
-        dev = color0.device
+        dev = xs[0].device
         dt = GIM_BF16 if self.precision == "bf16" else GIM_F32
         tdt = torch_dtype(dt)
         P = self._prepack(dev)
         cfg = self.config
-        bs = color0.shape[0]
-        if color0.shape[2:] == color1.shape[2:]:
-            c_all, f_all = self._backbone(P, [color0, color1], dt)
+        if len(xs) == 1:
+            c_all, f_all = self._backbone(P, xs[0], dt)
             c0, c1 = c_all[:bs], c_all[bs:]
             f0, f1 = f_all[:bs], f_all[bs:]
         else:  # different input shapes (loftr.py:62-63)
-            c0, f0 = self._backbone(P, [color0], dt)
-            c1, f1 = self._backbone(P, [color1], dt)
+            c0, f0 = self._backbone(P, xs[0], dt)
+            c1, f1 = self._backbone(P, xs[1], dt)
         hw0_c, hw1_c = c0.shape[1:3], c1.shape[1:3]
         # 2. coarse transformer on pos-encoded tokens (NHWC rows == 'n (h w) c', loftr.py:74-75)
         C = cfg["coarse"]["d_model"]
@@ -450,7 +458,7 @@ class LoFTR(nn.Module):
         self._transformer(P, "c", self.loftr_coarse, T, bs, L, bs, S)
         # 3. coarse matching (coarse_matching.py:88-259), fused
         mc = cfg["match_coarse"]
-        scale = color0.shape[2] / hw0_c[0]
+        scale = xs[0].shape[1] / hw0_c[0]
         if dt == GIM_BF16 and self.coarse_sim == "bf16":
             # opt-in: the operand-dtype copy of the final tokens (written by the last LayerNorm for the next GEMM)
             # feeds the similarity -- bf16 MFMA with fp32 accumulation, not index-exact against the fp32 tokens
@@ -469,11 +477,22 @@ class LoFTR(nn.Module):
                 self.coarse_sim, str(color0.device))
 
     def _coarse_stage_graphed(self, key, color0, color1, scale0, scale1, mask0=None, mask1=None):
-        """HIP-graph replay of `_coarse_stage` (one graph per input shape / precision).  ~300 kernel launches
-        collapse into one graph launch; inputs are copied into the graph's static buffers."""
+        """HIP-graph replay of `_coarse_stage` (one graph per input shape / precision).  ~140 kernel launches collapse into one
+        graph launch.  The graph's static input is the NHWC image tensor: the two layout kernels that fill it from the caller's
+        NCHW images run eagerly in front of the replay, so the images are never copied as such."""
         ent = self._graphs.get(key)
+        dt = GIM_BF16 if self.precision == "bf16" else GIM_F32
+        same = color0.shape[2:] == color1.shape[2:]
+        groups = [[color0, color1]] if same else [[color0], [color1]]
         if ent is None:
-            sin = [color0.clone(), color1.clone(),
+            # host-side caches (weight packing does pageable H2D copies, the position table is built on the CPU) must be
+            # filled BEFORE capture starts, whatever ran earlier
+            self._prepack(color0.device)
+            C = self.config["coarse"]["d_model"]
+            half = lambda n: (n - 1) // 2 + 1   # noqa: E731  the three stride-2 convs (k7 p3, k3 p1, k3 p1)
+            for c in (color0, color1):
+                self._pos_encoding(C, half(half(half(c.shape[2]))), half(half(half(c.shape[3]))), c.device)
+            sin = [[self._to_nhwc(g, dt) for g in groups],
                    scale0.clone().float() if scale0 is not None else None,
                    scale1.clone().float() if scale1 is not None else None,
                    mask0.clone() if mask0 is not None else None, mask1.clone() if mask1 is not None else None]
@@ -481,21 +500,21 @@ class LoFTR(nn.Module):
             graph = torch.cuda.CUDAGraph()
             # thread_local: other threads (e.g. RCCL's watchdog in multi-GPU runs) may issue HIP calls meanwhile
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                out = self._coarse_stage(*sin)
+                out = self._coarse_stage(sin[0], color0.shape[0], *sin[1:])
             while len(self._graphs) >= self.graph_cache_size:  # LRU eviction frees that graph's pool
                 self._graphs.popitem(last=False)
             ent = self._graphs[key] = (graph, sin, out)
         else:
             self._graphs.move_to_end(key)
+            for g, x in zip(groups, ent[1][0]):
+                self._to_nhwc(g, dt, out=x)
         graph, sin, out = ent
-        sin[0].copy_(color0)
-        sin[1].copy_(color1)
+        small = []
         if scale0 is not None:
-            sin[2].copy_(scale0)
-            sin[3].copy_(scale1)
+            small += [(scale0, sin[1]), (scale1, sin[2])]
         if mask0 is not None:
-            sin[4].copy_(mask0)
-            sin[5].copy_(mask1)
+            small += [(mask0, sin[3]), (mask1, sin[4])]
+        ops.copy_segments(small)
         graph.replay()
         return out
 
@@ -541,18 +560,20 @@ class LoFTR(nn.Module):
                 except RuntimeError as e:
                     # only a failed *capture* (HIP graphs unsupported in this environment) lands here: input errors
                     # (ValueError / GimHipError from argument checks) were raised by this shape's eager first call
-                    if key in self._graphs or "capture" not in str(e).lower():
+                    if key in self._graphs or "captur" not in str(e).lower():   # '... when stream is capturing', 'StreamCapture...'
                         raise
                     import warnings
                     warnings.warn(f"gim_amd: HIP graph capture failed ({e!r}); using eager kernel launches")
                     self.use_graph = False
                     self._graphs.clear()
-            else:
+        if not graphed:
+            same = color0.shape[2:] == color1.shape[2:]
+            xs = [self._to_nhwc([color0, color1], dt)] if same else [self._to_nhwc([color0], dt), self._to_nhwc([color1], dt)]
+            st = self._coarse_stage(xs, bs, scale0, scale1, mask0, mask1)
+            if self.use_graph and self.debug is None:   # counted only once the eager call went through (bad inputs raise above)
                 self._seen[key] = self._seen.get(key, 0) + 1
                 while len(self._seen) > 64:
                     self._seen.popitem(last=False)
-        if not graphed:
-            st = self._coarse_stage(color0, color1, scale0, scale1, mask0, mask1)
         c0, c1, f0, f1, cr = st["c0"], st["c1"], st["f0"], st["f1"], st["cr"]
         if self.debug is not None:
             self.debug.update({k: st[k] for k in ("c0", "c1", "f0", "f1", "feat_c0", "feat_c1")})
@@ -569,14 +590,24 @@ class LoFTR(nn.Module):
         if M > 0:
             fine = self._fine_level(f0, f1, cr.b_ids[:M], cr.i_ids[:M], cr.j_ids[:M], cr.mkpts1_c[:M], scale1, "scale0" in data,
                                     hw0_c, hw1_c, data["hw0_i"], self.fine_fused)
-        # graph replays reuse their output buffers: hand out private copies of the (small) match lists
-        own = (lambda t: t.clone()) if graphed else (lambda t: t)
-        b_ids, i_ids, j_ids = own(cr.b_ids[:M]), own(cr.i_ids[:M]), own(cr.j_ids[:M])
-        mkpts0_c, mkpts1_c, mconf = own(cr.mkpts0_c[:M]), own(cr.mkpts1_c[:M]), own(cr.mconf[:M])
+        # graph replays reuse their output buffers: hand out private copies of the (small) match lists -- one launch for all of
+        # them and the all-false gt_mask (mconf == 0 never holds: mconf > thr), not one torch copy kernel each
+        if graphed:
+            ib = torch.empty(4, M, dtype=torch.int64, device=dev)
+            fb = torch.empty(5 * M, dtype=torch.float32, device=dev)
+            gt_mask = torch.empty(M, dtype=torch.bool, device=dev)
+            b_ids, i_ids, j_ids, m_bids = ib[0], ib[1], ib[2], ib[3]
+            mkpts0_c, mkpts1_c, mconf = fb[:2 * M].view(M, 2), fb[2 * M:4 * M].view(M, 2), fb[4 * M:]
+            ops.copy_segments([(cr.b_ids[:M], b_ids), (cr.i_ids[:M], i_ids), (cr.j_ids[:M], j_ids), (cr.b_ids[:M], m_bids),
+                               (cr.mkpts0_c[:M], mkpts0_c), (cr.mkpts1_c[:M], mkpts1_c), (cr.mconf[:M], mconf), (None, gt_mask)])
+        else:
+            ib = torch.empty(M, dtype=torch.int64, device=dev)
+            gt_mask = torch.empty(M, dtype=torch.bool, device=dev)
+            b_ids, i_ids, j_ids, m_bids = cr.b_ids[:M], cr.i_ids[:M], cr.j_ids[:M], ib
+            mkpts0_c, mkpts1_c, mconf = cr.mkpts0_c[:M], cr.mkpts1_c[:M], cr.mconf[:M]
+            ops.copy_segments([(cr.b_ids[:M], m_bids), (None, gt_mask)])
         data.update({"conf_matrix": LazyConfMatrix(cr, self, self._generation if graphed else None)})   # key order = the reference's
-        data.update({"b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids,
-                     "gt_mask": torch.zeros(M, dtype=torch.bool, device=dev),  # mconf == 0 never holds (> thr)
-                     "m_bids": b_ids.clone(),
+        data.update({"b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids, "gt_mask": gt_mask, "m_bids": m_bids,
                      "mkpts0_c": mkpts0_c, "mkpts1_c": mkpts1_c, "mconf": mconf})
         data.update({"W": self.W})
         if fine is None:

@@ -76,6 +76,36 @@ def nchw_to_nhwc(src, dst, b_off=0):
                                gim_dtype(dst), _stream()), "gim_nchw_to_nhwc")
 
 
+def copy_segments(pairs):
+    """[(src or None, dst), ...] contiguous device tensors of equal byte size per pair (src None: dst is zero filled) -> all of
+    them in ONE launch (gim_copy_segments); more than 12 pairs go out in batches."""
+    pairs = [(s, d) for s, d in pairs if d.numel() > 0]
+    for i in range(0, len(pairs), _lib.CopySegs.MAX):
+        seg = _lib.CopySegs()
+        chunk = pairs[i:i + _lib.CopySegs.MAX]
+        for k, (s, d) in enumerate(chunk):
+            _req_cuda(s, d)
+            assert d.is_contiguous() and (s is None or (s.is_contiguous() and s.numel() * s.element_size() == d.numel() * d.element_size()))
+            seg.src[k] = s.data_ptr() if s is not None else None
+            seg.dst[k] = d.data_ptr()
+            seg.bytes[k] = d.numel() * d.element_size()
+        seg.n = len(chunk)
+        check(lib.gim_copy_segments(ctypes.byref(seg), _stream()), "gim_copy_segments")
+
+
+def pack_matches(m_bids, mkpts0, mkpts1, mconf, pair_ids=None, pid_base=0):
+    """rows [pair_id, x0, y0, x1, y1, conf] fp32 [M, 6]; pair_id = pair_ids[m_bids] (device int64 tensor) or pid_base + m_bids"""
+    _req_cuda(m_bids, mkpts0, mkpts1, mconf, pair_ids)
+    M = m_bids.numel()
+    assert m_bids.dtype == torch.int64 and mkpts0.dtype == mkpts1.dtype == mconf.dtype == torch.float32
+    assert mkpts0.shape == (M, 2) and mkpts1.shape == (M, 2) and mconf.shape == (M,)
+    assert pair_ids is None or pair_ids.dtype == torch.int64
+    out = torch.empty(M, 6, dtype=torch.float32, device=m_bids.device)
+    check(lib.gim_pack_matches(_p(m_bids.contiguous()), _p(mkpts0.contiguous()), _p(mkpts1.contiguous()), _p(mconf.contiguous()),
+                               _p(pair_ids), int(pid_base), _p(out), M, _stream()), "gim_pack_matches")
+    return out
+
+
 def nhwc_to_nchw(src, C):
     """src [B,H,W,cstore] -> new fp32 [B,C,H,W] (reference layout, for tests / lazy outputs)"""
     _req_cuda(src)
@@ -143,11 +173,11 @@ def conv2d(x, pk, act=ACT_NONE, res=None, out_dtype=None, lds_dma=True, ups=None
     if pk.kh == 1 and pk.kw == 1 and pk.stride == 1 and pk.pad == 0:
         geom = (1, 1, B * H * W, 1, B * H * W)  # pixel index == row index: the kernel skips the coordinate decode
     if HALO and pk.halo is not None and res is None and lds_dma and x.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 \
-            and _halo_pays(pk, B, H, W):
+            and x.is_contiguous() and _halo_pays(pk, B, H, W):
         conv3x3_halo(x, pk, y, act)
         return y
     if ups is not None:
-        assert ups.shape == (B, Ho // 2, Wo // 2, pk.n_store) and res is None
+        assert ups.shape == (B, Ho // 2, Wo // 2, pk.n_store) and res is None and ups.is_contiguous()
         if not conv_rows(x.view(-1, cs), pk, geom, y.view(-1, pk.n_store), act, r, 0, lds_dma, ups=ups):
             upsample2x_add(ups, y)
         return y
@@ -176,6 +206,7 @@ def _halo_pays(pk, B, H, W):
 def conv3x3_halo(x, pk, y, act=ACT_NONE):
     """x [B,H,W,cin_pad] bf16 -> y [B,H,W,n_store] bf16 through the halo-tile kernel (3x3, stride 1, pad 1, no residual)"""
     _req_cuda(x, y)
+    assert x.is_contiguous() and y.is_contiguous(), "conv3x3_halo addresses pixels as (b*H + y)*W + x rows of width cin_pad"
     B, H, W, cs = x.shape
     w, tab, nslab, bias = pk.halo
     a = _lib.ConvArgs()
@@ -380,8 +411,11 @@ def token_mlp(msg, xb, x32, weights, ln_params, eps, kv=None, L=0, S=0, q_mask=N
 
 
 def linear_attention_state(k, v, nb_kv, S, H, ws=None, kv_mask=None):
-    """First half of linear_attention: KV / Ksum state of nb_kv sequences of S rows -> (fp32 state view [nb_kv*H*(D*D+D)], ws).
-    The state sits behind the per-chunk partials in the workspace when S spans several chunks (gim_linear_attention_kv)."""
+    """First half of linear_attention: KV / Ksum state of nb_kv sequences of S rows.  Returns (ws, need): the fp32 workspace
+    (re-used when the one passed in is large enough) and the bytes the call needs of it.  The final state -- per sequence and
+    head a D x D KV block followed by the D-vector Ksum, nb_kv*H*(D*D+D) floats -- sits at the START of the workspace, the
+    per-chunk partials behind it (gim_linear_attention_kv); `ws` itself is what gim_token_mlp takes as `kv`.  NB the fused apply
+    in token_mlp rounds KV to bf16 for the bf16 MFMA, the stand-alone la_apply kernel multiplies it in fp32."""
     _req_cuda(k, v, kv_mask)
     D = k.shape[1] // H
     need = lib.gim_linear_attention_ws_bytes(nb_kv, S, H, D)

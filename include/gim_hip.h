@@ -317,6 +317,24 @@ int gim_lg_emit_matches(const int64_t* matches0, const float* mscores0, const in
                         const float* scale1, int64_t* matches, float* scores, float* mkpts0, float* mkpts1,
                         int64_t* m_bids, int B, int M, int N, gim_stream_t stream);
 
+/* --------------------------------------------------------------------------------------------
+ * Output hand-out.  gim_copy_segments: up to GIM_MAX_COPY_SEGS independent device byte ranges moved (src == NULL: zero
+ * filled) in ONE launch -- the private copies of b_ids / i_ids / j_ids / m_bids / mkpts0_c / mkpts1_c / mconf and the
+ * all-false gt_mask that `data` receives after coarse matching (coarse_matching.py:236-259: tensor construction only).
+ * gim_pack_matches: reporting rows [pair_id, x0, y0, x1, y1, conf] (24 B per match; the packed form of the per-pair rows of
+ * trainer/lightning.py:258-270); pair_id = pair_ids[m_bids[m]] (device int64, one per batch element) or, with
+ * pair_ids == NULL, pid_base + m_bids[m]. */
+enum { GIM_MAX_COPY_SEGS = 12 };
+typedef struct gim_copy_segs {
+    const void* src[12];
+    void* dst[12];
+    int64_t bytes[12];
+    int n;
+} gim_copy_segs;
+int gim_copy_segments(const gim_copy_segs* segs, gim_stream_t stream);
+int gim_pack_matches(const int64_t* m_bids, const float* mkpts0, const float* mkpts1, const float* mconf,
+                     const int64_t* pair_ids, int64_t pid_base, float* out, int M, gim_stream_t stream);
+
 /* ======================================================================================================
  * gim_dkm path (kernels D1-D9).  Convolutions / 1x1 projections / the cosine-kernel and
  * posterior-mean products run on gim_conv2d_bn_act (runtime "weights" = row buffers in [N][K] layout).

@@ -9,6 +9,14 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 
+try:  # the reference's hloc (h5py, pycolmap ...) is not installed here: a protocol stand-in for the plugin tests
+    import hloc.utils.base_model  # noqa: F401
+except Exception:  # noqa: BLE001
+    for _m in [m for m in sys.modules if m == "hloc" or m.startswith("hloc.")]:
+        del sys.modules[_m]
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hloc_stub"))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

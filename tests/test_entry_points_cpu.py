@@ -53,7 +53,7 @@ def test_checkpoint_prefix_rules(tmp_path):
 def test_hloc_plugin_lookup_and_checkpoint(tmp_path, monkeypatch):
     import dkm_oracle as DO
     import gim_amd.hloc_matchers as plugins
-    from gim_amd.hloc_matchers.base import BaseModel, dynamic_load
+    from hloc.utils.base_model import BaseModel, dynamic_load
     cls = dynamic_load(plugins, "gim_dkm_hip")                      # hloc/utils/base_model.py:36-47
     assert issubclass(cls, BaseModel) and cls.required_inputs == ["image0", "image1"]
     sd = DO.make_state_dict(0)

@@ -53,7 +53,7 @@ def test_demo_other_models_run_and_keep_the_contract():
 def test_hloc_plugin_forward_contract():
     import dkm_oracle as DO
     import gim_amd.hloc_matchers as plugins
-    from gim_amd.hloc_matchers.base import dynamic_load
+    from hloc.utils.base_model import dynamic_load
     Model = dynamic_load(plugins, "gim_dkm_hip")
     m = Model({"max_num_matches": 300}).eval().to("cuda:0")       # match_dense.py:220: Model(conf['model']).eval().to(device)
     m.net.load_state_dict(DO.make_state_dict(0))

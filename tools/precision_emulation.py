@@ -1,0 +1,196 @@
+"""Where do the bf16-mode index flips of gim_loftr come from?  CPU study, no GPU needed.
+
+Runs the fp32 CPU oracle (test infrastructure) on one match-rich 640x480 pair, then re-runs it with the operands of
+selected stages rounded the way the engine's 16-bit modes round them (BatchNorm folded into the conv weights first,
+weights and every conv / linear input rounded, ReLU outputs = stored activations rounded, attention operands
+rounded) and prints the match-set flip rate of every variant against the unrounded run.
+
+Formats: 'bf16' (8 significand bits), 'fp16' (11 bits), 'bf16x2' (hi + lo bf16 pair = 16 bits: what a 3-product
+split bf16 MFMA carries), 'fp32' (no rounding).  Stages: stem, layer1, layer2, layer3, fpn, transformer, sim (profiles/r03_precision_emulation_stage1.txt: the first run, per-stage
+isolation with stem and layer1 as one stage).
+
+    python tools/precision_emulation.py [n_pairs]   ->  table on stdout (profiles/r03_precision_emulation.txt)
+"""
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import loftr_oracle as O  # noqa: E402
+from tools import synth_loftr as S  # noqa: E402
+from tools.parity import parity_vs_oracle  # noqa: E402
+
+
+def rnd(x, fmt):
+    if fmt == "fp32":
+        return x
+    if fmt == "bf16":
+        return x.bfloat16().float()
+    if fmt == "fp16":
+        return x.half().float()
+    if fmt == "bf16x2":
+        hi = x.bfloat16().float()
+        return hi + (x - hi).bfloat16().float()
+    raise ValueError(fmt)
+
+
+def fold_bn(sd):
+    """conv weight *= gamma / sqrt(var + eps); the BatchNorm that follows becomes a bias add (same fp32 function up to
+    rounding) -- the engine rounds the FOLDED weights (gim_amd/packing.py)."""
+    sd = {k: v.clone() for k, v in sd.items()}
+    pairs = []
+    for k in sd:
+        if k.endswith(".running_mean"):
+            bn = k[:-len(".running_mean")]
+            if bn.endswith(".bn1") and ".layer" not in bn:
+                conv = bn[:-3] + "conv1"
+            elif bn[-4:-1] == ".bn":
+                conv = bn[:-4] + ".conv" + bn[-1]
+            elif bn.endswith("downsample.1"):
+                conv = bn[:-1] + "0"
+            elif bn.endswith("outconv2.1"):
+                conv = bn[:-1] + "0"
+            else:
+                raise KeyError(bn)
+            pairs.append((conv, bn))
+    for conv, bn in pairs:
+        s = sd[bn + ".weight"] / torch.sqrt(sd[bn + ".running_var"] + 1e-5)
+        sd[conv + ".weight"] = sd[conv + ".weight"] * s[:, None, None, None]
+        sd[bn + ".running_mean"] = sd[bn + ".running_mean"] * s
+        sd[bn + ".running_var"] = torch.full_like(s, 1.0 - 1e-5)
+        sd[bn + ".weight"] = torch.ones_like(s)
+    return sd
+
+
+class Emu:
+    """Patches the oracle module's F.conv2d / F.linear / F.relu / linear_attention / similarity by stage."""
+
+    def __init__(self, sd, fmts):
+        self.fmts = fmts      # stage -> format
+        self.sd = sd
+        self.stage_of = {}    # id(weight tensor) -> stage
+        for k, v in sd.items():
+            if not k.endswith("weight") or v.dim() < 2:
+                continue
+            if k.startswith("backbone.encode.layer2"):
+                st = "layer2"
+            elif k.startswith("backbone.encode.layer3"):
+                st = "layer3"
+            elif k.startswith("backbone.encode.layer1"):
+                st = "layer1"
+            elif k.startswith("backbone.encode"):
+                st = "stem"
+            elif k.startswith("backbone"):
+                st = "fpn"
+            elif k.startswith("loftr_coarse"):
+                st = "transformer"
+            else:
+                st = "fine"
+            self.stage_of[id(v)] = st
+        self.cur = "stem"
+        self.keep_stream = fmts.get("keep_stream", False)   # True: the ResNet residual stream x (ReLU outputs) is NOT rounded
+
+    def fmt(self, w):
+        st = self.stage_of.get(id(w), "fine")
+        self.cur = st
+        return self.fmts.get(st, "fp32")
+
+    def run(self, data):
+        conv0, lin0, relu0, la0, cm0 = F.conv2d, F.linear, F.relu, O.linear_attention, O.conf_matrix_dual_softmax
+        emu = self
+
+        class FF:
+            def __getattr__(self, n):
+                return getattr(F, n)
+
+            @staticmethod
+            def conv2d(x, w, *a, **k):
+                f = emu.fmt(w)
+                return conv0(rnd(x, f), rnd(w, f), *a, **k)
+
+            @staticmethod
+            def linear(x, w, *a, **k):
+                f = emu.fmt(w)
+                return lin0(rnd(x, f), rnd(w, f), *a, **k)
+
+            @staticmethod
+            def relu(x, *a, **k):
+                if emu.keep_stream and emu.cur in ("stem", "layer1", "layer2", "layer3"):
+                    return relu0(x)
+                return rnd(relu0(x), emu.fmts.get(emu.cur, "fp32"))
+
+        def la(q, k, v, q_mask=None, kv_mask=None, eps=1e-6):
+            f = emu.fmts.get(emu.cur, "fp32")   # 'transformer' or 'fine'
+            Q = rnd(F.elu(q) + 1, f)
+            K = rnd(F.elu(k) + 1, f)
+            v = rnd(v, f)
+            vl = v.size(1)
+            KV = torch.einsum("nshd,nshv->nhdv", K, v / vl)
+            Z = 1 / (torch.einsum("nlhd,nhd->nlh", Q, K.sum(dim=1)) + eps)
+            return (torch.einsum("nlhd,nhdv,nlh->nlhv", Q, rnd(KV, f), Z) * vl).contiguous()
+
+        def cm(f0, f1, temperature=0.1, m0=None, m1=None):
+            f = emu.fmts.get("sim", "fp32")
+            return cm0(rnd(f0, f), rnd(f1, f), temperature, m0, m1)
+
+        O.F = FF()
+        O.linear_attention = la
+        O.conf_matrix_dual_softmax = cm
+        try:
+            with torch.no_grad():
+                return O.loftr_forward(self.sd, data)
+        finally:
+            O.F = F
+            O.linear_attention = la0
+            O.conf_matrix_dual_softmax = cm0
+
+
+def main():
+    npairs = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    torch.set_num_threads(os.cpu_count() or 1)
+    model, sd = S.synthetic_model("fp32")
+    sdf = fold_bn(sd)
+    c0, c1 = S.textured_pairs(npairs, 480, 640, seed=1234, frac=0.45)
+
+    def data():
+        return {"image0": c0[:, :1], "image1": c1[:, :1], "color0": c0, "color1": c1}
+
+    t = time.time()
+    with torch.no_grad():
+        ref = O.loftr_forward(sd, data())
+    print(f"oracle: {ref['b_ids'].numel()} matches over {npairs} pair(s), {time.time() - t:.1f} s", flush=True)
+    ST = ("stem", "layer1", "layer2", "layer3", "fpn", "transformer", "sim")
+    BB = ST[:5]
+    allf = lambda f: {s_: f for s_ in ST}   # noqa: E731
+    variants = [("all bf16", allf("bf16")),
+                ("all fp16", allf("fp16")),
+                ("backbone fp16, transformer+sim bf16", {**{s_: "fp16" for s_ in BB}, "transformer": "bf16", "sim": "bf16"}),
+                ("backbone+sim fp16, transformer bf16", {**{s_: "fp16" for s_ in BB}, "transformer": "bf16", "sim": "fp16"}),
+                ("all fp16, sim fp32", {**allf("fp16"), "sim": "fp32"}),
+                ("stem fp32, rest bf16", {**allf("bf16"), "stem": "fp32"}),
+                ("stem fp16, rest bf16", {**allf("bf16"), "stem": "fp16"}),
+                ("stem+layer1 fp16, rest bf16", {**allf("bf16"), "stem": "fp16", "layer1": "fp16"}),
+                ("stem+layer1 fp32, rest bf16", {**allf("bf16"), "stem": "fp32", "layer1": "fp32"}),
+                ("all bf16, unrounded ResNet residual stream", {**allf("bf16"), "keep_stream": True}),
+                ("all bf16, unrounded stream, stem fp32", {**allf("bf16"), "stem": "fp32", "keep_stream": True}),
+                ]
+    for name, fm in variants:
+        t = time.time()
+        out = Emu(sdf, fm).run(data())
+        fr, dc, n = [], [], 0
+        for b in range(npairs):
+            p = parity_vs_oracle(out, ref, b, b)
+            fr.append(p["flip_rate"])
+            dc.append(p.get("mean_abs_dmconf", 0.0))
+            n += p["engine_matches"]
+        print(f"{name:58s} flip {100 * sum(fr) / len(fr):6.3f} %   mean|dmconf| {sum(dc) / len(dc):.5f}   matches {n}   "
+              f"({time.time() - t:.0f} s)", flush=True)
+
+
+if __name__ == "__main__":
+    main()

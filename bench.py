@@ -40,7 +40,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 H, W = 480, 640
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense, MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense, MI355X_MICROARCH.md
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_traffic.json")
 if not os.path.exists(TRAFFIC_JSON):
     TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")
@@ -52,8 +52,8 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="pairs per rank per step")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--coarse-sim", default=None, choices=["fp32", "bf16"], help="override LoFTR config['coarse_sim']")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--coarse-sim", default=None, choices=["fp32", "bf16", "fp16"], help="override LoFTR config['coarse_sim']")
     ap.add_argument("--frac", type=float, default=0.45, help="corresponding fraction of the frame (match count knob)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=1)
@@ -267,24 +267,28 @@ def main():
                        "copy stream so that the transfer of step s+1 overlaps the kernels of step s (incl. the first, exposed copy); "
                        "serial_copy = the same copies issued on the compute stream (round 2's figure)"}
 
-    # ---- the parity mode on the same workload: precision='fp32' (exact fp32 MFMA products), the mode whose match indices equal
-    # the oracle's -- timed on the driver's line next to the bf16 headline -------------------
-    parity_mode = None
+    # ---- the other precision modes on the same workload and batch, timed the same way -----------------------------------------
+    #   parity_mode: precision='fp32' (exact fp32 MFMA products) -- the mode whose match indices equal the oracle's
+    #   fp16_mode:   precision='fp16' -- the 16-bit kernels in their IEEE-fp16 flavour: same MFMA rate and bytes as the bf16
+    #                headline, 11 instead of 8 significand bits per stored activation (a quarter of bf16's index flips)
+    alt_modes = {}
     if solo and args.precision == "bf16" and not os.environ.get("GIM_BENCH_SKIP_PARITY_MODE"):
-        model.set_precision("fp32")
-        for _ in range(2):
-            d32 = step()
-        torch.cuda.synchronize()
-        n32 = 5
-        t32 = time.perf_counter()
-        for _ in range(n32):
-            d32 = step()
-        torch.cuda.synchronize()
-        t32 = (time.perf_counter() - t32) / n32
-        parity_mode = {"precision": "fp32", "pairs_per_s": round(nb / t32, 2), "ms_per_step": round(1e3 * t32, 3), "steps": n32,
-                       "matches_per_pair": round(d32["b_ids"].numel() / nb, 1),
-                       "note": "same workload and batch with every GEMM on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)"}
-        d32 = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in d32.items() if k != "conf_matrix"}
+        for name, prec, n_alt, note in (
+                ("parity_mode", "fp32", 5, "every GEMM on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
+                ("fp16_mode", "fp16", args.steps, "the bf16 mode's kernels in their IEEE fp16 flavour (v_mfma_f32_32x32x16_f16, "
+                                                  "v_cvt_pk_f16_f32): same instruction counts and bytes, |activation| < 65504")):
+            model.set_precision(prec)
+            for _ in range(3):
+                da = step()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for _ in range(n_alt):
+                da = step()
+            torch.cuda.synchronize()
+            ta = (time.perf_counter() - ta) / n_alt
+            alt_modes[name] = ({"precision": prec, "pairs_per_s": round(nb / ta, 2), "ms_per_step": round(1e3 * ta, 3), "steps": n_alt,
+                                "matches_per_pair": round(da["b_ids"].numel() / nb, 1), "note": "same workload and batch; " + note},
+                               {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in da.items() if k != "conf_matrix"})
         model.set_precision("bf16", args.coarse_sim)
         torch.cuda.empty_cache()
 
@@ -466,8 +470,8 @@ def main():
                 parity["other_coarse_sim"] = {"coarse_sim": model.coarse_sim, "flip_rate": alt["flip_rate"],
                                               "mean_abs_dmconf": alt.get("mean_abs_dmconf"), "mean_abs_dmkpts1_px": alt.get("mean_abs_dmkpts1_px")}
                 model.coarse_sim = was
-            if parity_mode is not None:
-                parity_mode["parity"] = parity_vs_oracle(d32, ref, 0)
+            for nm, (rec, d_alt) in alt_modes.items():
+                rec["parity"] = parity_vs_oracle(d_alt, ref, 0)
 
     if rank == 0 and os.environ.get("GIM_BENCH_DEBUG"):
         print("per-step ms:", [round(1e3 * (b - a), 2) for a, b in zip([t0] + tstep[:-1], tstep)], file=sys.stderr)
@@ -482,10 +486,11 @@ def main():
                                    f"(calibrated BatchNorm statistics), textured image pairs with {args.frac:.2f} of the frame "
                                    "in correspondence (device resident), fine level loaded, outputs incl. match count read back",
                        "pairs_per_step": world * nb, "matches_per_pair": round(n_matches / max(1, pairs), 1),
-                       "coarse_sim": model.coarse_sim,
+                       "coarse_sim": model.coarse_sim, "stem_operands": "fp16" if (args.precision == "bf16" and model.stem_fp16) else args.precision,
                        "parallelism": f"pairs sharded over {world} GPU(s), no collective per step",
                        "hip_graph": bool(model.use_graph)},
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "parity_mode": parity_mode, "h2d_inclusive": h2d, "fine_idle": idle,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "parity_mode": alt_modes.get("parity_mode", (None,))[0],
+            "fp16_mode": alt_modes.get("fp16_mode", (None,))[0], "h2d_inclusive": h2d, "fine_idle": idle,
             "secondary_workloads": {"gim_lightglue": lightglue, **dense},
         }
         print(json.dumps(out), flush=True)

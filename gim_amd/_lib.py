@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgimhip.so")
 
-GIM_F32, GIM_BF16 = 0, 1
+GIM_F32, GIM_BF16, GIM_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU1, ACT_GELU = 0, 1, 2, 3, 4
 
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -80,10 +80,13 @@ PROTOTYPES = {
     "gim_fine_gather": (c_int, [c_void_p] * 7 + [c_int] * 14 + [c_void_p]),
     "gim_fine_match": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_float, c_int, c_void_p]),
     "gim_bneck64_fused": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p]),
+    "gim_bneck64_fused_f16": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p]),
     "gim_token_mlp_weight_bytes": (c_int64, []),
     "gim_token_mlp": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_float, c_void_p]),
+    "gim_token_mlp_f16": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_float, c_void_p]),
     "gim_fine_fused_weight_bytes": (c_int64, []),
     "gim_fine_fused": (c_int, [c_void_p] * 13 + [c_int] * 11 + [c_float, c_float, c_int, c_void_p]),
+    "gim_fine_fused_f16": (c_int, [c_void_p] * 13 + [c_int] * 11 + [c_float, c_float, c_int, c_void_p]),
     "gim_copy_segments": (c_int, [ctypes.POINTER(CopySegs), c_void_p]),
     "gim_pack_matches": (c_int, [c_void_p] * 5 + [c_int64, c_void_p, c_int, c_void_p]),
     # gim_lightglue path

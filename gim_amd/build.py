@@ -14,6 +14,10 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgimhip.so")
 SOURCES = ["runtime.hip", "conv_igemm.hip", "elementwise.hip", "linear_attention.hip", "coarse_match.hip",
            "fine_match.hip", "fine_fused.hip", "token_mlp.hip", "bneck_fused.hip", "emit.hip", "superpoint.hip", "lightglue.hip", "lg_assign.hip", "dkm.hip", "gp_solve.hip", "sample.hip"]
+# the gim_loftr path exists in two 16-bit operand flavours (bf16 / IEEE fp16, csrc/gim_common.h): these files are compiled a
+# second time with -DGIM_HALF_KIND=1 into *_f16.o, whose entry points carry the suffix `_f16`
+F16_SOURCES = ["conv_igemm.hip", "elementwise.hip", "linear_attention.hip", "coarse_match.hip", "fine_match.hip", "fine_fused.hip",
+               "token_mlp.hip", "bneck_fused.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"] + os.environ.get("GIM_HIPCC_EXTRA", "").split()
 
 
@@ -38,12 +42,12 @@ def build(force=False, verbose=True):
     newest_hdr = max(os.path.getmtime(h) for h in _deps())
     jobs = []
     objs = []
-    for src in SOURCES:
+    for src, extra, suffix in [(s_, [], ".o") for s_ in SOURCES] + [(s_, ["-DGIM_HALF_KIND=1"], "_f16.o") for s_ in F16_SOURCES]:
         sp = os.path.join(CSRC, src)
-        op = os.path.join(objdir, src.replace(".hip", ".o"))
+        op = os.path.join(objdir, src.replace(".hip", suffix))
         objs.append(op)
         if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), newest_hdr):
-            jobs.append([hipcc, *FLAGS, "-c", sp, "-o", op])
+            jobs.append([hipcc, *FLAGS, *extra, "-c", sp, "-o", op])
 
     def run(cmd):
         if verbose:
@@ -53,7 +57,7 @@ def build(force=False, verbose=True):
             raise RuntimeError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
         return r
 
-    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(int(os.environ.get("GIM_BUILD_JOBS", "6")), max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if jobs or force or not os.path.exists(LIB):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])

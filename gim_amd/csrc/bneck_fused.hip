@@ -120,8 +120,8 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
                 const bf16x8_t px = *(const bf16x8_t*)(prow + (((2 * ks + lh) ^ pk) << 4));
                 const int ws = ((tap * 8) | ((2 * ks + lh) ^ wk)) << 4;
                 const bf16x8_t w0 = *(const bf16x8_t*)(wrow0 + ws), w1 = *(const bf16x8_t*)(wrow1 + ws);
-                c2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, px, c2[0], 0, 0, 0);
-                c2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, px, c2[1], 0, 0, 0);
+                c2[0] = mfma_h16_32x32x16(w0, px, c2[0]);
+                c2[1] = mfma_h16_32x32x16(w1, px, c2[1]);
             }
         }
     }
@@ -145,8 +145,8 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
 #pragma unroll
             for (int hq = 0; hq < 2; ++hq) {
                 const int rg = 2 * t + hq;
-                u[2 * hq] = cvt_pk_bf16(fmaxf(c2[f][rg * 4], 0.f), fmaxf(c2[f][rg * 4 + 1], 0.f));
-                u[2 * hq + 1] = cvt_pk_bf16(fmaxf(c2[f][rg * 4 + 2], 0.f), fmaxf(c2[f][rg * 4 + 3], 0.f));
+                u[2 * hq] = cvt_pk_h16(fmaxf(c2[f][rg * 4], 0.f), fmaxf(c2[f][rg * 4 + 1], 0.f));
+                u[2 * hq + 1] = cvt_pk_h16(fmaxf(c2[f][rg * 4 + 2], 0.f), fmaxf(c2[f][rg * 4 + 3], 0.f));
             }
             t2[2 * f + t] = __builtin_bit_cast(bf16x8_t, make_uint4(u[0], u[1], u[2], u[3]));
         }
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const bf16x8_t wv = *(const bf16x8_t*)(smem + OFF_W3 + (32 * j + l31) * 128 + (((2 * s + lh) ^ wk) << 4));
-                c3[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, t2[s], c3[j], 0, 0, 0);
+                c3[j] = mfma_h16_32x32x16(wv, t2[s], c3[j]);
             }
     }
     // ---- + identity, relu; x' out; bf16 operand of conv1' -- in four 64-channel passes through this wave's LDS patch ----
@@ -196,10 +196,10 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const uint2 r = *(const uint2*)(patch + l31 * 128 + (((4 * ff + rg) ^ (l31 & 7)) << 4) + lh * 8);
-                c3[j][rg * 4] = fmaxf(c3[j][rg * 4] + __uint_as_float(r.x << 16), 0.f);
-                c3[j][rg * 4 + 1] = fmaxf(c3[j][rg * 4 + 1] + __uint_as_float(r.x & 0xffff0000u), 0.f);
-                c3[j][rg * 4 + 2] = fmaxf(c3[j][rg * 4 + 2] + __uint_as_float(r.y << 16), 0.f);
-                c3[j][rg * 4 + 3] = fmaxf(c3[j][rg * 4 + 3] + __uint_as_float(r.y & 0xffff0000u), 0.f);
+                c3[j][rg * 4] = fmaxf(c3[j][rg * 4] + h16_lo(r.x), 0.f);
+                c3[j][rg * 4 + 1] = fmaxf(c3[j][rg * 4 + 1] + h16_hi(r.x), 0.f);
+                c3[j][rg * 4 + 2] = fmaxf(c3[j][rg * 4 + 2] + h16_lo(r.y), 0.f);
+                c3[j][rg * 4 + 3] = fmaxf(c3[j][rg * 4 + 3] + h16_hi(r.y), 0.f);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -209,8 +209,8 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
             unsigned u[8];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                u[2 * rg] = cvt_pk_bf16(c3[j][rg * 4], c3[j][rg * 4 + 1]);
-                u[2 * rg + 1] = cvt_pk_bf16(c3[j][rg * 4 + 2], c3[j][rg * 4 + 3]);
+                u[2 * rg] = cvt_pk_h16(c3[j][rg * 4], c3[j][rg * 4 + 1]);
+                u[2 * rg + 1] = cvt_pk_h16(c3[j][rg * 4 + 2], c3[j][rg * 4 + 3]);
                 *(uint2*)(patch + l31 * 128 + (((4 * ff + rg) ^ (l31 & 7)) << 4) + lh * 8) = make_uint2(u[2 * rg], u[2 * rg + 1]);
             }
             xq[2 * j] = __builtin_bit_cast(bf16x8_t, make_uint4(u[0], u[1], u[2], u[3]));
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 const bf16x8_t wv = *(const bf16x8_t*)(smem + OFF_W1 + (32 * f + l31) * 512 + so);
-                c1[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xq[s], c1[f], 0, 0, 0);
+                c1[f] = mfma_h16_32x32x16(wv, xq[s], c1[f]);
             }
         }
 #pragma unroll
@@ -255,8 +255,8 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg)
                     *(uint2*)(patch + l31 * 128 + (((4 * ff + rg) ^ (l31 & 7)) << 4) + lh * 8) =
-                        make_uint2(cvt_pk_bf16(fmaxf(c1[2 * h2 + ff][rg * 4], 0.f), fmaxf(c1[2 * h2 + ff][rg * 4 + 1], 0.f)),
-                                   cvt_pk_bf16(fmaxf(c1[2 * h2 + ff][rg * 4 + 2], 0.f), fmaxf(c1[2 * h2 + ff][rg * 4 + 3], 0.f)));
+                        make_uint2(cvt_pk_h16(fmaxf(c1[2 * h2 + ff][rg * 4], 0.f), fmaxf(c1[2 * h2 + ff][rg * 4 + 1], 0.f)),
+                                   cvt_pk_h16(fmaxf(c1[2 * h2 + ff][rg * 4 + 2], 0.f), fmaxf(c1[2 * h2 + ff][rg * 4 + 3], 0.f)));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
 
 }  // namespace
 
-extern "C" int gim_bneck64_fused(const void* t1, const void* res, void* x_out, void* t1_next, const void* w2, const void* w3,
+extern "C" int GIM_FN(gim_bneck64_fused)(const void* t1, const void* res, void* x_out, void* t1_next, const void* w2, const void* w3,
                                  const void* w1n, const float* b2, const float* b3, const float* b1n, int B, int H, int W,
                                  int n_next, gim_stream_t stream) {
     GIM_REQUIRE(t1 && res && x_out && w2 && w3 && b2 && b3, "bneck64_fused: NULL pointer");

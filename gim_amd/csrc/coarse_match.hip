@@ -538,9 +538,9 @@ __global__ void cm_emit_kernel(const CmWs w, const EmitArgs e) {
 int validate(const gim_coarse_args& a) {
     GIM_REQUIRE(a.feat0 && a.feat1 && a.ws && a.count, "coarse_match: NULL pointer");
     GIM_REQUIRE(a.N > 0 && a.L > 0 && a.S > 0, "coarse_match: bad sizes");
-    GIM_REQUIRE(a.feat_dtype == GIM_F32 || a.feat_dtype == GIM_BF16, "coarse_match: feat_dtype %d", a.feat_dtype);
-    GIM_REQUIRE(a.C > 0 && a.C % (a.feat_dtype == GIM_BF16 ? 64 : 32) == 0, "coarse_match: C=%d must be a multiple of the 128-byte K slab", a.C);
-    GIM_REQUIRE(a.ldf == 0 || (a.ldf >= a.C && a.ldf % (a.feat_dtype == GIM_BF16 ? 8 : 4) == 0), "coarse_match: ldf=%d", a.ldf);
+    GIM_REQUIRE(a.feat_dtype == GIM_F32 || a.feat_dtype == GIM_H16, "coarse_match: feat_dtype %d", a.feat_dtype);
+    GIM_REQUIRE(a.C > 0 && a.C % (a.feat_dtype == GIM_H16 ? 64 : 32) == 0, "coarse_match: C=%d must be a multiple of the 128-byte K slab", a.C);
+    GIM_REQUIRE(a.ldf == 0 || (a.ldf >= a.C && a.ldf % (a.feat_dtype == GIM_H16 ? 8 : 4) == 0), "coarse_match: ldf=%d", a.ldf);
     GIM_REQUIRE(a.h0c * a.w0c == a.L && a.h1c * a.w1c == a.S, "coarse_match: hw0_c/hw1_c do not match L/S");
     GIM_REQUIRE((int64_t)a.L * (a.ldf ? a.ldf : a.C) * 4 < (int64_t)0xFFFFFFF0ll && (int64_t)a.S * (a.ldf ? a.ldf : a.C) * 4 < (int64_t)0xFFFFFFF0ll, "coarse_match: feature map too large");
     GIM_REQUIRE(a.temperature > 0.f, "coarse_match: temperature must be positive");
@@ -558,14 +558,14 @@ int set_smem(K kern) {
 
 }  // namespace
 
-extern "C" int64_t gim_coarse_match_ws_bytes(int N, int L, int S) {
+extern "C" int64_t GIM_FN(gim_coarse_match_ws_bytes)(int N, int L, int S) {
     CmWs w;
     return (int64_t)carve(w, nullptr, N, L, S, 1024) + 256;
 }
 
 static int cm_prepare(const gim_coarse_args& a, CmWs& w, CmGeom& g) {
     carve(w, (char*)a.ws, a.N, a.L, a.S, a.C);
-    g.feat0 = a.feat0; g.feat1 = a.feat1; g.bf16 = a.feat_dtype == GIM_BF16; g.ldf = a.ldf ? a.ldf : a.C; g.mask0 = a.mask0; g.mask1 = a.mask1; g.N = a.N; g.L = a.L; g.S = a.S; g.C = a.C;
+    g.feat0 = a.feat0; g.feat1 = a.feat1; g.bf16 = a.feat_dtype == GIM_H16; g.ldf = a.ldf ? a.ldf : a.C; g.mask0 = a.mask0; g.mask1 = a.mask1; g.N = a.N; g.L = a.L; g.S = a.S; g.C = a.C;
     g.inv_c = 1.0f / (float)a.C; g.temperature = a.temperature; g.thr = a.thr;
     g.inv_ct = 1.0f / ((float)a.C * a.temperature);
     static GimPerDevice attr;
@@ -582,7 +582,13 @@ static int cm_prepare(const gim_coarse_args& a, CmWs& w, CmGeom& g) {
     return GIM_OK;
 }
 
-extern "C" int gim_coarse_match(const gim_coarse_args* ap, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+extern "C" int gim_coarse_match_f16(const gim_coarse_args* ap, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_coarse_match)(const gim_coarse_args* ap, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (ap && ap->feat_dtype == GIM_F16) return gim_coarse_match_f16(ap, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(ap, "coarse_match: NULL args");
     const gim_coarse_args& a = *ap;
     int rc = validate(a);
@@ -615,7 +621,13 @@ extern "C" int gim_coarse_match(const gim_coarse_args* ap, gim_stream_t stream) 
     return gim_check_launch("coarse_match");
 }
 
-extern "C" int gim_coarse_conf_matrix(const gim_coarse_args* ap, float* conf, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+extern "C" int gim_coarse_conf_matrix_f16(const gim_coarse_args* ap, float* conf, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_coarse_conf_matrix)(const gim_coarse_args* ap, float* conf, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (ap && ap->feat_dtype == GIM_F16) return gim_coarse_conf_matrix_f16(ap, conf, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(ap && conf, "coarse_conf_matrix: NULL args");
     const gim_coarse_args& a = *ap;
     int rc = validate(a);

@@ -17,7 +17,7 @@
 // The MFMA computes the transposed tile (weights as the A operand, pixels as B) so that each lane
 // ends up with 4 *consecutive channels* of one pixel per accumulator quad -> 8/16-byte NHWC stores.
 //
-// dtype GIM_BF16: v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  dtype GIM_F32: v_mfma_f32_32x32x2_f32,
+// dtype GIM_H16: v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  dtype GIM_F32: v_mfma_f32_32x32x2_f32,
 // bit-equivalent to an fp32 fmaf chain -- the exact-parity mode.
 //
 // Replaces (reference file:line): networks/loftr/backbone/resnet.py:109-126,230-233,316-327 and the
@@ -28,6 +28,9 @@
 namespace {
 
 using gim::KTB;
+
+// 16-bit output?  (the fp16 objects can also write bf16 -- gim_conv2d_bn_act)
+inline bool out_is16(const gim_conv_args& a) { return a.out_dtype == GIM_H16 || (GIM_HALF_KIND && a.out_dtype == GIM_BF16); }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == GIM_ACT_RELU) return fmaxf(v, 0.f);
@@ -63,7 +66,7 @@ __device__ __forceinline__ void epilogue_rows(const gim_conv_args& a, const floa
             const size_t ro = (size_t)(a.res_mod > 0 ? m % a.res_mod : m) * a.ldres + n;
 #pragma unroll
             for (int e = 0; e < G; e += 4) {
-                const float4 rr = a.res_dtype == GIM_BF16 ? ElemIO<true>::ld4(a.res, ro + e) : ElemIO<false>::ld4(a.res, ro + e);
+                const float4 rr = a.res_dtype == GIM_H16 ? ElemIO<true>::ld4(a.res, ro + e) : ElemIO<false>::ld4(a.res, ro + e);
                 v[e] += rr.x; v[e + 1] += rr.y; v[e + 2] += rr.z; v[e + 3] += rr.w;
             }
         }
@@ -74,8 +77,8 @@ __device__ __forceinline__ void epilogue_rows(const gim_conv_args& a, const floa
         const size_t yo = (size_t)m * a.ldy + n;
         if constexpr (OUT_BF16) {
             uint4 o;
-            o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-            o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+            o.x = cvt_pk_h16(v[0], v[1]); o.y = cvt_pk_h16(v[2], v[3]);
+            o.z = cvt_pk_h16(v[4], v[5]); o.w = cvt_pk_h16(v[6], v[7]);
             *(uint4*)((unsigned short*)a.y + yo) = o;
         } else {
             *(float4*)((float*)a.y + yo) = make_float4(v[0], v[1], v[2], v[3]);
@@ -127,7 +130,7 @@ igemm_kernel(const gim_conv_args a, const int mtiles, const int ntiles, const in
     __syncthreads();
     // ---- phase 2: each lane owns one 16-byte channel group of a pixel row -> bias, residual, activation,
     // fully coalesced NHWC stores (a 256-byte bf16 row is written by 16 adjacent lanes).
-    if (a.out_dtype == GIM_BF16) epilogue_rows<BM, BN, true>(a, Ct, m0, n0, M);
+    if (a.out_dtype == GIM_H16) epilogue_rows<BM, BN, true>(a, Ct, m0, n0, M);
     else epilogue_rows<BM, BN, false>(a, Ct, m0, n0, M);
 }
 
@@ -203,6 +206,9 @@ struct Epilogue {
         char* wl = stage + wave * WAVE_BYTES;  // this wave's transposition tile [32 px][RB]
         const bool full = (m0 + G::A_BYTES / KTB <= M) && (n0 + G::B_BYTES / KTB <= a.N);
         const int act = (a.act_cols > 0 && n0 >= a.act_cols) ? GIM_ACT_NONE : a.act;  // tile-uniform
+        // kind of a 16-bit output: the flavour of this translation unit, except that the fp16 objects can also write bf16
+        // (no residual / upsample operand then: checked at launch)
+        const bool out_bf = GIM_HALF_KIND ? a.out_dtype == GIM_BF16 : true;
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
 #pragma unroll
@@ -221,10 +227,10 @@ struct Epilogue {
                         for (int rg = 0; rg < 4; ++rg) {
                             if constexpr (OUT_BF16) {
                                 const uint2 u = *(const uint2*)(wl + l31 * RB + (((i * 4 + rg) ^ (l31 & 7)) << 4) + lh * 8);
-                                acc[i][j][rg * 4 + 0] += __uint_as_float(u.x << 16);
-                                acc[i][j][rg * 4 + 1] += __uint_as_float(u.x & 0xffff0000u);
-                                acc[i][j][rg * 4 + 2] += __uint_as_float(u.y << 16);
-                                acc[i][j][rg * 4 + 3] += __uint_as_float(u.y & 0xffff0000u);
+                                acc[i][j][rg * 4 + 0] += h16_lo(u.x);
+                                acc[i][j][rg * 4 + 1] += h16_hi(u.x);
+                                acc[i][j][rg * 4 + 2] += h16_lo(u.y);
+                                acc[i][j][rg * 4 + 3] += h16_hi(u.y);
                             } else {
                                 const float4 rr = *(const float4*)(wl + l31 * RB + (((i * 8 + rg * 2 + lh) ^ (l31 & 7)) << 4));
                                 acc[i][j][rg * 4 + 0] += rr.x; acc[i][j][rg * 4 + 1] += rr.y;
@@ -261,7 +267,7 @@ struct Epilogue {
                         const f32x16_t& v = acc[nh * 2 + i][j];
                         if constexpr (OUT_BF16) {
                             *(uint2*)(wl + l31 * RB + (((i * 4 + rg) ^ (l31 & 7)) << 4) + lh * 8) =
-                                make_uint2(cvt_pk_bf16(v[rg * 4 + 0], v[rg * 4 + 1]), cvt_pk_bf16(v[rg * 4 + 2], v[rg * 4 + 3]));
+                                make_uint2(cvt_pk_16(v[rg * 4 + 0], v[rg * 4 + 1], out_bf), cvt_pk_16(v[rg * 4 + 2], v[rg * 4 + 3], out_bf));
                         } else {
                             *(float4*)(wl + l31 * RB + (((i * 8 + rg * 2 + lh) ^ (l31 & 7)) << 4)) =
                                 make_float4(v[rg * 4 + 0], v[rg * 4 + 1], v[rg * 4 + 2], v[rg * 4 + 3]);
@@ -300,12 +306,12 @@ struct Epilogue {
                             unsigned rv[4];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float o0 = __uint_as_float(ov[e] << 16), o1 = __uint_as_float(ov[e] & 0xffff0000u);
-                                const float a0 = __uint_as_float(av[e] << 16), a1 = __uint_as_float(av[e] & 0xffff0000u);
-                                const float b0 = __uint_as_float(bv[e] << 16), b1 = __uint_as_float(bv[e] & 0xffff0000u);
-                                const float c0 = __uint_as_float(cv[e] << 16), c1 = __uint_as_float(cv[e] & 0xffff0000u);
-                                const float d0 = __uint_as_float(dv[e] << 16), d1 = __uint_as_float(dv[e] & 0xffff0000u);
-                                rv[e] = cvt_pk_bf16(o0 + (ly0 * (lx0 * a0 + lx1 * b0) + ly1 * (lx0 * c0 + lx1 * d0)),
+                                const float o0 = h16_lo(ov[e]), o1 = h16_hi(ov[e]);
+                                const float a0 = h16_lo(av[e]), a1 = h16_hi(av[e]);
+                                const float b0 = h16_lo(bv[e]), b1 = h16_hi(bv[e]);
+                                const float c0 = h16_lo(cv[e]), c1 = h16_hi(cv[e]);
+                                const float d0 = h16_lo(dv[e]), d1 = h16_hi(dv[e]);
+                                rv[e] = cvt_pk_h16(o0 + (ly0 * (lx0 * a0 + lx1 * b0) + ly1 * (lx0 * c0 + lx1 * d0)),
                                                     o1 + (ly0 * (lx0 * a1 + lx1 * b1) + ly1 * (lx0 * c1 + lx1 * d1)));
                             }
                             o = make_uint4(rv[0], rv[1], rv[2], rv[3]);
@@ -836,7 +842,7 @@ conv3x3_halo_kernel(const gim_conv_args a, const int tiles_x, const int tiles_y,
                         for (int rg = 0; rg < 4; ++rg) {
                             const f32x16_t& v = acc[nh * 2 + i][j];
                             *(uint2*)(wl + epi.l31 * E::RB + (((i * 4 + rg) ^ (epi.l31 & 7)) << 4) + epi.lh * 8) =
-                                make_uint2(cvt_pk_bf16(v[rg * 4 + 0], v[rg * 4 + 1]), cvt_pk_bf16(v[rg * 4 + 2], v[rg * 4 + 3]));
+                                make_uint2(cvt_pk_h16(v[rg * 4 + 0], v[rg * 4 + 1]), cvt_pk_h16(v[rg * 4 + 2], v[rg * 4 + 3]));
                         }
                     const int ncol = n0 + epi.wn * G::WTN + nh * 64 + epi.rslot * 8;
 #pragma unroll
@@ -925,7 +931,7 @@ static int big_min_nkt() { static const int v = env_int("GIM_IGEMM_BIG_MIN_NKT",
 
 template <int BM, int BN, int WM, int WN, bool BF16>
 int dispatch_res(const gim_conv_args& a, hipStream_t s) {
-    const bool obf = a.out_dtype == GIM_BF16;
+    const bool obf = out_is16(a);
     if (a.res) {
         if (obf) return launch_persistent<BM, BN, WM, WN, BF16, true, true>(a, s);
         return launch_persistent<BM, BN, WM, WN, BF16, false, true>(a, s);
@@ -946,7 +952,7 @@ int dispatch_persistent(const gim_conv_args& a, hipStream_t s) {
         // 256 x 256 tile, 8 waves, 64 x 128 wave tile: twice the MFMAs per wave and slab against nearly the same
         // staging / addressing overhead -- for the MFMA-bound layers (no residual, bf16 out, N % 256 == 0)
         const int bmode = big_mode();
-        if (a.npad % 256 == 0 && a.out_dtype == GIM_BF16 && !a.res &&
+        if (a.npad % 256 == 0 && out_is16(a) && !a.res &&
             (bmode == 2 || (bmode == 1 && nkt >= big_min_nkt() && ((M + 255) / 256) * (a.npad / 256) >= big_min_tiles())))
         {
             // N <= 224 (the FPN's 196-channel layers): the second column half's last fragment is pure padding
@@ -965,7 +971,7 @@ int dispatch_persistent(const gim_conv_args& a, hipStream_t s) {
         // (a 512 x 128 tile with 128 x 64 wave tiles for the N = 128 layers measured slower than 128 x 128: 875 vs 716 us
         //  on 196->128 3x3 -- not built)
         const int mode = ring3_mode();
-        const bool can = a.out_dtype == GIM_BF16 && nkt <= 72;
+        const bool can = a.out_dtype == GIM_H16 && nkt <= 72;   // (experimental ring kernel: the flavour's own type only)
         if (can && (mode == 2 || (mode == 1 && nkt >= 8 && T >= 4 * 256)))
             return a.res ? launch_ring3<BF16, true>(a, s) : launch_ring3<BF16, false>(a, s);
         return dispatch_res<128, 128, 2, 2, BF16>(a, s);
@@ -1003,7 +1009,7 @@ int dispatch_tile(const gim_conv_args& a, hipStream_t s) {
 
 // a->ups is only built into the 256 x 256 / 8-wave bf16 tile: the launch must be one that dispatch_persistent sends there
 static bool ups_supported(const gim_conv_args& a) {
-    if (a.dtype != GIM_BF16 || a.out_dtype != GIM_BF16 || a.res || a.use_lds_dma != 1 || a.npad % 256 != 0) return false;
+    if (a.dtype != GIM_H16 || a.out_dtype != GIM_H16 || a.res || a.use_lds_dma != 1 || a.npad % 256 != 0) return false;
     // output rows are (image, Y, X) with Y < 2 ups_h, X < 2 ups_w whatever geometry the launch states (a 1x1 conv is launched flat)
     const long long Mo = (long long)a.B * a.Ho * a.Wo;
     if (a.ups_h <= 0 || a.ups_w <= 0 || Mo % (4ll * a.ups_h * a.ups_w) != 0 || (2 * a.ups_w) % 32 != 0 || a.ups_ld % 8 != 0 || a.ups_ld < a.N) return false;
@@ -1013,13 +1019,32 @@ static bool ups_supported(const gim_conv_args& a) {
     return big_mode() == 2 || (nkt >= big_min_nkt() && ((M + 255) / 256) * (a.npad / 256) >= big_min_tiles());
 }
 
-extern "C" int gim_conv_ups_supported(const gim_conv_args* ap) { return ap && ups_supported(*ap) ? 1 : 0; }
+#if !GIM_HALF_KIND
+extern "C" int gim_conv_ups_supported_f16(const gim_conv_args* ap);
+extern "C" int gim_conv2d_bn_act_f16(const gim_conv_args* ap, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_conv_ups_supported)(const gim_conv_args* ap) {
+#if !GIM_HALF_KIND
+    if (ap && ap->dtype == GIM_F16) return gim_conv_ups_supported_f16(ap);
+#endif
+    return ap && ups_supported(*ap) ? 1 : 0;
+}
 
-extern "C" int gim_conv2d_bn_act(const gim_conv_args* ap, gim_stream_t stream) {
+extern "C" int GIM_FN(gim_conv2d_bn_act)(const gim_conv_args* ap, gim_stream_t stream) {
     GIM_REQUIRE(ap, "gim_conv2d_bn_act: NULL args");
+#if !GIM_HALF_KIND
+    if (ap->dtype == GIM_F16) return gim_conv2d_bn_act_f16(ap, stream);   // the fp16 objects of this file
+    GIM_REQUIRE(ap->out_dtype != GIM_F16 && (!ap->res || ap->res_dtype != GIM_F16), "conv: fp16 output / residual needs fp16 operands");
+#endif
     const gim_conv_args& a = *ap;
-    const int es = a.dtype == GIM_BF16 ? 2 : 4;
-    GIM_REQUIRE(a.dtype == GIM_BF16 || a.dtype == GIM_F32, "conv: bad dtype %d", a.dtype);
+#if GIM_HALF_KIND
+    // the other 16-bit kind as OUTPUT only (the bf16 mode's stem: fp16 image in, bf16 feature map out): the persistent kernels'
+    // epilogue packs either kind (out_is16 / Epilogue::run); everything else here works on the flavour's own type
+    GIM_REQUIRE(a.out_dtype != GIM_BF16 || (a.dtype == GIM_H16 && !a.res && !a.ups && a.use_lds_dma == 1),
+                "conv: fp16 operands with bf16 output: no residual, no upsample operand, LDS-DMA path only");
+#endif
+    const int es = a.dtype == GIM_H16 ? 2 : 4;
+    GIM_REQUIRE(a.dtype == GIM_H16 || a.dtype == GIM_F32, "conv: bad dtype %d", a.dtype);
     GIM_REQUIRE(a.x && a.w && a.y && a.ktab, "conv: NULL x/w/y/ktab");
     GIM_REQUIRE(a.npad > 0 && a.npad % 64 == 0, "conv: npad=%d must be a multiple of 64", a.npad);
     GIM_REQUIRE(a.kpad > 0 && (a.kpad * es) % KTB == 0, "conv: kpad=%d is not a multiple of the %d-byte K slab", a.kpad, KTB);
@@ -1027,19 +1052,19 @@ extern "C" int gim_conv2d_bn_act(const gim_conv_args* ap, gim_stream_t stream) {
     GIM_REQUIRE(a.x_bytes > 0 && a.x_bytes < (int64_t)0xFFFFFFF0ll, "conv: x_bytes=%lld must be < 4 GiB", (long long)a.x_bytes);
     GIM_REQUIRE(a.ldx % (16 / es) == 0, "conv: ldx=%d breaks 16-byte alignment", a.ldx);
     GIM_REQUIRE(a.ldy % 4 == 0 && (!a.res || a.ldres % 4 == 0), "conv: ldy/ldres must be multiples of 4");
-    GIM_REQUIRE(a.out_dtype != GIM_BF16 || (a.N % 8 == 0 && a.ldy % 8 == 0), "conv: bf16 output needs N and ldy multiples of 8 (16-byte row stores)");
-    GIM_REQUIRE(!a.res || (a.res_dtype == a.out_dtype && (a.res_dtype != GIM_BF16 || a.ldres % 8 == 0)), "conv: residual must have the output dtype (and ldres %% 8 == 0 for bf16)");
+    GIM_REQUIRE(!out_is16(a) || (a.N % 8 == 0 && a.ldy % 8 == 0), "conv: 16-bit output needs N and ldy multiples of 8 (16-byte row stores)");
+    GIM_REQUIRE(!a.res || (a.res_dtype == a.out_dtype && (a.res_dtype != GIM_H16 || a.ldres % 8 == 0)), "conv: residual must have the output dtype (and ldres %% 8 == 0 for 16-bit rows)");
     GIM_REQUIRE(a.act_cols >= 0 && a.act_cols % 128 == 0, "conv: act_cols=%d must be a multiple of 128", a.act_cols);
     GIM_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.Ho > 0 && a.Wo > 0 && a.stride > 0, "conv: bad geometry");
     GIM_REQUIRE((int64_t)a.B * a.Ho * a.Wo < (int64_t)0x7fffffff, "conv: too many output rows");
     GIM_REQUIRE(!a.ups || ups_supported(a), "conv: this launch cannot take the fused upsample-add (see gim_conv_ups_supported)");
     hipStream_t s = (hipStream_t)stream;
     if (a.use_lds_dma == 2) {  // 3x3 halo kernel: w / ktab / kpad describe the halo packing (gim_amd/packing.py::pack_halo)
-        GIM_REQUIRE(a.dtype == GIM_BF16 && a.out_dtype == GIM_BF16 && !a.res && a.stride == 1 && a.pad == 1 && a.H == a.Ho && a.W == a.Wo,
-                    "conv3x3 halo: bf16 in / out, stride 1, pad 1, no residual");
+        GIM_REQUIRE(a.dtype == GIM_H16 && a.out_dtype == GIM_H16 && !a.res && a.stride == 1 && a.pad == 1 && a.H == a.Ho && a.W == a.Wo,
+                    "conv3x3 halo: 16-bit in / out, stride 1, pad 1, no residual");
         GIM_REQUIRE(a.npad % 128 == 0 && a.kpad % 64 == 0 && a.res_mod > 0 && a.res_mod <= a.ldx && a.act_cols == 0, "conv3x3 halo: bad packing");
         return a.npad % 256 == 0 ? launch_halo<4>(a, s) : launch_halo<2>(a, s);
     }
-    if (a.dtype == GIM_BF16) return a.use_lds_dma ? dispatch_persistent<true>(a, s) : dispatch_tile<true, false>(a, s);
+    if (a.dtype == GIM_H16) return a.use_lds_dma ? dispatch_persistent<true>(a, s) : dispatch_tile<true, false>(a, s);
     return a.use_lds_dma ? dispatch_persistent<false>(a, s) : dispatch_tile<false, false>(a, s);
 }

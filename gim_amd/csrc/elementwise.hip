@@ -142,67 +142,103 @@ inline unsigned nblocks(size_t n, int bs) { return (unsigned)((n + bs - 1) / bs)
 
 }  // namespace
 
-extern "C" int gim_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int cpad, int ld,
+#if !GIM_HALF_KIND
+extern "C" int gim_nchw_to_nhwc_f16(const float* src, void* dst, int B, int C, int H, int W, int cpad, int ld,
+                                int b_off, int dtype, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_nchw_to_nhwc)(const float* src, void* dst, int B, int C, int H, int W, int cpad, int ld,
                                 int b_off, int dtype, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16) return gim_nchw_to_nhwc_f16(src, dst, B, C, H, W, cpad, ld, b_off, dtype, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc: bad args");
     GIM_REQUIRE(cpad % 4 == 0 && cpad >= C && ld >= cpad && ld % 4 == 0, "nchw_to_nhwc: cpad=%d ld=%d", cpad, ld);
     const size_t n = (size_t)B * H * W;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GIM_BF16)
+    if (dtype == GIM_H16)
         hipLaunchKernelGGL(nchw_to_nhwc_kernel<true>, dim3(nblocks(n, 256)), dim3(256), 0, s, src, dst, B, C, H * W, cpad, ld, b_off);
     else
         hipLaunchKernelGGL(nchw_to_nhwc_kernel<false>, dim3(nblocks(n, 256)), dim3(256), 0, s, src, dst, B, C, H * W, cpad, ld, b_off);
     return gim_check_launch("nchw_to_nhwc");
 }
 
-extern "C" int gim_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int ld, int dtype,
+#if !GIM_HALF_KIND
+extern "C" int gim_nhwc_to_nchw_f16(const void* src, float* dst, int B, int C, int H, int W, int ld, int dtype,
+                                gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_nhwc_to_nchw)(const void* src, float* dst, int B, int C, int H, int W, int ld, int dtype,
                                 gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16) return gim_nhwc_to_nchw_f16(src, dst, B, C, H, W, ld, dtype, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && ld >= C, "nhwc_to_nchw: bad args");
     const int HW = H * W;
     dim3 grid((HW + 63) / 64, (C + 63) / 64, B);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GIM_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<true>, grid, dim3(256), 0, s, src, dst, C, HW, ld);
+    if (dtype == GIM_H16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<true>, grid, dim3(256), 0, s, src, dst, C, HW, ld);
     else hipLaunchKernelGGL(nhwc_to_nchw_kernel<false>, grid, dim3(256), 0, s, src, dst, C, HW, ld);
     return gim_check_launch("nhwc_to_nchw");
 }
 
-extern "C" int gim_upsample2x_add(const void* x, void* y, int B, int h, int w, int C, int ldx, int ldy, int dtype,
+#if !GIM_HALF_KIND
+extern "C" int gim_upsample2x_add_f16(const void* x, void* y, int B, int h, int w, int C, int ldx, int ldy, int dtype,
+                                  gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_upsample2x_add)(const void* x, void* y, int B, int h, int w, int C, int ldx, int ldy, int dtype,
                                   gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16) return gim_upsample2x_add_f16(x, y, B, h, w, C, ldx, ldy, dtype, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(x && y && B > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0, "upsample2x_add: bad args (C=%d)", C);
     GIM_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "upsample2x_add: ld must be a multiple of 4");
-    const int G = dtype == GIM_BF16 ? 8 : 4;
+    const int G = dtype == GIM_H16 ? 8 : 4;
     GIM_REQUIRE(C % G == 0, "upsample2x_add: C=%d must be a multiple of %d (16-byte groups)", C, G);
     const size_t n = (size_t)B * 2 * h * 2 * w * (C / G);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GIM_BF16)
+    if (dtype == GIM_H16)
         hipLaunchKernelGGL(upsample2x_add_kernel<true>, dim3(nblocks(n, 256)), dim3(256), 0, s, x, y, B, h, w, C / G, ldx, ldy);
     else
         hipLaunchKernelGGL(upsample2x_add_kernel<false>, dim3(nblocks(n, 256)), dim3(256), 0, s, x, y, B, h, w, C / G, ldx, ldy);
     return gim_check_launch("upsample2x_add");
 }
 
-extern "C" int gim_posenc_add(const void* x, const float* pe, float* out_f32, void* out_t, int rows, int hw, int C,
+#if !GIM_HALF_KIND
+extern "C" int gim_posenc_add_f16(const void* x, const float* pe, float* out_f32, void* out_t, int rows, int hw, int C,
+                              int ldx, int ld_f32, int ld_t, int dtype, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_posenc_add)(const void* x, const float* pe, float* out_f32, void* out_t, int rows, int hw, int C,
                               int ldx, int ld_f32, int ld_t, int dtype, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16) return gim_posenc_add_f16(x, pe, out_f32, out_t, rows, hw, C, ldx, ld_f32, ld_t, dtype, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(x && pe && (out_f32 || out_t) && rows > 0 && hw > 0 && C > 0 && C % 4 == 0, "posenc_add: bad args");
     GIM_REQUIRE(ldx % 4 == 0 && ld_f32 % 4 == 0 && ld_t % 4 == 0, "posenc_add: ld must be a multiple of 4");
     const size_t n = (size_t)rows * (C / 4);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GIM_BF16)
+    if (dtype == GIM_H16)
         hipLaunchKernelGGL(posenc_add_kernel<true>, dim3(nblocks(n, 256)), dim3(256), 0, s, x, pe, out_f32, out_t, (size_t)rows, hw, C / 4, ldx, ld_f32, ld_t);
     else
         hipLaunchKernelGGL(posenc_add_kernel<false>, dim3(nblocks(n, 256)), dim3(256), 0, s, x, pe, out_f32, out_t, (size_t)rows, hw, C / 4, ldx, ld_f32, ld_t);
     return gim_check_launch("posenc_add");
 }
 
-extern "C" int gim_layernorm_residual(const void* x, const float* gamma, const float* beta, const float* res,
+#if !GIM_HALF_KIND
+extern "C" int gim_layernorm_residual_f16(const void* x, const float* gamma, const float* beta, const float* res,
+                                      float* out_f32, void* out_t, int rows, int C, int ldx, int ldres, int ld_f32,
+                                      int ld_t, int x_dtype, int dtype, float eps, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_layernorm_residual)(const void* x, const float* gamma, const float* beta, const float* res,
                                       float* out_f32, void* out_t, int rows, int C, int ldx, int ldres, int ld_f32,
                                       int ld_t, int x_dtype, int dtype, float eps, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (x_dtype == GIM_F16 || dtype == GIM_F16) return gim_layernorm_residual_f16(x, gamma, beta, res, out_f32, out_t, rows, C, ldx, ldres, ld_f32, ld_t, x_dtype, dtype, eps, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(x && gamma && beta && (out_f32 || out_t) && rows > 0, "layernorm: bad args");
     GIM_REQUIRE(C > 0 && C % 4 == 0 && C <= 512, "layernorm: C=%d unsupported (multiple of 4, <= 512)", C);
     GIM_REQUIRE(ldx % 4 == 0 && ld_f32 % 4 == 0 && ld_t % 4 == 0 && (!res || ldres % 4 == 0), "layernorm: ld alignment");
     hipStream_t s = (hipStream_t)stream;
     const unsigned g = (unsigned)((rows + 3) / 4);
-    const bool ob = dtype == GIM_BF16, xb = x_dtype == GIM_BF16;
+    const bool ob = dtype == GIM_H16, xb = x_dtype == GIM_H16;
     if (ob && xb) hipLaunchKernelGGL((layernorm_kernel<true, true>), dim3(g), dim3(256), 0, s, x, gamma, beta, res, out_f32, out_t, rows, C, ldx, ldres, ld_f32, ld_t, eps);
     else if (ob) hipLaunchKernelGGL((layernorm_kernel<true, false>), dim3(g), dim3(256), 0, s, x, gamma, beta, res, out_f32, out_t, rows, C, ldx, ldres, ld_f32, ld_t, eps);
     else if (xb) hipLaunchKernelGGL((layernorm_kernel<false, true>), dim3(g), dim3(256), 0, s, x, gamma, beta, res, out_f32, out_t, rows, C, ldx, ldres, ld_f32, ld_t, eps);

@@ -144,8 +144,8 @@ __device__ __forceinline__ void mma8(const char* a, const W8& w, f32x16_t (&acc)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const bf16x8_t v = *(const bf16x8_t*)(ab + j * 32 * ROWB);
-            if constexpr (SWAP) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v, wf, acc[j], 0, 0, 0);
-            else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, v, acc[j], 0, 0, 0);
+            if constexpr (SWAP) acc[j] = mfma_h16_32x32x16(v, wf, acc[j]);
+            else acc[j] = mfma_h16_32x32x16(wf, v, acc[j]);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -164,7 +164,7 @@ __device__ __forceinline__ void store_rows(char* buf, const f32x16_t (&acc)[2], 
                 const float x = acc[j][rg * 4 + e];
                 v[e] = ACT == 1 ? fmaxf(x, 0.f) : (ACT == 2 ? elu1(x) : x);
             }
-            *(uint2*)(buf + L.st4[rg] + j * 32 * ROWB) = make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
+            *(uint2*)(buf + L.st4[rg] + j * 32 * ROWB) = make_uint2(cvt_pk_h16(v[0], v[1]), cvt_pk_h16(v[2], v[3]));
         }
 }
 
@@ -183,7 +183,7 @@ __device__ __forceinline__ void store_transposed(char* buf, const f32x16_t (&acc
                 v[e] = (8 * rg + 4 * L.lh + e < WW) ? (ACT == 2 ? elu1(x) : x) : 0.f;
             }
             *(uint2*)(buf + (32 * L.wn + L.l31) * TROWB + (((4 * j + rg) ^ L.tsw) << 4) + L.lh * 8) =
-                make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
+                make_uint2(cvt_pk_h16(v[0], v[1]), cvt_pk_h16(v[2], v[3]));
         }
 }
 
@@ -230,14 +230,14 @@ __device__ __forceinline__ void load_master(f32x16_t (&xm)[2], const char* xb, c
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             const uint2 u = *(const uint2*)(xb + L.st4[rg] + j * 32 * ROWB);
-            xm[j][rg * 4] = __uint_as_float(u.x << 16); xm[j][rg * 4 + 1] = __uint_as_float(u.x & 0xffff0000u);
-            xm[j][rg * 4 + 2] = __uint_as_float(u.y << 16); xm[j][rg * 4 + 3] = __uint_as_float(u.y & 0xffff0000u);
+            xm[j][rg * 4] = h16_lo(u.x); xm[j][rg * 4 + 1] = h16_hi(u.x);
+            xm[j][rg * 4 + 2] = h16_lo(u.y); xm[j][rg * 4 + 3] = h16_hi(u.y);
             if constexpr (WITH_LO) {
                 if (L.l31 < WW) {
                     const int cr = j * WW + L.l31;
                     const uint2 v = *(const uint2*)(lo + cr * ROWB + (((4 * L.wn + rg) ^ (cr & 15)) << 4) + L.lh * 8);
-                    xm[j][rg * 4] += __uint_as_float(v.x << 16); xm[j][rg * 4 + 1] += __uint_as_float(v.x & 0xffff0000u);
-                    xm[j][rg * 4 + 2] += __uint_as_float(v.y << 16); xm[j][rg * 4 + 3] += __uint_as_float(v.y & 0xffff0000u);
+                    xm[j][rg * 4] += h16_lo(v.x); xm[j][rg * 4 + 1] += h16_hi(v.x);
+                    xm[j][rg * 4 + 2] += h16_lo(v.y); xm[j][rg * 4 + 3] += h16_hi(v.y);
                 }
             }
         }
@@ -249,9 +249,9 @@ __device__ __forceinline__ void pack_lo(uint2 (&lo)[2][4], const f32x16_t (&xm)[
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-            const unsigned h0 = cvt_pk_bf16(xm[j][rg * 4], xm[j][rg * 4 + 1]), h1 = cvt_pk_bf16(xm[j][rg * 4 + 2], xm[j][rg * 4 + 3]);
-            lo[j][rg] = make_uint2(cvt_pk_bf16(xm[j][rg * 4] - __uint_as_float(h0 << 16), xm[j][rg * 4 + 1] - __uint_as_float(h0 & 0xffff0000u)),
-                                   cvt_pk_bf16(xm[j][rg * 4 + 2] - __uint_as_float(h1 << 16), xm[j][rg * 4 + 3] - __uint_as_float(h1 & 0xffff0000u)));
+            const unsigned h0 = cvt_pk_h16(xm[j][rg * 4], xm[j][rg * 4 + 1]), h1 = cvt_pk_h16(xm[j][rg * 4 + 2], xm[j][rg * 4 + 3]);
+            lo[j][rg] = make_uint2(cvt_pk_h16(xm[j][rg * 4] - h16_lo(h0), xm[j][rg * 4 + 1] - h16_hi(h0)),
+                                   cvt_pk_h16(xm[j][rg * 4 + 2] - h16_lo(h1), xm[j][rg * 4 + 3] - h16_hi(h1)));
         }
 }
 __device__ __forceinline__ void store_lo(char* lob, const uint2 (&lo)[2][4], const Lane& L) {
@@ -277,7 +277,7 @@ __device__ __forceinline__ void store_lo(char* lob, const uint2 (&lo)[2][4], con
                                                    : *(const unsigned short*)((BUFPTR) + row * ROWB + ((((col >> 3)) ^ (row & 15)) << 4) + (col & 7) * 2); \
             const int tokrow = (TRANSPOSED) ? col : row, ch = (TRANSPOSED) ? row : col;                               \
             const int mq = tokrow >> 5, tok = tokrow & 31;                                                            \
-            if (tok < WW && L.dbg_m_base + mq < L.dbg_M) L.dbg_out[((size_t)(L.dbg_m_base + mq) * WW + tok) * C + ch] = __uint_as_float(((unsigned)hv) << 16); \
+            if (tok < WW && L.dbg_m_base + mq < L.dbg_M) L.dbg_out[((size_t)(L.dbg_m_base + mq) * WW + tok) * C + ch] = h16_to_f32(hv); \
         }                                                                                                             \
         L.dbg_stage = -1;                                                                                             \
     }
@@ -324,7 +324,7 @@ __device__ __forceinline__ void encoder_layer(char* smem, char* bx, const char* 
             const uint4 u = *(const uint4*)(T1 + ch * TROWB + (((4 * mm + sl) ^ ((ch >> 1) & 7)) << 4));
             const unsigned uu[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-            for (int t = 0; t < 4; ++t) s += __uint_as_float(uu[t] << 16) + __uint_as_float(uu[t] & 0xffff0000u);
+            for (int t = 0; t < 4; ++t) s += h16_lo(uu[t]) + h16_hi(uu[t]);
         }
         ksum[mm * C + ch] = s;
     }
@@ -338,7 +338,7 @@ __device__ __forceinline__ void encoder_layer(char* smem, char* bx, const char* 
         for (int ks = 0; ks < 2; ++ks) {
             const int off = (32 * (ig0 + ii) + L.l31) * TROWB + (((4 * mm + 2 * ks + L.lh) ^ L.tsw) << 4);
             const bf16x8_t a = *(const bf16x8_t*)(T1 + off), b = *(const bf16x8_t*)(T2 + off);
-            kv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, kv, 0, 0, 0);  // lane: v-channel l31, k-channels 8rg+4lh+e
+            kv = mfma_h16_32x32x16(a, b, kv);  // lane: v-channel l31, k-channels 8rg+4lh+e
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -347,8 +347,8 @@ __device__ __forceinline__ void encoder_layer(char* smem, char* bx, const char* 
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 const int rg = 2 * ks + h2;
-                p[h2 * 2] = keep ? cvt_pk_bf16(kv[rg * 4], kv[rg * 4 + 1]) : 0u;
-                p[h2 * 2 + 1] = keep ? cvt_pk_bf16(kv[rg * 4 + 2], kv[rg * 4 + 3]) : 0u;
+                p[h2 * 2] = keep ? cvt_pk_h16(kv[rg * 4], kv[rg * 4 + 1]) : 0u;
+                p[h2 * 2 + 1] = keep ? cvt_pk_h16(kv[rg * 4 + 2], kv[rg * 4 + 3]) : 0u;
             }
             kvp[ii][ks] = __builtin_bit_cast(bf16x8_t, make_uint4(p[0], p[1], p[2], p[3]));
         }
@@ -372,10 +372,10 @@ __device__ __forceinline__ void encoder_layer(char* smem, char* bx, const char* 
             for (int half = 0; half < 2; ++half) {
                 const uint4 u = *(const uint4*)(T1 + row * ROWB + (((2 * h + half) ^ L.sw) << 4));
                 const float4 k0 = *(const float4*)(ksum + mm * C + 16 * h + 8 * half), k1 = *(const float4*)(ksum + mm * C + 16 * h + 8 * half + 4);
-                d = fmaf(__uint_as_float(u.x << 16), k0.x, d); d = fmaf(__uint_as_float(u.x & 0xffff0000u), k0.y, d);
-                d = fmaf(__uint_as_float(u.y << 16), k0.z, d); d = fmaf(__uint_as_float(u.y & 0xffff0000u), k0.w, d);
-                d = fmaf(__uint_as_float(u.z << 16), k1.x, d); d = fmaf(__uint_as_float(u.z & 0xffff0000u), k1.y, d);
-                d = fmaf(__uint_as_float(u.w << 16), k1.z, d); d = fmaf(__uint_as_float(u.w & 0xffff0000u), k1.w, d);
+                d = fmaf(h16_lo(u.x), k0.x, d); d = fmaf(h16_hi(u.x), k0.y, d);
+                d = fmaf(h16_lo(u.y), k0.z, d); d = fmaf(h16_hi(u.y), k0.w, d);
+                d = fmaf(h16_lo(u.z), k1.x, d); d = fmaf(h16_hi(u.z), k1.y, d);
+                d = fmaf(h16_lo(u.w), k1.z, d); d = fmaf(h16_hi(u.w), k1.w, d);
             }
             const float zz = 1.0f / (d + 1e-6f);
             const float other = __shfl_xor(zz, 32, 64);
@@ -394,13 +394,13 @@ __device__ __forceinline__ void encoder_layer(char* smem, char* bx, const char* 
                 const uint2 lo = *(const uint2*)(T1 + row * ROWB + (((4 * i + 2 * ks) ^ L.sw) << 4) + L.lh * 8);
                 const uint2 hi = *(const uint2*)(T1 + row * ROWB + (((4 * i + 2 * ks + 1) ^ L.sw) << 4) + L.lh * 8);
                 const bf16x8_t qf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
-                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kvp[ii][ks], qf, o, 0, 0, 0);  // lane: token l31, v-channels 8rg+4lh+e
+                o = mfma_h16_32x32x16(kvp[ii][ks], qf, o);  // lane: token l31, v-channels 8rg+4lh+e
             }
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const float zz = zq[2 * ii + (rg >> 1)];
                 *(uint2*)(T2 + row * ROWB + (((4 * i + rg) ^ L.sw) << 4) + L.lh * 8) =
-                    make_uint2(cvt_pk_bf16(o[rg * 4] * zz, o[rg * 4 + 1] * zz), cvt_pk_bf16(o[rg * 4 + 2] * zz, o[rg * 4 + 3] * zz));
+                    make_uint2(cvt_pk_h16(o[rg * 4] * zz, o[rg * 4 + 1] * zz), cvt_pk_h16(o[rg * 4 + 2] * zz, o[rg * 4 + 3] * zz));
             }
         }
     }
@@ -582,9 +582,9 @@ __global__ void __launch_bounds__(256, 2) fine_fused_kernel(const FineArgs a) {
 
 }  // namespace
 
-extern "C" int64_t gim_fine_fused_weight_bytes(void) { return (int64_t)2 * W_LAYER * 16; }
+extern "C" int64_t GIM_FN(gim_fine_fused_weight_bytes)(void) { return (int64_t)2 * W_LAYER * 16; }
 
-extern "C" int gim_fine_fused(const void* feat_f0, const void* feat_f1, const int64_t* b_ids, const int64_t* i_ids,
+extern "C" int GIM_FN(gim_fine_fused)(const void* feat_f0, const void* feat_f1, const int64_t* b_ids, const int64_t* i_ids,
                               const int64_t* j_ids, const float* mkpts1_c, const float* scale1, const void* weights,
                               const float* ln_params, float* expec_f, float* mkpts1_f, float* dbg_fine0, float* dbg_fine1,
                               int M, int hf0, int wf0, int hf1, int wf1, int C_, int ldf, int w0c, int w1c, int stride, int W,

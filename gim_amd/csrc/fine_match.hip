@@ -85,10 +85,19 @@ fine_match_kernel(const float* __restrict__ f0, const float* __restrict__ f1, co
 
 }  // namespace
 
-extern "C" int gim_fine_gather(const void* feat_f0, const void* feat_f1, const int64_t* b_ids, const int64_t* i_ids,
+#if !GIM_HALF_KIND
+extern "C" int gim_fine_gather_f16(const void* feat_f0, const void* feat_f1, const int64_t* b_ids, const int64_t* i_ids,
+                               const int64_t* j_ids, float* out_f32, void* out_t, int M, int hf0, int wf0, int hf1,
+                               int wf1, int C, int ldf, int w0c, int w1c, int stride, int W, int ld_f32, int ld_t,
+                               int dtype, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_fine_gather)(const void* feat_f0, const void* feat_f1, const int64_t* b_ids, const int64_t* i_ids,
                                const int64_t* j_ids, float* out_f32, void* out_t, int M, int hf0, int wf0, int hf1,
                                int wf1, int C, int ldf, int w0c, int w1c, int stride, int W, int ld_f32, int ld_t,
                                int dtype, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16) return gim_fine_gather_f16(feat_f0, feat_f1, b_ids, i_ids, j_ids, out_f32, out_t, M, hf0, wf0, hf1, wf1, C, ldf, w0c, w1c, stride, W, ld_f32, ld_t, dtype, stream);   // the fp16 objects of this file
+#endif
     if (M == 0) return GIM_OK;
     GIM_REQUIRE(feat_f0 && feat_f1 && b_ids && i_ids && j_ids && (out_f32 || out_t), "fine_gather: NULL pointer");
     GIM_REQUIRE(M > 0 && hf0 > 0 && wf0 > 0 && hf1 > 0 && wf1 > 0 && C > 0 && C % 4 == 0 && W > 0 && (W & 1) && stride > 0, "fine_gather: bad sizes");
@@ -96,14 +105,14 @@ extern "C" int gim_fine_gather(const void* feat_f0, const void* feat_f1, const i
     const size_t total = (size_t)2 * M * W * W * (C / 4);
     const unsigned grid = (unsigned)((total + 255) / 256);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GIM_BF16)
+    if (dtype == GIM_H16)
         hipLaunchKernelGGL(fine_gather_kernel<true>, dim3(grid), dim3(256), 0, s, feat_f0, feat_f1, b_ids, i_ids, j_ids, out_f32, out_t, M, hf0, wf0, hf1, wf1, C / 4, ldf, w0c, w1c, stride, W, ld_f32, ld_t);
     else
         hipLaunchKernelGGL(fine_gather_kernel<false>, dim3(grid), dim3(256), 0, s, feat_f0, feat_f1, b_ids, i_ids, j_ids, out_f32, out_t, M, hf0, wf0, hf1, wf1, C / 4, ldf, w0c, w1c, stride, W, ld_f32, ld_t);
     return gim_check_launch("fine_gather");
 }
 
-extern "C" int gim_fine_match(const float* f0, const float* f1, const float* mkpts1_c, const int64_t* b_ids,
+extern "C" int GIM_FN(gim_fine_match)(const float* f0, const float* f1, const float* mkpts1_c, const int64_t* b_ids,
                               const float* scale1, float* expec_f, float* mkpts1_f, int M, int WW, int C, int ld,
                               float scale, int has_scale0, gim_stream_t stream) {
     if (M == 0) return GIM_OK;

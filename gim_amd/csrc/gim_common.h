@@ -55,20 +55,106 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
 }
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return cvt_pk_bf16(lo, hi); }
 
-// generic typed element access used by the small memory-bound kernels
+// ---- the 16-bit operand flavour of a translation unit ------------------------------------------------------------------
+// The kernels of the gim_loftr path exist in two 16-bit flavours with identical instruction counts: bf16 (8 significand bits,
+// fp32 range) and IEEE fp16 (11 bits; |x| < 65504).  Measured on the CPU emulation of the engine's roundings
+// (tools/precision_emulation.py, profiles/r03_precision_emulation*.txt): fp16 operands cut the match-set flip rate against the
+// fp32 reference from 1.95 % to 0.47 %, because three more significand bits survive every activation store.
+// A source file is compiled ONCE PER FLAVOUR (gim_amd/build.py: -DGIM_HALF_KIND=0 / 1): everything that touches 16-bit values
+// goes through the helpers below, `GIM_H16` is the dtype tag of the flavour and GIM_FN() names the entry points of the
+// fp16 objects (`*_f16`); the bf16 objects carry the public names and forward dtype == GIM_F16 calls.
+#ifndef GIM_HALF_KIND
+#define GIM_HALF_KIND 0
+#endif
+#if GIM_HALF_KIND
+#define GIM_H16 GIM_F16
+#define GIM_FN(name) name##_f16
+#else
+#define GIM_H16 GIM_BF16
+#define GIM_FN(name) name
+#endif
+typedef _Float16 gim_f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 gim_f16x8_t __attribute__((ext_vector_type(8)));
+typedef __attribute__((ext_vector_type(4))) float gim_f32x4v_t;
+
+// fp32 pair -> packed fp16x2, round to nearest even: one v_cvt_pk_f16_f32
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
+    const gim_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, gim_f16x2_t));
+}
+__device__ __forceinline__ float f16_lo(unsigned u) { return (float)__builtin_bit_cast(gim_f16x2_t, u)[0]; }
+__device__ __forceinline__ float f16_hi(unsigned u) { return (float)__builtin_bit_cast(gim_f16x2_t, u)[1]; }
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// the flavour of this translation unit
+__device__ __forceinline__ unsigned cvt_pk_h16(float lo, float hi) {
+#if GIM_HALF_KIND
+    return cvt_pk_f16(lo, hi);
+#else
+    return cvt_pk_bf16(lo, hi);
+#endif
+}
+__device__ __forceinline__ float h16_lo(unsigned u) {
+#if GIM_HALF_KIND
+    return f16_lo(u);
+#else
+    return bf16_lo(u);
+#endif
+}
+__device__ __forceinline__ float h16_hi(unsigned u) {
+#if GIM_HALF_KIND
+    return f16_hi(u);
+#else
+    return bf16_hi(u);
+#endif
+}
+__device__ __forceinline__ float h16_to_f32(unsigned short h) {
+#if GIM_HALF_KIND
+    return (float)__builtin_bit_cast(_Float16, h);
+#else
+    return bf16_to_f32(h);
+#endif
+}
+__device__ __forceinline__ unsigned short f32_to_h16(float f) {
+#if GIM_HALF_KIND
+    return __builtin_bit_cast(unsigned short, (_Float16)f);
+#else
+    return f32_to_bf16(f);
+#endif
+}
+// 16-bit output of either kind from a translation unit of either flavour (the bf16 mode's first convolution reads an fp16
+// image -- its rounding is half of that mode's error -- and writes bf16); `bf` is wave-uniform
+__device__ __forceinline__ unsigned cvt_pk_16(float lo, float hi, bool bf) { return bf ? cvt_pk_bf16(lo, hi) : cvt_pk_f16(lo, hi); }
+// MFMAs on 8 x 16-bit operand lanes (carried as bf16x8_t = 8 shorts whatever the flavour)
+__device__ __forceinline__ f32x16_t mfma_h16_32x32x16(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+#if GIM_HALF_KIND
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gim_f16x8_t, a), __builtin_bit_cast(gim_f16x8_t, b), c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ f32x4_t mfma_h16_16x16x32(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+#if GIM_HALF_KIND
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(gim_f16x8_t, a), __builtin_bit_cast(gim_f16x8_t, b), c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+
+// generic typed element access used by the small memory-bound kernels (<true>: the 16-bit flavour of the translation unit)
 template <bool BF16> struct ElemIO;
 template <> struct ElemIO<true> {
     typedef unsigned short type;
-    static __device__ __forceinline__ float ld(const void* p, size_t i) { return bf16_to_f32(((const unsigned short*)p)[i]); }
-    static __device__ __forceinline__ void st(void* p, size_t i, float v) { ((unsigned short*)p)[i] = f32_to_bf16(v); }
+    static __device__ __forceinline__ float ld(const void* p, size_t i) { return h16_to_f32(((const unsigned short*)p)[i]); }
+    static __device__ __forceinline__ void st(void* p, size_t i, float v) { ((unsigned short*)p)[i] = f32_to_h16(v); }
     // 4 consecutive elements (8-byte aligned)
     static __device__ __forceinline__ float4 ld4(const void* p, size_t i) {
         uint2 u = *(const uint2*)((const unsigned short*)p + i);
-        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
-                           __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+        return make_float4(h16_lo(u.x), h16_hi(u.x), h16_lo(u.y), h16_hi(u.y));
     }
     static __device__ __forceinline__ void st4(void* p, size_t i, float4 v) {
-        *(uint2*)((unsigned short*)p + i) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        *(uint2*)((unsigned short*)p + i) = make_uint2(cvt_pk_h16(v.x, v.y), cvt_pk_h16(v.z, v.w));
     }
 };
 template <> struct ElemIO<false> {

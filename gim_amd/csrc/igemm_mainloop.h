@@ -196,7 +196,7 @@ struct Igemm {
             for (int i = 0; i < LIVE; ++i)
 #pragma unroll
                 for (int j = 0; j < TM; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.b[i], r.a[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_h16_32x32x16(r.b[i], r.a[j], acc[i][j]);
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q)

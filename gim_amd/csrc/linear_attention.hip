@@ -254,8 +254,8 @@ la_kv_mfma_kernel(const void* __restrict__ k, const void* __restrict__ v, const 
             const int row = 2 * st + lh;
             float a, bv;
             if constexpr (BF16) {
-                a = bf16_to_f32(*(const unsigned short*)(Ks + row * ROWB + col));
-                bv = bf16_to_f32(*(const unsigned short*)(Vs + row * ROWB + col)) * inv_s;
+                a = h16_to_f32(*(const unsigned short*)(Ks + row * ROWB + col));
+                bv = h16_to_f32(*(const unsigned short*)(Vs + row * ROWB + col)) * inv_s;
             } else {
                 a = *(const float*)(Ks + row * ROWB + col);
                 bv = *(const float*)(Vs + row * ROWB + col) / slen;  // values / v_length (attentions.py:42)
@@ -332,26 +332,33 @@ inline int nchunks(int S) { return (S + CH - 1) / CH; }
 
 }  // namespace
 
-extern "C" int64_t gim_linear_attention_ws_bytes(int nb, int S, int H, int D) {
+extern "C" int64_t GIM_FN(gim_linear_attention_ws_bytes)(int nb, int S, int H, int D) {
     const int64_t per = (int64_t)D * D + D;
     const int64_t nc = nchunks(S);
     return (int64_t)nb * H * per * 4 * (nc > 1 ? nc + 1 : 1);
 }
 
-extern "C" int gim_linear_attention_kv(const void* k, const void* v, const uint8_t* kv_mask, float* kv_ws, int nb,
+#if !GIM_HALF_KIND
+extern "C" int gim_linear_attention_kv_f16(const void* k, const void* v, const uint8_t* kv_mask, float* kv_ws, int nb,
+                                       int S, int H, int D, int ldk, int ldv, int dtype, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_linear_attention_kv)(const void* k, const void* v, const uint8_t* kv_mask, float* kv_ws, int nb,
                                        int S, int H, int D, int ldk, int ldv, int dtype, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16) return gim_linear_attention_kv_f16(k, v, kv_mask, kv_ws, nb, S, H, D, ldk, ldv, dtype, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(k && v && kv_ws && nb > 0 && S > 0 && H > 0, "linear_attention_kv: bad args");
     GIM_REQUIRE(D == 32 || D == 16, "linear_attention_kv: head dim %d unsupported (16 or 32)", D);
     GIM_REQUIRE(ldk % 4 == 0 && ldv % 4 == 0, "linear_attention_kv: ld alignment");
     hipStream_t s = (hipStream_t)stream;
-    const bool mfma_path = D == 32 && H == 8 && (ldk * (dtype == GIM_BF16 ? 2 : 4)) % 16 == 0 &&
-                           (ldv * (dtype == GIM_BF16 ? 2 : 4)) % 16 == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0;
+    const bool mfma_path = D == 32 && H == 8 && (ldk * (dtype == GIM_H16 ? 2 : 4)) % 16 == 0 &&
+                           (ldv * (dtype == GIM_H16 ? 2 : 4)) % 16 == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0;
     const int nc = mfma_path ? (S + CHM - 1) / CHM : nchunks(S);
     const int per = D * D + D;
     float* fin = kv_ws;
     float* part = nc > 1 ? kv_ws + (size_t)nb * H * per : kv_ws;
     dim3 grid((unsigned)(nb * H), (unsigned)nc);
-    const bool bf = dtype == GIM_BF16;
+    const bool bf = dtype == GIM_H16;
     if (mfma_path) {
         // coarse level: fp32-MFMA kernel, 4 heads of a 128-row chunk per workgroup
         const int smem = 2 * 64 * 128 * (bf ? 2 : 4);
@@ -382,9 +389,17 @@ extern "C" int gim_linear_attention_kv(const void* k, const void* v, const uint8
     return rc;
 }
 
-extern "C" int gim_linear_attention_apply(const void* q, const uint8_t* q_mask, const float* kv_ws, void* out, int nb,
+#if !GIM_HALF_KIND
+extern "C" int gim_linear_attention_apply_f16(const void* q, const uint8_t* q_mask, const float* kv_ws, void* out, int nb,
+                                          int L, int S, int H, int D, int ldq, int ldo, int dtype, int out_dtype,
+                                          gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_linear_attention_apply)(const void* q, const uint8_t* q_mask, const float* kv_ws, void* out, int nb,
                                           int L, int S, int H, int D, int ldq, int ldo, int dtype, int out_dtype,
                                           gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16 || out_dtype == GIM_F16) return gim_linear_attention_apply_f16(q, q_mask, kv_ws, out, nb, L, S, H, D, ldq, ldo, dtype, out_dtype, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(q && kv_ws && out && nb > 0 && L > 0 && S > 0 && H > 0, "linear_attention_apply: bad args");
     GIM_REQUIRE(D == 32 || D == 16, "linear_attention_apply: head dim %d unsupported (16 or 32)", D);
     GIM_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0, "linear_attention_apply: ld alignment");
@@ -392,7 +407,7 @@ extern "C" int gim_linear_attention_apply(const void* q, const uint8_t* q_mask, 
     dim3 grid((unsigned)nb, (unsigned)((L + 63) / 64));
     const size_t smem = (size_t)H * (D * D + D) * 4;
     GIM_REQUIRE(smem <= 64 * 1024, "linear_attention_apply: H=%d too large", H);
-    const bool bf = dtype == GIM_BF16, obf = out_dtype == GIM_BF16;
+    const bool bf = dtype == GIM_H16, obf = out_dtype == GIM_H16;
     if (D == 32 && H == 8) {  // coarse level: fp32-MFMA kernel, 64 rows per workgroup
         const dim3 g2((unsigned)nb, (unsigned)((L + 63) / 64));
 #define LA_APPLY_M(A, B) hipLaunchKernelGGL((la_apply_mfma_kernel<A, B>), g2, dim3(256), 0, s, q, q_mask, kv_ws, out, L, S, ldq, ldo)
@@ -419,16 +434,25 @@ extern "C" int gim_linear_attention_apply(const void* q, const uint8_t* q_mask, 
     return gim_check_launch("la_apply");
 }
 
-extern "C" int gim_linear_attention_short(const void* q, const void* k, const void* v, const uint8_t* q_mask,
+#if !GIM_HALF_KIND
+extern "C" int gim_linear_attention_short_f16(const void* q, const void* k, const void* v, const uint8_t* q_mask,
+                                          const uint8_t* kv_mask, void* out, int nb, int L, int S, int H, int D,
+                                          int ldq, int ldk, int ldv, int ldo, int dtype, int out_dtype,
+                                          gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_linear_attention_short)(const void* q, const void* k, const void* v, const uint8_t* q_mask,
                                           const uint8_t* kv_mask, void* out, int nb, int L, int S, int H, int D,
                                           int ldq, int ldk, int ldv, int ldo, int dtype, int out_dtype,
                                           gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16 || out_dtype == GIM_F16) return gim_linear_attention_short_f16(q, k, v, q_mask, kv_mask, out, nb, L, S, H, D, ldq, ldk, ldv, ldo, dtype, out_dtype, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(q && k && v && out && nb > 0 && L > 0 && S > 0, "linear_attention_short: bad args");
     GIM_REQUIRE(H == 8 && (D == 16 || D == 32), "linear_attention_short: needs H == 8 and D in {16, 32} (got H=%d D=%d)", H, D);
     GIM_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0, "linear_attention_short: ld alignment");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)((nb + 3) / 4));
-    const bool bf = dtype == GIM_BF16, obf = out_dtype == GIM_BF16;
+    const bool bf = dtype == GIM_H16, obf = out_dtype == GIM_H16;
 #define LA_SHORT(DD, A, B) hipLaunchKernelGGL((la_short_kernel<DD, A, B>), grid, dim3(256), 0, s, q, k, v, q_mask, kv_mask, out, nb, L, S, ldq, ldk, ldv, ldo)
     if (D == 16) {
         if (bf && obf) LA_SHORT(16, true, true);

@@ -87,11 +87,11 @@ __device__ __forceinline__ void mma_n64(const char* tile, const int (&tab)[8], i
                 f32x16_t z;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                acc[nf][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[2 * k + nf], v0, z, 0, 0, 0);
-                acc[nf][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[2 * k + nf], v1, z, 0, 0, 0);
+                acc[nf][0] = mfma_h16_32x32x16(w.f[2 * k + nf], v0, z);
+                acc[nf][1] = mfma_h16_32x32x16(w.f[2 * k + nf], v1, z);
             } else {
-                acc[nf][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[2 * k + nf], v0, acc[nf][0], 0, 0, 0);
-                acc[nf][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[2 * k + nf], v1, acc[nf][1], 0, 0, 0);
+                acc[nf][0] = mfma_h16_32x32x16(w.f[2 * k + nf], v0, acc[nf][0]);
+                acc[nf][1] = mfma_h16_32x32x16(w.f[2 * k + nf], v1, acc[nf][1]);
             }
         }
     }
@@ -110,11 +110,11 @@ __device__ __forceinline__ void mma_n32(const char* tile, const int (&tab)[8], c
             f32x16_t z;
 #pragma unroll
             for (int r = 0; r < 16; ++r) z[r] = 0.f;
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[k], v0, z, 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[k], v1, z, 0, 0, 0);
+            acc[0] = mfma_h16_32x32x16(w.f[k], v0, z);
+            acc[1] = mfma_h16_32x32x16(w.f[k], v1, z);
         } else {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[k], v0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[k], v1, acc[1], 0, 0, 0);
+            acc[0] = mfma_h16_32x32x16(w.f[k], v0, acc[0]);
+            acc[1] = mfma_h16_32x32x16(w.f[k], v1, acc[1]);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
                     t[p] = KV[(16 * ks + 8 * L.lh + p) * 32 + L.l31];          // A operand: m = v (l31), k = d
                     ksum[ks][p] = KV[32 * 32 + 16 * ks + 8 * L.lh + p];
                 }
-                kf[ks] = __builtin_bit_cast(bf16x8_t, make_uint4(cvt_pk_bf16(t[0], t[1]), cvt_pk_bf16(t[2], t[3]), cvt_pk_bf16(t[4], t[5]), cvt_pk_bf16(t[6], t[7])));
+                kf[ks] = __builtin_bit_cast(bf16x8_t, make_uint4(cvt_pk_h16(t[0], t[1]), cvt_pk_h16(t[2], t[3]), cvt_pk_h16(t[4], t[5]), cvt_pk_h16(t[6], t[7])));
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -227,10 +227,10 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
                     const unsigned qq[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
-                        z = fmaf(__uint_as_float(qq[p] << 16), ksum[ks][2 * p], z);
-                        z = fmaf(__uint_as_float(qq[p] & 0xffff0000u), ksum[ks][2 * p + 1], z);
+                        z = fmaf(h16_lo(qq[p]), ksum[ks][2 * p], z);
+                        z = fmaf(h16_hi(qq[p]), ksum[ks][2 * p + 1], z);
                     }
-                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], __builtin_bit_cast(bf16x8_t, q), o, 0, 0, 0);
+                    o = mfma_h16_32x32x16(kf[ks], __builtin_bit_cast(bf16x8_t, q), o);
                 }
                 z += __shfl_xor(z, 32, 64);
                 const int m = r0 + 32 * j + L.l31;
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg)
                     *(uint2*)(A + (32 * j + L.l31) * ROWB + (((4 * h + rg) ^ L.sw) << 4) + L.lh * 8) =
-                        make_uint2(cvt_pk_bf16(o[rg * 4] * sc, o[rg * 4 + 1] * sc), cvt_pk_bf16(o[rg * 4 + 2] * sc, o[rg * 4 + 3] * sc));
+                        make_uint2(cvt_pk_h16(o[rg * 4] * sc, o[rg * 4 + 1] * sc), cvt_pk_h16(o[rg * 4 + 2] * sc, o[rg * 4 + 3] * sc));
             }
         }
         __syncthreads();
@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg)
                 *(uint2*)(A + (32 * j + L.l31) * ROWB + (((8 * L.w + 4 * nf + rg) ^ L.sw) << 4) + L.lh * 8) =
-                    make_uint2(cvt_pk_bf16(acc[nf][j][rg * 4], acc[nf][j][rg * 4 + 1]), cvt_pk_bf16(acc[nf][j][rg * 4 + 2], acc[nf][j][rg * 4 + 3]));
+                    make_uint2(cvt_pk_h16(acc[nf][j][rg * 4], acc[nf][j][rg * 4 + 1]), cvt_pk_h16(acc[nf][j][rg * 4 + 2], acc[nf][j][rg * 4 + 3]));
     __syncthreads();
     // ---- mlp: four hidden quarters (transformer.py:55-56) --------------------------------------------------------------
     f32x16_t out[2][2];
@@ -291,8 +291,8 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg)
                 *(uint2*)(H + (32 * j + L.l31) * HROWB + (((4 * L.w + rg) ^ L.sw) << 4) + L.lh * 8) =
-                    make_uint2(cvt_pk_bf16(fmaxf(hid[j][rg * 4], 0.f), fmaxf(hid[j][rg * 4 + 1], 0.f)),
-                               cvt_pk_bf16(fmaxf(hid[j][rg * 4 + 2], 0.f), fmaxf(hid[j][rg * 4 + 3], 0.f)));
+                    make_uint2(cvt_pk_h16(fmaxf(hid[j][rg * 4], 0.f), fmaxf(hid[j][rg * 4 + 1], 0.f)),
+                               cvt_pk_h16(fmaxf(hid[j][rg * 4 + 2], 0.f), fmaxf(hid[j][rg * 4 + 3], 0.f)));
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 2; ++q) {      // out += H x W2[:, quarter]: K = 128, 2 units of 4 k16 steps
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
                 float4 x = *(const float4*)xp;
                 x.x += v.x; x.y += v.y; x.z += v.z; x.w += v.w;   // x + message
                 *(float4*)xp = x;
-                *(uint2*)(a.xb + (size_t)m * a.ldxb + 64 * L.w + 4 * slot) = make_uint2(cvt_pk_bf16(x.x, x.y), cvt_pk_bf16(x.z, x.w));
+                *(uint2*)(a.xb + (size_t)m * a.ldxb + 64 * L.w + 4 * slot) = make_uint2(cvt_pk_h16(x.x, x.y), cvt_pk_h16(x.z, x.w));
             }
         }
     }
@@ -335,9 +335,9 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
 
 }  // namespace
 
-extern "C" int64_t gim_token_mlp_weight_bytes(void) { return (int64_t)4 * UNITS_PER_WAVE * UNIT_U4 * 16; }
+extern "C" int64_t GIM_FN(gim_token_mlp_weight_bytes)(void) { return (int64_t)4 * UNITS_PER_WAVE * UNIT_U4 * 16; }
 
-extern "C" int gim_token_mlp(const void* msg, void* xb, float* x32, const void* weights, const float* ln_params, const float* kv,
+extern "C" int GIM_FN(gim_token_mlp)(const void* msg, void* xb, float* x32, const void* weights, const float* ln_params, const float* kv,
                              const uint8_t* q_mask, int R, int C_, int L, int S, int ldm, int ldxb, int ldx32, float ln_eps,
                              gim_stream_t stream) {
     if (R == 0) return GIM_OK;

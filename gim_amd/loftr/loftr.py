@@ -16,7 +16,15 @@ fallback: without the HIP library the import fails, without a GPU tensor the cal
 Precision modes (`config['precision']`, default env GIM_PRECISION or 'bf16'):
   'fp32'  fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32 products/accumulate) -- the parity mode;
   'bf16'  bf16 operands / fp32 accumulate for the backbone and the transformer GEMMs -- the throughput
-          mode.  The token residual stream stays fp32 and coarse matching reads those fp32 tokens.
+          mode BASELINE config 2 names.  The token residual stream stays fp32.  The FIRST convolution reads the image
+          as fp16 (`config['stem_fp16']`, env GIM_STEM_FP16, default on): rounding the image and the 7x7 filters to 8
+          significand bits in front of an edge-detecting (cancelling) convolution is HALF of this mode's deviation from
+          the fp32 reference (tools/precision_emulation.py: index flip rate 1.95 % -> 0.98 % with the stem alone on fp16
+          operands; same MFMA rate, same bytes);
+  'fp16'  IEEE fp16 operands / fp32 accumulate everywhere the bf16 mode uses bf16: same kernels in their second flavour
+          (csrc/gim_common.h), same speed, 11 instead of 8 significand bits per stored activation -- flip rate 0.47 % in the
+          emulation.  Range: |activation| < 65504 (BatchNorm-folded ResNet activations and LayerNorm'd tokens are O(1..100));
+          a checkpoint that overflows shows inf / nan in the outputs -- use 'bf16' for it.
 
 Coarse similarity (`config['coarse_sim']`, env GIM_COARSE_SIM; default = the precision mode):
   'fp32'  similarity of the fp32 tokens with fp32-exact products: on the same features the mutual-NN indices equal the
@@ -35,8 +43,10 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .._lib import ACT_ELU1, ACT_LEAKY, ACT_NONE, ACT_RELU, GIM_BF16, GIM_F32, GimHipError
-from ..packing import cstore, pack_bneck, pack_conv, pack_fine_fused, pack_token_mlp, torch_dtype
+from .._lib import ACT_ELU1, ACT_LEAKY, ACT_NONE, ACT_RELU, GIM_BF16, GIM_F16, GIM_F32, GimHipError
+from ..packing import cstore, is_half, pack_bneck, pack_conv, pack_fine_fused, pack_token_mlp, torch_dtype
+
+_DT = {"bf16": GIM_BF16, "fp16": GIM_F16, "fp32": GIM_F32}
 
 
 # --------------------------------------------------------------------------------------------------
@@ -156,8 +166,8 @@ class LazyConfMatrix:
 
 def _precision_from(config):
     p = (config.get("precision") or os.environ.get("GIM_PRECISION") or "bf16").lower()
-    if p not in ("bf16", "fp32"):
-        raise ValueError(f"precision must be 'bf16' or 'fp32', got {p!r}")
+    if p not in _DT:
+        raise ValueError(f"precision must be 'bf16', 'fp16' or 'fp32', got {p!r}")
     return p
 
 
@@ -173,9 +183,9 @@ class LoFTR(nn.Module):
         if config["fine_concat_coarse_feat"]:
             raise NotImplementedError("fine_concat_coarse_feat=True is not used by gim_loftr and is not built")
         self.precision = _precision_from(config)
-        self.coarse_sim = (config.get("coarse_sim") or os.environ.get("GIM_COARSE_SIM") or self.precision).lower()
-        if self.coarse_sim not in ("fp32", "bf16"):
-            raise ValueError(f"coarse_sim must be 'fp32' or 'bf16', got {self.coarse_sim!r}")
+        self.coarse_sim = self._check_sim((config.get("coarse_sim") or os.environ.get("GIM_COARSE_SIM") or self.precision).lower())
+        sf = config.get("stem_fp16")
+        self.stem_fp16 = (os.environ.get("GIM_STEM_FP16", "1") != "0") if sf is None else bool(sf)
         self.backbone = _ResNetFPN_8_2(config["resnetfpn"])
         self.loftr_coarse = _LocalFeatureTransformer(config["coarse"])
         self.loftr_fine = _LocalFeatureTransformer(config["fine"])
@@ -227,10 +237,23 @@ class LoFTR(nn.Module):
         self._invalidate()
         return super()._apply(fn, *a, **k)
 
+    def _check_sim(self, sim):
+        """'fp32' (fp32 tokens on the fp32 MFMA) or the mode's own 16-bit type (operand copy of the tokens on the 16-bit MFMA)"""
+        if sim not in ("fp32", self.precision):
+            raise ValueError(f"coarse_sim must be 'fp32' or the precision mode's own type {self.precision!r}, got {sim!r}")
+        return sim
+
+    def _dt(self):
+        return _DT[self.precision]
+
+    def _img_dt(self):
+        """dtype of the NHWC image tensor = operand type of the first convolution (see the module docstring)"""
+        return GIM_F16 if (self.precision == "bf16" and self.stem_fp16) else self._dt()
+
     def set_precision(self, precision, coarse_sim=None):
-        assert precision in ("bf16", "fp32")
+        assert precision in _DT
         self.precision = precision
-        self.coarse_sim = coarse_sim or precision
+        self.coarse_sim = self._check_sim(coarse_sim or precision)
         self._invalidate()
         return self
 
@@ -240,13 +263,15 @@ class LoFTR(nn.Module):
         return (m.weight, m.bias, m.running_mean, m.running_var, m.eps)
 
     def _prepack(self, device):
-        key = (str(device), self.precision)
+        key = (str(device), self.precision, self._img_dt())
         if self._packed is not None and self._packed_key == key:
             return self._packed
-        dt = GIM_BF16 if self.precision == "bf16" else GIM_F32
+        dt = self._dt()
+        tdt = torch_dtype(dt)
         P = {}
         enc = self.backbone.encode
-        P["stem"] = pack_conv(enc.conv1.weight, self._bn(enc.bn1), dt, device, stride=2, pad=3, cin_pad=cstore(3, dt))
+        idt = self._img_dt()
+        P["stem"] = pack_conv(enc.conv1.weight, self._bn(enc.bn1), idt, device, stride=2, pad=3, cin_pad=cstore(3, idt))
         for li in (1, 2, 3):
             for bi, blk in enumerate(getattr(enc, f"layer{li}")):
                 p = f"l{li}.{bi}."
@@ -256,10 +281,10 @@ class LoFTR(nn.Module):
                 if blk.downsample is not None:
                     P[p + "ds"] = pack_conv(blk.downsample[0].weight, self._bn(blk.downsample[1]), dt, device,
                                             stride=blk.stride)
-        if dt == GIM_BF16:
+        if is_half(dt):
             l1 = list(enc.layer1)
             for bi, blk in enumerate(l1):   # the last block's trailing conv1 is layer2's first one (256 -> 128, same resolution)
-                P[f"l1.{bi}.fused"] = pack_bneck(blk, l1[bi + 1] if bi + 1 < len(l1) else enc.layer2[0], device)
+                P[f"l1.{bi}.fused"] = pack_bneck(blk, l1[bi + 1] if bi + 1 < len(l1) else enc.layer2[0], device, tdt)
         bb = self.backbone
         P["l3o"] = pack_conv(bb.layer3_outconv.weight, None, dt, device)
         P["l2o"] = pack_conv(bb.layer2_outconv.weight, None, dt, device)
@@ -283,12 +308,12 @@ class LoFTR(nn.Module):
                     ln = getattr(layer, nm)
                     P[p + nm] = (ln.weight.detach().float().to(device).contiguous(),
                                  ln.bias.detach().float().to(device).contiguous(), ln.eps)
-        if dt == GIM_BF16 and self.loftr_coarse.d_model == 256:
+        if is_half(dt) and self.loftr_coarse.d_model == 256:
             for li, layer in enumerate(self.loftr_coarse.layers):
-                P[f"c{li}.tok"] = pack_token_mlp(layer, device)
+                P[f"c{li}.tok"] = pack_token_mlp(layer, device, tdt)
         fl = self.loftr_fine
-        if dt == GIM_BF16 and fl.d_model == 128 and fl.nhead == 8 and fl.layer_names == ["self", "cross"] and self.W == 5:
-            P["fine_fused"] = pack_fine_fused(fl.layers, device) + (fl.layers[0].norm1.eps,)
+        if is_half(dt) and fl.d_model == 128 and fl.nhead == 8 and fl.layer_names == ["self", "cross"] and self.W == 5:
+            P["fine_fused"] = pack_fine_fused(fl.layers, device, tdt) + (fl.layers[0].norm1.eps,)
         self._packed, self._packed_key = P, key
         return P
 
@@ -330,7 +355,7 @@ class LoFTR(nn.Module):
         """x: NHWC [B,H,W,cstore(3)] images in the compute dtype.  Returns (x3_out NHWC [B,h8,w8,256], feat_f NHWC [B,h2,w2,128])
         in the compute dtype.  (resnet.py:230-235, 306-329)"""
         dma = self.use_lds_dma
-        x = ops.conv2d(x, P["stem"], ACT_RELU, lds_dma=dma)
+        x = ops.conv2d(x, P["stem"], ACT_RELU, out_dtype=torch_dtype(dt), lds_dma=dma)   # image dtype may be fp16 in bf16 mode
         feats = []
         o = None   # conv1 output of the upcoming block when the previous fused kernel already produced it
         for li, nblk in ((1, 3), (2, 4), (3, 6)):
@@ -432,7 +457,7 @@ class LoFTR(nn.Module):
         xs: [x_all] (both images of all pairs in one [2 bs, H, W, c] tensor: equal image shapes) or [x0, x1] (loftr.py:59-63).
         Returns a dict of device tensors (graph-owned when captured)."""
         dev = xs[0].device
-        dt = GIM_BF16 if self.precision == "bf16" else GIM_F32
+        dt = self._dt()
         tdt = torch_dtype(dt)
         P = self._prepack(dev)
         cfg = self.config
@@ -459,7 +484,7 @@ class LoFTR(nn.Module):
         # 3. coarse matching (coarse_matching.py:88-259), fused
         mc = cfg["match_coarse"]
         scale = xs[0].shape[1] / hw0_c[0]
-        if dt == GIM_BF16 and self.coarse_sim == "bf16":
+        if is_half(dt) and self.coarse_sim == self.precision:
             # opt-in: the operand-dtype copy of the final tokens (written by the last LayerNorm for the next GEMM)
             # feeds the similarity -- bf16 MFMA with fp32 accumulation, not index-exact against the fp32 tokens
             fc0 = T.CAT[r0].view(bs, L, 2 * C)[:, :, :C]
@@ -474,14 +499,14 @@ class LoFTR(nn.Module):
 
     def _graph_key(self, color0, color1, scale0, mask0):
         return (tuple(color0.shape), tuple(color1.shape), scale0 is not None, mask0 is not None, self.precision,
-                self.coarse_sim, str(color0.device))
+                self.coarse_sim, self._img_dt(), str(color0.device))
 
     def _coarse_stage_graphed(self, key, color0, color1, scale0, scale1, mask0=None, mask1=None):
         """HIP-graph replay of `_coarse_stage` (one graph per input shape / precision).  ~140 kernel launches collapse into one
         graph launch.  The graph's static input is the NHWC image tensor: the two layout kernels that fill it from the caller's
         NCHW images run eagerly in front of the replay, so the images are never copied as such."""
         ent = self._graphs.get(key)
-        dt = GIM_BF16 if self.precision == "bf16" else GIM_F32
+        dt = self._dt()
         same = color0.shape[2:] == color1.shape[2:]
         groups = [[color0, color1]] if same else [[color0], [color1]]
         if ent is None:
@@ -492,7 +517,7 @@ class LoFTR(nn.Module):
             half = lambda n: (n - 1) // 2 + 1   # noqa: E731  the three stride-2 convs (k7 p3, k3 p1, k3 p1)
             for c in (color0, color1):
                 self._pos_encoding(C, half(half(half(c.shape[2]))), half(half(half(c.shape[3]))), c.device)
-            sin = [[self._to_nhwc(g, dt) for g in groups],
+            sin = [[self._to_nhwc(g, self._img_dt()) for g in groups],
                    scale0.clone().float() if scale0 is not None else None,
                    scale1.clone().float() if scale1 is not None else None,
                    mask0.clone() if mask0 is not None else None, mask1.clone() if mask1 is not None else None]
@@ -507,7 +532,7 @@ class LoFTR(nn.Module):
         else:
             self._graphs.move_to_end(key)
             for g, x in zip(groups, ent[1][0]):
-                self._to_nhwc(g, dt, out=x)
+                self._to_nhwc(g, self._img_dt(), out=x)
         graph, sin, out = ent
         small = []
         if scale0 is not None:
@@ -528,7 +553,7 @@ class LoFTR(nn.Module):
             raise GimHipError("gim_amd LoFTR runs on the HIP device only (no CPU fallback): move the inputs "
                               "and the module to 'cuda'")
         dev = color0.device
-        dt = GIM_BF16 if self.precision == "bf16" else GIM_F32
+        dt = self._dt()
         tdt = torch_dtype(dt)
         cfg = self.config
         color0 = color0.contiguous().float()
@@ -568,7 +593,8 @@ class LoFTR(nn.Module):
                     self._graphs.clear()
         if not graphed:
             same = color0.shape[2:] == color1.shape[2:]
-            xs = [self._to_nhwc([color0, color1], dt)] if same else [self._to_nhwc([color0], dt), self._to_nhwc([color1], dt)]
+            idt = self._img_dt()
+            xs = [self._to_nhwc([color0, color1], idt)] if same else [self._to_nhwc([color0], idt), self._to_nhwc([color1], idt)]
             st = self._coarse_stage(xs, bs, scale0, scale1, mask0, mask1)
             if self.use_graph and self.debug is None:   # counted only once the eager call went through (bad inputs raise above)
                 self._seen[key] = self._seen.get(key, 0) + 1
@@ -624,13 +650,13 @@ class LoFTR(nn.Module):
         Returns (expec_f, mkpts1_f, fine0, fine1); fine0/fine1 = fp32 [M, WW, C] transformer outputs (None unless
         self.debug is set on the fused path)."""
         dev = f0.device
-        dt = GIM_BF16 if self.precision == "bf16" else GIM_F32
+        dt = self._dt()
         M, W, WW, Cf = b_ids.numel(), self.W, self.W * self.W, self.config["fine"]["d_model"]
         P = self._prepack(dev)
         hw0_f, hw1_f = f0.shape[1:3], f1.shape[1:3]
         stride = hw0_f[0] // hw0_c[0]
         fscale = hw0_i[0] / hw0_f[0]
-        if fused and "fine_fused" in P and f0.dtype == torch.bfloat16:
+        if fused and "fine_fused" in P and f0.dtype in ops.HALF:
             wts, lnp, eps = P["fine_fused"]
             return ops.fine_fused(f0, f1, b_ids, i_ids, j_ids, mkpts1_c, scale1 if has_s0 else None, wts, lnp, M,
                                   hw0_c[1], hw1_c[1], stride, W, fscale, eps, has_s0, debug=self.debug is not None)

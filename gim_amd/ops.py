@@ -7,10 +7,11 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ACT_ELU1, ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, GIM_BF16, GIM_F32, check, lib  # noqa: F401
+from ._lib import ACT_ELU1, ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, GIM_BF16, GIM_F16, GIM_F32, check, lib  # noqa: F401
 from .packing import elem_size, torch_dtype
 
-_DT = {torch.float32: GIM_F32, torch.bfloat16: GIM_BF16}
+_DT = {torch.float32: GIM_F32, torch.bfloat16: GIM_BF16, torch.float16: GIM_F16}
+HALF = (torch.bfloat16, torch.float16)   # the two 16-bit operand kinds: same kernels in two flavours (csrc/gim_common.h)
 
 
 # When set to a list, every gim_conv2d_bn_act launch is bracketed by HIP events recorded on the launch
@@ -142,7 +143,7 @@ def conv_rows(x, pk, geom, y, act=ACT_NONE, res=None, res_mod=0, lds_dma=True, a
     assert y.shape[0] >= B * Ho * Wo and y.shape[1] >= pk.n_store
     if ups is not None:
         a.ups, a.ups_h, a.ups_w, a.ups_ld = ups.data_ptr(), ups.shape[1], ups.shape[2], ups.shape[3]
-        if not (UPS_FUSED and ups.dtype == torch.bfloat16 and lib.gim_conv_ups_supported(ctypes.byref(a))):
+        if not (UPS_FUSED and ups.dtype in HALF and ups.dtype == y.dtype and lib.gim_conv_ups_supported(ctypes.byref(a))):
             a.ups = None
     fused_ups = ups is not None and a.ups is not None
     if PROFILE is None:
@@ -172,7 +173,7 @@ def conv2d(x, pk, act=ACT_NONE, res=None, out_dtype=None, lds_dma=True, ups=None
     geom = (B, H, W, Ho, Wo)
     if pk.kh == 1 and pk.kw == 1 and pk.stride == 1 and pk.pad == 0:
         geom = (1, 1, B * H * W, 1, B * H * W)  # pixel index == row index: the kernel skips the coordinate decode
-    if HALO and pk.halo is not None and res is None and lds_dma and x.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 \
+    if HALO and pk.halo is not None and res is None and lds_dma and x.dtype in HALF and y.dtype == x.dtype \
             and x.is_contiguous() and _halo_pays(pk, B, H, W):
         conv3x3_halo(x, pk, y, act)
         return y
@@ -219,7 +220,7 @@ def conv3x3_halo(x, pk, y, act=ACT_NONE):
     a.ldx, a.ldy, a.ldres = cs, y.shape[-1], 0
     a.N, a.npad, a.kpad = pk.n_store, w.shape[0], nslab * 64
     a.act, a.res_mod, a.act_cols = act, pk.cin_pad, 0
-    a.dtype = a.out_dtype = _lib.GIM_BF16
+    a.dtype = a.out_dtype = gim_dtype(x)
     a.res_dtype = GIM_F32
     a.use_lds_dma = 2
     if PROFILE is None:
@@ -304,7 +305,7 @@ def coarse_match(feat0, feat1, hw0_c, hw1_c, scale, temperature=0.1, thr=0.2, bo
     fp32 accumulation).  Returns CoarseResult with cap-sized device buffers; count[0] (device int32) is the number of
     valid leading entries."""
     _req_cuda(feat0, feat1, scale0, scale1)
-    assert feat0.dtype == feat1.dtype and feat0.dtype in (torch.float32, torch.bfloat16)
+    assert feat0.dtype == feat1.dtype and feat0.dtype in (torch.float32, torch.bfloat16, torch.float16)
     ldf = feat0.stride(1)
     for f in (feat0, feat1):
         assert f.dim() == 3 and f.stride(2) == 1 and f.stride(1) == ldf and f.stride(0) == f.shape[1] * ldf, (f.shape, f.stride())
@@ -385,15 +386,17 @@ def bneck64(t1, res, pk, want_next):
     """Fused Bottleneck tail (+ the next conv1): t1 [B,H,W,64] bf16, res [B,H,W,256] bf16 -> (x' [B,H,W,256], t1' [B,H,W,N1] or None).
     pk = packing.pack_bneck(...); N1 = 64 (next block of the layer) or 128 (the next layer's first conv1) from the packed weights."""
     _req_cuda(t1, res)
-    assert t1.dtype == torch.bfloat16 and res.dtype == torch.bfloat16 and t1.is_contiguous() and res.is_contiguous()
+    assert t1.dtype in HALF and res.dtype == t1.dtype and t1.is_contiguous() and res.is_contiguous()
+    assert pk[0].dtype == t1.dtype, "bneck64: weights packed for the other 16-bit kind"
+    fn = lib.gim_bneck64_fused_f16 if t1.dtype == torch.float16 else lib.gim_bneck64_fused
     B, H, W, _ = t1.shape
     w2, w3, w1n, b2, b3, b1n = pk
     n1 = w1n.shape[0] if (want_next and w1n is not None) else 0
     assert not want_next or n1 in (64, 128)
-    xo = torch.empty(B, H, W, 256, dtype=torch.bfloat16, device=t1.device)
-    t1n = torch.empty(B, H, W, n1, dtype=torch.bfloat16, device=t1.device) if n1 else None
+    xo = torch.empty(B, H, W, 256, dtype=t1.dtype, device=t1.device)
+    t1n = torch.empty(B, H, W, n1, dtype=t1.dtype, device=t1.device) if n1 else None
     with _Timed("bneck64_fused", 2.0 * B * H * W * (576 * 64 + 64 * 256 + 256 * n1)):
-        check(lib.gim_bneck64_fused(_p(t1), _p(res), _p(xo), _p(t1n), _p(w2), _p(w3), _p(w1n if n1 else None), _p(b2), _p(b3),
+        check(fn(_p(t1), _p(res), _p(xo), _p(t1n), _p(w2), _p(w3), _p(w1n if n1 else None), _p(b2), _p(b3),
                                     _p(b1n if n1 else None), B, H, W, n1, _stream()), "gim_bneck64_fused")
     return xo, t1n
 
@@ -403,10 +406,11 @@ def token_mlp(msg, xb, x32, weights, ln_params, eps, kv=None, L=0, S=0, q_mask=N
     of x, updated in place), x32 [R, >=256] fp32 (updated in place).  With `kv` (the fp32 state of linear_attention_state) the
     attention's apply step is fused in front: `msg` then holds the elu+1 query rows of R / L sequences, S = source length."""
     _req_cuda(msg, xb, x32, weights, ln_params, kv, q_mask)
-    assert msg.dtype == torch.bfloat16 and xb.dtype == torch.bfloat16 and x32.dtype == torch.float32
+    assert msg.dtype in HALF and xb.dtype == msg.dtype and weights.dtype == msg.dtype and x32.dtype == torch.float32
+    fn = lib.gim_token_mlp_f16 if msg.dtype == torch.float16 else lib.gim_token_mlp
     assert msg.stride(1) == 1 and xb.stride(1) == 1 and x32.stride(1) == 1 and msg.shape[0] == xb.shape[0] == x32.shape[0]
     with _Timed("token_mlp", 2.0 * msg.shape[0] * (256 * 256 + 512 * 512 + 512 * 256 + (32 * 256 if kv is not None else 0))):
-        check(lib.gim_token_mlp(_p(msg), _p(xb), _p(x32), _p(weights), _p(ln_params), _p(kv), _p(q_mask), msg.shape[0], 256, L, S,
+        check(fn(_p(msg), _p(xb), _p(x32), _p(weights), _p(ln_params), _p(kv), _p(q_mask), msg.shape[0], 256, L, S,
                                 msg.stride(0), xb.stride(0), x32.stride(0), eps, _stream()), "gim_token_mlp")
 
 
@@ -431,7 +435,9 @@ def fine_fused(feat_f0, feat_f1, b_ids, i_ids, j_ids, mkpts1_c, scale1, weights,
     """Whole fine level in one launch (bf16 fine maps).  Returns (expec_f [M,3], mkpts1_f [M,2], fine0, fine1) where
     fine0/fine1 are fp32 [M, W*W, C] dumps of the transformer output when `debug`, else None."""
     _req_cuda(feat_f0, feat_f1, b_ids, mkpts1_c, weights, ln_params)
-    assert feat_f0.dtype == torch.bfloat16 and feat_f0.is_contiguous() and feat_f1.is_contiguous()
+    assert feat_f0.dtype in HALF and feat_f1.dtype == feat_f0.dtype and weights.dtype == feat_f0.dtype
+    assert feat_f0.is_contiguous() and feat_f1.is_contiguous()
+    fn = lib.gim_fine_fused_f16 if feat_f0.dtype == torch.float16 else lib.gim_fine_fused
     _, hf0, wf0, C = feat_f0.shape
     _, hf1, wf1, _ = feat_f1.shape
     dev = feat_f0.device
@@ -441,7 +447,7 @@ def fine_fused(feat_f0, feat_f1, b_ids, i_ids, j_ids, mkpts1_c, scale1, weights,
     d1 = torch.empty(M, W * W, C, dtype=torch.float32, device=dev) if debug else None
     assert weights.numel() * weights.element_size() == lib.gim_fine_fused_weight_bytes()
     with _Timed("fine_fused", 33.6e6 * M):   # 33.6 MFLOP per match
-        check(lib.gim_fine_fused(_p(feat_f0), _p(feat_f1), _p(b_ids), _p(i_ids), _p(j_ids), _p(mkpts1_c), _p(scale1),
+        check(fn(_p(feat_f0), _p(feat_f1), _p(b_ids), _p(i_ids), _p(j_ids), _p(mkpts1_c), _p(scale1),
                                  _p(weights), _p(ln_params), _p(expec), _p(mk1), _p(d0), _p(d1), M, hf0, wf0, hf1, wf1, C, C,
                                  w0c, w1c, stride, W, scale, ln_eps, 1 if has_scale0 else 0, _stream()), "gim_fine_fused")
     return expec, mk1, d0, d1

@@ -18,11 +18,16 @@ NPAD = _lib.lib.gim_npad_granule()
 
 
 def torch_dtype(dt):
-    return torch.bfloat16 if dt == _lib.GIM_BF16 else torch.float32
+    return {_lib.GIM_BF16: torch.bfloat16, _lib.GIM_F16: torch.float16, _lib.GIM_F32: torch.float32}[dt]
+
+
+def is_half(dt):
+    """one of the two 16-bit operand kinds (bf16 / IEEE fp16: same kernels, same layouts)"""
+    return dt in (_lib.GIM_BF16, _lib.GIM_F16)
 
 
 def elem_size(dt):
-    return 2 if dt == _lib.GIM_BF16 else 4
+    return 2 if is_half(dt) else 4
 
 
 def group_elems(dt):
@@ -107,8 +112,8 @@ def pack_conv(weight, bn, dtype, device, stride=1, pad=0, cin_pad=None, bias=Non
     p.n_store = cstore(cout, dtype)
     p.npad, p.kpad, p.dtype = npad, kpad, dtype
     p.halo = None
-    if dtype == _lib.GIM_BF16 and kh == 3 and kw == 3 and stride == 1 and pad == 1:
-        wh, tab, nslab = pack_halo(wp, cin_pad, device)
+    if is_half(dtype) and kh == 3 and kw == 3 and stride == 1 and pad == 1:
+        wh, tab, nslab = pack_halo(wp, cin_pad, device, torch_dtype(dtype))
         bh = p.bias
         if bh is not None and wh.shape[0] > npad:      # the halo kernel's N tile is 128 wide: its bias reads cover wh.shape[0] entries
             bh = torch.zeros(wh.shape[0], dtype=torch.float32, device=device)
@@ -120,7 +125,7 @@ def pack_conv(weight, bn, dtype, device, stride=1, pad=0, cin_pad=None, bias=Non
 HALO_W2 = 34  # halo row length of the 8 x 32-pixel patch (gim_amd/csrc/conv_igemm.hip: conv3x3_halo_kernel)
 
 
-def pack_halo(wp, cin_pad, device):
+def pack_halo(wp, cin_pad, device, tdt=torch.bfloat16):
     """Second packing of a 3x3 / stride-1 / pad-1 bf16 layer for the halo kernel.  wp: fp32 [npad, 3, 3, cin_pad] (BN folded,
     zero padded).  Returns (w [npad128, nslab * 64] bf16, table int32 [nslab * 8], nslab).  K order: for every full 64-channel
     chunk the nine taps (one slab each), then the remaining channels in 16-channel sub-steps, tap-major, four to a slab.
@@ -163,7 +168,7 @@ def pack_halo(wp, cin_pad, device):
     wk = torch.zeros(npad, len(cols) * 64)
     wk[:wp.shape[0]] = torch.cat(cols, 1)
     tab = torch.tensor(table, dtype=torch.int32).reshape(-1)
-    return wk.to(device).to(torch.bfloat16).contiguous(), tab.to(device), len(cols)
+    return wk.to(device).to(tdt).contiguous(), tab.to(device), len(cols)
 
 
 def _frag_order(w):
@@ -173,7 +178,7 @@ def _frag_order(w):
     return w.reshape(4, 32, k // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
 
 
-def pack_fine_fused(layers, device):
+def pack_fine_fused(layers, device, tdt=torch.bfloat16):
     """Weights of the 2-layer fine LocalFeatureTransformer for gim_fine_fused (see include/gim_hip.h): one bf16 stream
     [Wq | Wk | Wv | Wmerge | mlp.0[:128] | mlp.0[128:] | mlp.2[:, :128] | mlp.2[:, 128:]] per layer in fragment order,
     plus the fp32 LayerNorm parameters [g1 | b1 | g2 | b2] per layer.  `layers`: modules with q_proj/k_proj/v_proj/merge/
@@ -188,7 +193,7 @@ def pack_fine_fused(layers, device):
             ws.append(_frag_order(blk.contiguous()))
         lns += [f(layer.norm1.weight), f(layer.norm1.bias), f(layer.norm2.weight), f(layer.norm2.bias)]
         assert abs(layer.norm1.eps - layer.norm2.eps) == 0
-    w = torch.cat(ws).to(device).to(torch.bfloat16).contiguous()
+    w = torch.cat(ws).to(device).to(tdt).contiguous()
     assert w.numel() * 2 == _lib.lib.gim_fine_fused_weight_bytes()
     return w, torch.cat(lns).to(device).contiguous()
 
@@ -198,7 +203,7 @@ def _frag(w, n0, k0):
     return w[n0:n0 + 32, k0:k0 + 16].reshape(32, 2, 8).permute(1, 0, 2).reshape(-1)
 
 
-def pack_token_mlp(layer, device):
+def pack_token_mlp(layer, device, tdt=torch.bfloat16):
     """Weights of one coarse LoFTREncoderLayer's token-wise tail for gim_token_mlp: per wave w (output columns 64w.. of merge / mlp.2,
     hidden columns 32w.. of every 128-column quarter) the fragments in the order the kernel consumes them:
       merge:   4 units x (4 k16 steps x 2 column fragments)
@@ -221,7 +226,7 @@ def pack_token_mlp(layer, device):
                 for k in range(4):
                     for nf in range(2):
                         out.append(_frag(w2, 64 * w + 32 * nf, 128 * hq + 16 * (4 * q + k)))
-    wts = torch.cat(out).to(device).to(torch.bfloat16).contiguous()
+    wts = torch.cat(out).to(device).to(tdt).contiguous()
     assert wts.numel() * 2 == _lib.lib.gim_token_mlp_weight_bytes()
     ln = torch.cat([f(layer.norm1.weight), f(layer.norm1.bias), f(layer.norm2.weight), f(layer.norm2.bias)]).to(device).contiguous()
     assert layer.norm1.eps == layer.norm2.eps
@@ -237,14 +242,14 @@ def _acc_order(k):
     return 32 * (s_ // 2) + 16 * (s_ % 2) + 8 * (p // 4) + 4 * lh + (p % 4)
 
 
-def pack_bneck(blk, nxt, device):
+def pack_bneck(blk, nxt, device, tdt=torch.bfloat16):
     """gim_bneck64_fused operands of Bottleneck `blk` (conv2/bn2, conv3/bn3) and, if given, the next block's conv1/bn1:
     (w2 [64][576] bf16 K=(ky,kx,c), w3 [256][64] bf16 K in accumulator order, w1n [64 or 128][256] bf16 or None, b2, b3, b1n fp32)."""
     bn = lambda m: (m.weight, m.bias, m.running_mean, m.running_var, m.eps)  # noqa: E731
     w2, b2 = fold_bn(blk.conv2.weight, bn(blk.bn2))
     w3, b3 = fold_bn(blk.conv3.weight, bn(blk.bn3))
     assert tuple(w2.shape) == (64, 64, 3, 3) and tuple(w3.shape) == (256, 64, 1, 1) and blk.conv2.stride == (1, 1)
-    to = lambda t: t.to(device).to(torch.bfloat16).contiguous()  # noqa: E731
+    to = lambda t: t.to(device).to(tdt).contiguous()  # noqa: E731
     w2p = to(w2.permute(0, 2, 3, 1).reshape(64, 576).cpu())
     w3p = to(w3.reshape(256, 64).cpu()[:, _acc_order(64)])
     w1p = b1 = None

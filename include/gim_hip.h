@@ -11,7 +11,12 @@
  *   - every call is asynchronous on `stream` (pass torch.cuda.current_stream().cuda_stream);
  *   - the library never allocates user-visible memory: outputs / workspaces are caller-allocated;
  *   - return 0 on success, negative GIM_ERR_* otherwise; message via gim_last_error() (thread local);
- *   - `dtype` arguments: GIM_F32 (exact-parity mode, fp32 MFMA) or GIM_BF16 (throughput mode);
+ *   - `dtype` arguments: GIM_F32 (exact-parity mode, fp32 MFMA), GIM_BF16 (throughput mode, 8 significand bits, fp32 range)
+ *     or -- on the gim_loftr entry points (conv, layout / pos-enc / LayerNorm glue, linear attention, coarse matching, fine
+ *     gather) -- GIM_F16 (throughput mode, IEEE fp16 operands: 11 significand bits at the same MFMA rate, |x| < 65504; a
+ *     quarter of bf16's index flips against the fp32 reference).  A call is of ONE 16-bit kind; the one
+ *     mixed form is gim_conv2d_bn_act with dtype GIM_F16 and out_dtype GIM_BF16 (no residual / upsample operand): the bf16
+ *     mode's first convolution reads the image as fp16;
  *   - activations are NHWC ("pixel rows"): row m = ((b*H + y)*W + x), `ld*` = row stride in ELEMENTS.
  */
 #ifndef GIM_HIP_H
@@ -24,7 +29,7 @@ extern "C" {
 
 typedef void* gim_stream_t; /* hipStream_t */
 
-enum { GIM_F32 = 0, GIM_BF16 = 1 };
+enum { GIM_F32 = 0, GIM_BF16 = 1, GIM_F16 = 2 };
 enum { GIM_ACT_NONE = 0, GIM_ACT_RELU = 1, GIM_ACT_LEAKY = 2, GIM_ACT_ELU1 = 3 /* elu(x)+1 */, GIM_ACT_GELU = 4 /* exact erf GELU */ };
 enum { GIM_OK = 0, GIM_ERR_INVALID = -1, GIM_ERR_LAUNCH = -2, GIM_ERR_UNSUPPORTED = -3 };
 
@@ -173,6 +178,10 @@ int gim_coarse_conf_matrix(const gim_coarse_args* a, float* conf, gim_stream_t s
 int gim_bneck64_fused(const void* t1, const void* res, void* x_out, void* t1_next, const void* w2, const void* w3,
                       const void* w1n, const float* b2, const float* b3, const float* b1n, int B, int H, int W,
                       int n_next, gim_stream_t stream);
+/* the same kernel on IEEE fp16 tensors / weights (GIM_F16 mode) */
+int gim_bneck64_fused_f16(const void* t1, const void* res, void* x_out, void* t1_next, const void* w2, const void* w3,
+                          const void* w1n, const float* b2, const float* b3, const float* b1n, int B, int H, int W,
+                          int n_next, gim_stream_t stream);
 
 /* Token-wise tail of a LoFTREncoderLayer in ONE kernel (bf16 operand mode, d_model 256; transformer.py:52-58):
  *     x += norm2(mlp.2(relu(mlp.0(cat[x, norm1(merge(msg))]))))
@@ -187,6 +196,10 @@ int64_t gim_token_mlp_weight_bytes(void);
 int gim_token_mlp(const void* msg, void* xb, float* x32, const void* weights, const float* ln_params, const float* kv,
                   const uint8_t* q_mask, int R, int C, int L, int S, int ldm, int ldxb, int ldx32, float ln_eps,
                   gim_stream_t stream);
+/* the same kernel with fp16 operand rows / weights (GIM_F16 mode) */
+int gim_token_mlp_f16(const void* msg, void* xb, float* x32, const void* weights, const float* ln_params, const float* kv,
+                      const uint8_t* q_mask, int R, int C, int L, int S, int ldm, int ldxb, int ldx32, float ln_eps,
+                      gim_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * Fine level.  gim_fine_gather = F.unfold(k=W,stride,pad=W/2) + [b_ids,i_ids] pick
@@ -217,6 +230,12 @@ int gim_fine_fused(const void* feat_f0, const void* feat_f1, const int64_t* b_id
                    const float* ln_params, float* expec_f, float* mkpts1_f, float* dbg_fine0, float* dbg_fine1,
                    int M, int hf0, int wf0, int hf1, int wf1, int C, int ldf, int w0c, int w1c, int stride, int W,
                    float scale, float ln_eps, int has_scale0, gim_stream_t stream);
+/* the same kernel on fp16 fine maps / weights (GIM_F16 mode) */
+int gim_fine_fused_f16(const void* feat_f0, const void* feat_f1, const int64_t* b_ids, const int64_t* i_ids,
+                       const int64_t* j_ids, const float* mkpts1_c, const float* scale1, const void* weights,
+                       const float* ln_params, float* expec_f, float* mkpts1_f, float* dbg_fine0, float* dbg_fine1,
+                       int M, int hf0, int wf0, int hf1, int wf1, int C, int ldf, int w0c, int w1c, int stride, int W,
+                       float scale, float ln_eps, int has_scale0, gim_stream_t stream);
 
 
 /* ======================================================================================================

@@ -13,16 +13,20 @@ from tools import synth_loftr as S
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def model_sd():
-    model, sd = S.synthetic_model("bf16")
+@pytest.fixture(scope="module", params=["bf16", "fp16"])   # the two 16-bit flavours of the kernel (csrc/gim_common.h)
+def model_sd(request):
+    model, sd = S.synthetic_model(request.param)
     return model.to("cuda:0"), sd
 
 
-def _case(M, seed, hc=12, wc=16, bs=2):
+def _t(model):
+    return torch.float16 if model.precision == "fp16" else torch.bfloat16
+
+
+def _case(M, seed, hc=12, wc=16, bs=2, tdt=torch.bfloat16):
     g = torch.Generator().manual_seed(seed)
-    f0 = torch.randn(bs, 4 * hc, 4 * wc, 128, generator=g).to(torch.bfloat16)
-    f1 = torch.randn(bs, 4 * hc, 4 * wc, 128, generator=g).to(torch.bfloat16)
+    f0 = torch.randn(bs, 4 * hc, 4 * wc, 128, generator=g).to(tdt)
+    f1 = torch.randn(bs, 4 * hc, 4 * wc, 128, generator=g).to(tdt)
     b = torch.randint(0, bs, (M,), generator=g)
     i = torch.randint(0, hc * wc, (M,), generator=g)
     j = torch.randint(0, hc * wc, (M,), generator=g)
@@ -60,7 +64,7 @@ def _oracle(sd, case, scale1=None):
 @pytest.mark.parametrize("M,seed", [(37, 1), (256, 2), (1, 3), (5, 4)])
 def test_fused_matches_unfused_and_oracle(model_sd, M, seed):
     model, sd = model_sd
-    case = _case(M, seed)
+    case = _case(M, seed, tdt=_t(model))
     e_f, k_f, a0, a1 = _run(model, case, True)
     e_u, k_u, u0, u1 = _run(model, case, False)
     t0, t1, fm = _oracle(sd, case)
@@ -83,7 +87,7 @@ def test_fused_matches_unfused_and_oracle(model_sd, M, seed):
 
 def test_fused_with_scales_and_no_debug(model_sd):
     model, sd = model_sd
-    case = _case(64, 7)
+    case = _case(64, 7, tdt=_t(model))
     scale1 = torch.tensor([[1.5, 0.75], [2.0, 1.25]])
     e_f, k_f, d0, d1 = _run(model, case, True, scale1.cuda(), debug=False)
     assert d0 is None and d1 is None

@@ -12,7 +12,7 @@ import loftr_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-DTS = ["fp32", "bf16"]
+DTS = ["fp32", "bf16", "fp16"]   # fp16: the second 16-bit flavour of every gim_loftr kernel (csrc/gim_common.h)
 
 
 def _dev():
@@ -22,11 +22,11 @@ def _dev():
 
 def _gim(dt):
     from gim_amd import _lib
-    return _lib.GIM_BF16 if dt == "bf16" else _lib.GIM_F32
+    return {"bf16": _lib.GIM_BF16, "fp16": _lib.GIM_F16, "fp32": _lib.GIM_F32}[dt]
 
 
 def _tdt(dt):
-    return torch.bfloat16 if dt == "bf16" else torch.float32
+    return {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[dt]
 
 
 def _rnd(t, dt):
@@ -35,7 +35,12 @@ def _rnd(t, dt):
 
 
 def _tol(dt):
-    return 1.5e-2 if dt == "bf16" else 2e-5
+    return {"bf16": 1.5e-2, "fp16": 2e-3, "fp32": 2e-5}[dt]
+
+
+def _ht(dt, half, full):
+    """tolerance of a memory-bound kernel: `half` for bf16 outputs, an eighth of it for fp16 (3 more bits), `full` for fp32"""
+    return {"bf16": half, "fp16": half / 8, "fp32": full}[dt]
 
 
 def _assert_close(got, ref, tol, what=""):
@@ -157,7 +162,7 @@ def test_layout_roundtrip_and_upsample_posenc(dt):
     ops.upsample2x_add(lod, hid_)
     ref = _rnd(hi, dt) + F.interpolate(_rnd(lo, dt), scale_factor=2.0, mode="bilinear", align_corners=True)
     torch.cuda.synchronize()
-    _assert_close(hid_.float().cpu()[..., :196].permute(0, 3, 1, 2), ref, 1e-2 if dt == "bf16" else 1e-6, "upsample2x_add")
+    _assert_close(hid_.float().cpu()[..., :196].permute(0, 3, 1, 2), ref, _ht(dt, 1e-2, 1e-6), "upsample2x_add")
     # posenc
     pe = O.position_encoding(256, 6, 8)[0]  # [C,h,w]
     feat = torch.randn(2, 256, 6, 8, generator=g)
@@ -168,7 +173,7 @@ def test_layout_roundtrip_and_upsample_posenc(dt):
     torch.cuda.synchronize()
     ref = (_rnd(feat, dt) + pe[None]).flatten(2).transpose(1, 2).reshape(96, 256)
     _assert_close(out32, ref, 1e-6, "posenc f32")
-    _assert_close(outt[:, :256], ref, 1e-2 if dt == "bf16" else 1e-6, "posenc T")
+    _assert_close(outt[:, :256], ref, _ht(dt, 1e-2, 1e-6), "posenc T")
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -188,8 +193,8 @@ def test_layernorm_residual(dt, C):
     torch.cuda.synchronize()
     ref = F.layer_norm(x, (C,), gamma, beta, 1e-5)
     _assert_close(o32, ref + res, 1e-5, "ln+res f32")
-    _assert_close(ot[:, C:], ref + res, 1e-2 if dt == "bf16" else 1e-5, "ln+res T")
-    _assert_close(ot[:, :C], ref, 1e-2 if dt == "bf16" else 1e-5, "ln T")
+    _assert_close(ot[:, C:], ref + res, _ht(dt, 1e-2, 1e-5), "ln+res T")
+    _assert_close(ot[:, :C], ref, _ht(dt, 1e-2, 1e-5), "ln T")
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -221,7 +226,7 @@ def test_linear_attention(dt, shape):
     ops.linear_attention(Qe.reshape(nb * L, C).to(_tdt(dt)).to(dev), Ke.reshape(nb * S, C).to(_tdt(dt)).to(dev),
                          vr.reshape(nb * S, C).to(_tdt(dt)).to(dev), out, nb, L, nb, S, H)
     torch.cuda.synchronize()
-    _assert_close(out.view(nb, L, H, D), ref, 1e-2 if dt == "bf16" else 1e-5, f"linear attention {shape}")
+    _assert_close(out.view(nb, L, H, D), ref, _ht(dt, 1e-2, 1e-5), f"linear attention {shape}")
 
 
 COARSE_CASES = [
@@ -287,19 +292,20 @@ def test_coarse_match_different_shapes_and_empty():
     assert int(r.count[0]) == 0
 
 
-def test_coarse_match_bf16_features_strided():
-    """bf16 features (the throughput mode's token buffers, rows strided inside a wider buffer): the bf16 MFMA computes exact
+@pytest.mark.parametrize("tdt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_coarse_match_bf16_features_strided(tdt):
+    """16-bit features (the throughput mode's token buffers, rows strided inside a wider buffer): the bf16 MFMA computes exact
     products with fp32 accumulation, so against the oracle evaluated on the SAME bf16-valued features the indices are
     exact and the confidences differ by summation order only"""
     from gim_amd import ops
     dev = _dev()
     N, h0, w0 = 2, 15, 20
     f0, f1, _ = O.planted_coarse_features(N, (h0, w0), sigma=1.0, eps=0.5, seed=33)
-    b0, b1 = f0.bfloat16(), f1.bfloat16()
+    b0, b1 = f0.to(tdt), f1.to(tdt)
     conf = O.conf_matrix_dual_softmax(b0.float(), b1.float(), 0.1)
     ref = O.get_coarse_match(conf, (h0 * 8, w0 * 8), (h0 * 8, w0 * 8), (h0, w0), (h0, w0), 0.2, 2)
     C = 256
-    buf = torch.zeros(2 * N * h0 * w0, 2 * C, dtype=torch.bfloat16, device=dev)           # [x | other columns], like T.CAT
+    buf = torch.zeros(2 * N * h0 * w0, 2 * C, dtype=tdt, device=dev)           # [x | other columns], like T.CAT
     buf[:N * h0 * w0, :C] = b0.reshape(-1, C).to(dev)
     buf[N * h0 * w0:, :C] = b1.reshape(-1, C).to(dev)
     buf[:, C:] = 7.0                                                                          # must never be read

@@ -23,8 +23,12 @@ def _layer(seed):
     return layer
 
 
-def _reference(layer, msg, x32):
-    bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+KINDS = [torch.bfloat16, torch.float16]   # the two 16-bit flavours of the kernel (csrc/gim_common.h)
+KIDS = ["bf16", "fp16"]
+
+
+def _reference(layer, msg, x32, tdt=torch.bfloat16):
+    bf = lambda t: t.to(tdt).float()  # noqa: E731
     m = bf(msg) @ bf(layer.merge.weight).T
     m = bf(F.layer_norm(m, (256,), layer.norm1.weight, layer.norm1.bias, layer.norm1.eps))
     h = bf(F.relu(torch.cat([bf(x32), m], 1) @ bf(layer.mlp[0].weight).T))
@@ -32,27 +36,29 @@ def _reference(layer, msg, x32):
     return x32 + F.layer_norm(o, (256,), layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
 
 
+@pytest.mark.parametrize("tdt", KINDS, ids=KIDS)
 @pytest.mark.parametrize("R", [64, 200, 4800 * 2 + 7])
-def test_token_mlp_matches_reference(R):
+def test_token_mlp_matches_reference(R, tdt):
     from gim_amd import ops
     from gim_amd.packing import pack_token_mlp
     layer = _layer(R)
     g = torch.Generator().manual_seed(R)
-    msg = (0.5 * torch.randn(R, 256, generator=g)).to(torch.bfloat16)
+    msg = (0.5 * torch.randn(R, 256, generator=g)).to(tdt)
     x32 = torch.randn(R, 256, generator=g) * 2.0
     with torch.no_grad():
-        ref = _reference(layer, msg.float(), x32)
-    wts, ln, eps = pack_token_mlp(layer, "cuda")
-    cat = torch.zeros(R, 512, dtype=torch.bfloat16, device="cuda")      # [x | msg] buffer of the engine: x in the left half
-    cat[:, :256] = x32.cuda().to(torch.bfloat16)
+        ref = _reference(layer, msg.float(), x32, tdt)
+    wts, ln, eps = pack_token_mlp(layer, "cuda", tdt)
+    cat = torch.zeros(R, 512, dtype=tdt, device="cuda")      # [x | msg] buffer of the engine: x in the left half
+    cat[:, :256] = x32.cuda().to(tdt)
     cat[:, 256:] = 7.0                                                   # must stay untouched
     xd = x32.cuda().clone()
     ops.token_mlp(msg.cuda(), cat[:, :256], xd, wts, ln, eps)
     torch.cuda.synchronize()
     got = xd.cpu()
     err = (got - ref).abs()
-    assert err.max() < 3e-2 and err.mean() < 2e-3, (err.max().item(), err.mean().item())
-    assert torch.equal(cat[:, :256].cpu(), got.to(torch.bfloat16))       # operand copy of the new x
+    k = 1.0 if tdt == torch.bfloat16 else 0.25   # fp16: three more significand bits at every rounding point
+    assert err.max() < 3e-2 * k and err.mean() < 2e-3 * k, (err.max().item(), err.mean().item())
+    assert torch.equal(cat[:, :256].cpu(), got.to(tdt))       # operand copy of the new x
     assert bool((cat[:, 256:] == 7.0).all())
 
 

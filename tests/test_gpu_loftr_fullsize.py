@@ -71,11 +71,12 @@ def test_fp32_640x480_exact_vs_oracle(synth, pairs, oracle_two_pairs):
             assert torch.equal(d[k].cpu(), ref[k]), k
 
 
-# (precision, coarse_sim, stem_fp16) -> bound on the index flip rate = 2 x the rate of the engine's roundings on these pairs
-# (CPU emulation, tools/precision_emulation.py / profiles/r03_precision_emulation.txt: bf16 1.95 %, bf16 with the fp16 stem
-# 0.98 %, fp16 0.47 %), bound on mean |d mconf|
-MODES = [("bf16", "fp32", True, 0.022, 0.02), ("bf16", "bf16", True, 0.022, 0.02), ("bf16", "bf16", False, 0.045, 0.04),
-         ("fp16", "fp16", True, 0.011, 0.008), ("fp16", "fp32", True, 0.011, 0.008)]
+# (precision, coarse_sim, stem_fp16, bound on the index flip rate, bound on mean |d mconf|): bounds = 2 x the worse of the two
+# pairs measured on MI355X (profiles/r03_parity_modes.txt): bf16 with the fp16 stem 0.67 % / 1.30 % flips, mean |d mconf| 0.009;
+# bf16 incl. a bf16 stem (round 2's mode) 1.68 % / 2.61 %, 0.018; fp16 0.27 % / 0.15 %, 0.0024.  The CPU emulation of the engine's
+# roundings (tools/precision_emulation.py, profiles/r03_precision_emulation.txt) predicts 0.98 % / 1.95 % / 0.47 %.
+MODES = [("bf16", "fp32", True, 0.026, 0.018), ("bf16", "bf16", True, 0.026, 0.018), ("bf16", "bf16", False, 0.052, 0.036),
+         ("fp16", "fp16", True, 0.0055, 0.005), ("fp16", "fp32", True, 0.0055, 0.005)]
 
 
 @pytest.mark.parametrize("precision,coarse_sim,stem_fp16,max_flip,max_dconf", MODES,

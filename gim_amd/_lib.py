@@ -119,6 +119,8 @@ PROTOTYPES = {
     "gim_cos_kernel_finish": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_float] * 3 + [c_void_p]),
     "gim_gp_solve_ws_bytes": (c_int64, [c_int] * 3),
     "gim_gp_solve": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "gim_gp_posterior_f64_ws_bytes": (c_int64, [c_int] * 4),
+    "gim_gp_posterior_f64": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_float] * 3 + [c_void_p]),
     "gim_global_avgpool": (c_int, [c_void_p] * 2 + [c_int] * 7 + [c_void_p]),
     "gim_cab_scale_add": (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p]),
     "gim_dkm_flow_update": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_float, c_float, c_int, c_int, c_void_p]),

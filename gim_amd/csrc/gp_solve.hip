@@ -378,23 +378,11 @@ void launch_gemm(hipStream_t s, int B, const GemmArgs& g) {
 }
 }  // namespace
 
-extern "C" int gim_gp_solve(const float* K, const float* F, float* Xt, void* ws, int B, int n, int ldk, int nrhs, int npad,
-                            gim_stream_t stream) {
-    GIM_REQUIRE(K && F && Xt && ws && B > 0 && B <= 16 && n > 0 && nrhs > 0 && ldk >= n && npad >= n, "gp_solve: bad args");
-    hipStream_t s = (hipStream_t)stream;
-    double* A = (double*)ws;
-    double* Lf = (double*)((char*)A + al((size_t)B * n * n * 8));     // L^-1, full lower-triangular matrix
-    double* Tb = (double*)((char*)Lf + al((size_t)B * n * n * 8));    // products of the inversion levels
-    double* R = (double*)((char*)Tb + al((size_t)B * n * n * 8));
-    double* R2 = (double*)((char*)R + al((size_t)B * n * nrhs * 8));
-    int* info = (int*)((char*)R2 + al((size_t)B * n * nrhs * 8));
+namespace {
+// Blocked fp64 Cholesky of A [B][n][n] (lower triangle overwritten by L) and X = A^-1 R for the right-hand sides R [B][n][nrhs]
+// (overwritten by X).  Lf: zeroed [B][n][n] (receives L^-1), Tb: [B][n][n] scratch, R2: [B][n][nrhs] scratch, info: zeroed ints.
+void chol_solve(hipStream_t s, double* A, double* Lf, double* Tb, double* R, double* R2, int* info, int B, int n, int nrhs) {
     const size_t as = (size_t)n * n, fs = (size_t)n * nrhs;
-    if (hipMemsetAsync(info, 0, 64, s) != hipSuccess) return gim_check_launch("gp_solve memset");
-    if (hipMemsetAsync(Lf, 0, (size_t)B * as * 8, s) != hipSuccess) return gim_check_launch("gp_solve memset");
-    for (int b = 0; b < B; ++b) {
-        hipLaunchKernelGGL(to_f64_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, s, K + (size_t)b * n * ldk, A + b * as, n, n, ldk, n);
-        hipLaunchKernelGGL(to_f64_kernel, dim3((unsigned)(((size_t)n * nrhs + 255) / 256)), dim3(256), 0, s, F + (size_t)b * fs, R + b * fs, n, nrhs, nrhs, nrhs);
-    }
     // ---- A = L L^T (lower triangle of A overwritten by L); the inverses of the diagonal blocks land on the diagonal of Lf ----
     for (int k0 = 0; k0 < n; k0 += NB) {
         const int nb = n - k0 < NB ? n - k0 : NB;
@@ -441,6 +429,120 @@ extern "C" int gim_gp_solve(const float* K, const float* F, float* Xt, void* ws,
         h.C = R; h.B = R2; h.ta = 1; h.tri = 2;
         launch_gemm(s, B, h);
     }
+}
+}  // namespace
+
+extern "C" int gim_gp_solve(const float* K, const float* F, float* Xt, void* ws, int B, int n, int ldk, int nrhs, int npad,
+                            gim_stream_t stream) {
+    GIM_REQUIRE(K && F && Xt && ws && B > 0 && B <= 16 && n > 0 && nrhs > 0 && ldk >= n && npad >= n, "gp_solve: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    double* A = (double*)ws;
+    double* Lf = (double*)((char*)A + al((size_t)B * n * n * 8));     // L^-1, full lower-triangular matrix
+    double* Tb = (double*)((char*)Lf + al((size_t)B * n * n * 8));    // products of the inversion levels
+    double* R = (double*)((char*)Tb + al((size_t)B * n * n * 8));
+    double* R2 = (double*)((char*)R + al((size_t)B * n * nrhs * 8));
+    int* info = (int*)((char*)R2 + al((size_t)B * n * nrhs * 8));
+    const size_t as = (size_t)n * n, fs = (size_t)n * nrhs;
+    if (hipMemsetAsync(info, 0, 64, s) != hipSuccess) return gim_check_launch("gp_solve memset");
+    if (hipMemsetAsync(Lf, 0, (size_t)B * as * 8, s) != hipSuccess) return gim_check_launch("gp_solve memset");
+    for (int b = 0; b < B; ++b) {
+        hipLaunchKernelGGL(to_f64_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, s, K + (size_t)b * n * ldk, A + b * as, n, n, ldk, n);
+        hipLaunchKernelGGL(to_f64_kernel, dim3((unsigned)(((size_t)n * nrhs + 255) / 256)), dim3(256), 0, s, F + (size_t)b * fs, R + b * fs, n, nrhs, nrhs, nrhs);
+    }
+    chol_solve(s, A, Lf, Tb, R, R2, info, B, n, nrhs);
     hipLaunchKernelGGL(store_xt_kernel, dim3((npad + 63) / 64, (nrhs + 63) / 64, B), dim3(256), 0, s, R, Xt, n, nrhs, npad);
     return gim_check_launch("gp_solve");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The whole posterior in fp64 from the fp32 feature rows (the parity mode of the two dense matchers):
+//     mu = K_xy (K_yy + sigma I)^-1 f,   K[i][j] = exp((x_i . y_j / (|x_i| |y_j| + eps) - 1) / T)      (dkm.py:135-144, 340-370)
+// K_yy + sigma I has a condition number of ~2e4: fp32 rounding of the kernel ENTRIES alone (1e-7 relative) moves mu by ~1e-4 of
+// its scale (tests/test_gpu_gp_pins.py: engine with fp32 entries 6e-5 ... 2e-4, the reference's fp32 LU inverse 4e-5 ... 8e-5 from
+// an all-fp64 evaluation).  Here entries, factorisation and both products are fp64 (fp64 MFMA GEMM above), so this side sits
+// at the exact-arithmetic value of the reference's formula (<= 1e-9 of scale) and the remaining difference to a reference
+// run is the reference's own rounding.
+namespace {
+__global__ void norms_f64_kernel(const double* __restrict__ x, double* __restrict__ out, int rows, int d) {   // one wave per row
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    double acc = 0.0;
+    for (int c = lane; c < d; c += 64) { const double v = x[(size_t)row * d + c]; acc += v * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) out[row] = sqrt(acc);
+}
+// K[i][j] = exp((K[i][j] / (nx[i] ny[j] + eps) - 1) / T) + (i == j ? diag : 0), in place, [B][n][n]
+__global__ void cos_finish_f64_kernel(double* __restrict__ k, const double* __restrict__ nx, const double* __restrict__ ny, int n,
+                                      double T, double eps, double diag) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (idx >= (size_t)n * n) return;
+    const int i = (int)(idx / n), j = (int)(idx - (size_t)i * n);
+    double* p = k + (size_t)b * n * n + idx;
+    const double c = *p / (nx[(size_t)b * n + i] * ny[(size_t)b * n + j] + eps);
+    *p = exp((c - 1.0) / T) + (i == j ? diag : 0.0);
+}
+__global__ void to_f32_rows_kernel(const double* __restrict__ src, float* __restrict__ dst, int rows, int cols, int ldd) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)rows * cols) return;
+    const size_t r = idx / cols, c = idx - r * cols;
+    dst[r * ldd + c] = (float)src[idx];
+}
+}  // namespace
+
+extern "C" int64_t gim_gp_posterior_f64_ws_bytes(int B, int n, int d, int nrhs) {
+    // X, Y rows and norms; K_xy; then the solver's A, L^-1, scratch (n x n each) and two right-hand-side blocks
+    return (int64_t)(2 * al((size_t)B * n * d * 8) + 2 * al((size_t)B * n * 8) + 4 * al((size_t)B * n * n * 8) + 2 * al((size_t)B * n * nrhs * 8) + 256);
+}
+
+extern "C" int gim_gp_posterior_f64(const float* X, const float* Y, const float* F, float* mu, void* ws, int B, int n, int d,
+                                    int ldx, int nrhs, int ld_mu, float T, float eps, float sigma, gim_stream_t stream) {
+    GIM_REQUIRE(X && Y && F && mu && ws && B > 0 && B <= 16 && n > 0 && d > 0 && nrhs > 0 && ldx >= d && ld_mu >= nrhs, "gp_posterior_f64: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    char* w = (char*)ws;
+    auto take = [&](size_t bytes) { char* p = w; w += al(bytes); return p; };
+    double* Xd = (double*)take((size_t)B * n * d * 8);
+    double* Yd = (double*)take((size_t)B * n * d * 8);
+    double* nx = (double*)take((size_t)B * n * 8);
+    double* ny = (double*)take((size_t)B * n * 8);
+    double* Kxy = (double*)take((size_t)B * n * n * 8);
+    double* A = (double*)take((size_t)B * n * n * 8);
+    double* Lf = (double*)take((size_t)B * n * n * 8);
+    double* Tb = (double*)take((size_t)B * n * n * 8);
+    double* R = (double*)take((size_t)B * n * nrhs * 8);
+    double* R2 = (double*)take((size_t)B * n * nrhs * 8);
+    int* info = (int*)w;
+    const size_t as = (size_t)n * n, fs = (size_t)n * nrhs, xs = (size_t)n * d;
+    if (hipMemsetAsync(info, 0, 64, s) != hipSuccess) return gim_check_launch("gp_posterior_f64 memset");
+    if (hipMemsetAsync(Lf, 0, (size_t)B * as * 8, s) != hipSuccess) return gim_check_launch("gp_posterior_f64 memset");
+    const unsigned gx = (unsigned)((xs + 255) / 256), gf = (unsigned)((fs + 255) / 256);
+    for (int b = 0; b < B; ++b) {
+        hipLaunchKernelGGL(to_f64_kernel, dim3(gx), dim3(256), 0, s, X + (size_t)b * n * ldx, Xd + b * xs, n, d, ldx, d);
+        hipLaunchKernelGGL(to_f64_kernel, dim3(gx), dim3(256), 0, s, Y + (size_t)b * n * ldx, Yd + b * xs, n, d, ldx, d);
+        hipLaunchKernelGGL(to_f64_kernel, dim3(gf), dim3(256), 0, s, F, R + b * fs, n, nrhs, nrhs, nrhs);   // the same f for every direction
+    }
+    hipLaunchKernelGGL(norms_f64_kernel, dim3((unsigned)((B * n + 3) / 4)), dim3(256), 0, s, Xd, nx, B * n, d);
+    hipLaunchKernelGGL(norms_f64_kernel, dim3((unsigned)((B * n + 3) / 4)), dim3(256), 0, s, Yd, ny, B * n, d);
+    {   // dot products: K_yy <- Y Y^T, K_xy <- X Y^T
+        GemmArgs g{};
+        g.C = A; g.ldc = n; g.bsC = as; g.A = Yd; g.lda = d; g.ta = 0; g.bsA = xs; g.B = Yd; g.ldb = d; g.tb = 1; g.bsB = xs;
+        g.M = n; g.Mlast = n; g.N = n; g.K = d; g.Klast = d; g.tri = 0; g.npair = 1; g.sign = 1.0;
+        launch_gemm(s, B, g);
+        g.C = Kxy; g.A = Xd;
+        launch_gemm(s, B, g);
+    }
+    const dim3 ge((unsigned)((as + 255) / 256), (unsigned)B);
+    hipLaunchKernelGGL(cos_finish_f64_kernel, ge, dim3(256), 0, s, A, ny, ny, n, (double)T, (double)eps, (double)sigma);
+    hipLaunchKernelGGL(cos_finish_f64_kernel, ge, dim3(256), 0, s, Kxy, nx, ny, n, (double)T, (double)eps, 0.0);
+    chol_solve(s, A, Lf, Tb, R, R2, info, B, n, nrhs);     // R <- (K_yy + sigma I)^-1 f
+    {   // mu = K_xy R  (into R2), then fp32 rows
+        GemmArgs g{};
+        g.C = R2; g.ldc = nrhs; g.bsC = fs; g.A = Kxy; g.lda = n; g.ta = 0; g.bsA = as; g.B = R; g.ldb = nrhs; g.tb = 0; g.bsB = fs;
+        g.M = n; g.Mlast = n; g.N = nrhs; g.K = n; g.Klast = n; g.tri = 0; g.npair = 1; g.sign = 1.0;
+        launch_gemm(s, B, g);
+    }
+    for (int b = 0; b < B; ++b)
+        hipLaunchKernelGGL(to_f32_rows_kernel, dim3(gf), dim3(256), 0, s, R2 + b * fs, mu + (size_t)b * n * ld_mu, n, nrhs, ld_mu);
+    return gim_check_launch("gp_posterior_f64");
 }

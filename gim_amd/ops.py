@@ -699,6 +699,19 @@ def gp_solve(K, F, npad):
     return Xt
 
 
+def gp_posterior_f64(X, Y, F, out, T=0.2, eps=1e-6, sigma=0.1):
+    """GP posterior mean, every step in fp64 (the dense matchers' parity mode): X / Y [B,n,d] fp32 query / support rows (contiguous),
+    F [n,nrhs] fp32 -> out: fp32 row view [B*n, >= nrhs] receives K_xy (K_yy + sigma I)^-1 F, K = exp((cos - 1) / T)."""
+    _req_cuda(X, Y, F, out)
+    B, n, d = X.shape
+    nrhs = F.shape[1]
+    assert X.is_contiguous() and Y.is_contiguous() and F.is_contiguous() and Y.shape == X.shape and F.shape[0] == n
+    assert X.dtype == Y.dtype == F.dtype == out.dtype == torch.float32 and out.stride(1) == 1 and out.shape[0] >= B * n and out.shape[1] >= nrhs
+    ws = torch.empty(lib.gim_gp_posterior_f64_ws_bytes(B, n, d, nrhs), dtype=torch.uint8, device=X.device)
+    check(lib.gim_gp_posterior_f64(_p(X), _p(Y), _p(F), _p(out), _p(ws), B, n, d, d, nrhs, out.stride(0), T, eps, sigma, _stream()),
+          "gim_gp_posterior_f64")
+
+
 def global_avgpool(x, out, c_off):
     """x [B,h,w,C] -> out[b, c_off:c_off+C] (fp32 [B, ldo])"""
     _req_cuda(x, out)

@@ -395,6 +395,14 @@ int gim_cos_kernel_finish(float* k, const float* nx, const float* ny, int B, int
 int64_t gim_gp_solve_ws_bytes(int B, int n, int nrhs);
 int gim_gp_solve(const float* K, const float* F, float* Xt, void* ws, int B, int n, int ldk, int nrhs, int npad,
                  gim_stream_t stream);
+/* The same posterior evaluated ENTIRELY in fp64 from fp32 feature rows (the dense matchers' parity mode): cosine-kernel entries,
+ * Cholesky and both products on the fp64 MFMA.  X (queries) / Y (supports): [B][n][ldx] fp32, d features per row; F [n][nrhs] fp32
+ * (shared by all B directions); mu [B][n][ld_mu] fp32 = K_xy (K_yy + sigma I)^-1 F with K = exp((cos - 1) / T), cos = x.y / (|x||y| + eps)
+ * (dkm.py:135-144, 340-370; roma.py:94-136).  The system's condition number (~2e4) turns the 1e-7 rounding of fp32 kernel entries
+ * into ~1e-4 of mu; this entry point removes that term from the engine's side. */
+int64_t gim_gp_posterior_f64_ws_bytes(int B, int n, int d, int nrhs);
+int gim_gp_posterior_f64(const float* X, const float* Y, const float* F, float* mu, void* ws, int B, int n, int d, int ldx,
+                         int nrhs, int ld_mu, float T, float eps, float sigma, gim_stream_t stream);
 /* CAB -- dkm.py:160-168: global average pool of NHWC rows into out[b][c_off + c]; out = sigmoid(g) * x2 + x1. */
 int gim_global_avgpool(const void* x, float* out, int B, int HW, int C, int ld, int ldo, int c_off, int dtype,
                        gim_stream_t stream);

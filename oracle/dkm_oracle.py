@@ -173,6 +173,30 @@ def cos_kernel(x, y, T=0.2, eps=1e-6):
     return ((c - 1.0) / T).exp()
 
 
+# Test switch (never set by the golden-vector generators): evaluate the GP posterior -- the ONE ill-conditioned step of the dense
+# matchers, cond(K_yy + sigma I) ~ 2e4 -- with the reference's formula in fp64 instead of its fp32 kernel matrix + fp32 LU inverse.
+# fp32 arithmetic is ~1e-4 of mu away from the formula's exact value whatever the operation order (tests/test_gpu_gp_pins.py), so two
+# fp32 implementations cannot be compared below that; with GP_FP64 the oracle IS the formula and the engine's parity mode (fp64 GP,
+# csrc/gp_solve.hip) is compared with it at 1e-4 end to end, next to the reference arithmetic's own distance from it.
+GP_FP64 = False
+
+
+def gp_posterior_fp64(xr, yr, fr, sigma_noise=0.1, T=0.2, eps=1e-6):
+    """mu = K_xy (K_yy + sigma I)^-1 f in fp64 from fp32 rows [b, n, d] / [b, n, c] (cos_kernel + dkm.py:352-362)"""
+    x, y, f = xr.double(), yr.double(), fr.double()
+
+    def k(a, b):
+        c = torch.einsum("bnd,bmd->bnm", a, b) / (a.norm(dim=-1)[..., None] * b.norm(dim=-1)[:, None] + eps)
+        return ((c - 1.0) / T).exp()
+    kyy = k(y, y) + sigma_noise * torch.eye(y.shape[1], dtype=torch.float64)[None]
+    try:
+        sol = torch.linalg.solve(kyy, f)
+    except RuntimeError:   # this image's torch CPU LU can fail for n >= 588 ("Pivots given to lu_solve ..."): numpy's LAPACK
+        import numpy as np
+        sol = torch.from_numpy(np.linalg.solve(kyy.numpy(), f.numpy()))
+    return k(x, y).matmul(sol).float()
+
+
 def gp_forward(sd, scale, x, y, sigma_noise=0.1):
     """GP.forward with no_cov=True (dkm.py:340-370): mu = K_xy (K_yy + sigma I)^-1 f, f = cos(8 pi pos_conv(coords)).
     (The reference also evaluates K_xx and discards it.)"""
@@ -180,6 +204,8 @@ def gp_forward(sd, scale, x, y, sigma_noise=0.1):
     _, _, h2, w2 = y.shape
     f = torch.cos(8 * math.pi * _conv(sd, f"decoder.gps.{scale}.pos_conv", grid_coords(b, h2, w2)))
     xr, yr, fr = (t.flatten(2).transpose(1, 2) for t in (x, y, f))
+    if GP_FP64:
+        return gp_posterior_fp64(xr, yr, fr, sigma_noise).transpose(1, 2).reshape(b, -1, h1, w1)
     K_yy = cos_kernel(yr, yr)
     K_xy = cos_kernel(xr, yr)
     K_inv = torch.linalg.inv(K_yy + sigma_noise * torch.eye(h2 * w2)[None])

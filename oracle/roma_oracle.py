@@ -26,6 +26,7 @@ import math
 import torch
 import torch.nn.functional as F
 
+import dkm_oracle as _DO
 from dkm_oracle import BN_EPS, _bn, _conv, cos_kernel, grid_coords, kde, local_correlation  # noqa: F401  (shared arithmetic)
 
 VGG_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M"]      # vgg19_bn.features[:40]
@@ -229,6 +230,8 @@ def gp_forward(sd, x, y, sigma_noise=0.1):
     _, _, h2, w2 = y.shape
     f = torch.cos(8 * math.pi * _conv(sd, "decoder.gps.16.pos_conv", grid_coords(b, h2, w2)))
     xr, yr, fr = (t.float().flatten(2).transpose(1, 2) for t in (x, y, f))
+    if _DO.GP_FP64:   # test switch: the formula in fp64 (see dkm_oracle.GP_FP64)
+        return _DO.gp_posterior_fp64(xr, yr, fr, sigma_noise).transpose(1, 2).reshape(b, -1, h1, w1)
     K_inv = torch.linalg.inv(cos_kernel(yr, yr) + sigma_noise * torch.eye(h2 * w2)[None])
     mu = cos_kernel(xr, yr).matmul(K_inv.matmul(fr))
     return mu.transpose(1, 2).reshape(b, -1, h1, w1)

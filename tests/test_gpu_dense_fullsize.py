@@ -71,9 +71,10 @@ def test_dkm_672x896_vs_oracle(monkeypatch):
     warp, cert = m.match(im0.to("cuda:0"), im1.to("cuda:0"))
     _close(warp, ref_warp, 2e-3, "dkm warp 672x896 vs the reference arithmetic")
     _close(cert, ref_cert, 5e-3, "dkm certainty 672x896 vs the reference arithmetic")
-    # (b) against the exact-GP oracle: 1e-4 (isolated pixels behind the certainty threshold of the refinement may flip)
-    _close(warp, x_warp, 1e-4, "dkm warp 672x896 vs the fp64-GP oracle", frac=0.999, mean_tol=2e-5)
-    _close(cert, x_cert, 1e-4, "dkm certainty 672x896 vs the fp64-GP oracle", frac=0.999, mean_tol=2e-5)
+    # (b) against the exact-GP oracle: EVERY value within 2e-5 of scale (north_star: 1e-4; measured max 3.0e-6 / 1.1e-6,
+    # profiles/r03_dense_parity.txt)
+    _close(warp, x_warp, 2e-5, "dkm warp 672x896 vs the fp64-GP oracle", frac=1.0, mean_tol=2e-6)
+    _close(cert, x_cert, 2e-5, "dkm certainty 672x896 vs the fp64-GP oracle", frac=1.0, mean_tol=2e-6)
     (rw_max, rw_mean), (ew_max, ew_mean) = _dist(ref_warp, x_warp), _dist(warp, x_warp)
     print(f"dkm 672x896 warp: reference arithmetic vs fp64-GP oracle max {rw_max:.2e} mean {rw_mean:.2e}; engine vs fp64-GP oracle max {ew_max:.2e} mean {ew_mean:.2e}")
     assert ew_mean <= rw_mean, "the engine's parity mode must sit closer to the formula than the reference's fp32 arithmetic does"
@@ -99,9 +100,10 @@ def test_roma_672_vs_oracle(monkeypatch):
     # behind a decision that the GP's 1e-4 noise flips
     _close(warp, ref_warp, 2e-3, "roma warp 672x672 vs the reference arithmetic", frac=0.99, mean_tol=2e-3)
     _close(cert, ref_cert, 5e-3, "roma certainty 672x672 vs the reference arithmetic", frac=0.99, mean_tol=5e-3)
-    # (b) against the exact-GP oracle: the anchor arg-max no longer sees GP noise, so the flipped decisions go away
-    _close(warp, x_warp, 1e-4, "roma warp 672x672 vs the fp64-GP oracle", frac=0.995, mean_tol=1e-4)
-    _close(cert, x_cert, 1e-4, "roma certainty 672x672 vs the fp64-GP oracle", frac=0.995, mean_tol=1e-4)
+    # (b) against the exact-GP oracle: the anchor arg-max no longer sees GP noise, so the flipped decisions go away: EVERY value
+    # within 2e-5 of scale (measured max 3.6e-7 / 3.0e-6); a flipped arg-max at an isolated pixel would show as a value of O(1)
+    _close(warp, x_warp, 2e-5, "roma warp 672x672 vs the fp64-GP oracle", frac=1.0, mean_tol=2e-6)
+    _close(cert, x_cert, 2e-5, "roma certainty 672x672 vs the fp64-GP oracle", frac=1.0, mean_tol=4e-6)
     (rw_max, rw_mean), (ew_max, ew_mean) = _dist(ref_warp, x_warp), _dist(warp, x_warp)
     print(f"roma 672 warp: reference arithmetic vs fp64-GP oracle max {rw_max:.2e} mean {rw_mean:.2e}; engine vs fp64-GP oracle max {ew_max:.2e} mean {ew_mean:.2e}")
     assert ew_mean <= rw_mean, "the engine's parity mode must sit closer to the formula than the reference's fp32 arithmetic does"

@@ -230,6 +230,12 @@ def main():
                 "kernel_ms_per_step": round(tot_ms / 2, 3),
                 "fused_kernels": fused,   # the hand-fused kernels that took work OUT of the implicit-GEMM kernel (same live HIP-event timing)
                 "top_layers_ms_tflops": [[k, round(v[0] / 2, 3), round(v[1] / (v[0] * 1e-3) / 1e12, 1)] for k, v in top]}
+        if os.environ.get("GIM_BENCH_ALL_LAYERS"):   # every conv / linear shape: [label, launches per step, ms per step, TFLOP/s]
+            cnt = {}
+            for _, _, _, lab in prof:
+                cnt[lab] = cnt.get(lab, 0) + 1
+            roof["all_layers"] = [[k, cnt[k] // 2, round(v[0] / 2, 3), round(v[1] / (v[0] * 1e-3) / 1e12, 1)]
+                                  for k, v in sorted(by.items(), key=lambda kv: -kv[1][0])]
 
     # ---- the same step with the images starting in (pinned) host memory: PCIe-inclusive rate -------------
     # double-buffered staging on a copy stream (gim_amd.runner.HostPairFeeder): the transfer of step s + 1 overlaps step s

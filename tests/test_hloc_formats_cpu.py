@@ -77,3 +77,27 @@ def test_edge_cases_and_writers():
     assert sp["matches0"].dtype == np.int16 and sp["matching_scores0"].dtype == np.float16
     kg = H.write_keypoints(fd, "a", kps, score)
     assert kg["keypoints"].dtype == np.float32
+
+
+def test_writers_through_a_real_h5py_file(tmp_path):
+    """the wire formats written through h5py itself (skipped where h5py is not installed): group layout,
+    dtypes and the replace-on-rewrite behaviour of match_dense.py:248-257,353-356,375-381 / match_features.py:150-160"""
+    import pytest
+    h5py = pytest.importorskip("h5py")
+    rng = np.random.default_rng(3)
+    kp0, kp1, sc = rng.random((50, 2)) * 640, rng.random((50, 2)) * 480, rng.random(50)
+    path = str(tmp_path / "matches.h5")
+    with h5py.File(path, "a", libver="latest") as fd:
+        grp = H.write_dense_pair(fd, "db/a.jpg", "q/b.jpg", kp0, kp1, sc)
+        H.write_matches0(grp, np.arange(50) % 7 - 1, sc)
+        H.write_dense_pair(fd, "db/a.jpg", "q/b.jpg", kp0[:10], kp1[:10], sc[:10])           # same pair again: replaced, not duplicated
+        H.write_sparse_matches(fd, "db/a.jpg", "q/c.jpg", np.arange(2048) % 300 - 1, rng.random(2048))
+        H.write_keypoints(fd, "db/a.jpg", kp0, sc)
+    with h5py.File(path, "r") as fd:
+        g = fd[H.pair_key("db/a.jpg", "q/b.jpg")]
+        assert g["keypoints0"].shape == (10, 2) and g["keypoints0"].dtype == np.float32 and g["scores"].dtype == np.float32
+        assert "matches0" not in g                                                              # the rewrite started a fresh group
+        s = fd[H.pair_key("db/a.jpg", "q/c.jpg")]
+        assert s["matches0"].dtype == np.int16 and s["matching_scores0"].dtype == np.float16 and s["matches0"].shape == (2048,)
+        k = fd["db/a.jpg"]
+        assert k["keypoints"].dtype == np.float32 and np.allclose(k["keypoints"][()], kp0.astype(np.float32))

@@ -113,3 +113,33 @@ def test_run_scene_world2(tmp_path):
     per, mean = zeb.score_dir(str(tmp_path), "gim_loftr", "test")
     assert per["GL3D"][5.0] > 99.9
     assert zeb.run_scene(None, [], out) is None  # restartable: an existing dump is kept
+
+
+def test_estimate_pose_runs_opencv_ransac_where_available():
+    """`zeb.estimate_pose` (= tools/metrics.py:77-103: cv2.findEssentialMat RANSAC + recoverPose) executed for real
+    wherever OpenCV is installed (skipped otherwise -- not in this image): a synthetic two-view scene with a known relative pose,
+    20 % gross outliers; the recovered rotation / translation direction must be within a degree."""
+    import pytest
+    pytest.importorskip("cv2")
+    import numpy as np
+    from gim_amd import zeb
+    rng = np.random.default_rng(0)
+    K0 = np.array([[525.0, 0, 320], [0, 525.0, 240], [0, 0, 1]])
+    K1 = np.array([[500.0, 0, 310], [0, 500.0, 250], [0, 0, 1]])
+    ang = np.deg2rad(8.0)
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    t = np.array([0.4, -0.05, 0.1])
+    X = np.concatenate([rng.uniform(-2, 2, (400, 2)), rng.uniform(4, 9, (400, 1))], 1)
+    p0 = (K0 @ X.T).T
+    p1 = (K1 @ (X @ R.T + t).T).T
+    k0, k1 = p0[:, :2] / p0[:, 2:], p1[:, :2] / p1[:, 2:]
+    k1[:80] = rng.uniform(0, 480, (80, 2))                                      # outliers
+    ret = zeb.estimate_pose(k0, k1, K0, K1, 0.5, 0.99999)
+    assert ret is not None
+    Re, te, inl = ret
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R, t
+    t_err, R_err, _ = zeb.relative_pose_error(T, Re, te)
+    assert R_err < 1.0 and t_err < 1.0, (R_err, t_err)
+    assert inl[80:].mean() > 0.9 and inl[:80].mean() < 0.2
+    assert zeb.estimate_pose(k0[:4], k1[:4], K0, K1) is None                    # < 5 matches (tools/metrics.py:78-79)

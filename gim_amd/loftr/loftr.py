@@ -398,8 +398,11 @@ class LoFTR(nn.Module):
             self.ws = None
             self.MASK = None  # optional uint8 [R] padding mask aligned with the rows (coarse level only)
 
-    def _encoder_layer(self, P, p, T, xs, ss, nb, L, S, H):
-        """LoFTREncoderLayer.forward (transformer.py:35-58) on row ranges xs (queries) / ss (source)."""
+    def _encoder_layer(self, P, p, T, xs, ss, nb, L, S, H, have_q=False, with_q_of_source=False):
+        """LoFTREncoderLayer.forward (transformer.py:35-58) on row ranges xs (queries) / ss (source).
+        Cross layers run as a pair (feat0 against feat1, then feat1 against the updated feat0, transformer.py:95-96): the FIRST call
+        also projects the source's queries for the second one (`with_q_of_source`: one [q|k|v] GEMM on the source rows instead of a
+        [k|v] GEMM now and a q GEMM later -- those rows do not change in between), which then runs with `have_q`."""
         C = T.X32.shape[1]
         dma = self.use_lds_dma
         x_t, s_t = T.CAT[xs, :C], T.CAT[ss, :C]
@@ -407,8 +410,12 @@ class LoFTR(nn.Module):
         if xs == ss:
             ops.linear(x_t, P[p + "qkv"], T.QKV[xs], ACT_ELU1, dma, act_cols=2 * C)
         else:
-            ops.linear(x_t, P[p + "q_proj"], T.QKV[xs, :C], ACT_ELU1, dma)
-            ops.linear(s_t, P[p + "kv"], T.QKV[ss, C:], ACT_ELU1, dma, act_cols=C)
+            if not have_q:
+                ops.linear(x_t, P[p + "q_proj"], T.QKV[xs, :C], ACT_ELU1, dma)
+            if with_q_of_source:
+                ops.linear(s_t, P[p + "qkv"], T.QKV[ss], ACT_ELU1, dma, act_cols=2 * C)
+            else:
+                ops.linear(s_t, P[p + "kv"], T.QKV[ss, C:], ACT_ELU1, dma, act_cols=C)
         qm = T.MASK[xs] if T.MASK is not None else None  # x_mask / source_mask (transformer.py:50, attentions.py:35-39)
         km = T.MASK[ss] if T.MASK is not None else None
         fused = self.token_fused and (p + "tok") in P
@@ -447,8 +454,8 @@ class LoFTR(nn.Module):
                     self._encoder_layer(P, p, T, r0, r0, n0, L, L, H)
                     self._encoder_layer(P, p, T, r1, r1, n1, S, S, H)
             else:  # cross: feat0 first, then feat1 against the *updated* feat0 (transformer.py:95-96)
-                self._encoder_layer(P, p, T, r0, r1, n0, L, S, H)
-                self._encoder_layer(P, p, T, r1, r0, n1, S, L, H)
+                self._encoder_layer(P, p, T, r0, r1, n0, L, S, H, with_q_of_source=True)
+                self._encoder_layer(P, p, T, r1, r0, n1, S, L, H, have_q=True)
 
     # ---- forward (loftr.py:43-91) -------------------------------------------------------------------
     def _coarse_stage(self, xs, bs, scale0, scale1, mask0=None, mask1=None):

@@ -209,44 +209,6 @@ struct Epilogue {
         // kind of a 16-bit output: the flavour of this translation unit, except that the fp16 objects can also write bf16
         // (no residual / upsample operand then: checked at launch)
         const bool out_bf = GIM_HALF_KIND ? a.out_dtype == GIM_BF16 : true;
-        // UPS: the half-resolution neighbours (y0,x0) (y0,x1) (y1,x0) (y1,x1) of the NI row groups of pass (j, nh), 16 bytes each
-        constexpr int UG = NI / 2;   // row groups per pipelined unit (half a pass: the whole pass in flight spilled 450 B per lane)
-        uint4 uq[UPS ? UG : 1][4];
-        auto ups_gather = [&](const int gj, const int gnh, const int gkh) __attribute__((always_inline)) {
-            if constexpr (UPS && OUT_BF16) {
-                const int gcol = n0 + wn * WTN + gnh * 64 + rslot * (16 / OES);
-                const bool gcol_ok = full || gcol < a.N;
-                const int mb = m0 + wm * WTM + gj * 32;
-                const int W2 = 2 * a.ups_w, H2 = 2 * a.ups_h;
-                const int pr = mb / W2;
-                const int uX0 = mb - pr * W2, ub = pr / H2, uY = pr - ub * H2;
-                const int h = a.ups_h, w = a.ups_w;
-                const float sy = (float)(h - 1) / (float)(2 * h - 1), sx = (float)(w - 1) / (float)(2 * w - 1);
-                const int y0 = (int)(sy * uY);
-                const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
-                // 32-bit byte offsets through a buffer descriptor (one address VGPR per load instead of a 64-bit pair: the epilogue
-                // holds the whole accumulator tile and spills otherwise); ups_supported() bounds the tensor below 2 GiB
-                const auto ru = __builtin_amdgcn_make_buffer_rsrc((void*)a.ups, 0, 0x7fffffff, 0x00020000);
-                const unsigned cb = (unsigned)(gcol_ok ? gcol : 0) * 2u, ldb = (unsigned)a.ups_ld * 2u;
-                const unsigned r0 = (unsigned)((ub * h + y0) * w), r1 = (unsigned)((ub * h + y1) * w);
-#pragma unroll
-                for (int k = 0; k < UG; ++k) {
-                    const int row = (gkh * UG + k) * RPI + rrow;
-                    const int x0 = (int)(sx * (uX0 + row));
-                    const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
-                    // rows / columns beyond the tile's valid range load (and never store) pixel 0: a load that is branched around
-                    // makes the compiler wait for every outstanding memory operation at the join
-                    const bool ok = gcol_ok && (full || mb + row < M);
-                    const unsigned o00 = ok ? (r0 + x0) * ldb + cb : 0u, o01 = ok ? (r0 + x1) * ldb + cb : 0u;
-                    const unsigned o10 = ok ? (r1 + x0) * ldb + cb : 0u, o11 = ok ? (r1 + x1) * ldb + cb : 0u;
-                    uq[k][0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ru, o00, 0, 0));
-                    uq[k][1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ru, o01, 0, 0));
-                    uq[k][2] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ru, o10, 0, 0));
-                    uq[k][3] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ru, o11, 0, 0));
-                }
-            }
-        };
-        ups_gather(0, 0, 0);
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
 #pragma unroll
@@ -313,29 +275,37 @@ struct Epilogue {
                     }
                 // UPS: y += bilinear x2 (align_corners=True) of a.ups, arithmetic of upsample2x_add_kernel (elementwise.hip) on
                 // the rounded conv output.  The 32 pixels of a pass lie in one image row (Wo % 32 == 0, checked at launch).
-                if constexpr (UPS && OUT_BF16) {
-                    // The four neighbours of every output row were fetched ONE PASS AHEAD (ups_gather, issued before the previous
-                    // pass's stores): vector memory operations return in order, so a gather issued behind a store cannot be waited
-                    // for without waiting for that store's acknowledgement -- with gathers and stores alternating per row group the
-                    // epilogue paid one store round trip per 8 rows (16 per tile: the 256->196 lateral conv ran at 2.3 TB/s).
+                // (Round 3, measured: this epilogue costs 0.23 ms on the 256->196 lateral conv -- 0.49 ms fused against 0.25 ms for the
+                // bare conv -- because every row group's gathers queue behind the previous group's stores (vector memory returns in
+                // order).  Issuing the gathers one pass / half a pass ahead of the stores removes that wait but keeps 32-64 more
+                // VGPRs live across the transposition: 170-450 B of scratch per lane, 1.8 ms.  Not kept; the fix is staging the
+                // half-resolution rows in LDS with half-pass transposition patches.)
+                int ub = 0, uY = 0, uX0 = 0;
+                if constexpr (UPS) {
                     const int mb = m0 + wm * WTM + j * 32;  // wave-uniform
                     const int W2 = 2 * a.ups_w, H2 = 2 * a.ups_h;
                     const int pr = mb / W2;
-                    const int uX0 = mb - pr * W2, uY = pr - (pr / H2) * H2;
-                    const int h = a.ups_h, w = a.ups_w;
-                    const float sy = (float)(h - 1) / (float)(2 * h - 1), sx = (float)(w - 1) / (float)(2 * w - 1);
-                    const float fy = sy * uY;
-                    const float ly1 = fy - (int)fy, ly0 = 1.f - ly1;
+                    uX0 = mb - pr * W2; ub = pr / H2; uY = pr - ub * H2;
+                }
 #pragma unroll
-                    for (int kh = 0; kh < 2; ++kh) {
-                        uint4 outv[UG];
-#pragma unroll
-                        for (int kk = 0; kk < UG; ++kk) {
-                            const int row = (kh * UG + kk) * RPI + rrow;
-                            const uint4 o = *(const uint4*)(wl + row * RB + ((rslot ^ (row & 7)) << 4));
-                            const float fx = sx * (uX0 + row);
-                            const float lx1 = fx - (int)fx, lx0 = 1.f - lx1;
-                            const uint4 qa = uq[kk][0], qb = uq[kk][1], qc = uq[kk][2], qd = uq[kk][3];
+                for (int k = 0; k < NI; ++k) {
+                    const int row = k * RPI + rrow;
+                    const int m = m0 + wm * WTM + j * 32 + row;
+                    uint4 o = *(const uint4*)(wl + row * RB + ((rslot ^ (row & 7)) << 4));
+                    if constexpr (UPS && OUT_BF16) {
+                        if (ncol_ok && (full || m < M)) {
+                            const int h = a.ups_h, w = a.ups_w;
+                            const float sy = (float)(h - 1) / (float)(2 * h - 1), sx = (float)(w - 1) / (float)(2 * w - 1);
+                            const float fy = sy * uY, fx = sx * (uX0 + row);
+                            const int y0 = (int)fy, x0 = (int)fx;
+                            const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+                            const float ly1 = fy - y0, ly0 = 1.f - ly1, lx1 = fx - x0, lx0 = 1.f - lx1;
+                            const size_t base = (size_t)ub * h * w;
+                            const unsigned short* up = (const unsigned short*)a.ups + ncol;
+                            const uint4 qa = *(const uint4*)(up + (base + (size_t)y0 * w + x0) * a.ups_ld);
+                            const uint4 qb = *(const uint4*)(up + (base + (size_t)y0 * w + x1) * a.ups_ld);
+                            const uint4 qc = *(const uint4*)(up + (base + (size_t)y1 * w + x0) * a.ups_ld);
+                            const uint4 qd = *(const uint4*)(up + (base + (size_t)y1 * w + x1) * a.ups_ld);
                             const unsigned ov[4] = {o.x, o.y, o.z, o.w}, av[4] = {qa.x, qa.y, qa.z, qa.w}, bv[4] = {qb.x, qb.y, qb.z, qb.w};
                             const unsigned cv[4] = {qc.x, qc.y, qc.z, qc.w}, dv[4] = {qd.x, qd.y, qd.z, qd.w};
                             unsigned rv[4];
@@ -349,26 +319,10 @@ struct Epilogue {
                                 rv[e] = cvt_pk_h16(o0 + (ly0 * (lx0 * a0 + lx1 * b0) + ly1 * (lx0 * c0 + lx1 * d0)),
                                                     o1 + (ly0 * (lx0 * a1 + lx1 * b1) + ly1 * (lx0 * c1 + lx1 * d1)));
                             }
-                            outv[kk] = make_uint4(rv[0], rv[1], rv[2], rv[3]);
-                        }
-                        // the next unit's neighbours go out BEFORE this unit's stores
-                        if (kh == 0) ups_gather(j, nh, 1);
-                        else if (nh + 1 < NH) ups_gather(j, nh + 1, 0);
-                        else if (j + 1 < TM) ups_gather(j + 1, 0, 0);
-#pragma unroll
-                        for (int kk = 0; kk < UG; ++kk) {
-                            const int m = mb + (kh * UG + kk) * RPI + rrow;
-                            if (ncol_ok && (full || m < M)) *(uint4*)((char*)a.y + ((size_t)m * a.ldy + ncol) * OES) = outv[kk];
+                            o = make_uint4(rv[0], rv[1], rv[2], rv[3]);
                         }
                     }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < NI; ++k) {
-                        const int row = k * RPI + rrow;
-                        const int m = m0 + wm * WTM + j * 32 + row;
-                        const uint4 o = *(const uint4*)(wl + row * RB + ((rslot ^ (row & 7)) << 4));
-                        if (ncol_ok && (full || m < M)) *(uint4*)((char*)a.y + ((size_t)m * a.ldy + ncol) * OES) = o;
-                    }
+                    if (ncol_ok && (full || m < M)) *(uint4*)((char*)a.y + ((size_t)m * a.ldy + ncol) * OES) = o;
                 }
             }
         }
@@ -1063,7 +1017,6 @@ static bool ups_supported(const gim_conv_args& a) {
     if (a.dtype != GIM_H16 || a.out_dtype != GIM_H16 || a.res || a.use_lds_dma != 1 || a.npad % 256 != 0) return false;
     // output rows are (image, Y, X) with Y < 2 ups_h, X < 2 ups_w whatever geometry the launch states (a 1x1 conv is launched flat)
     const long long Mo = (long long)a.B * a.Ho * a.Wo;
-    if ((long long)(Mo / 4) * a.ups_ld * 2 >= 0x7fffffffll) return false;   // 32-bit byte offsets into the half-resolution tensor
     if (a.ups_h <= 0 || a.ups_w <= 0 || Mo % (4ll * a.ups_h * a.ups_w) != 0 || (2 * a.ups_w) % 32 != 0 || a.ups_ld % 8 != 0 || a.ups_ld < a.N) return false;
     if (a.act_cols != 0 || big_mode() == 0 || pp_mode() != 0) return false;
     const int nkt = a.kpad * 2 / KTB;

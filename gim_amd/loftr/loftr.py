@@ -44,7 +44,7 @@ import torch.nn as nn
 
 from .. import ops
 from .._lib import ACT_ELU1, ACT_LEAKY, ACT_NONE, ACT_RELU, GIM_BF16, GIM_F16, GIM_F32, GimHipError
-from ..packing import cstore, is_half, pack_bneck, pack_conv, pack_fine_fused, pack_token_mlp, torch_dtype
+from ..packing import cstore, is_half, pack_bneck, pack_bneck_tail, pack_conv, pack_fine_fused, pack_token_mlp, torch_dtype
 
 _DT = {"bf16": GIM_BF16, "fp16": GIM_F16, "fp32": GIM_F32}
 
@@ -200,6 +200,9 @@ class LoFTR(nn.Module):
         # bf16 mode, layer1 (planes 64): conv2 -> conv3 (+identity) -> the next block's conv1 chained through registers
         # (bneck_fused.hip); GIM_BNECK_FUSED=0 keeps one implicit-GEMM launch per convolution
         self.bneck_fused = os.environ.get("GIM_BNECK_FUSED", "1") != "0"
+        # 16-bit modes, layer2 (planes 128): conv3 (+identity) -> the next block's conv1 in one kernel (bneck_tail.hip);
+        # GIM_BNECK_TAIL=0 keeps the two implicit-GEMM launches
+        self.bneck_tail = os.environ.get("GIM_BNECK_TAIL", "1") != "0"
         self._packed = None
         self._packed_key = None
         self._pe_cache = {}
@@ -285,6 +288,9 @@ class LoFTR(nn.Module):
             l1 = list(enc.layer1)
             for bi, blk in enumerate(l1):   # the last block's trailing conv1 is layer2's first one (256 -> 128, same resolution)
                 P[f"l1.{bi}.fused"] = pack_bneck(blk, l1[bi + 1] if bi + 1 < len(l1) else enc.layer2[0], device, tdt)
+            l2 = list(enc.layer2)
+            for bi in range(len(l2) - 1):   # layer 2: conv3 + identity + relu of block bi with conv1 of block bi + 1 (bneck_tail.hip)
+                P[f"l2.{bi}.tail"] = pack_bneck_tail(l2[bi], l2[bi + 1], device, tdt)
         bb = self.backbone
         P["l3o"] = pack_conv(bb.layer3_outconv.weight, None, dt, device)
         P["l2o"] = pack_conv(bb.layer2_outconv.weight, None, dt, device)
@@ -369,6 +375,9 @@ class LoFTR(nn.Module):
                     x, o = ops.bneck64(o, idn, P[p + "fused"], True)
                     continue
                 o = ops.conv2d(o, P[p + "c2"], ACT_RELU, lds_dma=dma)
+                if self.bneck_tail and (p + "tail") in P and (o.shape[0] * o.shape[1] * o.shape[2]) % 256 == 0:
+                    x, o = ops.bneck_tail(o, idn.contiguous(), P[p + "tail"])   # x' and the next block's conv1 output
+                    continue
                 x = ops.conv2d(o, P[p + "c3"], ACT_RELU, res=idn, lds_dma=dma)
                 o = None
             feats.append(x)

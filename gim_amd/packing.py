@@ -260,3 +260,17 @@ def pack_bneck(blk, nxt, device, tdt=torch.bfloat16):
         w1p = to(w1.reshape(n1, 256).cpu()[:, _acc_order(256)])
         b1 = b1.float().to(device).contiguous()
     return w2p, w3p, w1p, b2.float().to(device).contiguous(), b3.float().to(device).contiguous(), b1
+
+
+def pack_bneck_tail(blk, nxt, device, tdt=torch.bfloat16):
+    """gim_bneck_tail128 operands: conv3 / bn3 of Bottleneck `blk` (planes 128) and conv1 / bn1 of the next block `nxt`:
+    (w3 [512][128] K in channel order, w1n [8][N1][64] -- per 64-channel chunk of x' the K axis in accumulator order --, b3, b1n fp32)."""
+    bn = lambda m: (m.weight, m.bias, m.running_mean, m.running_var, m.eps)  # noqa: E731
+    w3, b3 = fold_bn(blk.conv3.weight, bn(blk.bn3))
+    w1, b1 = fold_bn(nxt.conv1.weight, bn(nxt.bn1))
+    n1 = w1.shape[0]
+    assert tuple(w3.shape) == (512, 128, 1, 1) and tuple(w1.shape) == (n1, 512, 1, 1) and n1 in (128, 256)
+    to = lambda t: t.to(device).to(tdt).contiguous()  # noqa: E731
+    w3p = to(w3.reshape(512, 128).cpu())
+    w1c = w1.reshape(n1, 8, 64).cpu()[:, :, _acc_order(64)].permute(1, 0, 2)       # [chunk][n1][64]
+    return w3p, to(w1c), b3.float().to(device).contiguous(), b1.float().to(device).contiguous()

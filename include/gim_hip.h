@@ -183,6 +183,17 @@ int gim_bneck64_fused_f16(const void* t1, const void* res, void* x_out, void* t1
                           const void* w1n, const float* b2, const float* b3, const float* b1n, int B, int H, int W,
                           int n_next, gim_stream_t stream);
 
+/* The same fusion one layer up (planes 128: layer 2), without the 3x3 -- x' = relu(bn3(conv3_1x1(t2)) + identity), t1' =
+ * act(bn1'(conv1'_1x1(x'))) of the NEXT block (resnet.py:117-124, 109-111) -- so that x' [M,512], the widest tensor of the block, is
+ * written once and not read back.  t2: [M,128] (the block's conv2 output), res: [M,512], x_out: [M,512], t1_next: [M,n_next], n_next
+ * in {128, 256}; M = pixel rows, a multiple of 256 (both convolutions are 1x1: no spatial structure).  w3 [512][128] K in channel
+ * order, w1n [8][n_next][64]: per 64-channel chunk of x', K in accumulator order (gim_amd/packing.py::pack_bneck_tail); the 256+ KiB
+ * of weights stream through LDS two chunks ahead of the MFMAs.  act_next: GIM_ACT_RELU / GIM_ACT_NONE. */
+int gim_bneck_tail128(const void* t2, const void* res, void* x_out, void* t1_next, const void* w3, const void* w1n,
+                      const float* b3, const float* b1n, int M, int n_next, int act_next, gim_stream_t stream);
+int gim_bneck_tail128_f16(const void* t2, const void* res, void* x_out, void* t1_next, const void* w3, const void* w1n,
+                          const float* b3, const float* b1n, int M, int n_next, int act_next, gim_stream_t stream);
+
 /* Token-wise tail of a LoFTREncoderLayer in ONE kernel (bf16 operand mode, d_model 256; transformer.py:52-58):
  *     x += norm2(mlp.2(relu(mlp.0(cat[x, norm1(merge(msg))]))))
  * msg: [R][ldm] bf16 attention output; xb: [R][ldxb] bf16 operand copy of x (read, then overwritten with the new x);

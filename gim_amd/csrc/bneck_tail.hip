@@ -69,7 +69,11 @@ typedef __attribute__((address_space(3))) void lds_t;
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void dma16(const u32x4_t rsrc, unsigned lds_addr, unsigned voff) {
     lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);   // wave-uniform by construction; the "s" constraint needs it provable
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory", "m0");
+    // s_nop 4: the descriptor SGPRs come out of v_readfirstlane (VALU writes SGPR -> VMEM reads it: 5 wait states, which hipcc
+    // cannot insert for an instruction inside an asm string).  Without it the first pieces of a workgroup that starts on a CU with
+    // a warm instruction cache fetched through a stale descriptor: wrong weights in SOME tiles of SOME launches once the grid
+    // exceeded one workgroup per CU (tests/test_gpu_bneck_tail.py::test_bneck_tail_many_tiles_and_repeatability).
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory", "m0");
 }
 __device__ __forceinline__ u32x4_t make_rsrc(const void* p, unsigned bytes) {
     const unsigned long long a = (unsigned long long)p;
@@ -103,13 +107,12 @@ __device__ __forceinline__ void issue_chunk(const u32x4_t rw3, const u32x4_t rw1
     }
 }
 
-// Identity rows through inline asm: a load hipcc can see next to LDS-DMA in flight makes it wait vmcnt(0) -- which drains the weight
-// DMA in every chunk (cdna_hip_programming.md section 5, trap (b)).  Hidden loads are counted by hand: the counted waits at the top
-// of the chunk loop name the four destinations ("+v"), so nothing reads them earlier.
-__device__ __forceinline__ void load_row16(u32x4_t& d, const unsigned short* p) {
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
-}
-#define TAIL_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : : "memory")
+// The identity rows take the same road as the weights: LDS-DMA straight into this wave's patch (row layout, XOR swizzle on the source
+// slot), issued through inline asm and counted by hand.  No vector memory load of the chunk loop has a VGPR destination: a load
+// hipcc can see beside LDS-DMA makes it wait vmcnt(0), and a load hidden in inline asm has its destination registers copied
+// (v_mov) by the register allocator BEFORE the hand-placed wait whenever the wait sits in more than one branch (measured: garbage
+// identity rows in some tiles of launches with more workgroups than CUs).
+#define TAIL_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
 template <int N1>
 __global__ void __launch_bounds__(512, 2) bneck_tail_kernel(const Args a) {
@@ -142,12 +145,17 @@ __global__ void __launch_bounds__(512, 2) bneck_tail_kernel(const Args a) {
     // (rematerialisation beats 32 live VGPRs in its cost model) and waits vmcnt(0) for them -- draining the weight DMA each time
 #pragma unroll
     for (int s = 0; s < PT / 16; ++s) asm volatile("" : "+v"(t2[s]));
-    // identity rows of chunk 0 (8 lanes x 16 B per pixel, 8 pixels per instruction); named registers, see bneck_fused.hip
-    const unsigned short* rp = a.res + (prow0 + (lane >> 3)) * C4 + (lane & 7) * 8;
-    const int psl = lane & 7, ppx = lane >> 3;
-    u32x4_t i0, i1, i2, i3;
-    load_row16(i0, rp); load_row16(i1, rp + 8 * C4); load_row16(i2, rp + 16 * C4); load_row16(i3, rp + 24 * C4);
-    if constexpr (C::NBUF == 3) issue_chunk<N1>(rw3, rw1, smem_addr, 1, 1, w, lane);   // behind the loads chunk 0 needs: may stay in flight
+    // identity rows of chunk q: 32 px x 128 B = 4 pieces; lane i of piece k -> pixel 8k + (i >> 3), patch slot i & 7 <- source slot
+    // (i & 7) ^ (pixel & 7)
+    const u32x4_t rres = make_rsrc(a.res, (unsigned)((size_t)a.M * C4 * 2));
+    const unsigned patch_addr = smem_addr + (unsigned)(C::OFF_PATCH + w * PATCH);
+    const unsigned id_voff = (unsigned)((prow0 + (lane >> 3)) * (C4 * 2)) + (unsigned)((((lane & 7) ^ ((lane >> 3) & 7))) << 4);
+    auto issue_identity = [&](const int q) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dma16(rres, patch_addr + (unsigned)(k * 1024), id_voff + (unsigned)(k * 8 * C4 * 2 + q * CH * 2));
+    };
+    issue_identity(0);
+    if constexpr (C::NBUF == 3) issue_chunk<N1>(rw3, rw1, smem_addr, 1, 1, w, lane);   // behind what chunk 0 needs: may stay in flight
     __syncthreads();             // biases are in LDS (the compiler knows nothing of the DMA / identity loads in flight: no drain)
 
     f32x16_t c1[NF];
@@ -163,8 +171,8 @@ __global__ void __launch_bounds__(512, 2) bneck_tail_kernel(const Args a) {
 #pragma unroll 1
     for (int q = 0; q < NCHUNK; ++q) {
         // chunk q's weights (this wave's pieces) and identity rows have landed.  Younger operations that may fly on: the four stores
-        // of the previous chunk and, with three buffers, the DMA of chunk q + 1 (issued behind the identity loads of chunk q).  The
-        // count must be exact -- vmcnt(n) only guarantees that all but the n YOUNGEST operations are complete.
+        // of the previous chunk and, with three buffers, the weight DMA of chunk q + 1 (issued behind the identity DMA of chunk q).
+        // The count must be exact -- vmcnt(n) only guarantees that all but the n YOUNGEST operations are complete.
         const bool dma_ahead = C::NBUF == 3 && q + 1 < NCHUNK;
         static_assert(C::PPW == 4 || C::PPW == 6, "the counted waits below spell out PPW and PPW + 4");
         if (q == 0) {
@@ -197,18 +205,7 @@ __global__ void __launch_bounds__(512, 2) bneck_tail_kernel(const Args a) {
                 c3[f] = mfma_h16_32x32x16(wv, t2[s], c3[f]);
             }
         }
-        // ---- + identity, relu; x' chunk out; operand of conv1' -- through this wave's LDS patch ----------------------------------
-        *(u32x4_t*)(patch + (ppx) * 128 + ((psl ^ (ppx & 7)) << 4)) = i0;
-        *(u32x4_t*)(patch + (ppx + 8) * 128 + ((psl ^ (ppx & 7)) << 4)) = i1;     // (px + 8k) & 7 == px & 7
-        *(u32x4_t*)(patch + (ppx + 16) * 128 + ((psl ^ (ppx & 7)) << 4)) = i2;
-        *(u32x4_t*)(patch + (ppx + 24) * 128 + ((psl ^ (ppx & 7)) << 4)) = i3;
-        if (q + 1 < NCHUNK) {     // next chunk's identity rows: issued before this chunk's stores
-            const unsigned short* rn = rp + CH * (q + 1);
-            load_row16(i0, rn); load_row16(i1, rn + 8 * C4); load_row16(i2, rn + 16 * C4); load_row16(i3, rn + 24 * C4);
-        }
-        // weights of chunk q + NBUF - 1 into the buffer chunk q - 1 used (free since this chunk's barrier); behind the identity loads
-        if (q + C::NBUF - 1 < NCHUNK) issue_chunk<N1>(rw3, rw1, smem_addr, (q + C::NBUF - 1) % C::NBUF, q + C::NBUF - 1, w, lane);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // ---- + identity (DMA'd into the patch in row layout), relu; x' chunk out; operand of conv1' ----------------------------------
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
 #pragma unroll
@@ -235,13 +232,19 @@ __global__ void __launch_bounds__(512, 2) bneck_tail_kernel(const Args a) {
             xq[2 * f + 1] = __builtin_bit_cast(bf16x8_t, make_uint4(u[4], u[5], u[6], u[7]));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int px = it * 8 + (lane >> 3), sl = lane & 7;
-            const uint4 v = *(const uint4*)(patch + px * 128 + ((sl ^ (px & 7)) << 4));
-            *(uint4*)(a.xo + (prow0 + px) * C4 + CH * q + sl * 8) = v;
+        // four named registers, not an array: behind "memory"-clobbering asm statements an array lives in scratch (bneck_fused.hip)
+        const int spx = lane >> 3, ssl = lane & 7;
+        const char* prd = patch + spx * 128 + ((ssl ^ (spx & 7)) << 4);       // (px + 8k) & 7 == px & 7
+        const uint4 x0 = *(const uint4*)(prd), x1 = *(const uint4*)(prd + 8 * 128), x2 = *(const uint4*)(prd + 16 * 128), x3 = *(const uint4*)(prd + 24 * 128);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the patch is free: the next chunk's identity rows may land in it
+        // in THIS order: identity of chunk q + 1, weights of chunk q + NBUF - 1 (into the buffer chunk q - 1 used, free since this
+        // chunk's barrier), and only then this chunk's stores -- nothing the next chunks wait for sits behind a store
+        if (q + 1 < NCHUNK) issue_identity(q + 1);
+        if (q + C::NBUF - 1 < NCHUNK) issue_chunk<N1>(rw3, rw1, smem_addr, (q + C::NBUF - 1) % C::NBUF, q + C::NBUF - 1, w, lane);
+        {
+            unsigned short* xp = a.xo + (prow0 + spx) * C4 + CH * q + ssl * 8;
+            *(uint4*)(xp) = x0; *(uint4*)(xp + 8 * C4) = x1; *(uint4*)(xp + 16 * C4) = x2; *(uint4*)(xp + 24 * C4) = x3;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the patch is rewritten by the next chunk
         // ---- conv1' of the next block, this chunk's 64 input channels: 4 k16 steps x NF fragments ------------------------------
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -298,6 +301,7 @@ extern "C" int GIM_FN(gim_bneck_tail128)(const void* t2, const void* res, void* 
     GIM_REQUIRE(n_next == 128 || n_next == 256, "bneck_tail128: n_next must be 128 or 256 (got %d)", n_next);
     GIM_REQUIRE(act_next == GIM_ACT_RELU || act_next == GIM_ACT_NONE, "bneck_tail128: activation of the next conv1 must be relu or none");
     GIM_REQUIRE(M > 0 && M % ROWS == 0, "bneck_tail128: the pixel row count must be a multiple of %d (got %d)", ROWS, M);
+    GIM_REQUIRE((int64_t)M * C4 * 2 < (int64_t)0xFFFFFFF0ll, "bneck_tail128: tensor too large for 32-bit buffer offsets");
     Args a;
     a.t2 = (const unsigned short*)t2; a.res = (const unsigned short*)res; a.xo = (unsigned short*)x_out; a.t1n = (unsigned short*)t1_next;
     a.w3 = (const unsigned short*)w3; a.w1n = (const unsigned short*)w1n; a.b3 = b3; a.b1n = b1n; a.M = M; a.act1 = act_next;

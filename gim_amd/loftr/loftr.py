@@ -289,8 +289,9 @@ class LoFTR(nn.Module):
             for bi, blk in enumerate(l1):   # the last block's trailing conv1 is layer2's first one (256 -> 128, same resolution)
                 P[f"l1.{bi}.fused"] = pack_bneck(blk, l1[bi + 1] if bi + 1 < len(l1) else enc.layer2[0], device, tdt)
             l2 = list(enc.layer2)
-            for bi in range(len(l2) - 1):   # layer 2: conv3 + identity + relu of block bi with conv1 of block bi + 1 (bneck_tail.hip)
-                P[f"l2.{bi}.tail"] = pack_bneck_tail(l2[bi], l2[bi + 1], device, tdt)
+            for bi in range(len(l2)):   # layer 2: conv3 + identity + relu of block bi with conv1 of block bi + 1 -- for the last
+                #                         block the first conv1 of layer 3 (512 -> 256, same resolution: the stride sits on conv2)
+                P[f"l2.{bi}.tail"] = pack_bneck_tail(l2[bi], l2[bi + 1] if bi + 1 < len(l2) else enc.layer3[0], device, tdt)
         bb = self.backbone
         P["l3o"] = pack_conv(bb.layer3_outconv.weight, None, dt, device)
         P["l2o"] = pack_conv(bb.layer2_outconv.weight, None, dt, device)

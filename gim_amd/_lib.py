@@ -83,6 +83,8 @@ PROTOTYPES = {
     "gim_bneck64_fused_f16": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p]),
     "gim_bneck_tail128": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
     "gim_bneck_tail128_f16": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
+    "gim_bneck_tail256": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
+    "gim_bneck_tail256_f16": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
     "gim_token_mlp_weight_bytes": (c_int64, []),
     "gim_token_mlp": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_float, c_void_p]),
     "gim_token_mlp_f16": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_float, c_void_p]),

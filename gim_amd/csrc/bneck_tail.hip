@@ -1,4 +1,4 @@
-// Tail of a ResNet Bottleneck fused with the head of the next block, planes P = 128 (layer 2 of the gim_loftr backbone,
+// Tail of a ResNet Bottleneck fused with the head of the next block, planes P = 128 / 256 (layers 2 and 3 of the gim_loftr backbone,
 // networks/loftr/backbone/resnet.py:109-126), for gfx950:
 //
 //     x'  = relu(bn3(conv3_1x1(t2)) + identity)        P -> 4P          (resnet.py:117-124)
@@ -13,8 +13,8 @@
 // product's B fragment -- conv1's K axis is packed in that accumulator order (packing.py::pack_bneck_tail).
 //
 // The weights (conv3 4P x P, conv1' N1 x 4P: 256 KiB at N1 = 128) do not fit LDS next to anything else, so they STREAM: the 4P
-// output channels of conv3 are walked in chunks of 64; chunk q needs W3[64q .. 64q+63][:] (16 KiB) and W1'[:, 64q .. 64q+63]
-// (16 / 32 KiB), fetched by LDS-DMA into a double buffer one chunk ahead (L2-resident after the first workgroups).  Per chunk and
+// output channels of conv3 are walked in chunks of CH = 64 (P = 128) or 32 (P = 256); chunk q needs W3[CH q .. CH q + CH - 1][:] (16 KiB)
+// and W1'[:, CH q .. CH q + CH - 1] (16 / 32 KiB), fetched by LDS-DMA into a ring of chunk buffers ahead of their use (L2-resident after the first workgroups).  Per chunk and
 // wave: 16 MFMAs of conv3, the + identity / relu / store of 64 channels of x', 16 (32) MFMAs of conv1'.
 //
 // Vector memory operations return IN ORDER: anything issued behind a store cannot be waited for without waiting for that
@@ -25,34 +25,37 @@
 
 namespace {
 
-constexpr int PT = 128;              // planes
-constexpr int C4 = 4 * PT;           // 512
-constexpr int CH = 64;               // conv3 output channels per chunk
-constexpr int NCHUNK = C4 / CH;      // 8
 constexpr int ROWS = 256;            // pixel rows per workgroup (8 waves x 32)
-constexpr int W3C = CH * PT * 2;     // bytes of a conv3 weight chunk: [64 rows][256 B]
-constexpr int PATCH = 4096;          // per-wave transposition patch [32 px][128 B]
 
-template <int N1> struct Cfg {
-    static constexpr int W1C = N1 * CH * 2;                  // conv1' weight chunk: [N1 rows][128 B]
+template <int P, int N1> struct Cfg {
+    static constexpr int C4 = 4 * P;
+    static constexpr int CH = P == 128 ? 64 : 32;            // conv3 output channels per chunk
+    static constexpr int NCHUNK = C4 / CH;                   // 8 / 32
+    static constexpr int W3ROW = P * 2;                      // bytes of a conv3 weight row (K = P): 256 / 512
+    static constexpr int W3C = CH * W3ROW;                   // 16 KiB
+    static constexpr int W1ROW = CH * 2;                     // bytes of a conv1' weight row of one chunk (K = CH): 128 / 64
+    static constexpr int W1C = N1 * W1ROW;                   // 16 / 32 KiB
     static constexpr int BUF = W3C + W1C;
-    static constexpr int NBUF = (3 * BUF + 8 * PATCH <= 160 * 1024) ? 3 : 2;   // weight chunks in LDS: fetched NBUF - 1 chunks ahead
+    static constexpr int PROW = CH * 2;                      // bytes of one pixel row of the per-wave patch: 128 / 64
+    static constexpr int PATCH = 32 * PROW;                  // [32 px][PROW]
+    static constexpr int NBUF = (3 * BUF + 8 * PATCH + (C4 + N1) * 4 <= 160 * 1024) ? 3 : 2;   // chunk buffers: NBUF - 1 chunks ahead
     static constexpr int OFF_PATCH = NBUF * BUF;
-    static constexpr int OFF_BIAS = OFF_PATCH + 8 * PATCH;   // b3 [512] then b1' [N1], fp32
+    static constexpr int OFF_BIAS = OFF_PATCH + 8 * PATCH;   // b3 [C4] then b1' [N1], fp32
     static constexpr int SMEM = OFF_BIAS + (C4 + N1) * 4;
     static constexpr int PIECES = BUF / 1024;                // LDS-DMA instructions per chunk (32 / 48)
     static constexpr int PPW = PIECES / 8;                   // ... per wave
-    static_assert(SMEM <= 160 * 1024 && PIECES % 8 == 0, "LDS map");
+    static constexpr int IPC = PATCH / 1024;                 // identity pieces (= x' stores) per wave and chunk: 4 / 2
+    static_assert(SMEM <= 160 * 1024 && PIECES % 8 == 0 && (P == 128 || P == 256), "LDS map");
 };
 
 struct Args {
-    const unsigned short* t2;    // [M][128]  conv2 output (after bn2 + relu)
-    const unsigned short* res;   // [M][512]  identity / downsample branch
-    unsigned short* xo;          // [M][512]  x'
+    const unsigned short* t2;    // [M][P]    conv2 output (after bn2 + relu)
+    const unsigned short* res;   // [M][4P]   identity / downsample branch
+    unsigned short* xo;          // [M][4P]   x'  (NULL: not stored -- nobody reads the last block's output but the fused conv1')
     unsigned short* t1n;         // [M][N1]   t1'
-    const unsigned short* w3;    // [512][128], K in natural channel order
-    const unsigned short* w1n;   // [8 chunks][N1][64], K of a chunk in accumulator order
-    const float* b3;             // [512]
+    const unsigned short* w3;    // [4P][P], K in natural channel order
+    const unsigned short* w1n;   // [chunks][N1][CH], K of a chunk in accumulator order
+    const float* b3;             // [4P]
     const float* b1n;            // [N1]
     int M;
     int act1;                    // activation of conv1': GIM_ACT_RELU (next block's conv1) or GIM_ACT_NONE
@@ -63,16 +66,14 @@ typedef __attribute__((address_space(3))) void lds_t;
 
 // One LDS-DMA instruction (64 lanes x 16 B -> 1 KiB at LDS byte address `lds_addr`, lane-linear) through inline asm: hipcc makes the
 // first LDS access behind a DMA it can see (__builtin_amdgcn_raw_ptr_buffer_load_lds) wait vmcnt(0) -- it assumes every ds_read /
-// ds_write may alias the DMA's destination -- which here would drain the two-chunks-ahead weight stream inside every chunk.
-// Invisible to the compiler, the DMA is counted by hand (TAIL_WAIT below).  M0 carries the LDS address and is written in the same
+// ds_write may alias the DMA's destination -- which here would drain the chunks-ahead weight stream inside every chunk.
+// Invisible to the compiler, the DMA is counted by hand (tail_wait below).  M0 carries the LDS address and is written in the same
 // statement that reads it (cdna_hip_programming.md section 5.7).
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void dma16(const u32x4_t rsrc, unsigned lds_addr, unsigned voff) {
     lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);   // wave-uniform by construction; the "s" constraint needs it provable
     // s_nop 4: the descriptor SGPRs come out of v_readfirstlane (VALU writes SGPR -> VMEM reads it: 5 wait states, which hipcc
-    // cannot insert for an instruction inside an asm string).  Without it the first pieces of a workgroup that starts on a CU with
-    // a warm instruction cache fetched through a stale descriptor: wrong weights in SOME tiles of SOME launches once the grid
-    // exceeded one workgroup per CU (tests/test_gpu_bneck_tail.py::test_bneck_tail_many_tiles_and_repeatability).
+    // cannot insert for an instruction inside an asm string)
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory", "m0");
 }
 __device__ __forceinline__ u32x4_t make_rsrc(const void* p, unsigned bytes) {
@@ -84,49 +85,66 @@ __device__ __forceinline__ u32x4_t make_rsrc(const void* p, unsigned bytes) {
     r[3] = 0x00020000u;
     return r;
 }
+template <int N> __device__ __forceinline__ void tail_wait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 
-// chunk q -> LDS buffer `buf`: this wave's share of the pieces.  W3 rows are 256 B = 16 slots, swizzled slot ^ (row & 15);
-// W1' rows are 128 B = 8 slots, swizzled slot ^ ((row >> 1) & 7).  LDS-DMA is lane-linear, so the swizzle is on the SOURCE slot.
-template <int N1>
+// LDS images (LDS-DMA is lane-linear, so every swizzle is applied to the SOURCE slot and again on the ds_read side):
+//   rows of 512 / 256 B (32 / 16 slots of 16 B): slot' = (slot & ~15) | ((slot & 15) ^ (row & 15))
+//   rows of 128 B (8 slots):  slot' = slot ^ ((row >> 1) & 7)          (two rows share a 256-byte bank row)
+//   rows of  64 B (4 slots):  slot' = slot ^ ((row >> 2) & 3)          (four rows share one)
+template <int ROWB> __device__ __forceinline__ int swz(int row, int slot) {
+    if constexpr (ROWB >= 256) return (slot & ~15) | ((slot & 15) ^ (row & 15));
+    else if constexpr (ROWB == 128) return slot ^ ((row >> 1) & 7);
+    else return slot ^ ((row >> 2) & 3);
+}
+// the per-wave patch [32 px][PROW]: slot' = slot ^ (px & 7) for 128-byte rows, slot ^ ((px >> 2) & 3) for 64-byte rows
+template <int PROW> __device__ __forceinline__ int pswz(int px, int slot) {
+    if constexpr (PROW == 128) return slot ^ (px & 7);
+    else return slot ^ ((px >> 2) & 3);
+}
+
+// chunk q -> LDS buffer `buf`: this wave's share of the pieces
+template <int P, int N1>
 __device__ __forceinline__ void issue_chunk(const u32x4_t rw3, const u32x4_t rw1, unsigned smem_addr, int buf, int q, int w, int lane) {
-    typedef Cfg<N1> C;
+    typedef Cfg<P, N1> C;
+    constexpr int S3 = C::W3ROW / 16, S1 = C::W1ROW / 16;   // slots per row
     const unsigned base = smem_addr + (unsigned)(buf * C::BUF);
 #pragma unroll
-    for (int k = 0; k < C::PIECES / 8; ++k) {
+    for (int k = 0; k < C::PPW; ++k) {
         const int pc = w + 8 * k;                          // wave-uniform piece index
-        if (pc < W3C / 1024) {
-            const int idx = pc * 64 + lane, n = idx >> 4, d = idx & 15;
-            const unsigned voff = (unsigned)((q * CH + n) * (PT * 2) + ((d ^ (n & 15)) << 4));
+        if (pc < C::W3C / 1024) {
+            const int idx = pc * 64 + lane, n = idx / S3, d = idx % S3;
+            const unsigned voff = (unsigned)((q * C::CH + n) * C::W3ROW + (swz<C::W3ROW>(n, d) << 4));
             dma16(rw3, base + (unsigned)(pc * 1024), voff);
         } else {
-            const int p1 = pc - W3C / 1024;
-            const int idx = p1 * 64 + lane, n = idx >> 3, d = idx & 7;
-            const unsigned voff = (unsigned)((q * N1 + n) * (CH * 2) + ((d ^ ((n >> 1) & 7)) << 4));
-            dma16(rw1, base + (unsigned)(W3C + p1 * 1024), voff);
+            const int p1 = pc - C::W3C / 1024;
+            const int idx = p1 * 64 + lane, n = idx / S1, d = idx % S1;
+            const unsigned voff = (unsigned)((q * N1 + n) * C::W1ROW + (swz<C::W1ROW>(n, d) << 4));
+            dma16(rw1, base + (unsigned)(C::W3C + p1 * 1024), voff);
         }
     }
 }
 
-// The identity rows take the same road as the weights: LDS-DMA straight into this wave's patch (row layout, XOR swizzle on the source
-// slot), issued through inline asm and counted by hand.  No vector memory load of the chunk loop has a VGPR destination: a load
-// hipcc can see beside LDS-DMA makes it wait vmcnt(0), and a load hidden in inline asm has its destination registers copied
-// (v_mov) by the register allocator BEFORE the hand-placed wait whenever the wait sits in more than one branch (measured: garbage
-// identity rows in some tiles of launches with more workgroups than CUs).
-#define TAIL_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
-
-template <int N1>
+// No vector memory load of the chunk loop has a VGPR destination -- the identity rows take the same road as the weights: LDS-DMA
+// straight into this wave's patch (row layout).  A load hipcc can see beside LDS-DMA makes it wait vmcnt(0); a load hidden in inline
+// asm has its destination registers copied (v_mov) by the register allocator BEFORE the hand-placed wait whenever that wait sits in
+// more than one branch (measured: garbage identity rows in some tiles of launches with more workgroups than CUs).
+template <int P, int N1>
 __global__ void __launch_bounds__(512, 2) bneck_tail_kernel(const Args a) {
-    typedef Cfg<N1> C;
+    typedef Cfg<P, N1> C;
+    constexpr int C4 = C::C4, CH = C::CH, NCHUNK = C::NCHUNK, PROW = C::PROW;
     constexpr int NF = N1 / 32;                            // conv1' output fragments per wave
+    constexpr int TF = CH / 32;                            // conv3 output fragments per chunk (2 / 1)
+    constexpr int LPP = PROW / 16;                         // lanes per pixel in row layout (8 / 4)
+    constexpr int PPI = 64 / LPP;                          // pixels per wave instruction in row layout (8 / 16)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t prow0 = (size_t)blockIdx.x * ROWS + w * 32;   // first pixel row of this wave
-    char* patch = smem + C::OFF_PATCH + w * PATCH;
+    char* patch = smem + C::OFF_PATCH + w * C::PATCH;
 
     const u32x4_t rw3 = make_rsrc(a.w3, a.w3_bytes), rw1 = make_rsrc(a.w1n, a.w1n_bytes);
     const unsigned smem_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_t*)smem);   // LDS byte address of the dynamic array
-    issue_chunk<N1>(rw3, rw1, smem_addr, 0, 0, w, lane);
+    issue_chunk<P, N1>(rw3, rw1, smem_addr, 0, 0, w, lane);
     // biases -> LDS (a global bias load inside the chunk loop makes the compiler wait vmcnt(0): it would drain the weight DMA)
     float* bias = (float*)(smem + C::OFF_BIAS);
     {
@@ -134,29 +152,30 @@ __global__ void __launch_bounds__(512, 2) bneck_tail_kernel(const Args a) {
         if (t < C4 / 4) *(float4*)(bias + 4 * t) = *(const float4*)(a.b3 + 4 * t);
         else if (t < (C4 + N1) / 4) *(float4*)(bias + 4 * t) = *(const float4*)(a.b1n + 4 * t - C4);
     }
-    // conv3's pixel operand: 8 k16 steps, lane (pixel l31, half lh) holds channels 16s + 8lh .. + 7
-    bf16x8_t t2[PT / 16];
+    // conv3's pixel operand: P / 16 k16 steps, lane (pixel l31, half lh) holds channels 16s + 8lh .. + 7
+    bf16x8_t t2[P / 16];
     {
-        const unsigned short* tp = a.t2 + (prow0 + l31) * PT + 8 * lh;
+        const unsigned short* tp = a.t2 + (prow0 + l31) * P + 8 * lh;
 #pragma unroll
-        for (int s = 0; s < PT / 16; ++s) t2[s] = *(const bf16x8_t*)(tp + 16 * s);
+        for (int s = 0; s < P / 16; ++s) t2[s] = *(const bf16x8_t*)(tp + 16 * s);
     }
-    // opaque to the optimiser from here on: left alone, hipcc RE-LOADS these 8 fragments from global memory in every chunk
-    // (rematerialisation beats 32 live VGPRs in its cost model) and waits vmcnt(0) for them -- draining the weight DMA each time
+    // opaque to the optimiser from here on: left alone, hipcc RE-LOADS these fragments from global memory in every chunk
+    // (rematerialisation beats the live VGPRs in its cost model) and waits vmcnt(0) for them -- draining the weight DMA each time
 #pragma unroll
-    for (int s = 0; s < PT / 16; ++s) asm volatile("" : "+v"(t2[s]));
-    // identity rows of chunk q: 32 px x 128 B = 4 pieces; lane i of piece k -> pixel 8k + (i >> 3), patch slot i & 7 <- source slot
-    // (i & 7) ^ (pixel & 7)
+    for (int s = 0; s < P / 16; ++s) asm volatile("" : "+v"(t2[s]));
+    // identity rows of chunk q: 32 px x PROW bytes = IPC pieces; lane i of piece k -> pixel PPI k + i / LPP, patch slot i % LPP <-
+    // source slot pswz(pixel, i % LPP)
     const u32x4_t rres = make_rsrc(a.res, (unsigned)((size_t)a.M * C4 * 2));
-    const unsigned patch_addr = smem_addr + (unsigned)(C::OFF_PATCH + w * PATCH);
-    const unsigned id_voff = (unsigned)((prow0 + (lane >> 3)) * (C4 * 2)) + (unsigned)((((lane & 7) ^ ((lane >> 3) & 7))) << 4);
+    const unsigned patch_addr = smem_addr + (unsigned)(C::OFF_PATCH + w * C::PATCH);
+    const int ipx = lane / LPP, isl = lane % LPP;
+    const unsigned id_voff = (unsigned)((prow0 + ipx) * (C4 * 2)) + (unsigned)(pswz<PROW>(ipx, isl) << 4);   // (px + PPI k) keeps its key
     auto issue_identity = [&](const int q) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dma16(rres, patch_addr + (unsigned)(k * 1024), id_voff + (unsigned)(k * 8 * C4 * 2 + q * CH * 2));
+        for (int k = 0; k < C::IPC; ++k) dma16(rres, patch_addr + (unsigned)(k * 1024), id_voff + (unsigned)(k * PPI * C4 * 2 + q * CH * 2));
     };
     issue_identity(0);
-    if constexpr (C::NBUF == 3) issue_chunk<N1>(rw3, rw1, smem_addr, 1, 1, w, lane);   // behind what chunk 0 needs: may stay in flight
-    __syncthreads();             // biases are in LDS (the compiler knows nothing of the DMA / identity loads in flight: no drain)
+    if constexpr (C::NBUF == 3) issue_chunk<P, N1>(rw3, rw1, smem_addr, 1, 1, w, lane);   // behind what chunk 0 needs: may stay in flight
+    __syncthreads();             // biases are in LDS (the compiler knows nothing of the DMA in flight: no drain)
 
     f32x16_t c1[NF];
 #pragma unroll
@@ -170,26 +189,21 @@ __global__ void __launch_bounds__(512, 2) bneck_tail_kernel(const Args a) {
 
 #pragma unroll 1
     for (int q = 0; q < NCHUNK; ++q) {
-        // chunk q's weights (this wave's pieces) and identity rows have landed.  Younger operations that may fly on: the four stores
+        // chunk q's weights (this wave's pieces) and identity rows have landed.  Younger operations that may fly on: the IPC stores
         // of the previous chunk and, with three buffers, the weight DMA of chunk q + 1 (issued behind the identity DMA of chunk q).
         // The count must be exact -- vmcnt(n) only guarantees that all but the n YOUNGEST operations are complete.
         const bool dma_ahead = C::NBUF == 3 && q + 1 < NCHUNK;
-        static_assert(C::PPW == 4 || C::PPW == 6, "the counted waits below spell out PPW and PPW + 4");
-        if (q == 0) {
-            if (dma_ahead) { if constexpr (C::PPW == 4) TAIL_WAIT(4); else TAIL_WAIT(6); }
-            else TAIL_WAIT(0);
-        } else {
-            if (dma_ahead) { if constexpr (C::PPW == 4) TAIL_WAIT(8); else TAIL_WAIT(10); }
-            else TAIL_WAIT(4);
-        }
+        const bool stores_behind = q > 0 && a.xo != nullptr;
+        if (dma_ahead) { if (stores_behind) tail_wait<C::PPW + C::IPC>(); else tail_wait<C::PPW>(); }
+        else { if (stores_behind) tail_wait<C::IPC>(); else tail_wait<0>(); }
         __syncthreads();          // everybody's pieces are visible, and everybody is done with the buffer of chunk q - 1
         const char* wb3 = smem + (q % C::NBUF) * C::BUF;
-        const char* wb1 = wb3 + W3C;
+        const char* wb1 = wb3 + C::W3C;
 
-        // ---- conv3, 64 output channels: D[m = channel][n = pixel] over K = 128 ------------------------------------------
-        f32x16_t c3[2];
+        // ---- conv3, CH output channels: D[m = channel][n = pixel] over K = P ---------------------------------------------------
+        f32x16_t c3[TF];
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
+        for (int f = 0; f < TF; ++f) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const float4 bb = *(const float4*)(bias + q * CH + 32 * f + 8 * rg + 4 * lh);
@@ -197,20 +211,20 @@ __global__ void __launch_bounds__(512, 2) bneck_tail_kernel(const Args a) {
             }
         }
 #pragma unroll
-        for (int s = 0; s < PT / 16; ++s) {
+        for (int s = 0; s < P / 16; ++s) {
 #pragma unroll
-            for (int f = 0; f < 2; ++f) {
+            for (int f = 0; f < TF; ++f) {
                 const int n = 32 * f + l31;
-                const bf16x8_t wv = *(const bf16x8_t*)(wb3 + n * (PT * 2) + (((2 * s + lh) ^ (n & 15)) << 4));
+                const bf16x8_t wv = *(const bf16x8_t*)(wb3 + n * C::W3ROW + (swz<C::W3ROW>(n, 2 * s + lh) << 4));
                 c3[f] = mfma_h16_32x32x16(wv, t2[s], c3[f]);
             }
         }
         // ---- + identity (DMA'd into the patch in row layout), relu; x' chunk out; operand of conv1' ----------------------------------
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
+        for (int f = 0; f < TF; ++f) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const uint2 r = *(const uint2*)(patch + l31 * 128 + (((4 * f + rg) ^ (l31 & 7)) << 4) + lh * 8);
+                const uint2 r = *(const uint2*)(patch + l31 * PROW + (pswz<PROW>(l31, 4 * f + rg) << 4) + lh * 8);
                 c3[f][rg * 4] = fmaxf(c3[f][rg * 4] + h16_lo(r.x), 0.f);
                 c3[f][rg * 4 + 1] = fmaxf(c3[f][rg * 4 + 1] + h16_hi(r.x), 0.f);
                 c3[f][rg * 4 + 2] = fmaxf(c3[f][rg * 4 + 2] + h16_lo(r.y), 0.f);
@@ -218,45 +232,49 @@ __global__ void __launch_bounds__(512, 2) bneck_tail_kernel(const Args a) {
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        bf16x8_t xq[4];   // conv1' operand of this chunk: k16 step s = 2f + t (accumulator order)
+        bf16x8_t xq[2 * TF];   // conv1' operand of this chunk: k16 step s = 2f + t (accumulator order)
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
+        for (int f = 0; f < TF; ++f) {
             unsigned u[8];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 u[2 * rg] = cvt_pk_h16(c3[f][rg * 4], c3[f][rg * 4 + 1]);
                 u[2 * rg + 1] = cvt_pk_h16(c3[f][rg * 4 + 2], c3[f][rg * 4 + 3]);
-                *(uint2*)(patch + l31 * 128 + (((4 * f + rg) ^ (l31 & 7)) << 4) + lh * 8) = make_uint2(u[2 * rg], u[2 * rg + 1]);
+                *(uint2*)(patch + l31 * PROW + (pswz<PROW>(l31, 4 * f + rg) << 4) + lh * 8) = make_uint2(u[2 * rg], u[2 * rg + 1]);
             }
             xq[2 * f] = __builtin_bit_cast(bf16x8_t, make_uint4(u[0], u[1], u[2], u[3]));
             xq[2 * f + 1] = __builtin_bit_cast(bf16x8_t, make_uint4(u[4], u[5], u[6], u[7]));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // four named registers, not an array: behind "memory"-clobbering asm statements an array lives in scratch (bneck_fused.hip)
-        const int spx = lane >> 3, ssl = lane & 7;
-        const char* prd = patch + spx * 128 + ((ssl ^ (spx & 7)) << 4);       // (px + 8k) & 7 == px & 7
-        const uint4 x0 = *(const uint4*)(prd), x1 = *(const uint4*)(prd + 8 * 128), x2 = *(const uint4*)(prd + 16 * 128), x3 = *(const uint4*)(prd + 24 * 128);
+        // named registers, not an array: behind "memory"-clobbering asm statements an array lives in scratch (bneck_fused.hip)
+        const char* prd = patch + ipx * PROW + (pswz<PROW>(ipx, isl) << 4);       // row layout: pixel ipx + PPI k keeps its key
+        uint4 x0 = *(const uint4*)(prd), x1 = *(const uint4*)(prd + PPI * PROW), x2 = x0, x3 = x0;
+        if constexpr (C::IPC == 4) { x2 = *(const uint4*)(prd + 2 * PPI * PROW); x3 = *(const uint4*)(prd + 3 * PPI * PROW); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the patch is free: the next chunk's identity rows may land in it
         // in THIS order: identity of chunk q + 1, weights of chunk q + NBUF - 1 (into the buffer chunk q - 1 used, free since this
         // chunk's barrier), and only then this chunk's stores -- nothing the next chunks wait for sits behind a store
         if (q + 1 < NCHUNK) issue_identity(q + 1);
-        if (q + C::NBUF - 1 < NCHUNK) issue_chunk<N1>(rw3, rw1, smem_addr, (q + C::NBUF - 1) % C::NBUF, q + C::NBUF - 1, w, lane);
-        {
-            unsigned short* xp = a.xo + (prow0 + spx) * C4 + CH * q + ssl * 8;
-            *(uint4*)(xp) = x0; *(uint4*)(xp + 8 * C4) = x1; *(uint4*)(xp + 16 * C4) = x2; *(uint4*)(xp + 24 * C4) = x3;
+        if (q + C::NBUF - 1 < NCHUNK) issue_chunk<P, N1>(rw3, rw1, smem_addr, (q + C::NBUF - 1) % C::NBUF, q + C::NBUF - 1, w, lane);
+        if (a.xo != nullptr) {
+            unsigned short* xp = a.xo + (prow0 + ipx) * C4 + CH * q + isl * 8;
+            *(uint4*)(xp) = x0; *(uint4*)(xp + (size_t)PPI * C4) = x1;
+            if constexpr (C::IPC == 4) { *(uint4*)(xp + (size_t)2 * PPI * C4) = x2; *(uint4*)(xp + (size_t)3 * PPI * C4) = x3; }
         }
-        // ---- conv1' of the next block, this chunk's 64 input channels: 4 k16 steps x NF fragments ------------------------------
+        // ---- conv1' of the next block, this chunk's CH input channels: CH / 16 k16 steps x NF fragments ------------------------------
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < 2 * TF; ++s) {
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 const int n = 32 * f + l31;
-                const bf16x8_t wv = *(const bf16x8_t*)(wb1 + n * (CH * 2) + (((2 * s + lh) ^ ((n >> 1) & 7)) << 4));
+                const bf16x8_t wv = *(const bf16x8_t*)(wb1 + n * C::W1ROW + (swz<C::W1ROW>(n, 2 * s + lh) << 4));
                 c1[f] = mfma_h16_32x32x16(wv, xq[s], c1[f]);
             }
         }
     }
-    // ---- t1' out: 64 channels per pass through the patch ------------------------------------------------------------------------
+    // ---- t1' out: 64 channels per pass through a [32 px][128 B] transposition tile.  The per-wave patch is only 2 KiB when P = 256,
+    // so every wave takes 4 KiB of the (now idle) weight ring instead ---------------------------------------------------------------
+    __syncthreads();             // all waves are past their last weight reads and no DMA is in flight: the ring is free
+    char* opatch = smem + w * 4096;
     const bool relu1 = a.act1 == GIM_ACT_RELU;
 #pragma unroll
     for (int h2 = 0; h2 < NF / 2; ++h2) {
@@ -266,45 +284,60 @@ __global__ void __launch_bounds__(512, 2) bneck_tail_kernel(const Args a) {
             for (int rg = 0; rg < 4; ++rg) {
                 const f32x16_t& c = c1[2 * h2 + ff];
                 const float lo = relu1 ? 0.f : -INFINITY;
-                *(uint2*)(patch + l31 * 128 + (((4 * ff + rg) ^ (l31 & 7)) << 4) + lh * 8) =
+                *(uint2*)(opatch + l31 * 128 + (((4 * ff + rg) ^ (l31 & 7)) << 4) + lh * 8) =
                     make_uint2(cvt_pk_h16(fmaxf(c[rg * 4], lo), fmaxf(c[rg * 4 + 1], lo)), cvt_pk_h16(fmaxf(c[rg * 4 + 2], lo), fmaxf(c[rg * 4 + 3], lo)));
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int px = it * 8 + (lane >> 3), sl = lane & 7;
-            const uint4 v = *(const uint4*)(patch + px * 128 + ((sl ^ (px & 7)) << 4));
+            const uint4 v = *(const uint4*)(opatch + px * 128 + ((sl ^ (px & 7)) << 4));
             *(uint4*)(a.t1n + (prow0 + px) * N1 + 64 * h2 + sl * 8) = v;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
 
-template <int N1>
+template <int P, int N1>
 int launch_tail(const Args& a, hipStream_t s) {
-    typedef Cfg<N1> C;
+    typedef Cfg<P, N1> C;
     static GimPerDevice attr;
     if (attr.needed()) {
-        hipError_t e = hipFuncSetAttribute((const void*)bneck_tail_kernel<N1>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        hipError_t e = hipFuncSetAttribute((const void*)bneck_tail_kernel<P, N1>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
         if (e != hipSuccess) { gim_set_error("bneck_tail: hipFuncSetAttribute(%d B LDS): %s", C::SMEM, hipGetErrorString(e)); return GIM_ERR_LAUNCH; }
         attr.done();
     }
-    hipLaunchKernelGGL(bneck_tail_kernel<N1>, dim3((unsigned)(a.M / ROWS)), dim3(512), C::SMEM, s, a);
+    hipLaunchKernelGGL((bneck_tail_kernel<P, N1>), dim3((unsigned)(a.M / ROWS)), dim3(512), C::SMEM, s, a);
     return gim_check_launch("bneck_tail");
+}
+
+int tail_entry(int P, const void* t2, const void* res, void* x_out, void* t1_next, const void* w3, const void* w1n,
+               const float* b3, const float* b1n, int M, int n_next, int act_next, gim_stream_t stream) {
+    GIM_REQUIRE(t2 && res && t1_next && w3 && w1n && b3 && b1n, "bneck_tail: NULL pointer");
+    GIM_REQUIRE(act_next == GIM_ACT_RELU || act_next == GIM_ACT_NONE, "bneck_tail: activation of the next conv1 must be relu or none");
+    GIM_REQUIRE(M > 0 && M % ROWS == 0, "bneck_tail: the pixel row count must be a multiple of %d (got %d)", ROWS, M);
+    GIM_REQUIRE((int64_t)M * 4 * P * 2 < (int64_t)0xFFFFFFF0ll, "bneck_tail: tensor too large for 32-bit buffer offsets");
+    Args a;
+    a.t2 = (const unsigned short*)t2; a.res = (const unsigned short*)res; a.xo = (unsigned short*)x_out; a.t1n = (unsigned short*)t1_next;
+    a.w3 = (const unsigned short*)w3; a.w1n = (const unsigned short*)w1n; a.b3 = b3; a.b1n = b1n; a.M = M; a.act1 = act_next;
+    a.w3_bytes = (unsigned)(4 * P * P * 2); a.w1n_bytes = (unsigned)(n_next * 4 * P * 2);
+    if (P == 128) {
+        GIM_REQUIRE(n_next == 128 || n_next == 256, "bneck_tail128: n_next must be 128 or 256 (got %d)", n_next);
+        return n_next == 128 ? launch_tail<128, 128>(a, (hipStream_t)stream) : launch_tail<128, 256>(a, (hipStream_t)stream);
+    }
+    GIM_REQUIRE(n_next == 256, "bneck_tail256: n_next must be 256 (got %d)", n_next);
+    return launch_tail<256, 256>(a, (hipStream_t)stream);
 }
 
 }  // namespace
 
 extern "C" int GIM_FN(gim_bneck_tail128)(const void* t2, const void* res, void* x_out, void* t1_next, const void* w3, const void* w1n,
                                          const float* b3, const float* b1n, int M, int n_next, int act_next, gim_stream_t stream) {
-    GIM_REQUIRE(t2 && res && x_out && t1_next && w3 && w1n && b3 && b1n, "bneck_tail128: NULL pointer");
-    GIM_REQUIRE(n_next == 128 || n_next == 256, "bneck_tail128: n_next must be 128 or 256 (got %d)", n_next);
-    GIM_REQUIRE(act_next == GIM_ACT_RELU || act_next == GIM_ACT_NONE, "bneck_tail128: activation of the next conv1 must be relu or none");
-    GIM_REQUIRE(M > 0 && M % ROWS == 0, "bneck_tail128: the pixel row count must be a multiple of %d (got %d)", ROWS, M);
-    GIM_REQUIRE((int64_t)M * C4 * 2 < (int64_t)0xFFFFFFF0ll, "bneck_tail128: tensor too large for 32-bit buffer offsets");
-    Args a;
-    a.t2 = (const unsigned short*)t2; a.res = (const unsigned short*)res; a.xo = (unsigned short*)x_out; a.t1n = (unsigned short*)t1_next;
-    a.w3 = (const unsigned short*)w3; a.w1n = (const unsigned short*)w1n; a.b3 = b3; a.b1n = b1n; a.M = M; a.act1 = act_next;
-    a.w3_bytes = C4 * PT * 2; a.w1n_bytes = (unsigned)n_next * C4 * 2;
-    return n_next == 128 ? launch_tail<128>(a, (hipStream_t)stream) : launch_tail<256>(a, (hipStream_t)stream);
+    GIM_REQUIRE(x_out, "bneck_tail128: NULL x_out");
+    return tail_entry(128, t2, res, x_out, t1_next, w3, w1n, b3, b1n, M, n_next, act_next, stream);
+}
+
+extern "C" int GIM_FN(gim_bneck_tail256)(const void* t2, const void* res, void* x_out, void* t1_next, const void* w3, const void* w1n,
+                                         const float* b3, const float* b1n, int M, int n_next, int act_next, gim_stream_t stream) {
+    return tail_entry(256, t2, res, x_out, t1_next, w3, w1n, b3, b1n, M, n_next, act_next, stream);
 }

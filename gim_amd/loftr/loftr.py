@@ -288,10 +288,18 @@ class LoFTR(nn.Module):
             l1 = list(enc.layer1)
             for bi, blk in enumerate(l1):   # the last block's trailing conv1 is layer2's first one (256 -> 128, same resolution)
                 P[f"l1.{bi}.fused"] = pack_bneck(blk, l1[bi + 1] if bi + 1 < len(l1) else enc.layer2[0], device, tdt)
-            l2 = list(enc.layer2)
-            for bi in range(len(l2)):   # layer 2: conv3 + identity + relu of block bi with conv1 of block bi + 1 -- for the last
-                #                         block the first conv1 of layer 3 (512 -> 256, same resolution: the stride sits on conv2)
-                P[f"l2.{bi}.tail"] = pack_bneck_tail(l2[bi], l2[bi + 1] if bi + 1 < len(l2) else enc.layer3[0], device, tdt)
+            # layers 2 / 3: conv3 + identity + relu of block bi with the 1x1 convolution that reads its output next (bneck_tail.hip):
+            # the next block's conv1; for layer 2's last block the first conv1 of layer 3 (512 -> 256, same resolution: the stride sits
+            # on conv2); for layer 3's last block the FPN's layer3_outconv (no BatchNorm, no activation)
+            l2, l3 = list(enc.layer2), list(enc.layer3)
+            for bi in range(len(l2)):
+                nx = l2[bi + 1] if bi + 1 < len(l2) else l3[0]
+                P[f"l2.{bi}.tail"] = pack_bneck_tail(l2[bi], nx.conv1, nx.bn1, device, tdt)
+            for bi in range(len(l3)):
+                if bi + 1 < len(l3):
+                    P[f"l3.{bi}.tail"] = pack_bneck_tail(l3[bi], l3[bi + 1].conv1, l3[bi + 1].bn1, device, tdt)
+                else:
+                    P[f"l3.{bi}.tail"] = pack_bneck_tail(l3[bi], self.backbone.layer3_outconv, None, device, tdt)
         bb = self.backbone
         P["l3o"] = pack_conv(bb.layer3_outconv.weight, None, dt, device)
         P["l2o"] = pack_conv(bb.layer2_outconv.weight, None, dt, device)
@@ -364,6 +372,7 @@ class LoFTR(nn.Module):
         dma = self.use_lds_dma
         x = ops.conv2d(x, P["stem"], ACT_RELU, out_dtype=torch_dtype(dt), lds_dma=dma)   # image dtype may be fp16 in bf16 mode
         feats = []
+        x3_out = None   # produced by the last block's fused tail when that path is taken
         o = None   # conv1 output of the upcoming block when the previous fused kernel already produced it
         for li, nblk in ((1, 3), (2, 4), (3, 6)):
             fuse = li == 1 and self.bneck_fused and "l1.0.fused" in P and x.shape[1] % 8 == 0 and x.shape[2] % 32 == 0
@@ -377,13 +386,18 @@ class LoFTR(nn.Module):
                     continue
                 o = ops.conv2d(o, P[p + "c2"], ACT_RELU, lds_dma=dma)
                 if self.bneck_tail and (p + "tail") in P and (o.shape[0] * o.shape[1] * o.shape[2]) % 256 == 0:
-                    x, o = ops.bneck_tail(o, idn.contiguous(), P[p + "tail"])   # x' and the next block's conv1 output
+                    if li == 3 and bi == nblk - 1:   # last block: t1' IS x3_out (layer3_outconv), x3 itself is read by nothing else
+                        x, x3_out = ops.bneck_tail(o, idn.contiguous(), P[p + "tail"], ACT_NONE, store_x=self.debug is not None)
+                        o = None
+                    else:
+                        x, o = ops.bneck_tail(o, idn.contiguous(), P[p + "tail"])   # x' and the next block's conv1 output
                     continue
                 x = ops.conv2d(o, P[p + "c3"], ACT_RELU, res=idn, lds_dma=dma)
                 o = None
             feats.append(x)
         x1, x2, x3 = feats
-        x3_out = ops.conv2d(x3, P["l3o"], lds_dma=dma)
+        if x3_out is None:
+            x3_out = ops.conv2d(x3, P["l3o"], lds_dma=dma)
         # lateral 1x1 conv + F.interpolate(scale_factor=2, bilinear, align_corners=True) of the coarser level + add (resnet.py:
         # 321-327): the upsample-add runs in the conv's epilogue when the launch takes it, else as a second pass over the output
         x2_out = ops.conv2d(x2, P["l2o"], lds_dma=dma, ups=x3_out)

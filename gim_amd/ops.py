@@ -401,21 +401,23 @@ def bneck64(t1, res, pk, want_next):
     return xo, t1n
 
 
-def bneck_tail(t2, res, pk, act_next=ACT_RELU):
-    """Layer-2 Bottleneck tail + the next block's conv1 in one launch: t2 [B,H,W,128], res [B,H,W,512] (same 16-bit dtype) ->
-    (x' [B,H,W,512], t1' [B,H,W,N1]); pk = packing.pack_bneck_tail(...).  B*H*W must be a multiple of 256."""
+def bneck_tail(t2, res, pk, act_next=ACT_RELU, store_x=True):
+    """Bottleneck tail + the next 1x1 convolution in one launch (planes P = 128: layer 2, P = 256: layer 3): t2 [B,H,W,P], res
+    [B,H,W,4P] (same 16-bit dtype) -> (x' [B,H,W,4P] or None when store_x is False, t1' [B,H,W,N1]); pk = packing.pack_bneck_tail(...).
+    B*H*W must be a multiple of 256."""
     _req_cuda(t2, res)
     assert t2.dtype in HALF and res.dtype == t2.dtype and t2.is_contiguous() and res.is_contiguous()
     w3, w1n, b3, b1n = pk
     assert w3.dtype == t2.dtype, "bneck_tail: weights packed for the other 16-bit kind"
-    B, H, W, _ = t2.shape
+    B, H, W, pl = t2.shape
     M, n1 = B * H * W, w1n.shape[1]
-    assert t2.shape[3] == 128 and res.shape == (B, H, W, 512) and M % 256 == 0
-    xo = torch.empty(B, H, W, 512, dtype=t2.dtype, device=t2.device)
+    assert pl in (128, 256) and w3.shape == (4 * pl, pl) and res.shape == (B, H, W, 4 * pl) and M % 256 == 0
+    assert store_x or pl == 256
+    xo = torch.empty(B, H, W, 4 * pl, dtype=t2.dtype, device=t2.device) if store_x else None
     t1n = torch.empty(B, H, W, n1, dtype=t2.dtype, device=t2.device)
-    fn = lib.gim_bneck_tail128_f16 if t2.dtype == torch.float16 else lib.gim_bneck_tail128
-    with _Timed("bneck_tail", 2.0 * M * (128 * 512 + 512 * n1)):
-        check(fn(_p(t2), _p(res), _p(xo), _p(t1n), _p(w3), _p(w1n), _p(b3), _p(b1n), M, n1, act_next, _stream()), "gim_bneck_tail128")
+    name = "gim_bneck_tail%d%s" % (pl, "_f16" if t2.dtype == torch.float16 else "")
+    with _Timed("bneck_tail", 2.0 * M * (pl * 4 * pl + 4 * pl * n1)):
+        check(getattr(lib, name)(_p(t2), _p(res), _p(xo), _p(t1n), _p(w3), _p(w1n), _p(b3), _p(b1n), M, n1, act_next, _stream()), name)
     return xo, t1n
 
 

@@ -262,15 +262,21 @@ def pack_bneck(blk, nxt, device, tdt=torch.bfloat16):
     return w2p, w3p, w1p, b2.float().to(device).contiguous(), b3.float().to(device).contiguous(), b1
 
 
-def pack_bneck_tail(blk, nxt, device, tdt=torch.bfloat16):
-    """gim_bneck_tail128 operands: conv3 / bn3 of Bottleneck `blk` (planes 128) and conv1 / bn1 of the next block `nxt`:
-    (w3 [512][128] K in channel order, w1n [8][N1][64] -- per 64-channel chunk of x' the K axis in accumulator order --, b3, b1n fp32)."""
+def pack_bneck_tail(blk, next_conv, next_bn, device, tdt=torch.bfloat16):
+    """gim_bneck_tail128 / 256 operands: conv3 / bn3 of Bottleneck `blk` (planes P = 128 or 256) and the 1x1 convolution that consumes
+    the block's output next -- the following block's conv1 with its bn1, or (last block of layer 3) the FPN's layer3_outconv, which has
+    no BatchNorm (next_bn = None):
+    (w3 [4P][P] K in channel order, w1n [chunks][N1][CH] -- per CH-channel chunk of x' the K axis in accumulator order, CH = 64 for
+    P = 128, 32 for P = 256 --, b3, b1n fp32)."""
     bn = lambda m: (m.weight, m.bias, m.running_mean, m.running_var, m.eps)  # noqa: E731
     w3, b3 = fold_bn(blk.conv3.weight, bn(blk.bn3))
-    w1, b1 = fold_bn(nxt.conv1.weight, bn(nxt.bn1))
+    w1, b1 = fold_bn(next_conv.weight, bn(next_bn) if next_bn is not None else None)
+    c4, pl = w3.shape[0], w3.shape[1]
     n1 = w1.shape[0]
-    assert tuple(w3.shape) == (512, 128, 1, 1) and tuple(w1.shape) == (n1, 512, 1, 1) and n1 in (128, 256)
+    assert pl in (128, 256) and c4 == 4 * pl and tuple(w1.shape) == (n1, c4, 1, 1) and n1 in ((128, 256) if pl == 128 else (256,))
+    ch = 64 if pl == 128 else 32
     to = lambda t: t.to(device).to(tdt).contiguous()  # noqa: E731
-    w3p = to(w3.reshape(512, 128).cpu())
-    w1c = w1.reshape(n1, 8, 64).cpu()[:, :, _acc_order(64)].permute(1, 0, 2)       # [chunk][n1][64]
+    w3p = to(w3.reshape(c4, pl).cpu())
+    w1c = w1.reshape(n1, c4 // ch, ch).cpu()[:, :, _acc_order(ch)].permute(1, 0, 2)       # [chunk][n1][ch]
+    b1 = b1 if b1 is not None else torch.zeros(n1)
     return w3p, to(w1c), b3.float().to(device).contiguous(), b1.float().to(device).contiguous()

@@ -193,6 +193,13 @@ int gim_bneck_tail128(const void* t2, const void* res, void* x_out, void* t1_nex
                       const float* b3, const float* b1n, int M, int n_next, int act_next, gim_stream_t stream);
 int gim_bneck_tail128_f16(const void* t2, const void* res, void* x_out, void* t1_next, const void* w3, const void* w1n,
                           const float* b3, const float* b1n, int M, int n_next, int act_next, gim_stream_t stream);
+/* Planes 256 (layer 3): t2 [M,256], res / x_out [M,1024], t1_next [M,256] (n_next = 256); w3 [1024][256], w1n [32][256][32] (chunks of
+ * 32 channels).  x_out may be NULL: the last block's output is read by nothing but the fused 1x1 convolution -- the FPN's
+ * layer3_outconv (resnet.py:316), act_next = GIM_ACT_NONE, zero bias -- so it is never written. */
+int gim_bneck_tail256(const void* t2, const void* res, void* x_out, void* t1_next, const void* w3, const void* w1n,
+                      const float* b3, const float* b1n, int M, int n_next, int act_next, gim_stream_t stream);
+int gim_bneck_tail256_f16(const void* t2, const void* res, void* x_out, void* t1_next, const void* w3, const void* w1n,
+                          const float* b3, const float* b1n, int M, int n_next, int act_next, gim_stream_t stream);
 
 /* Token-wise tail of a LoFTREncoderLayer in ONE kernel (bf16 operand mode, d_model 256; transformer.py:52-58):
  *     x += norm2(mlp.2(relu(mlp.0(cat[x, norm1(merge(msg))]))))

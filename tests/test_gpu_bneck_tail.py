@@ -11,10 +11,10 @@ KINDS = [torch.bfloat16, torch.float16]
 KIDS = ["bf16", "fp16"]
 
 
-def _blocks(seed, n1):
+def _blocks(seed, n1, planes=128):
     from gim_amd.loftr.loftr import _Bottleneck
     torch.manual_seed(seed)
-    blk, nxt = _Bottleneck(512, 128, 1, None), _Bottleneck(512, n1, 1, None)
+    blk, nxt = _Bottleneck(4 * planes, planes, 1, None), _Bottleneck(4 * planes, n1, 1, None)
     with torch.no_grad():
         for m in list(blk.modules()) + list(nxt.modules()):
             if isinstance(m, torch.nn.Conv2d):
@@ -27,33 +27,42 @@ def _blocks(seed, n1):
     return blk.eval(), nxt.eval()
 
 
-def _ref(blk, nxt, t2, res, tdt):
+def _ref(blk, nxt, t2, res, tdt, plain_next=False):
+    """plain_next: the next convolution has no BatchNorm and no activation (the FPN's layer3_outconv behind layer 3's last block)"""
     from gim_amd.packing import fold_bn
     r = lambda t: t.to(tdt).float()  # noqa: E731
     bn = lambda m: (m.weight, m.bias, m.running_mean, m.running_var, m.eps)  # noqa: E731
     w3, b3 = fold_bn(blk.conv3.weight, bn(blk.bn3))
-    w1, b1 = fold_bn(nxt.conv1.weight, bn(nxt.bn1))
+    w1, b1 = fold_bn(nxt.conv1.weight, None if plain_next else bn(nxt.bn1))
     x = F.relu(F.conv2d(t2, r(w3), b3) + res)
-    return x, F.relu(F.conv2d(r(x), r(w1), b1))
+    t1 = F.conv2d(r(x), r(w1), b1)
+    return x, (t1 if plain_next else F.relu(t1))
 
 
 @pytest.mark.parametrize("tdt", KINDS, ids=KIDS)
-@pytest.mark.parametrize("B,H,W,n1", [(1, 8, 32, 128), (2, 24, 64, 128), (3, 16, 80, 128), (1, 16, 48, 256)])
-def test_bneck_tail_matches_reference(B, H, W, n1, tdt):
+@pytest.mark.parametrize("B,H,W,planes,n1,plain", [(1, 8, 32, 128, 128, False), (2, 24, 64, 128, 128, False), (3, 16, 80, 128, 128, False),
+                                                   (1, 16, 48, 128, 256, False), (1, 8, 32, 256, 256, False), (2, 16, 40, 256, 256, False),
+                                                   (1, 16, 32, 256, 256, True)])
+def test_bneck_tail_matches_reference(B, H, W, planes, n1, plain, tdt):
+    """planes 128 = layer 2 (chunks of 64 channels), 256 = layer 3 (chunks of 32); plain = layer3_outconv as the next convolution
+    (no BatchNorm, no activation) with x' not stored"""
     from gim_amd import ops
     from gim_amd.packing import pack_bneck_tail
-    blk, nxt = _blocks(H + W, n1)
+    blk, nxt = _blocks(H + W, n1, planes)
     g = torch.Generator().manual_seed(B * H + n1)
-    t2 = F.relu(torch.randn(B, 128, H, W, generator=g)).to(tdt)        # post-ReLU like the real conv2 output
-    res = torch.randn(B, 512, H, W, generator=g).to(tdt)
+    t2 = F.relu(torch.randn(B, planes, H, W, generator=g)).to(tdt)        # post-ReLU like the real conv2 output
+    res = torch.randn(B, 4 * planes, H, W, generator=g).to(tdt)
     with torch.no_grad():
-        x_ref, t1_ref = _ref(blk, nxt, t2.float(), res.float(), tdt)
-    pk = pack_bneck_tail(blk, nxt, "cuda", tdt)
+        x_ref, t1_ref = _ref(blk, nxt, t2.float(), res.float(), tdt, plain)
+    pk = pack_bneck_tail(blk, nxt.conv1, None if plain else nxt.bn1, "cuda", tdt)
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()  # noqa: E731
-    xo, t1n = ops.bneck_tail(nhwc(t2), nhwc(res), pk)
+    xo, t1n = ops.bneck_tail(nhwc(t2), nhwc(res), pk, ops.ACT_NONE if plain else ops.ACT_RELU, store_x=not plain)
     torch.cuda.synchronize()
     k = 1.0 if tdt == torch.bfloat16 else 0.25
+    assert plain == (xo is None)
     for got, ref, nm in ((xo, x_ref, "x'"), (t1n, t1_ref, "t1'")):
+        if got is None:
+            continue
         got = got.float().cpu().permute(0, 3, 1, 2)
         assert torch.isfinite(got).all(), nm
         sc = ref.abs().max().item()
@@ -61,16 +70,18 @@ def test_bneck_tail_matches_reference(B, H, W, n1, tdt):
         assert err.max().item() < 2e-2 * k * sc and err.mean().item() < 2e-3 * k * sc, (nm, err.max().item() / sc, err.mean().item() / sc)
 
 
-def test_bneck_tail_many_tiles_and_repeatability():
+@pytest.mark.parametrize("planes", [128, 256])
+def test_bneck_tail_many_tiles_and_repeatability(planes):
     """more workgroups than CUs (the weight stream is shared through L2) and bitwise-identical results on a second launch (the
     hand-counted vmcnt waits leave loads in flight across barriers: a miscount shows as run-to-run differences)"""
     from gim_amd import ops
     from gim_amd.packing import pack_bneck_tail
-    blk, nxt = _blocks(7, 128)
+    n1 = planes
+    blk, nxt = _blocks(7, n1, planes)
     g = torch.Generator().manual_seed(3)
-    t2 = F.relu(torch.randn(4, 120, 160, 128, generator=g)).to(torch.bfloat16).cuda()    # 300 workgroups
-    res = torch.randn(4, 120, 160, 512, generator=g).to(torch.bfloat16).cuda()
-    pk = pack_bneck_tail(blk, nxt, "cuda")
+    t2 = F.relu(torch.randn(4, 120, 160, planes, generator=g)).to(torch.bfloat16).cuda()    # 300 workgroups
+    res = torch.randn(4, 120, 160, 4 * planes, generator=g).to(torch.bfloat16).cuda()
+    pk = pack_bneck_tail(blk, nxt.conv1, nxt.bn1, "cuda")
     a = ops.bneck_tail(t2, res, pk)
     b = ops.bneck_tail(t2, res, pk)
     c = ops.bneck_tail(t2[:1].contiguous(), res[:1].contiguous(), pk)

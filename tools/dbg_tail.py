@@ -13,7 +13,7 @@ g = torch.Generator().manual_seed(3)
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 t2 = F.relu(torch.randn(nb, 120, 160, 128, generator=g)).to(torch.bfloat16).cuda()
 res = torch.randn(nb, 120, 160, 512, generator=g).to(torch.bfloat16).cuda()
-pk = pack_bneck_tail(blk, nxt, "cuda")
+pk = pack_bneck_tail(blk, nxt.conv1, nxt.bn1, "cuda")
 bn = lambda m: (m.weight, m.bias, m.running_mean, m.running_var, m.eps)
 w3, b3 = fold_bn(blk.conv3.weight, bn(blk.bn3)); w1, b1 = fold_bn(nxt.conv1.weight, bn(nxt.bn1))
 r = lambda t: t.to(torch.bfloat16).float()

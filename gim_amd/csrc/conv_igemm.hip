@@ -931,7 +931,7 @@ static int skip_mode() { static const int v = env_int("GIM_IGEMM_SKIP", 1); retu
 // GIM_IGEMM_PP: ping-pong variant of the 256 x 256 tile: 0 = never (default), 1 = for K loops of at least GIM_IGEMM_PP_MIN_NKT slabs, 2 = always
 static int pp_mode() { static const int v = env_int("GIM_IGEMM_PP", 0); return v; }
 static int pp_min_nkt() { static const int v = env_int("GIM_IGEMM_PP_MIN_NKT", 8); return v; }
-static int big_min_tiles() { static const int v = env_int("GIM_IGEMM_BIG_MIN_TILES", 512); return v; }
+static int big_min_tiles() { static const int v = env_int("GIM_IGEMM_BIG_MIN_TILES", 1024); return v; }   // round-3 sweep (profiles/r03_knob_sweep.txt)
 static int big_min_nkt() { static const int v = env_int("GIM_IGEMM_BIG_MIN_NKT", 4); return v; }
 
 template <int BM, int BN, int WM, int WN, bool BF16>

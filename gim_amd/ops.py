@@ -188,7 +188,7 @@ def conv2d(x, pk, act=ACT_NONE, res=None, out_dtype=None, lds_dma=True, ups=None
 
 # 3x3 halo kernel (conv_igemm.hip: conv3x3_halo_kernel): GIM_CONV_HALO=0 disables, GIM_CONV_HALO_MIN_TILES = smallest launch it takes
 HALO = os.environ.get("GIM_CONV_HALO", "1") != "0"
-HALO_MIN_TILES = int(os.environ.get("GIM_CONV_HALO_MIN_TILES", "512"))
+HALO_MIN_TILES = int(os.environ.get("GIM_CONV_HALO_MIN_TILES", "2000"))   # round 3 sweep: below ~2000 tiles (the 1/4-resolution layers) the generic kernel is 5-8 % faster
 
 
 def _halo_pays(pk, B, H, W):

@@ -64,27 +64,10 @@ struct Args {
 
 typedef __attribute__((address_space(3))) void lds_t;
 
-// One LDS-DMA instruction (64 lanes x 16 B -> 1 KiB at LDS byte address `lds_addr`, lane-linear) through inline asm: hipcc makes the
-// first LDS access behind a DMA it can see (__builtin_amdgcn_raw_ptr_buffer_load_lds) wait vmcnt(0) -- it assumes every ds_read /
-// ds_write may alias the DMA's destination -- which here would drain the chunks-ahead weight stream inside every chunk.
-// Invisible to the compiler, the DMA is counted by hand (tail_wait below).  M0 carries the LDS address and is written in the same
-// statement that reads it (cdna_hip_programming.md section 5.7).
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void dma16(const u32x4_t rsrc, unsigned lds_addr, unsigned voff) {
-    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);   // wave-uniform by construction; the "s" constraint needs it provable
-    // s_nop 4: the descriptor SGPRs come out of v_readfirstlane (VALU writes SGPR -> VMEM reads it: 5 wait states, which hipcc
-    // cannot insert for an instruction inside an asm string)
-    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory", "m0");
-}
-__device__ __forceinline__ u32x4_t make_rsrc(const void* p, unsigned bytes) {
-    const unsigned long long a = (unsigned long long)p;
-    u32x4_t r;
-    r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
-    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
-    r[2] = __builtin_amdgcn_readfirstlane(bytes);
-    r[3] = 0x00020000u;
-    return r;
-}
+// The weight and identity streams use gim_dma16 (gim_common.h): LDS-DMA through inline asm, counted by hand (tail_wait below).
+typedef gim_u32x4_t u32x4_t;
+__device__ __forceinline__ void dma16(const u32x4_t rsrc, unsigned lds_addr, unsigned voff) { gim_dma16(rsrc, lds_addr, voff); }
+__device__ __forceinline__ u32x4_t make_rsrc(const void* p, unsigned bytes) { return gim_make_rsrc(p, bytes); }
 template <int N> __device__ __forceinline__ void tail_wait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 
 // LDS images (LDS-DMA is lane-linear, so every swizzle is applied to the SOURCE slot and again on the ds_read side):

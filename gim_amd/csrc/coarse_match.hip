@@ -31,6 +31,7 @@
 
 namespace {
 
+using gim::KTB;
 constexpr int BM = 128, BN = 128, WM = 2, WN = 2;
 constexpr int TLD = BN + 4;  // LDS similarity tile row stride in floats
 constexpr int PLIST = 512;  // per-tile pre-candidate list in LDS (4 per row can pass the tile-local test)
@@ -53,7 +54,7 @@ struct CmWs {  // device pointers carved out of the caller's workspace
     int* ncand;        // [N]
     Cand* cand;        // [N][capc]
     int* ext;          // [N][4] valid extents of the padding masks
-    int* npre;         // [N] pre-candidate counters, npre[N] = overflow flag
+    int* npre;         // [N] pre-candidate counters, npre[N] = overflow flag, npre[N + 1] = "wide logit range" flag of the panel kernel
     PreCand* pre;      // [N][capp]
     int* ktab;         // dense K table for the mainloop
     int ntL, ntS, capc, capp;
@@ -83,7 +84,7 @@ size_t carve(CmWs& w, char* base, int N, int L, int S, int C) {
     w.ncand = (int*)take((size_t)N * 4);
     w.cand = (Cand*)take((size_t)N * w.capc * sizeof(Cand));
     w.ext = (int*)take((size_t)N * 16);
-    w.npre = (int*)take((size_t)(N + 1) * 4);
+    w.npre = (int*)take((size_t)(N + 2) * 4);
     w.pre = (PreCand*)take((size_t)N * w.capp * sizeof(PreCand));
     w.ktab = (int*)take((size_t)(C / 32 + 2) * 8 * 4);
     return o;
@@ -157,9 +158,13 @@ __device__ __forceinline__ void sim_tile_to_lds(const CmGeom& g, const int* ktab
 // <= ~|x| * 6e-8 -- 1e-6 for every term that contributes more than e^-15 of a sum -- while each of the few
 // final confidences is evaluated with the accurate expf (cm_precand / cm_cand).
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+// `gated`: launched behind the row-panel kernel as its fallback -- runs only if that kernel found a logit range too wide for its
+// shared exponentials (npre[N + 1]); it then redoes all partials (and adds its own pre-candidates to the list, which may hold
+// duplicates afterwards: every entry is an exact (i, j, similarity) triple that cm_precand evaluates with the final statistics).
 template <bool BF16>
-__global__ void __launch_bounds__(256) cm_stats_kernel(const CmGeom g, const CmWs w) {
+__global__ void __launch_bounds__(256) cm_stats_kernel(const CmGeom g, const CmWs w, const int gated) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (gated && !w.npre[g.N + 1]) return;
     const int n = blockIdx.y;
     const int mt = blockIdx.x / w.ntS, nt = blockIdx.x - mt * w.ntS;
     const int m0 = mt * BM, n0 = nt * BN;
@@ -327,6 +332,225 @@ __global__ void __launch_bounds__(256) cm_stats_kernel(const CmGeom g, const CmW
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Pass A as a PERSISTENT ROW-PANEL kernel (16-bit features, C = 256, no padding masks): round 3.
+//
+// The tile-per-workgroup kernel above spends 14 us per 128 x 128 tile for 1 us of MFMAs: every tile re-stages both operand panels
+// through five dependent L2 round trips, writes the fp32 similarity tile to LDS, re-reads it twice (rows, columns) behind five
+// barriers and evaluates TWO exponentials per element (row and column softmax use different maxima).  Here
+//   * a workgroup owns a 128-row panel of feat0 for a third of the columns: the A panel (64 KiB) is staged ONCE, the B tiles stream
+//     through a single 64 KiB buffer -- tile t + 1 is fetched (LDS-DMA issued through inline asm, invisible to the compiler's
+//     waits) while tile t's statistics run;
+//   * the statistics come straight out of the MFMA accumulators (lane = feat0 row, registers = 32 of the wave's 64 columns):
+//     row max / sum-exp in the lane (+ one exchange with lane ^ 32), ONE exponential per element e = exp(v - rowmax), and the
+//     column sums as sum_i e_ij * exp(rowmax_i - ref) with one wave-wide reference `ref` -- the row weights cost two exps per
+//     lane -- reduced over the 32 row lanes by a halving butterfly (31 exchanges instead of 32 x 5);
+//   * row statistics are carried ONLINE across the panel's tiles (max, rescaled sum) and written once per panel third;
+//   * pre-candidates are tested on the registers.
+// Range guard: exp(v - ref) underflows when a wave tile's logits span more than ~87; at 80 the kernel raises npre[N + 1] and the
+// tile-per-workgroup kernel (gated launch right behind this one) redoes the statistics.  exp() rounding: as above (fast_exp for
+// the sums, expf for every decision).
+constexpr int PJ = 3;                                   // column thirds per row panel: N x ntL x 3 workgroups (912 at 640x480 batch 8)
+constexpr int P2_OFF_B = 4 * BM * KTB;                  // A panel: 4 K slabs of [128 rows][128 B]
+constexpr int P2_OFF_X = P2_OFF_B + 4 * BN * KTB;       // B tile : 4 K slabs
+struct P2X {
+    float2 rowx[2][128];      // [column half wn][row]: (max, sum-exp) over the wave tile's 64 columns
+    float2 colx[2][128];      // [row half wm][column]: (reference, sum-exp) over the wave tile's 64 rows
+    float rowm[128], rowz[128], colm[128], colz[128];   // statistics of the whole tile (exact pre-candidate test)
+    float trow[128], tcol[128];                          // cheap thresholds m + log(thr z)
+    PreCand plist[PLIST];
+    int pcnt[4];
+};
+constexpr int P2_SMEM = P2_OFF_X + (int)sizeof(P2X);
+static_assert(P2_SMEM <= 160 * 1024, "row-panel kernel: LDS");
+
+__global__ void __launch_bounds__(256) cm_stats_panel_kernel(const CmGeom g, const CmWs w, const int force_wide) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void lds_t;
+    const int n = blockIdx.y;
+    const int mt = blockIdx.x / PJ, jc = blockIdx.x - mt * PJ;
+    const int m0 = mt * BM;
+    const int jt0 = jc * w.ntS / PJ, jt1 = (jc + 1) * w.ntS / PJ;
+    const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), wm = wave >> 1, wn = wave & 1;
+    P2X& X = *(P2X*)(smem + P2_OFF_X);
+    const unsigned smem_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_t*)smem);
+    const unsigned rowb = (unsigned)g.ldf * 2u;
+    const gim_u32x4_t rA = gim_make_rsrc((const char*)g.feat0 + (size_t)n * g.L * rowb, (unsigned)(((size_t)(g.L - 1) * g.ldf + g.C) * 2));
+    const gim_u32x4_t rB = gim_make_rsrc((const char*)g.feat1 + (size_t)n * g.S * rowb, (unsigned)(((size_t)(g.S - 1) * g.ldf + g.C) * 2));
+    // staging: a piece = 8 rows x 128 B; this wave fetches pieces wave, wave + 4, wave + 8, wave + 12 of every K slab; lane -> row
+    // piece * 8 + (lane >> 3), LDS slot lane & 7 <- source slot (lane & 7) ^ ((row >> 1) & 7).  Rows beyond L / S lie beyond the
+    // descriptor's bound and read as zeros.
+    const int srow = lane >> 3, sslot = lane & 7;
+    auto issue = [&](const gim_u32x4_t rs, const unsigned lds_base, const int r0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (i * 4 + wave) * 8 + srow;
+                const unsigned voff = (unsigned)(r0 + row) * rowb + (unsigned)(kt * KTB) + (unsigned)((sslot ^ ((row >> 1) & 7)) << 4);
+                gim_dma16(rs, lds_base + (unsigned)(kt * BM * KTB + (i * 4 + wave) * 1024), voff);
+            }
+    };
+    issue(rA, smem_addr, m0);
+    issue(rB, smem_addr + P2_OFF_B, jt0 * BN);
+    if (force_wide && t == 0) w.npre[g.N + 1] = 1;   // tests: exercise the gated fallback
+    float runM = -INFINITY, runZ = 0.f;            // threads 0..127: online row statistics of row m0 + t over this panel third
+    const float thr_pre = g.thr * (1.0f - 1e-4f);  // slack: rounding must never drop a true candidate
+    const int lswz = (l31 >> 1) & 7;
+    const char* sA = smem + (wm * 64 + l31) * KTB;
+    const char* sB = smem + P2_OFF_B + (wn * 64 + l31) * KTB;
+    const int irow0 = m0 + wm * 64 + l31;           // this lane's rows: irow0, irow0 + 32
+    for (int nt = jt0; nt < jt1; ++nt) {
+        const int n0 = nt * BN;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                             // both operands of this tile have landed (every wave waited for its pieces)
+        f32x16_t acc[2][2];                          // [column fragment ic][row fragment jr]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int so = ((2 * ks + lh) ^ lswz) << 4;
+                const bf16x8_t a0 = *(const bf16x8_t*)(sA + kt * BM * KTB + so), a1 = *(const bf16x8_t*)(sA + kt * BM * KTB + 32 * KTB + so);
+                const bf16x8_t b0 = *(const bf16x8_t*)(sB + kt * BN * KTB + so), b1 = *(const bf16x8_t*)(sB + kt * BN * KTB + 32 * KTB + so);
+                acc[0][0] = mfma_h16_32x32x16(b0, a0, acc[0][0]);
+                acc[0][1] = mfma_h16_32x32x16(b0, a1, acc[0][1]);
+                acc[1][0] = mfma_h16_32x32x16(b1, a0, acc[1][0]);
+                acc[1][1] = mfma_h16_32x32x16(b1, a1, acc[1][1]);
+            }
+        __syncthreads();                             // everybody is done with the B tile
+        if (nt + 1 < jt1) issue(rB, smem_addr + P2_OFF_B, n0 + BN);   // lands under the statistics below
+        // ---- statistics on the registers: acc[ic][jr][4 rg + e] = sim(row irow0 + 32 jr, column n0 + 64 wn + 32 ic + 8 rg + 4 lh + e) ----
+        const bool edge = (m0 + BM > g.L) || (n0 + BN > g.S);   // block-uniform
+        const int jcol0 = n0 + wn * 64 + lh * 4;
+        float rmax[2], rsum[2], vmin = INFINITY;
+#pragma unroll
+        for (int jr = 0; jr < 2; ++jr) {
+            const bool rok = irow0 + 32 * jr < g.L;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int ic = 0; ic < 2; ++ic)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[ic][jr][r] * g.inv_ct;   // (f0/sqrt C).(f1/sqrt C)/T as one multiply (see sim_tile_to_lds)
+                    if (edge && !(rok && jcol0 + ic * 32 + (r >> 2) * 8 + (r & 3) < g.S)) v = -INFINITY;
+                    acc[ic][jr][r] = v;
+                    mx = fmaxf(mx, v);
+                    vmin = fminf(vmin, v == -INFINITY ? INFINITY : v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            rmax[jr] = mx == -INFINITY ? 0.f : mx;       // a row without a valid column (beyond L): any finite reference
+        }
+        float mw = fmaxf(rmax[0], rmax[1]);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { mw = fmaxf(mw, __shfl_xor(mw, o, 64)); vmin = fminf(vmin, __shfl_xor(vmin, o, 64)); }
+        vmin = fminf(vmin, __shfl_xor(vmin, 32, 64));
+        if (mw - vmin > 80.f && lane == 0) w.npre[g.N + 1] = 1;   // shared exponentials would underflow: the gated fallback redoes it
+        const float wg0 = fast_exp(rmax[0] - mw), wg1 = fast_exp(rmax[1] - mw);
+        float cs[32];
+        rsum[0] = rsum[1] = 0.f;
+#pragma unroll
+        for (int ic = 0; ic < 2; ++ic)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e0 = fast_exp(acc[ic][0][r] - rmax[0]), e1 = fast_exp(acc[ic][1][r] - rmax[1]);
+                rsum[0] += e0; rsum[1] += e1;
+                cs[ic * 16 + r] = e0 * wg0 + e1 * wg1;     // this lane's two rows of column (ic, r), relative to mw
+            }
+        rsum[0] += __shfl_xor(rsum[0], 32, 64);
+        rsum[1] += __shfl_xor(rsum[1], 32, 64);
+        // column sums over the 32 row lanes: halving butterfly, lane l31 ends up with column x = l31 of its 32 (ic = x >> 4, r = x & 15)
+#pragma unroll
+        for (int lvl = 16; lvl > 0; lvl >>= 1) {
+            const bool up = (l31 & lvl) != 0;
+#pragma unroll
+            for (int x = 0; x < lvl; ++x) {
+                const float keep = up ? cs[x + lvl] : cs[x], send = up ? cs[x] : cs[x + lvl];
+                cs[x] = keep + __shfl_xor(send, lvl, 64);
+            }
+        }
+        const int cloc = wn * 64 + (l31 >> 4) * 32 + ((l31 & 15) >> 2) * 8 + lh * 4 + (l31 & 3);   // column of this lane within the tile
+        if (lh == 0) {
+            X.rowx[wn][wm * 64 + l31] = make_float2(rmax[0], rsum[0]);
+            X.rowx[wn][wm * 64 + 32 + l31] = make_float2(rmax[1], rsum[1]);
+        }
+        X.colx[wm][cloc] = make_float2(mw, cs[0]);
+        if (t == 0) X.pcnt[0] = 0;
+        __syncthreads();
+        if (t < 128) {                                // tile row statistics + the online update of this panel third
+            const float2 a = X.rowx[0][t], b = X.rowx[1][t];
+            const float m = fmaxf(a.x, b.x);
+            const float z = a.y * expf(a.x - m) + b.y * expf(b.x - m);
+            X.rowm[t] = m; X.rowz[t] = z; X.trow[t] = m + logf(thr_pre * z);
+            const float mn = fmaxf(runM, m);
+            runZ = runZ * expf(runM - mn) + z * expf(m - mn);
+            runM = mn;
+        } else {
+            const int c = t - 128;
+            const float2 a = X.colx[0][c], b = X.colx[1][c];
+            const float m = fmaxf(a.x, b.x);
+            const float z = a.y * expf(a.x - m) + b.y * expf(b.x - m);
+            X.colm[c] = m; X.colz[c] = z; X.tcol[c] = m + logf(thr_pre * z);
+            if (n0 + c < g.S) w.colpart[((size_t)n * w.ntL + mt) * g.S + n0 + c] = make_float2(m, z);
+        }
+        __syncthreads();
+        // ---- pre-candidates (same test as the tile kernel): cheap thresholds on the registers, the exact product for the survivors ----
+#pragma unroll
+        for (int jr = 0; jr < 2; ++jr) {
+            const int il = wm * 64 + jr * 32 + l31;
+            const float trow = X.trow[il];
+            unsigned hit = 0u;
+#pragma unroll
+            for (int ic = 0; ic < 2; ++ic)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const float4 t4 = *(const float4*)(X.tcol + wn * 64 + ic * 32 + rg * 8 + lh * 4);
+                    const f32x16_t& v = acc[ic][jr];
+                    hit |= (v[rg * 4] > trow && v[rg * 4] > t4.x) ? 1u << (ic * 16 + rg * 4) : 0u;
+                    hit |= (v[rg * 4 + 1] > trow && v[rg * 4 + 1] > t4.y) ? 1u << (ic * 16 + rg * 4 + 1) : 0u;
+                    hit |= (v[rg * 4 + 2] > trow && v[rg * 4 + 2] > t4.z) ? 1u << (ic * 16 + rg * 4 + 2) : 0u;
+                    hit |= (v[rg * 4 + 3] > trow && v[rg * 4 + 3] > t4.w) ? 1u << (ic * 16 + rg * 4 + 3) : 0u;
+                }
+            while (hit) {
+                const int x = __ffs(hit) - 1;
+                hit &= hit - 1;
+                const int ic = x >> 4, r = x & 15;
+                float sv = 0.f;                       // acc[ic][jr][r] with a run-time (ic, r): select, do not index (scratch)
+#pragma unroll
+                for (int q = 0; q < 32; ++q) sv = (q == x) ? acc[q >> 4][jr][q & 15] : sv;
+                const int jl = wn * 64 + ic * 32 + (r >> 2) * 8 + lh * 4 + (r & 3);
+                const float pr = expf(sv - X.rowm[il]) / X.rowz[il];
+                const float pc = expf(sv - X.colm[jl]) / X.colz[jl];
+                if (pr * pc > thr_pre) {
+                    const int k = atomicAdd(&X.pcnt[0], 1);
+                    if (k < PLIST) X.plist[k] = PreCand{m0 + il, n0 + jl, sv};
+                }
+            }
+        }
+        __syncthreads();
+        const int cnt = X.pcnt[0];
+        if (cnt > 0) {                                // block-uniform
+            if (cnt > PLIST) {
+                if (t == 0) w.npre[g.N] = 1;          // recompute path (cm_cand_kernel<0>)
+            } else {
+                if (t == 0) X.pcnt[1] = atomicAdd(&w.npre[n], cnt);
+                __syncthreads();
+                const int base = X.pcnt[1];
+                if (base + cnt > w.capp) { if (t == 0) w.npre[g.N] = 1; }
+                else for (int k = t; k < cnt; k += 256) w.pre[(size_t)n * w.capp + base + k] = X.plist[k];
+            }
+        }
+    }
+    if (t < 128 && m0 + t < g.L) w.rowpart[((size_t)n * w.ntS + jc) * g.L + m0 + t] = make_float2(runM, runZ);
+}
+
 // Pass B on the pre-candidate list: final statistics -> conf; candidates + row/column maxima
 __global__ void cm_precand_kernel(const CmGeom g, const CmWs w) {
     const int n = blockIdx.y;
@@ -348,15 +572,19 @@ __global__ void cm_precand_kernel(const CmGeom g, const CmWs w) {
 }
 
 // stat[n][x] = combine over tiles:  m = max m_t ; z = sum_t z_t * exp(m_t - m)   (ascending tile order)
-__global__ void cm_combine_kernel(const float2* __restrict__ part, float2* __restrict__ stat, int N, int len, int ntile) {
+// `stride` = tile slots per pair in `part`; `ntile_panel` > 0: the row-panel kernel filled only that many of them -- unless its
+// fallback ran (*wide), which filled all `ntile`
+__global__ void cm_combine_kernel(const float2* __restrict__ part, float2* __restrict__ stat, int N, int len, int ntile_all,
+                                  int ntile_panel, const int* __restrict__ wide) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)N * len) return;
+    const int ntile = (ntile_panel > 0 && !*wide) ? ntile_panel : ntile_all;
     const size_t n = idx / len, x = idx - n * len;
     float m = -INFINITY;
-    for (int t = 0; t < ntile; ++t) m = fmaxf(m, part[(n * ntile + t) * len + x].x);
+    for (int t = 0; t < ntile; ++t) m = fmaxf(m, part[(n * ntile_all + t) * len + x].x);
     float z = 0.f;
     for (int t = 0; t < ntile; ++t) {
-        const float2 p = part[(n * ntile + t) * len + x];
+        const float2 p = part[(n * ntile_all + t) * len + x];
         z += p.y * expf(p.x - m);
     }
     stat[idx] = make_float2(m, z);
@@ -367,7 +595,7 @@ __global__ void cm_init_kernel(const CmWs w, int N, int L, int S) {
     if (idx < (size_t)N * L) { w.rowmaxP[idx] = 0u; w.jsel[idx] = INT_MAX; w.psel[idx] = 0.f; }
     if (idx < (size_t)N * S) w.colmaxP[idx] = 0u;
     if (idx < (size_t)N) w.ncand[idx] = 0;
-    if (idx <= (size_t)N) w.npre[idx] = 0;
+    if (idx <= (size_t)N + 1) w.npre[idx] = 0;
 }
 
 __global__ void cm_ktab_kernel(int* ktab, int C, int ge) {  // dense table: K group g -> channel ge * g (ge = 4 fp32 / 8 bf16 per 16 B); 2 padding slabs
@@ -549,6 +777,10 @@ int validate(const gim_coarse_args& a) {
     return GIM_OK;
 }
 
+// GIM_CM_PANEL: 1 (default) = row-panel statistics kernel where it applies, 0 = tile-per-workgroup kernel always,
+// 2 = row-panel kernel AND its fallback forced (tests: the gated kernel runs although the range guard did not trip)
+static int panel_mode() { static const int v = [] { const char* e = getenv("GIM_CM_PANEL"); return e ? atoi(e) : 1; }(); return v; }
+
 template <typename K>
 int set_smem(K kern) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_SMEM);
@@ -576,6 +808,10 @@ static int cm_prepare(const gim_coarse_args& a, CmWs& w, CmGeom& g) {
         if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<1, false>);
         if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<0, true>);
         if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<1, true>);
+        if (rc == GIM_OK && hipFuncSetAttribute((const void*)cm_stats_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P2_SMEM) != hipSuccess) {
+            gim_set_error("coarse_match: hipFuncSetAttribute(panel kernel, %d B LDS)", P2_SMEM);
+            rc = GIM_ERR_LAUNCH;
+        }
         if (rc != GIM_OK) return rc;
         attr.done();
     }
@@ -602,10 +838,17 @@ extern "C" int GIM_FN(gim_coarse_match)(const gim_coarse_args* ap, gim_stream_t 
     hipLaunchKernelGGL(cm_init_kernel, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, s, w, a.N, a.L, a.S);
     hipLaunchKernelGGL(cm_ktab_kernel, dim3(1), dim3(256), 0, s, w.ktab, a.C, g.bf16 ? 8 : 4);
     dim3 tgrid((unsigned)(w.ntL * w.ntS), (unsigned)a.N);
-    if (g.bf16) hipLaunchKernelGGL(cm_stats_kernel<true>, tgrid, dim3(256), TILE_SMEM, s, g, w);
-    else hipLaunchKernelGGL(cm_stats_kernel<false>, tgrid, dim3(256), TILE_SMEM, s, g, w);
-    hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.L + 255) / 256)), dim3(256), 0, s, w.rowpart, w.rowstat, a.N, a.L, w.ntS);
-    hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.S + 255) / 256)), dim3(256), 0, s, w.colpart, w.colstat, a.N, a.S, w.ntL);
+    // row-panel statistics kernel: 16-bit features of 256 channels, no padding masks, enough column tiles for its three-way split
+    const bool panel = g.bf16 && a.C == 256 && !a.mask0 && w.ntS >= 2 * PJ && panel_mode();
+    if (panel) {
+        hipLaunchKernelGGL(cm_stats_panel_kernel, dim3((unsigned)(w.ntL * PJ), (unsigned)a.N), dim3(256), P2_SMEM, s, g, w, panel_mode() == 2 ? 1 : 0);
+        hipLaunchKernelGGL(cm_stats_kernel<true>, tgrid, dim3(256), TILE_SMEM, s, g, w, 1);   // gated fallback (wide logit range)
+    } else if (g.bf16) hipLaunchKernelGGL(cm_stats_kernel<true>, tgrid, dim3(256), TILE_SMEM, s, g, w, 0);
+    else hipLaunchKernelGGL(cm_stats_kernel<false>, tgrid, dim3(256), TILE_SMEM, s, g, w, 0);
+    hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.L + 255) / 256)), dim3(256), 0, s, w.rowpart, w.rowstat, a.N, a.L, w.ntS,
+                       panel ? PJ : 0, w.npre + a.N + 1);
+    hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.S + 255) / 256)), dim3(256), 0, s, w.colpart, w.colstat, a.N, a.S, w.ntL,
+                       0, w.npre + a.N + 1);
     hipLaunchKernelGGL(cm_precand_kernel, dim3((unsigned)((w.capp + 255) / 256), (unsigned)a.N), dim3(256), 0, s, g, w);
     if (g.bf16) hipLaunchKernelGGL((cm_cand_kernel<0, true>), tgrid, dim3(256), TILE_SMEM, s, g, w, (float*)nullptr);
     else hipLaunchKernelGGL((cm_cand_kernel<0, false>), tgrid, dim3(256), TILE_SMEM, s, g, w, (float*)nullptr);

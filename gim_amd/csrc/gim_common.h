@@ -165,6 +165,28 @@ template <> struct ElemIO<false> {
     static __device__ __forceinline__ void st4(void* p, size_t i, float4 v) { *(float4*)((float*)p + i) = v; }
 };
 
+// ---- LDS-DMA through inline asm (invisible to hipcc's s_waitcnt bookkeeping) --------------------------------------------------
+// hipcc makes the first LDS access behind an LDS-DMA it can see (__builtin_amdgcn_raw_ptr_buffer_load_lds) wait vmcnt(0): it assumes
+// every ds_read / ds_write may alias the DMA's destination.  Kernels that keep a DMA in flight ACROSS other LDS work (bneck_tail.hip,
+// the row-panel statistics kernel of coarse_match.hip) issue it through this statement and count vmcnt by hand.  One instruction =
+// 64 lanes x 16 B -> 1 KiB at LDS byte address `lds_addr` (wave-uniform), lane-linear; M0 carries the LDS address and is written in
+// the same statement that reads it (cdna_hip_programming.md section 5.7).  s_nop 4: descriptor SGPRs may come straight out of
+// v_readfirstlane (VALU writes SGPR -> VMEM reads it: 5 wait states the compiler cannot insert inside an asm string).
+typedef unsigned gim_u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gim_dma16(const gim_u32x4_t rsrc, unsigned lds_addr, unsigned voff) {
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);   // wave-uniform by construction; the "s" constraint needs it provable
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
+__device__ __forceinline__ gim_u32x4_t gim_make_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    gim_u32x4_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -418,3 +418,52 @@ def test_linear_attention_masks(shape):
                          nb, L, nb, S, H, None, qm.reshape(-1).to(torch.uint8).to(dev), km.reshape(-1).to(torch.uint8).to(dev))
     torch.cuda.synchronize()
     _assert_close(out.view(nb, L, H, D), ref, 1e-5, f"masked linear attention {shape}")
+
+
+@pytest.mark.parametrize("mode", ["1", "2", "0"], ids=["panel", "panel+forced-fallback", "tile-kernel"])
+@pytest.mark.parametrize("kind", ["bf16", "fp16"])
+def test_coarse_match_row_panel_statistics(mode, kind):
+    """The persistent row-panel statistics kernel (16-bit features, C = 256, no masks; round 3) against the oracle evaluated on the
+    SAME 16-bit-valued features: exact indices and order, confidences to 1e-5 -- on sizes with ragged last tiles in both directions,
+    unequal L / S, several pairs -- and the same through its gated fallback (GIM_CM_PANEL=2) and through the tile-per-workgroup
+    kernel (GIM_CM_PANEL=0).  Subprocess: the mode is read once per process."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, torch
+sys.path.insert(0, 'oracle'); sys.path.insert(0, '.')
+import loftr_oracle as O
+from gim_amd import ops
+tdt = torch.bfloat16 if sys.argv[1] == 'bf16' else torch.float16
+tot = 0
+for (N, hw0, hw1, sigma, eps, seed) in ((2, (30, 40), (30, 40), 1.0, 0.5, 3), (1, (36, 45), (36, 45), 2.0, 0.1, 4), (3, (25, 31), (25, 31), 1.0, 0.3, 5),
+                                     (1, (60, 80), (60, 80), 1.0, 0.5, 6)):
+    f0, f1, _ = O.planted_coarse_features(N, hw0, sigma=sigma, eps=eps, seed=seed)
+    b0, b1 = f0.to(tdt), f1.to(tdt)
+    conf = O.conf_matrix_dual_softmax(b0.float(), b1.float(), 0.1)
+    ref = O.get_coarse_match(conf, (hw0[0] * 8, hw0[1] * 8), (hw1[0] * 8, hw1[1] * 8), hw0, hw1, 0.2, 2)
+    r = ops.coarse_match(b0.cuda(), b1.cuda(), hw0, hw1, 8.0, 0.1, 0.2, 2)
+    M = int(r.count[0])
+    assert M == ref['b_ids'].numel() and M > 200, (M, ref['b_ids'].numel())
+    for k in ('b_ids', 'i_ids', 'j_ids'):
+        assert torch.equal(getattr(r, k)[:M].cpu(), ref[k]), k
+    assert (r.mconf[:M].cpu() - ref['mconf']).abs().max() < 1e-5
+    cm = ops.coarse_conf_matrix(r).cpu()
+    assert (cm - conf).abs().max() < 1e-5 * conf.abs().max().clamp_min(1e-6) + 1e-7
+    tot += M
+# unequal map sizes (L != S), ragged in both directions
+f0, f1, _ = O.planted_coarse_features(1, (30, 40), sigma=1.0, eps=0.5, seed=9)
+f1 = f1[:, :29 * 40]
+b0, b1 = f0.to(tdt), f1.to(tdt)
+conf = O.conf_matrix_dual_softmax(b0.float(), b1.float(), 0.1)
+ref = O.get_coarse_match(conf, (240, 320), (232, 320), (30, 40), (29, 40), 0.2, 2)
+r = ops.coarse_match(b0.cuda(), b1.contiguous().cuda(), (30, 40), (29, 40), 8.0, 0.1, 0.2, 2)
+M = int(r.count[0])
+assert M == ref['b_ids'].numel() and torch.equal(r.j_ids[:M].cpu(), ref['j_ids']) and torch.equal(r.i_ids[:M].cpu(), ref['i_ids'])
+print('OK', tot + M)
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code, kind], cwd=root, capture_output=True, text=True,
+                         env={**os.environ, "GIM_CM_PANEL": mode}, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -472,8 +472,10 @@ __global__ void __launch_bounds__(256) cm_stats_panel_kernel(const CmGeom g, con
             const bool up = (l31 & lvl) != 0;
 #pragma unroll
             for (int x = 0; x < lvl; ++x) {
-                const float keep = up ? cs[x + lvl] : cs[x], send = up ? cs[x] : cs[x + lvl];
-                cs[x] = keep + __shfl_xor(send, lvl, 64);
+                float lo = cs[x], hi = cs[x + lvl];
+                asm volatile("" : "+v"(lo), "+v"(hi));   // keep them values: hipcc otherwise folds the two selects into ONE
+                                                         // dynamically indexed read of cs[] = a 32-deep compare/select chain each
+                cs[x] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, lvl, 64);
             }
         }
         const int cloc = wn * 64 + (l31 >> 4) * 32 + ((l31 & 15) >> 2) * 8 + lh * 4 + (l31 & 3);   // column of this lane within the tile
@@ -779,7 +781,12 @@ int validate(const gim_coarse_args& a) {
 
 // GIM_CM_PANEL: 1 (default) = row-panel statistics kernel where it applies, 0 = tile-per-workgroup kernel always,
 // 2 = row-panel kernel AND its fallback forced (tests: the gated kernel runs although the range guard did not trip)
-static int panel_mode() { static const int v = [] { const char* e = getenv("GIM_CM_PANEL"); return e ? atoi(e) : 1; }(); return v; }
+// GIM_CM_PANEL: 0 (default) the tile-per-workgroup statistics kernel; 1 the row-panel kernel (+ gated fallback); 2 the row-panel
+// kernel with the fallback forced (tests).  Measured on MI355X (profiles/r03_cm_panel.txt): the panel kernel is exact but SLOWER
+// -- 410 us against 320 us on planted features, +0.7 ms per step on the bench's random-weight features (one wave per SIMD at 259
+// VGPRs has nothing to hide its ~3000 VALU instructions per tile behind; 912 workgroups = 3.56 rounds of one workgroup per CU) --
+// so it stays opt-in until it wins.
+static int panel_mode() { static const int v = [] { const char* e = getenv("GIM_CM_PANEL"); return e ? atoi(e) : 0; }(); return v; }
 
 template <typename K>
 int set_smem(K kern) {

@@ -453,12 +453,12 @@ for (N, hw0, hw1, sigma, eps, seed) in ((2, (30, 40), (30, 40), 1.0, 0.5, 3), (1
     assert (cm - conf).abs().max() < 1e-5 * conf.abs().max().clamp_min(1e-6) + 1e-7
     tot += M
 # unequal map sizes (L != S), ragged in both directions
-f0, f1, _ = O.planted_coarse_features(1, (30, 40), sigma=1.0, eps=0.5, seed=9)
-f1 = f1[:, :29 * 40]
+f0, f1, _ = O.planted_coarse_features(2, (30, 40), sigma=1.0, eps=0.5, seed=9)
+f1 = f1[:, :29 * 40].contiguous()
 b0, b1 = f0.to(tdt), f1.to(tdt)
 conf = O.conf_matrix_dual_softmax(b0.float(), b1.float(), 0.1)
 ref = O.get_coarse_match(conf, (240, 320), (232, 320), (30, 40), (29, 40), 0.2, 2)
-r = ops.coarse_match(b0.cuda(), b1.contiguous().cuda(), (30, 40), (29, 40), 8.0, 0.1, 0.2, 2)
+r = ops.coarse_match(b0.cuda(), b1.cuda(), (30, 40), (29, 40), 8.0, 0.1, 0.2, 2)
 M = int(r.count[0])
 assert M == ref['b_ids'].numel() and torch.equal(r.j_ids[:M].cpu(), ref['j_ids']) and torch.equal(r.i_ids[:M].cpu(), ref['i_ids'])
 print('OK', tot + M)

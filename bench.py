@@ -207,6 +207,16 @@ def main():
             fam[name] = (ms + e0.elapsed_time(e1), fl + f, n + 1)
         fused = {k: {"launches_per_step": v[2] // 2, "ms_per_step": round(v[0] / 2, 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1)}
                  for k, v in fam.items()}
+        # the coarse matching call (dual-softmax statistics over the [4800 x 4800] similarity GEMM of every pair + selection):
+        # its statistics kernel is the step's second-largest; priced as the GEMM it computes against the dense MFMA peak
+        cg = fused.pop("coarse_match", None)
+        coarse_gemm = None
+        if cg:
+            v = fam["coarse_match"]
+            coarse_gemm = {"us": round(1e3 * v[0] / v[2], 1), "tflops": cg["tflops"],
+                           "frac": round(cg["tflops"] / MFMA_PEAK_TFLOPS[args.precision], 4),
+                           "what": "whole gim_coarse_match call (init + statistics + combine + selection + emit kernels; the "
+                                   "statistics kernel is ~80 % of it: profiles/)"}
         tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in prof)
         tot_fl = sum(f for _, _, f, _ in prof)
         nlaunch = len(prof)
@@ -228,6 +238,7 @@ def main():
                 "avg_launch_us": round(1e3 * tot_ms / nlaunch, 2),
                 "gflop_per_launch": round(tot_fl / nlaunch / 1e9, 3),
                 "kernel_ms_per_step": round(tot_ms / 2, 3),
+                "coarse_gemm": coarse_gemm,
                 "fused_kernels": fused,   # the hand-fused kernels that took work OUT of the implicit-GEMM kernel (same live HIP-event timing)
                 "top_layers_ms_tflops": [[k, round(v[0] / 2, 3), round(v[1] / (v[0] * 1e-3) / 1e12, 1)] for k, v in top]}
         if os.environ.get("GIM_BENCH_ALL_LAYERS"):   # every conv / linear shape: [label, launches per step, ms per step, TFLOP/s]

@@ -343,7 +343,8 @@ def coarse_match(feat0, feat1, hw0_c, hw1_c, scale, temperature=0.1, thr=0.2, bo
     a.cap, a.temperature, a.thr, a.border_rm, a.scale = cap, temperature, thr, border_rm, scale
     a.feat_dtype, a.ldf = gim_dtype(feat0), ldf
     r.args = a
-    check(lib.gim_coarse_match(ctypes.byref(a), _stream()), "gim_coarse_match")
+    with _Timed("coarse_match", 2.0 * N * L * S * C):   # the similarity GEMM's flops (computed once in the common case)
+        check(lib.gim_coarse_match(ctypes.byref(a), _stream()), "gim_coarse_match")
     return r
 
 

@@ -52,7 +52,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="pairs per rank per step")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--precision", default="fp16", choices=["bf16", "fp16", "fp32"],
+                    help="gim_loftr's mode.  fp16 (default): the 16-bit kernels on IEEE-fp16 operands -- index flip rate 0.15-0.3 %% against "
+                         "the fp32 oracle; bf16: the same kernels on bf16 operands (2-3 %% faster, 0.7-1.3 %% flips); fp32: the parity mode")
     ap.add_argument("--coarse-sim", default=None, choices=["fp32", "bf16", "fp16"], help="override LoFTR config['coarse_sim']")
     ap.add_argument("--frac", type=float, default=0.45, help="corresponding fraction of the frame (match count knob)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -230,7 +232,7 @@ def main():
         # HBM bytes per launch from the TCC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected in
         # separate rocprofv3 --pmc passes of the same workload by tools/pmc_traffic.sh and committed under profiles/
         traffic = None
-        if args.precision == "bf16" and nb == 8 and os.path.exists(TRAFFIC_JSON):
+        if args.precision in ("bf16", "fp16") and nb == 8 and os.path.exists(TRAFFIC_JSON):   # same kernels, same bytes in both 16-bit flavours
             traffic = round(json.load(open(TRAFFIC_JSON))["traffic_bytes_per_launch"])
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
@@ -286,14 +288,18 @@ def main():
 
     # ---- the other precision modes on the same workload and batch, timed the same way -----------------------------------------
     #   parity_mode: precision='fp32' (exact fp32 MFMA products) -- the mode whose match indices equal the oracle's
-    #   fp16_mode:   precision='fp16' -- the 16-bit kernels in their IEEE-fp16 flavour: same MFMA rate and bytes as the bf16
-    #                headline, 11 instead of 8 significand bits per stored activation (a quarter of bf16's index flips)
+    #   bf16_mode / fp16_mode: the OTHER 16-bit flavour of the same kernels (same MFMA rate, same bytes): bf16 has fp32's exponent
+    #                range and 8 significand bits per stored activation, fp16 has 11 (a quarter of bf16's index flips)
     alt_modes = {}
-    if solo and args.precision == "bf16" and not os.environ.get("GIM_BENCH_SKIP_PARITY_MODE"):
+    if solo and args.precision in ("bf16", "fp16") and not os.environ.get("GIM_BENCH_SKIP_PARITY_MODE"):
+        other = {"fp16": ("bf16_mode", "bf16", "the same kernels in their bf16 flavour (v_mfma_f32_32x32x16_bf16; the first convolution "
+                                               "still reads fp16 operands): same instruction counts and bytes, fp32's exponent range, "
+                                               "8 instead of 11 significand bits per stored activation"),
+                 "bf16": ("fp16_mode", "fp16", "the same kernels in their IEEE fp16 flavour (v_mfma_f32_32x32x16_f16, v_cvt_pk_f16_f32): same "
+                                               "instruction counts and bytes, |activation| < 65504")}[args.precision]
         for name, prec, n_alt, note in (
                 ("parity_mode", "fp32", 5, "every GEMM on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
-                ("fp16_mode", "fp16", args.steps, "the bf16 mode's kernels in their IEEE fp16 flavour (v_mfma_f32_32x32x16_f16, "
-                                                  "v_cvt_pk_f16_f32): same instruction counts and bytes, |activation| < 65504")):
+                (other[0], other[1], args.steps, other[2])):
             model.set_precision(prec)
             for _ in range(3):
                 da = step()
@@ -306,7 +312,7 @@ def main():
             alt_modes[name] = ({"precision": prec, "pairs_per_s": round(nb / ta, 2), "ms_per_step": round(1e3 * ta, 3), "steps": n_alt,
                                 "matches_per_pair": round(da["b_ids"].numel() / nb, 1), "note": "same workload and batch; " + note},
                                {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in da.items() if k != "conf_matrix"})
-        model.set_precision("bf16", args.coarse_sim)
+        model.set_precision(args.precision, args.coarse_sim)
         torch.cuda.empty_cache()
 
     # ---- the fine level idle (random-init weights, uniform-noise images: what round 1 reported) ----------
@@ -341,13 +347,14 @@ def main():
         torch.cuda.empty_cache()
 
     # ---- secondary workload (reported, not the metric): gim_lightglue at the same resolution / batch ---------
+    sec_prec = "fp32" if args.precision == "fp32" else "bf16"   # the secondary engines have a bf16 and an fp32 mode
     lightglue = None
     if solo and not os.environ.get("GIM_BENCH_SKIP_LIGHTGLUE"):
         from gim_amd.lightglue import LightGlue, SuperPoint, gim_lightglue_inference
         torch.manual_seed(0)  # random-init weights of the reference architecture (no checkpoint in the container)
         det = SuperPoint({"max_num_keypoints": 2048, "force_num_keypoints": True, "detection_threshold": 0.0,
-                          "nms_radius": 3, "trainable": False, "precision": args.precision}).eval()
-        lgm = LightGlue({"filter_threshold": 0.1, "flash": False, "checkpointed": True, "precision": args.precision}).eval()
+                          "nms_radius": 3, "trainable": False, "precision": sec_prec}).eval()
+        lgm = LightGlue({"filter_threshold": 0.1, "flash": False, "checkpointed": True, "precision": sec_prec}).eval()
         gg = torch.Generator().manual_seed(1)
         g0 = torch.nn.functional.interpolate(torch.rand(nb, 1, H // 4, W // 4, generator=gg), size=(H, W), mode="bilinear")
         g0 = (0.7 * g0 + 0.3 * torch.rand(nb, 1, H, W, generator=gg)).contiguous().to(dev)  # textured synthetic images
@@ -370,7 +377,7 @@ def main():
         tl = (time.perf_counter() - tl) / 10
         lightglue = {"workload": f"gim_lightglue {W}x{H}, batch {nb} pairs, SuperPoint (2048 keypoints) x2 + LightGlue "
                                  "(9 layers) + adapter, random-init weights", "pairs_per_s": round(nb / tl, 2),
-                     "ms_per_step": round(1e3 * tl, 3), "dtype": args.precision,
+                     "ms_per_step": round(1e3 * tl, 3), "dtype": sec_prec,
                      "achieved_tflops": round(nb / tl * 334e9 / 1e12, 1),
                      "note": "algorithmic 334 GFLOP/pair (SURVEY 8d)"}
         del det, lgm
@@ -407,7 +414,7 @@ def main():
                 torch.cuda.synchronize()
                 t_sample = (time.perf_counter() - td) / n_it
                 dense[name] = {"workload": note, "pairs_per_s": round(1.0 / (t_match + t_sample), 2),
-                               "match_ms": round(1e3 * t_match, 2), "sample_ms": round(1e3 * t_sample, 2), "dtype": args.precision}
+                               "match_ms": round(1e3 * t_match, 2), "sample_ms": round(1e3 * t_sample, 2), "dtype": sec_prec}
                 if batch > 1:   # BASELINE's batched configuration: `batch` independent pairs in one engine pass (match_batch)
                     b0, b1 = im0.expand(batch, -1, -1, -1).contiguous(), im1.expand(batch, -1, -1, -1).contiguous()
                     for _ in range(2):
@@ -428,14 +435,14 @@ def main():
 
         def build_dkm():
             from gim_amd.dkm import DKMv3
-            m = DKMv3(None, 672, 896, upsample_preds=True, precision=args.precision)
+            m = DKMv3(None, 672, 896, upsample_preds=True, precision=sec_prec)
             m.upsample_res = (1152, 1536)
             return m
 
         def build_roma(size):
             def f():
                 from gim_amd.roma import RoMa, random_dinov2_weights
-                return RoMa([size], precision=args.precision, dinov2_weights=random_dinov2_weights(dev))
+                return RoMa([size], precision=sec_prec, dinov2_weights=random_dinov2_weights(dev))
             return f
 
         dense_bench("gim_dkm", build_dkm, "gim_dkm match() + sample(5000), 672x896 -> upsampling pass 1152x1536, one pair per call, "
@@ -480,9 +487,9 @@ def main():
             parity = parity_vs_oracle(d_last, ref, 0)
             parity["note"] = (f"pair 0 of the timed batch: {args.precision} engine (coarse_sim={model.coarse_sim}) vs the fp32 CPU "
                               "oracle; flip_rate = |engine matches XOR oracle matches| / |oracle matches|")
-            if args.precision == "bf16":   # the same batch with the other similarity setting: is the operand rounding visible?
+            if args.precision in ("bf16", "fp16"):   # the same batch with the other similarity setting: is the operand rounding visible?
                 was = model.coarse_sim
-                model.coarse_sim = "fp32" if was == "bf16" else "bf16"
+                model.coarse_sim = "fp32" if was == args.precision else args.precision
                 alt = parity_vs_oracle(step(), ref, 0)
                 parity["other_coarse_sim"] = {"coarse_sim": model.coarse_sim, "flip_rate": alt["flip_rate"],
                                               "mean_abs_dmconf": alt.get("mean_abs_dmconf"), "mean_abs_dmkpts1_px": alt.get("mean_abs_dmkpts1_px")}
@@ -507,7 +514,7 @@ def main():
                        "parallelism": f"pairs sharded over {world} GPU(s), no collective per step",
                        "hip_graph": bool(model.use_graph)},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity, "parity_mode": alt_modes.get("parity_mode", (None,))[0],
-            "fp16_mode": alt_modes.get("fp16_mode", (None,))[0], "h2d_inclusive": h2d, "fine_idle": idle,
+            "fp16_mode": alt_modes.get("fp16_mode", (None,))[0], "bf16_mode": alt_modes.get("bf16_mode", (None,))[0], "h2d_inclusive": h2d, "fine_idle": idle,
             "secondary_workloads": {"gim_lightglue": lightglue, **dense},
         }
         print(json.dumps(out), flush=True)

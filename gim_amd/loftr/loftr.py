@@ -13,7 +13,7 @@ torch op on the data path: weights are pre-packed once (BN folded, K-contiguous,
 is a libgimhip kernel launched through ctypes on torch's current HIP stream.  There is no CPU / eager
 fallback: without the HIP library the import fails, without a GPU tensor the call raises.
 
-Precision modes (`config['precision']`, default env GIM_PRECISION or 'bf16'):
+Precision modes (`config['precision']`, default env GIM_PRECISION or 'fp16'):
   'fp32'  fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32 products/accumulate) -- the parity mode;
   'bf16'  bf16 operands / fp32 accumulate for the backbone and the transformer GEMMs -- the throughput
           mode BASELINE config 2 names.  The token residual stream stays fp32.  The FIRST convolution reads the image
@@ -21,10 +21,13 @@ Precision modes (`config['precision']`, default env GIM_PRECISION or 'bf16'):
           significand bits in front of an edge-detecting (cancelling) convolution is HALF of this mode's deviation from
           the fp32 reference (tools/precision_emulation.py: index flip rate 1.95 % -> 0.98 % with the stem alone on fp16
           operands; same MFMA rate, same bytes);
-  'fp16'  IEEE fp16 operands / fp32 accumulate everywhere the bf16 mode uses bf16: same kernels in their second flavour
-          (csrc/gim_common.h), same speed, 11 instead of 8 significand bits per stored activation -- flip rate 0.47 % in the
-          emulation.  Range: |activation| < 65504 (BatchNorm-folded ResNet activations and LayerNorm'd tokens are O(1..100));
-          a checkpoint that overflows shows inf / nan in the outputs -- use 'bf16' for it.
+  'fp16'  (default) IEEE fp16 operands / fp32 accumulate everywhere the bf16 mode uses bf16: same kernels in their second flavour
+          (csrc/gim_common.h), same instruction counts and bytes (measured 2-3 % slower: lower clocks), 11 instead of 8
+          significand bits per stored activation -- index flip rate 0.15-0.3 % against the fp32 oracle where bf16 has 0.7-1.3 %
+          (0.47 % in the emulation).  It is the reference's own reduced-precision mode (its attention divides the values by
+          their length "prevent fp16 overflow", submodules/attentions.py:42).  Range: |activation| < 65504 (BatchNorm-folded
+          ResNet activations and LayerNorm'd tokens are O(1..100)); a checkpoint that overflows shows inf / nan in the
+          outputs -- use 'bf16' for it.
 
 Coarse similarity (`config['coarse_sim']`, env GIM_COARSE_SIM; default = the precision mode):
   'fp32'  similarity of the fp32 tokens with fp32-exact products: on the same features the mutual-NN indices equal the
@@ -165,7 +168,7 @@ class LazyConfMatrix:
 
 
 def _precision_from(config):
-    p = (config.get("precision") or os.environ.get("GIM_PRECISION") or "bf16").lower()
+    p = (config.get("precision") or os.environ.get("GIM_PRECISION") or "fp16").lower()
     if p not in _DT:
         raise ValueError(f"precision must be 'bf16', 'fp16' or 'fp32', got {p!r}")
     return p

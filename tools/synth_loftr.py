@@ -98,7 +98,7 @@ def calibrate_(model, seed=0, res_gain=0.15, size=(128, 160), affine_jitter=True
     return model
 
 
-def synthetic_model(precision="bf16", seed=0, res_gain=0.15, **cfg_over):
+def synthetic_model(precision="fp16", seed=0, res_gain=0.15, **cfg_over):
     """Seeded, calibrated `gim_amd.loftr.LoFTR` on the CPU + its reference-keyed state_dict (for the oracle)."""
     from gim_amd.loftr import LoFTR, get_cfg_defaults, lower_config
     torch.manual_seed(seed)

@@ -47,6 +47,13 @@ class CopySegs(ctypes.Structure):
     _fields_ = [("src", c_void_p * 12), ("dst", c_void_p * 12), ("bytes", c_int64 * 12), ("n", c_int)]
 
 
+class TokenEmit(ctypes.Structure):
+    """struct gim_token_emit (include/gim_hip.h)."""
+    MAX = 6
+    _fields_ = [("nblk", c_int), ("weights", c_void_p), ("out", c_void_p * 6), ("ld", c_int * 6), ("act", c_int * 6),
+                ("row_lo", c_int * 6), ("row_hi", c_int * 6)]
+
+
 class LgAssignArgs(ctypes.Structure):
     """struct gim_lg_assign_args (include/gim_hip.h)."""
     _fields_ = [
@@ -88,6 +95,8 @@ PROTOTYPES = {
     "gim_token_mlp_weight_bytes": (c_int64, []),
     "gim_token_mlp": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_float, c_void_p]),
     "gim_token_mlp_f16": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_float, c_void_p]),
+    "gim_token_mlp_emit": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_float, c_void_p, c_void_p]),
+    "gim_token_mlp_emit_f16": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_float, c_void_p, c_void_p]),
     "gim_fine_fused_weight_bytes": (c_int64, []),
     "gim_fine_fused": (c_int, [c_void_p] * 13 + [c_int] * 11 + [c_float, c_float, c_int, c_void_p]),
     "gim_fine_fused_f16": (c_int, [c_void_p] * 13 + [c_int] * 11 + [c_float, c_float, c_int, c_void_p]),

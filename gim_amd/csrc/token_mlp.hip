@@ -22,6 +22,13 @@
 // previous one.  v_mfma_f32_32x32x16_bf16, fp32 accumulate; LayerNorm statistics and the residual stream are fp32
 // (x32 is read, updated and written once, through an LDS transposition so that every global access is a full 256-byte row
 // segment); the operand copy of the new x is written as bf16.
+//
+// PROJECTION BLOCKS (round 3): the new x is the operand of the NEXT attention's q / k / v projections (transformer.py:42-44 of the
+// following layer -- and, in a cross layer, the k / v of the same layer's second call), each a bias-free [256 x 256] Linear.  Up to
+// six of them run here on the tile that is still in LDS: emit[b] = act_b(x_new W_b^T) (elu+1 on q and k, attentions.py:31-32),
+// per block a row range (a self layer over both images projects k / v only for the side that is a source next), weights streamed
+// the same way (4 units per block and wave).  The stand-alone projection GEMMs (K = 256: 4 slabs of prologue / epilogue per tile,
+// 350 TFLOP/s) and their re-read of x disappear.
 #include "gim_common.h"
 
 namespace {
@@ -36,6 +43,11 @@ static_assert(2 * SMEM <= 160 * 1024, "two workgroups per CU");
 constexpr int UNITS_PER_WAVE = 4 + 4 * (4 + 2);
 constexpr int UNIT_U4 = 8 * 64;      // uint4 per unit (8 fragments x 64 lanes x 16 B)
 
+constexpr int MAXBLK = GIM_TOKEN_EMIT_MAX;
+
+// elu(x) + 1 with the arithmetic of the projection GEMM's epilogue (conv_igemm.hip::apply_act): exactly torch's
+__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v + 1.f : (expf(v) - 1.f) + 1.f; }
+
 struct Args {
     const float* kv;             // NULL: `msg` is the attention output.  Else: [nb][8][32*32 + 32] fp32 KV / Ksum state of the linear
                                  // attention (gim_linear_attention_kv) and `msg` holds the elu+1 QUERY rows: the apply step runs here
@@ -49,6 +61,11 @@ struct Args {
     const float* ln;             // [g1 | b1 | g2 | b2] x 256
     int R, ldm, ldxb, ldx32;
     float eps;
+    // projection blocks of the new x
+    int nblk;
+    const uint4* ewts;           // 4 waves x nblk x 4 units x 8 fragments (packing.py::pack_token_emit)
+    unsigned short* eout[MAXBLK];
+    int eld[MAXBLK], eact[MAXBLK], elo[MAXBLK], ehi[MAXBLK];
 };
 
 struct W8 { bf16x8_t f[8]; };
@@ -174,6 +191,9 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
     char* H = smem + OFF_H;
     float2* stat = (float2*)H;   // [64 rows][4 waves] partial (sum, sum of squares): H is idle whenever a LayerNorm runs
     const uint4* wp = a.wts + (size_t)L.w * UNITS_PER_WAVE * UNIT_U4;
+    const uint4* ewp = a.ewts + (size_t)L.w * a.nblk * 4 * UNIT_U4;
+    unsigned emask = 0u;         // projection blocks whose row range holds this tile (block-uniform)
+    for (int b = 0; b < a.nblk; ++b) emask |= (r0 >= a.elo[b] && r0 < a.ehi[b]) ? 1u << b : 0u;
     W8 w;
     wload(w, wp, L.lane);   // merge, unit 0: in flight during the tile loads
     // ---- A <- attention output rows, X <- operand copy of x (512 B rows: 32 lanes x 16 B, 8 rows per pass) ----------
@@ -299,6 +319,7 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
             ++u;
             mma_n64<false>(H, L.h8, q * 4, 32 * HROWB, w, out);
             if (u < UNITS_PER_WAVE) wload(w, wp + (size_t)u * UNIT_U4, L.lane);
+            else if (emask) wload(w, ewp + (size_t)(4 * (__ffs(emask) - 1)) * UNIT_U4, L.lane);   // first projection unit: lands under norm2
         }
     }
     __syncthreads();   // H is consumed: its space serves the LayerNorm partial sums
@@ -316,20 +337,77 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
                     make_float4(out[nf][j][rg * 4], out[nf][j][rg * 4 + 1], out[nf][j][rg * 4 + 2], out[nf][j][rg * 4 + 3]);
             }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave reads below: LDS executes a wave's accesses in order
+    uint2 nx[16];   // this lane's share of the new x (16-bit): row it * 4 + rsub, channels 64w + 4 slot .. + 3
     {
         const int slot = L.lane & 15, rsub = L.lane >> 4;
-#pragma unroll 4
+#pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int row = it * 4 + rsub, m = r0 + row;
             const float4 v = *(const float4*)((char*)tr + row * 256 + ((slot ^ (row & 15)) << 4));
+            nx[it] = make_uint2(0u, 0u);
             if (m < a.R) {
                 float* xp = a.x32 + (size_t)m * a.ldx32 + 64 * L.w + 4 * slot;
                 float4 x = *(const float4*)xp;
                 x.x += v.x; x.y += v.y; x.z += v.z; x.w += v.w;   // x + message
                 *(float4*)xp = x;
-                *(uint2*)(a.xb + (size_t)m * a.ldxb + 64 * L.w + 4 * slot) = make_uint2(cvt_pk_h16(x.x, x.y), cvt_pk_h16(x.z, x.w));
+                nx[it] = make_uint2(cvt_pk_h16(x.x, x.y), cvt_pk_h16(x.z, x.w));
+                *(uint2*)(a.xb + (size_t)m * a.ldxb + 64 * L.w + 4 * slot) = nx[it];
             }
         }
+    }
+    if (!emask) return;
+    // ---- projection blocks of the new x ---------------------------------------------------------------------------------------
+    __syncthreads();   // every wave is done with its transposition tile: the operand tile of the new x overwrites waves 0 / 1's
+    {
+        const int slot = L.lane & 15, rsub = L.lane >> 4;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 4 + rsub;
+            *(uint2*)(A + row * ROWB + (((8 * L.w + (slot >> 1)) ^ (row & 15)) << 4) + (slot & 1) * 8) = nx[it];
+        }
+    }
+    __syncthreads();
+    char* t2 = X + L.w * 4096;   // wave-private [32 rows][64 channels] 16-bit: 16-byte slot s of row r at slot s ^ ((r >> 1) & 7), the
+                                 // slot's 8-byte halves swapped for rows 16..31 (32 accumulator rows x 8 B hit 32 distinct bank pairs)
+    int b = __ffs(emask) - 1;
+#pragma unroll 1
+    while (b >= 0) {
+        const unsigned rest = emask & ~((2u << b) - 1u);
+        const int nb = rest ? __ffs(rest) - 1 : -1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const char* tile = A + (q >> 1) * 256;
+            if (q == 0) mma_n64<true>(tile, L.a8, 0, 32 * ROWB, w, acc);
+            else mma_n64<false>(tile, L.a8, (q & 1) * 4, 32 * ROWB, w, acc);
+            if (q < 3) wload(w, ewp + (size_t)(4 * b + q + 1) * UNIT_U4, L.lane);
+            else if (nb >= 0) wload(w, ewp + (size_t)(4 * nb) * UNIT_U4, L.lane);
+        }
+        unsigned short* ob = a.eout[b];
+        const int ld = a.eld[b];
+        const bool elu = a.eact[b] == GIM_ACT_ELU1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    float v0 = acc[nf][j][rg * 4], v1 = acc[nf][j][rg * 4 + 1], v2 = acc[nf][j][rg * 4 + 2], v3 = acc[nf][j][rg * 4 + 3];
+                    if (elu) {
+                        v0 = elu1(v0); v1 = elu1(v1); v2 = elu1(v2); v3 = elu1(v3);
+                    }
+                    *(uint2*)(t2 + L.l31 * 128 + (((4 * nf + rg) ^ ((L.l31 >> 1) & 7)) << 4) + ((L.lh ^ (L.l31 >> 4)) << 3)) =
+                        make_uint2(cvt_pk_h16(v0, v1), cvt_pk_h16(v2, v3));
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave reads below (LDS executes a wave's accesses in order)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + (L.lane >> 3), slot = L.lane & 7, m = r0 + 32 * j + row;
+                uint4 v = *(const uint4*)(t2 + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+                if (row >> 4) v = make_uint4(v.z, v.w, v.x, v.y);
+                if (m < a.R) *(uint4*)(ob + (size_t)m * ld + 64 * L.w + 8 * slot) = v;
+            }
+        }
+        b = nb;
     }
 }
 
@@ -337,9 +415,9 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
 
 extern "C" int64_t GIM_FN(gim_token_mlp_weight_bytes)(void) { return (int64_t)4 * UNITS_PER_WAVE * UNIT_U4 * 16; }
 
-extern "C" int GIM_FN(gim_token_mlp)(const void* msg, void* xb, float* x32, const void* weights, const float* ln_params, const float* kv,
-                             const uint8_t* q_mask, int R, int C_, int L, int S, int ldm, int ldxb, int ldx32, float ln_eps,
-                             gim_stream_t stream) {
+static int token_mlp_launch(const void* msg, void* xb, float* x32, const void* weights, const float* ln_params, const float* kv,
+                            const uint8_t* q_mask, int R, int C_, int L, int S, int ldm, int ldxb, int ldx32, float ln_eps,
+                            const gim_token_emit* em, gim_stream_t stream) {
     if (R == 0) return GIM_OK;
     GIM_REQUIRE(msg && xb && x32 && weights && ln_params, "token_mlp: NULL pointer");
     GIM_REQUIRE(C_ == C, "token_mlp: built for d_model 256 (got %d)", C_);
@@ -355,6 +433,32 @@ extern "C" int GIM_FN(gim_token_mlp)(const void* msg, void* xb, float* x32, cons
     a.kv = kv; a.qmask = q_mask; a.L = L > 0 ? L : R; a.slen = (float)S;
     a.msg = (const unsigned short*)msg; a.xb = (unsigned short*)xb; a.x32 = x32; a.wts = (const uint4*)weights; a.ln = ln_params;
     a.R = R; a.ldm = ldm; a.ldxb = ldxb; a.ldx32 = ldx32; a.eps = ln_eps;
+    a.nblk = 0; a.ewts = nullptr;
+    for (int b = 0; b < MAXBLK; ++b) { a.eout[b] = nullptr; a.eld[b] = 0; a.eact[b] = GIM_ACT_NONE; a.elo[b] = a.ehi[b] = 0; }
+    if (em && em->nblk > 0) {
+        GIM_REQUIRE(em->nblk <= MAXBLK && em->weights, "token_mlp: %d projection blocks (at most %d), weights %p", em->nblk, MAXBLK, em->weights);
+        a.nblk = em->nblk; a.ewts = (const uint4*)em->weights;
+        for (int b = 0; b < em->nblk; ++b) {
+            GIM_REQUIRE(em->out[b] && em->ld[b] >= C && em->ld[b] % 8 == 0 && ((uintptr_t)em->out[b] & 15) == 0,
+                        "token_mlp: projection block %d: output %p, row stride %d", b, em->out[b], em->ld[b]);
+            GIM_REQUIRE(em->act[b] == GIM_ACT_NONE || em->act[b] == GIM_ACT_ELU1, "token_mlp: projection block %d: activation %d", b, em->act[b]);
+            GIM_REQUIRE(em->row_lo[b] % ROWS == 0 && em->row_lo[b] <= em->row_hi[b], "token_mlp: projection block %d: rows [%d, %d) (the start must be a multiple of %d)",
+                        b, em->row_lo[b], em->row_hi[b], ROWS);
+            a.eout[b] = (unsigned short*)em->out[b]; a.eld[b] = em->ld[b]; a.eact[b] = em->act[b]; a.elo[b] = em->row_lo[b]; a.ehi[b] = em->row_hi[b];
+        }
+    }
     hipLaunchKernelGGL(token_mlp_kernel, dim3((unsigned)((R + ROWS - 1) / ROWS)), dim3(256), SMEM, (hipStream_t)stream, a);
     return gim_check_launch("token_mlp");
+}
+
+extern "C" int GIM_FN(gim_token_mlp)(const void* msg, void* xb, float* x32, const void* weights, const float* ln_params, const float* kv,
+                             const uint8_t* q_mask, int R, int C_, int L, int S, int ldm, int ldxb, int ldx32, float ln_eps,
+                             gim_stream_t stream) {
+    return token_mlp_launch(msg, xb, x32, weights, ln_params, kv, q_mask, R, C_, L, S, ldm, ldxb, ldx32, ln_eps, nullptr, stream);
+}
+
+extern "C" int GIM_FN(gim_token_mlp_emit)(const void* msg, void* xb, float* x32, const void* weights, const float* ln_params, const float* kv,
+                                  const uint8_t* q_mask, int R, int C_, int L, int S, int ldm, int ldxb, int ldx32, float ln_eps,
+                                  const gim_token_emit* emit, gim_stream_t stream) {
+    return token_mlp_launch(msg, xb, x32, weights, ln_params, kv, q_mask, R, C_, L, S, ldm, ldxb, ldx32, ln_eps, emit, stream);
 }

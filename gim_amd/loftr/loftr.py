@@ -47,7 +47,7 @@ import torch.nn as nn
 
 from .. import ops
 from .._lib import ACT_ELU1, ACT_LEAKY, ACT_NONE, ACT_RELU, GIM_BF16, GIM_F16, GIM_F32, GimHipError
-from ..packing import cstore, is_half, pack_bneck, pack_bneck_tail, pack_conv, pack_fine_fused, pack_token_mlp, torch_dtype
+from ..packing import cstore, is_half, pack_bneck, pack_bneck_tail, pack_conv, pack_fine_fused, pack_token_mlp, pack_token_emit, torch_dtype
 
 _DT = {"bf16": GIM_BF16, "fp16": GIM_F16, "fp32": GIM_F32}
 
@@ -200,6 +200,8 @@ class LoFTR(nn.Module):
         # bf16 mode, d_model 256: merge -> norm1 -> mlp -> norm2 -> residual of every coarse encoder layer as ONE kernel
         # (token_mlp.hip); GIM_TOKEN_FUSED=0 keeps the five separate launches
         self.token_fused = os.environ.get("GIM_TOKEN_FUSED", "1") != "0"
+        # the token tail also computes the q / k / v projections its rows feed next (gim_token_mlp_emit): no projection GEMMs
+        self.token_emit = os.environ.get("GIM_TOKEN_EMIT", "1") != "0"
         # bf16 mode, layer1 (planes 64): conv2 -> conv3 (+identity) -> the next block's conv1 chained through registers
         # (bneck_fused.hip); GIM_BNECK_FUSED=0 keeps one implicit-GEMM launch per convolution
         self.bneck_fused = os.environ.get("GIM_BNECK_FUSED", "1") != "0"
@@ -329,6 +331,8 @@ class LoFTR(nn.Module):
         if is_half(dt) and self.loftr_coarse.d_model == 256:
             for li, layer in enumerate(self.loftr_coarse.layers):
                 P[f"c{li}.tok"] = pack_token_mlp(layer, device, tdt)
+            for same_len in (True, False):
+                P["c.emit", same_len] = self._emit_plan(self.loftr_coarse, same_len, device, tdt)
         fl = self.loftr_fine
         if is_half(dt) and fl.d_model == 128 and fl.nhead == 8 and fl.layer_names == ["self", "cross"] and self.W == 5:
             P["fine_fused"] = pack_fine_fused(fl.layers, device, tdt) + (fl.layers[0].norm1.eps,)
@@ -466,12 +470,99 @@ class LoFTR(nn.Module):
         g2, b2, e2 = P[p + "norm2"]
         ops.layernorm_residual(T.MLP[xs], g2, b2, T.X32[xs], T.X32[xs], T.CAT[xs, :C], e2)  # x + message
 
+    @staticmethod
+    def _emit_plan(tf, same_len, device, tdt):
+        """Launch plan of a LocalFeatureTransformer whose token tails emit the projections (gim_token_mlp_emit).
+        The call sequence (transformer.py:88-99) as (layer, query sides, source sides); after each call, the q / k / v projections
+        its rows feed before they are updated again: in a cross layer the first call's rows are the source of the second call (k, v
+        of the SAME layer), then the queries / source of the next layer.  Returns (calls, per call (weight stream, [(layer, column
+        block 0..2, sides)]) or None, the projections of the initial tokens)."""
+        calls = []
+        for li, kind in enumerate(tf.layer_names):
+            if kind == "self":
+                calls += [(li, (0, 1), (0, 1))] if same_len else [(li, (0,), (0,)), (li, (1,), (1,))]
+            else:
+                calls += [(li, (0,), (1,)), (li, (1,), (0,))]
+
+        def needs_after(ci, sides):
+            need = {}   # (layer, column block) -> sides, in first-use order
+            for sd in sides:
+                for li, xs, ss in calls[ci + 1:]:
+                    if sd in ss:
+                        need.setdefault((li, 1), []).append(sd)
+                        need.setdefault((li, 2), []).append(sd)
+                    if sd in xs:   # these rows are updated by that call: nothing later reads the current values
+                        need.setdefault((li, 0), []).append(sd)
+                        break
+            return [(li, blk, tuple(sorted(sd))) for (li, blk), sd in need.items()]
+
+        per_call = []
+        for ci, (li, xs, _) in enumerate(calls):
+            blocks = needs_after(ci, xs)
+            assert len(blocks) <= 6
+            if not blocks:
+                per_call.append(None)
+                continue
+            wsel = [(tf.layers[l2].q_proj, tf.layers[l2].k_proj, tf.layers[l2].v_proj)[blk].weight for l2, blk, _ in blocks]
+            per_call.append((pack_token_emit(wsel, device, tdt), blocks))
+        return calls, per_call, needs_after(-1, (0, 1))
+
+    def _transformer_emit(self, P, name, tf, T, n0, L, n1, S):
+        """LocalFeatureTransformer.forward with every projection after the first layer's computed by the token tail that produced
+        its operand rows (see _emit_plan).  Two [R, 3C] projection buffers alternate by layer parity: a tail writes the NEXT layer's
+        columns while its own layer's are still being read."""
+        C = T.X32.shape[1]
+        H = tf.nhead
+        calls, per_call, initial = P[name + ".emit", L == S]
+        T.QKV2 = torch.empty_like(T.QKV)
+        QK = (T.QKV, T.QKV2)
+        rows = (slice(0, n0 * L), slice(n0 * L, n0 * L + n1 * S))
+        rall = slice(0, n0 * L + n1 * S)
+        rs = lambda sides: rall if len(sides) == 2 else rows[sides[0]]   # noqa: E731
+        # projections of the initial tokens: GEMMs (one per layer and side set; q/k/v column blocks that go together in one launch)
+        groups = {}
+        for li, blk, sides in initial:
+            groups.setdefault((li, sides), []).append(blk)
+        for (li, sides), blks in groups.items():
+            p, r = f"{name}{li}.", rs(sides)
+            x_t, q = T.CAT[r, :C], QK[li & 1]
+            blks = sorted(blks)
+            if blks == [0, 1, 2]:
+                ops.linear(x_t, P[p + "qkv"], q[r], ACT_ELU1, self.use_lds_dma, act_cols=2 * C)
+            elif blks == [1, 2]:
+                ops.linear(x_t, P[p + "kv"], q[r, C:], ACT_ELU1, self.use_lds_dma, act_cols=C)
+            else:
+                assert blks == [0], blks
+                ops.linear(x_t, P[p + "q_proj"], q[r, :C], ACT_ELU1, self.use_lds_dma)
+        for (li, xs_s, ss_s), em in zip(calls, per_call):
+            xs, ss = rs(xs_s), rs(ss_s)
+            q = QK[li & 1]
+            nb_src = n0 + n1 if len(ss_s) == 2 else (n0, n1)[ss_s[0]]
+            len_q = L if xs_s[0] == 0 else S
+            len_src = L if ss_s[0] == 0 else S
+            qm = T.MASK[xs] if T.MASK is not None else None
+            km = T.MASK[ss] if T.MASK is not None else None
+            wts, lnp, eps = P[f"{name}{li}.tok"]
+            T.ws, _ = ops.linear_attention_state(q[ss, C:2 * C], q[ss, 2 * C:], nb_src, len_src, H, T.ws, km)
+            emit = None
+            if em is not None:
+                ew, blocks = em
+                spec = []
+                for l2, blk, sides in blocks:
+                    lo, hi = (0, xs.stop - xs.start) if sides == xs_s else ((0, n0 * L) if sides == (0,) else (n0 * L, xs.stop - xs.start))
+                    spec.append((QK[l2 & 1][xs, blk * C:(blk + 1) * C], ACT_ELU1 if blk < 2 else ACT_NONE, lo, hi))
+                emit = (ew, spec)
+            ops.token_mlp(q[xs, :C], T.CAT[xs, :C], T.X32[xs], wts, lnp, eps, kv=T.ws, L=len_q, S=len_src, q_mask=qm, emit=emit)
+
     def _transformer(self, P, name, tf, T, n0, L, n1, S):
         """LocalFeatureTransformer.forward (transformer.py:80-101).  Rows [0, n0*L) are feat0's tokens,
         rows [n0*L, n0*L + n1*S) feat1's; n0 == n1 sequences on each side."""
         r0, r1 = slice(0, n0 * L), slice(n0 * L, n0 * L + n1 * S)
         rall = slice(0, n0 * L + n1 * S)
         H = tf.nhead
+        if (self.token_emit and self.token_fused and (name + ".emit", L == S) in P and L % 64 == 0 and S % 64 == 0 and H == 8
+                and T.X32.shape[1] == 256 and all(f"{name}{li}.tok" in P for li in range(len(tf.layer_names)))):
+            return self._transformer_emit(P, name, tf, T, n0, L, n1, S)
         for li, kind in enumerate(tf.layer_names):
             p = f"{name}{li}."
             if kind == "self":

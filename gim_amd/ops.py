@@ -422,17 +422,38 @@ def bneck_tail(t2, res, pk, act_next=ACT_RELU, store_x=True):
     return xo, t1n
 
 
-def token_mlp(msg, xb, x32, weights, ln_params, eps, kv=None, L=0, S=0, q_mask=None):
+def token_mlp(msg, xb, x32, weights, ln_params, eps, kv=None, L=0, S=0, q_mask=None, emit=None):
     """x += norm2(mlp.2(relu(mlp.0(cat[x, norm1(merge(msg))])))) on row views: msg [R, >=256] bf16, xb [R, >=256] bf16 (operand copy
     of x, updated in place), x32 [R, >=256] fp32 (updated in place).  With `kv` (the fp32 state of linear_attention_state) the
-    attention's apply step is fused in front: `msg` then holds the elu+1 query rows of R / L sequences, S = source length."""
+    attention's apply step is fused in front: `msg` then holds the elu+1 query rows of R / L sequences, S = source length.
+    `emit` = (stream from packing.pack_token_emit, [(out [R, >=256] 16-bit row view, act, row_lo, row_hi), ...]): projection blocks
+    act(x_new W_b^T) of the new x, written for the rows of the 64-row tiles that start in [row_lo, row_hi)."""
     _req_cuda(msg, xb, x32, weights, ln_params, kv, q_mask)
     assert msg.dtype in HALF and xb.dtype == msg.dtype and weights.dtype == msg.dtype and x32.dtype == torch.float32
-    fn = lib.gim_token_mlp_f16 if msg.dtype == torch.float16 else lib.gim_token_mlp
+    f16 = msg.dtype == torch.float16
     assert msg.stride(1) == 1 and xb.stride(1) == 1 and x32.stride(1) == 1 and msg.shape[0] == xb.shape[0] == x32.shape[0]
-    with _Timed("token_mlp", 2.0 * msg.shape[0] * (256 * 256 + 512 * 512 + 512 * 256 + (32 * 256 if kv is not None else 0))):
-        check(fn(_p(msg), _p(xb), _p(x32), _p(weights), _p(ln_params), _p(kv), _p(q_mask), msg.shape[0], 256, L, S,
-                                msg.stride(0), xb.stride(0), x32.stride(0), eps, _stream()), "gim_token_mlp")
+    R = msg.shape[0]
+    flops = 2.0 * R * (256 * 256 + 512 * 512 + 512 * 256 + (32 * 256 if kv is not None else 0))
+    em = None
+    if emit:
+        ew, blocks = emit
+        assert 0 < len(blocks) <= _lib.TokenEmit.MAX and ew.dtype == msg.dtype and ew.is_cuda and ew.numel() == len(blocks) * 256 * 256
+        em = _lib.TokenEmit()
+        em.nblk, em.weights = len(blocks), ew.data_ptr()
+        for b, (out, act, lo, hi) in enumerate(blocks):
+            _req_cuda(out)
+            assert out.dtype == msg.dtype and out.stride(1) == 1 and out.shape[0] == R and out.shape[1] >= 256
+            em.out[b], em.ld[b], em.act[b], em.row_lo[b], em.row_hi[b] = out.data_ptr(), out.stride(0), act, lo, hi
+            flops += 2.0 * max(0, min(hi, R) - lo) * 256 * 256
+    with _Timed("token_mlp", flops):
+        if em is None:
+            fn = lib.gim_token_mlp_f16 if f16 else lib.gim_token_mlp
+            check(fn(_p(msg), _p(xb), _p(x32), _p(weights), _p(ln_params), _p(kv), _p(q_mask), R, 256, L, S,
+                     msg.stride(0), xb.stride(0), x32.stride(0), eps, _stream()), "gim_token_mlp")
+        else:
+            fn = lib.gim_token_mlp_emit_f16 if f16 else lib.gim_token_mlp_emit
+            check(fn(_p(msg), _p(xb), _p(x32), _p(weights), _p(ln_params), _p(kv), _p(q_mask), R, 256, L, S,
+                     msg.stride(0), xb.stride(0), x32.stride(0), eps, ctypes.byref(em), _stream()), "gim_token_mlp_emit")
 
 
 def linear_attention_state(k, v, nb_kv, S, H, ws=None, kv_mask=None):

@@ -233,6 +233,22 @@ def pack_token_mlp(layer, device, tdt=torch.bfloat16):
     return wts, ln, layer.norm1.eps
 
 
+def pack_token_emit(weights, device, tdt=torch.bfloat16):
+    """Projection blocks of gim_token_mlp_emit: `weights` = list of [256, 256] Linear weights (q_proj / k_proj / v_proj of the layer
+    that consumes the tokens next).  Per wave w (output columns 64w..) and block the fragments in the merge product's order: 4 units
+    x (4 k16 steps x 2 column fragments).  Returns the 16-bit stream [wave][block][unit]."""
+    out = []
+    ws = [t.detach().float().cpu() for t in weights]
+    assert ws and all(tuple(t.shape) == (256, 256) for t in ws)
+    for w in range(4):
+        for wb in ws:
+            for q in range(4):
+                for k in range(4):
+                    for nf in range(2):
+                        out.append(_frag(wb, 64 * w + 32 * nf, 16 * (4 * q + k)))
+    return torch.cat(out).to(device).to(tdt).contiguous()
+
+
 def _acc_order(k):
     """Column permutation that brings a weight's K axis into MFMA accumulator order: position 16s + 8lh + p of the packed row holds
     input channel 32(s >> 1) + 16(s & 1) + 8(p >> 2) + 4lh + (p & 3) -- what lane-half lh of a 32x32 accumulator fragment holds

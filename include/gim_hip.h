@@ -219,6 +219,27 @@ int gim_token_mlp_f16(const void* msg, void* xb, float* x32, const void* weights
                       const uint8_t* q_mask, int R, int C, int L, int S, int ldm, int ldxb, int ldx32, float ln_eps,
                       gim_stream_t stream);
 
+/* gim_token_mlp + projection blocks of the NEW x, computed on the tile while it is still in LDS: the q / k / v projections of
+ * the following LoFTREncoderLayer (transformer.py:42-44; in a cross layer also the k / v of the same layer's second call), each
+ * a bias-free [256 x 256] Linear with elu(.)+1 on q and k (attentions.py:31-32):   out[b][m, 0:256] = act[b](x_new[m] W_b^T)
+ * for the rows m of 64-row tiles whose first row lies in [row_lo[b], row_hi[b]).  weights: nblk x 128 KiB of 16-bit values in the
+ * per-wave fragment order of gim_amd/packing.py::pack_token_emit. */
+#define GIM_TOKEN_EMIT_MAX 6
+typedef struct gim_token_emit {
+    int nblk;
+    const void* weights;
+    void* out[GIM_TOKEN_EMIT_MAX];      /* row 0 of the block's output columns, 16-bit, 16-byte aligned */
+    int ld[GIM_TOKEN_EMIT_MAX];         /* row stride in elements (multiple of 8) */
+    int act[GIM_TOKEN_EMIT_MAX];        /* GIM_ACT_NONE or GIM_ACT_ELU1 */
+    int row_lo[GIM_TOKEN_EMIT_MAX], row_hi[GIM_TOKEN_EMIT_MAX];
+} gim_token_emit;
+int gim_token_mlp_emit(const void* msg, void* xb, float* x32, const void* weights, const float* ln_params, const float* kv,
+                       const uint8_t* q_mask, int R, int C, int L, int S, int ldm, int ldxb, int ldx32, float ln_eps,
+                       const gim_token_emit* emit, gim_stream_t stream);
+int gim_token_mlp_emit_f16(const void* msg, void* xb, float* x32, const void* weights, const float* ln_params, const float* kv,
+                           const uint8_t* q_mask, int R, int C, int L, int S, int ldm, int ldxb, int ldx32, float ln_eps,
+                           const gim_token_emit* emit, gim_stream_t stream);
+
 /* --------------------------------------------------------------------------------------------
  * Fine level.  gim_fine_gather = F.unfold(k=W,stride,pad=W/2) + [b_ids,i_ids] pick
  * (submodules/fine_preprocess.py:40-47) without materialising the unfold: windows of image0 go to

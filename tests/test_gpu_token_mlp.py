@@ -142,3 +142,74 @@ def test_token_mlp_with_fused_attention_apply(masked):
         ref = _reference(layer, att, x32)
     err = (xbf.cpu() - ref).abs()
     assert err.max() < 5e-2 and err.mean() < 3e-3, (err.max().item(), err.mean().item())
+
+
+@pytest.mark.parametrize("tdt", KINDS, ids=KIDS)
+@pytest.mark.parametrize("R", [128, 64 * 7 + 9])
+def test_token_mlp_projection_blocks(R, tdt):
+    """gim_token_mlp_emit: act(x_new W_b^T) of the new rows for up to six [256 x 256] projections (the next layer's q / k / v,
+    transformer.py:42-44, elu+1 on q and k: attentions.py:31-32), row-gated per block, into strided column views -- against fp32
+    products of the 16-bit x the kernel wrote; the token update itself must not change."""
+    from gim_amd import ops
+    from gim_amd._lib import ACT_ELU1, ACT_NONE
+    from gim_amd.packing import pack_token_emit, pack_token_mlp
+    layer = _layer(R)
+    g = torch.Generator().manual_seed(R + 1)
+    msg = (0.5 * torch.randn(R, 256, generator=g)).to(tdt)
+    x32 = torch.randn(R, 256, generator=g) * 2.0
+    ws = [torch.randn(256, 256, generator=g) / 16 for _ in range(5)]
+    wts, ln, eps = pack_token_mlp(layer, "cuda", tdt)
+    ew = pack_token_emit(ws, "cuda", tdt)
+
+    def run(emit):
+        cat = torch.zeros(R, 512, dtype=tdt, device="cuda")
+        cat[:, :256] = x32.cuda().to(tdt)
+        xd = x32.cuda().clone()
+        ops.token_mlp(msg.cuda(), cat[:, :256], xd, wts, ln, eps, emit=emit)
+        torch.cuda.synchronize()
+        return cat, xd
+
+    qa = torch.full((R, 768), 5.0, dtype=tdt, device="cuda")
+    qb = torch.full((R, 768), 5.0, dtype=tdt, device="cuda")
+    lo = 64 if R > 128 else 0
+    spec = [(qa[:, :256], ACT_ELU1, 0, R), (qa[:, 256:512], ACT_ELU1, lo, R), (qa[:, 512:], ACT_NONE, lo, R),
+            (qb[:, :256], ACT_ELU1, 0, 64), (qb[:, 512:], ACT_NONE, 0, R)]
+    cat0, x0 = run(None)
+    cat1, x1 = run((ew, spec))
+    assert torch.equal(x0, x1) and torch.equal(cat0, cat1)
+    xn = cat1[:, :256].float().cpu()
+    r16 = lambda t: t.to(tdt).float()  # noqa: E731
+    tol = 4e-2 if tdt == torch.bfloat16 else 6e-3
+    for (out, act, a, b), w in zip(spec, ws):
+        ref = xn @ r16(w).T
+        if act == ACT_ELU1:
+            ref = F.elu(ref) + 1
+        got = out.float().cpu()
+        hi = min(R, (b + 63) // 64 * 64)   # whole tiles
+        err = (got[a:hi] - ref[a:hi]).abs()
+        assert err.max() < tol * max(1.0, ref.abs().max().item()) and err.mean() < tol / 8, (err.max().item(), err.mean().item())
+        assert bool((got[:a] == 5.0).all()) and bool((got[hi:] == 5.0).all())    # rows outside the block's range are untouched
+    assert bool((qb[:, 256:512] == 5.0).all())
+
+
+def test_coarse_transformer_emitted_projections_vs_gemms():
+    """The coarse transformer with the projections emitted by the token tails against the same engine with projection GEMMs: same
+    operands and products, only the accumulation order inside a 256-long dot product differs."""
+    from tools import synth_loftr as S
+    model, sd = S.synthetic_model("fp16")
+    model = model.cuda()
+    c0, c1 = S.textured_pairs(2, 256, 256, seed=4)   # 32 x 32 coarse tokens: a multiple of the 64-row tile
+    outs = {}
+    for emit in (True, False):
+        model.token_emit = emit
+        model.debug = {}
+        d = {"image0": c0[:, :1].cuda(), "image1": c1[:, :1].cuda(), "color0": c0.cuda(), "color1": c1.cuda()}
+        model(d)
+        outs[emit] = (model.debug["feat_c0"].float().cpu(), model.debug["feat_c1"].float().cpu(), d["mconf"].numel())
+        model.debug = None
+    model.token_emit = True
+    for k in (0, 1):
+        scale = outs[False][k].abs().max().item()
+        e = (outs[True][k] - outs[False][k]).abs()
+        assert e.max().item() < 2e-2 * scale and e.mean().item() < 1e-3 * scale, (k, e.max().item(), e.mean().item(), scale)
+    assert outs[True][2] > 0 and abs(outs[True][2] - outs[False][2]) <= 0.05 * outs[False][2] + 2

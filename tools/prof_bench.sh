@@ -3,7 +3,7 @@
 #   tools/prof_bench.sh <tag> [steps]
 tag=${1:-final}; steps=${2:-10}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag; rm -rf $out; mkdir -p $out
-( cd /tmp && TMPDIR=/tmp GIM_BENCH_SKIP_DENSE=1 GIM_BENCH_SKIP_LIGHTGLUE=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o p -- \
+( cd /tmp && TMPDIR=/tmp GIM_BENCH_SKIP_DENSE=1 GIM_BENCH_SKIP_LIGHTGLUE=1 GIM_BENCH_SKIP_PARITY_MODE=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o p -- \
     python $GRAFT_REPO_ROOT/bench.py --steps $steps --warmup 2 --no-cpu-baseline ) > $out/log.txt 2>&1
 python - "$out" "$steps" <<'PY'
 import csv, glob, sys
@@ -15,7 +15,7 @@ rows = list(csv.DictReader(open(f[0])))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 ig = [r for r in rows if 'igemm' in r['Name'] or 'conv3x3_halo' in r['Name']]  # every kernel behind gim_conv2d_bn_act
 ig_calls = sum(int(r['Calls']) for r in ig); ig_ns = sum(float(r['TotalDurationNs']) for r in ig)
-lines = [f"rocprofv3 --kernel-trace --stats -- python bench.py --steps {steps} --warmup 2 --no-cpu-baseline (GIM_BENCH_SKIP_DENSE=1 GIM_BENCH_SKIP_LIGHTGLUE=1)",
+lines = [f"rocprofv3 --kernel-trace --stats -- python bench.py --steps {steps} --warmup 2 --no-cpu-baseline (GIM_BENCH_SKIP_DENSE=1 GIM_BENCH_SKIP_LIGHTGLUE=1 GIM_BENCH_SKIP_PARITY_MODE=1: the headline mode only)",
          f"total kernel time {tot/1e6:.3f} ms; igemm (gim_conv2d_bn_act) kernels: {ig_calls} launches, {ig_ns/1e6:.3f} ms, average {ig_ns/max(1,ig_calls)/1e3:.2f} us per launch"]
 for r in rows[:26]:
     lines.append(f"{r['Name'][:100]:100s} calls {int(r['Calls']):6d} total_us {float(r['TotalDurationNs'])/1e3:11.1f} avg_us {float(r['AverageNs'])/1e3:9.1f} pct {float(r['Percentage']):5.2f}")

@@ -39,6 +39,10 @@ def build(force=False, verbose=True):
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
+    # objects built with other flags (GIM_HIPCC_EXTRA: development builds) are stale
+    stamp = os.path.join(objdir, "flags.txt")
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(FLAGS):
+        force = True
     newest_hdr = max(os.path.getmtime(h) for h in _deps())
     jobs = []
     objs = []
@@ -61,6 +65,8 @@ def build(force=False, verbose=True):
         list(ex.map(run, jobs))
     if jobs or force or not os.path.exists(LIB):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    with open(stamp, "w") as f:
+        f.write(" ".join(FLAGS))
     return LIB
 
 

@@ -45,8 +45,9 @@ constexpr int UNIT_U4 = 8 * 64;      // uint4 per unit (8 fragments x 64 lanes x
 
 constexpr int MAXBLK = GIM_TOKEN_EMIT_MAX;
 
-// elu(x) + 1 with the arithmetic of the projection GEMM's epilogue (conv_igemm.hip::apply_act): exactly torch's
-__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v + 1.f : (expf(v) - 1.f) + 1.f; }
+// elu(x) + 1 for a 16-bit output: exp(x) for x <= 0 on v_exp_f32 (2 ulp in fp32, far below the output rounding; the libm expf of the
+// projection GEMM's epilogue costs ~20 instructions per value -- 4 k cycles per projection block and wave)
+__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v + 1.f : __expf(v); }
 
 struct Args {
     const float* kv;             // NULL: `msg` is the attention output.  Else: [nb][8][32*32 + 32] fp32 KV / Ksum state of the linear
@@ -69,6 +70,16 @@ struct Args {
 };
 
 struct W8 { bf16x8_t f[8]; };
+
+// -DGIM_TOKEN_TIMING (development builds only: tools/token_timing.py): shader-clock stamps at the phase boundaries, per wave, for the
+// first TT_WG workgroups of a launch
+#ifdef GIM_TOKEN_TIMING
+constexpr int TT_WG = 4096, TT_N = 10;
+__device__ unsigned long long g_tt[TT_WG][4][TT_N];
+#define TT(i) do { if (blockIdx.x < TT_WG && L.lane == 0) g_tt[blockIdx.x][L.w][i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TT(i) do { } while (0)
+#endif
 
 struct Lane {
     int lane, l31, lh, w, sw;
@@ -194,25 +205,50 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
     const uint4* ewp = a.ewts + (size_t)L.w * a.nblk * 4 * UNIT_U4;
     unsigned emask = 0u;         // projection blocks whose row range holds this tile (block-uniform)
     for (int b = 0; b < a.nblk; ++b) emask |= (r0 >= a.elo[b] && r0 < a.ehi[b]) ? 1u << b : 0u;
-    W8 w;
-    wload(w, wp, L.lane);   // merge, unit 0: in flight during the tile loads
+    // Weight units are requested TWO ahead of their use into alternating register sets (wa: even units, wb: odd units): with one
+    // set, unit u + 1 could only be requested once unit u's MFMAs had issued, and every unit waited out an L2 round trip.
+    // Unit sequence: the 28 base units, then 4 per active projection block.
+    int pf = 0;                                      // next base unit to request
+    int pb = emask ? __ffs(emask) - 1 : -1, pq = 0;  // next projection unit to request: block, unit
+    auto fetch = [&](W8& w) __attribute__((always_inline)) {
+        if (pf < UNITS_PER_WAVE) { wload(w, wp + (size_t)pf * UNIT_U4, L.lane); ++pf; return; }
+        if (pb < 0) return;
+        wload(w, ewp + (size_t)(4 * pb + pq) * UNIT_U4, L.lane);
+        if (++pq == 4) {
+            pq = 0;
+            const unsigned rest = emask & ~((2u << pb) - 1u);
+            pb = rest ? __ffs(rest) - 1 : -1;
+        }
+    };
+    W8 wa, wb;
+    TT(0);
+    fetch(wa);   // merge, units 0 and 1: in flight during the tile loads
+    fetch(wb);
     // ---- A <- attention output rows, X <- operand copy of x (512 B rows: 32 lanes x 16 B, 8 rows per pass) ----------
     {
+        // all 16 row loads of a lane are in flight before the first LDS write: ONE HBM round trip (measured with the phase stamps
+        // of -DGIM_TOKEN_TIMING: 14.3 k cycles for this phase when the loop was rolled 4 passes at a time)
         const int t = threadIdx.x, slot = t & 31;
-#pragma unroll 4
+        uint4 va[ROWS / 8], vx[ROWS / 8];
+#pragma unroll
         for (int pass = 0; pass < ROWS / 8; ++pass) {
-            const int row = pass * 8 + (t >> 5), m = r0 + row;
-            uint4 va = make_uint4(0u, 0u, 0u, 0u), vx = va;
+            const int m = r0 + pass * 8 + (t >> 5);
+            va[pass] = vx[pass] = make_uint4(0u, 0u, 0u, 0u);
             if (m < a.R) {
-                va = *(const uint4*)(a.msg + (size_t)m * a.ldm + slot * 8);
-                vx = *(const uint4*)(a.xb + (size_t)m * a.ldxb + slot * 8);
+                va[pass] = *(const uint4*)(a.msg + (size_t)m * a.ldm + slot * 8);
+                vx[pass] = *(const uint4*)(a.xb + (size_t)m * a.ldxb + slot * 8);
             }
+        }
+#pragma unroll
+        for (int pass = 0; pass < ROWS / 8; ++pass) {
+            const int row = pass * 8 + (t >> 5);
             const int off = row * ROWB + ((slot ^ (row & 15)) << 4);   // XOR on the low 4 slot bits: conflict-free b128 rows
-            *(uint4*)(A + off) = va;
-            *(uint4*)(X + off) = vx;
+            *(uint4*)(A + off) = va[pass];
+            *(uint4*)(X + off) = vx[pass];
         }
     }
     __syncthreads();
+    TT(1);
     if (a.kv) {
         // ---- linear-attention apply (attentions.py:44-45), in place on A: this wave owns heads 2w, 2w+1 = channels 64w..64w+63, and
         // nothing else reads or writes those columns.  msg[row, 32h + v] = S * Z[row,h] * sum_d Q[row, 32h + d] KV[h][d][v]  on the
@@ -264,17 +300,18 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
         }
         __syncthreads();
     }
+    TT(2);
     // ---- merge: [64 x 256] x W_merge^T, this wave's 64 output channels (transformer.py:52) ----------------------------
     f32x16_t acc[2][2];
-    int u = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {          // 4 units x 4 k16 steps = K 256
-        ++u;
         const char* tile = A + (q >> 1) * 256;   // k16 steps 0..7 -> first 256 B of the row, 8..15 -> second
+        W8& w = (q & 1) ? wb : wa;
         if (q == 0) mma_n64<true>(tile, L.a8, 0, 32 * ROWB, w, acc);
         else mma_n64<false>(tile, L.a8, (q & 1) * 4, 32 * ROWB, w, acc);
-        wload(w, wp + (size_t)u * UNIT_U4, L.lane);
+        fetch(w);
     }
+    TT(3);
     // ---- norm1 -> A (the attention output is consumed: barrier inside the LayerNorm) ---------------------------------
     layernorm_rows(acc, a.ln, a.ln + C, stat, a.eps, L);
 #pragma unroll
@@ -286,6 +323,7 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
                 *(uint2*)(A + (32 * j + L.l31) * ROWB + (((8 * L.w + 4 * nf + rg) ^ L.sw) << 4) + L.lh * 8) =
                     make_uint2(cvt_pk_h16(acc[nf][j][rg * 4], acc[nf][j][rg * 4 + 1]), cvt_pk_h16(acc[nf][j][rg * 4 + 2], acc[nf][j][rg * 4 + 3]));
     __syncthreads();
+    TT(4);
     // ---- mlp: four hidden quarters (transformer.py:55-56) --------------------------------------------------------------
     f32x16_t out[2][2];
 #pragma unroll
@@ -299,11 +337,11 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
         f32x16_t hid[2];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {      // K = 512: [x | msg], 4 units of 8 k16 steps
-            ++u;
             const char* tile = (q < 2 ? X : A) + (q & 1) * 256;
+            W8& w = (q & 1) ? wb : wa;
             if (q == 0) mma_n32<true>(tile, L.a8, w, hid);
             else mma_n32<false>(tile, L.a8, w, hid);
-            wload(w, wp + (size_t)u * UNIT_U4, L.lane);
+            fetch(w);
         }
         if (hq > 0) __syncthreads();       // every wave is done reading the previous quarter
 #pragma unroll
@@ -316,15 +354,16 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 2; ++q) {      // out += H x W2[:, quarter]: K = 128, 2 units of 4 k16 steps
-            ++u;
+            W8& w = (q & 1) ? wb : wa;
             mma_n64<false>(H, L.h8, q * 4, 32 * HROWB, w, out);
-            if (u < UNITS_PER_WAVE) wload(w, wp + (size_t)u * UNIT_U4, L.lane);
-            else if (emask) wload(w, ewp + (size_t)(4 * (__ffs(emask) - 1)) * UNIT_U4, L.lane);   // first projection unit: lands under norm2
+            fetch(w);                      // (the last quarter requests the first two projection units: they land under norm2)
         }
     }
+    TT(5);
     __syncthreads();   // H is consumed: its space serves the LayerNorm partial sums
     // ---- norm2 (transformer.py:57); residual add + stores through a wave-private LDS transposition --------------------
     layernorm_rows(out, a.ln + 2 * C, a.ln + 3 * C, stat, a.eps, L);   // barrier inside: A and X are dead from here on
+    TT(6);
     float* tr = (float*)(smem + L.w * 16384);   // this wave's [64 rows][64 channels] fp32, 16-byte slots XOR-swizzled by row
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf)
@@ -340,22 +379,30 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
     uint2 nx[16];   // this lane's share of the new x (16-bit): row it * 4 + rsub, channels 64w + 4 slot .. + 3
     {
         const int slot = L.lane & 15, rsub = L.lane >> 4;
+        // every residual row of the lane is requested before the first store: the stores below alias the loads for all the compiler
+        // knows, and a rolled read-modify-write waited out 16 HBM round trips one after the other (19.3 k cycles per tile, -DGIM_TOKEN_TIMING)
+        float4 xin[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int m = r0 + it * 4 + rsub;
+            xin[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < a.R) xin[it] = *(const float4*)(a.x32 + (size_t)m * a.ldx32 + 64 * L.w + 4 * slot);
+        }
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int row = it * 4 + rsub, m = r0 + row;
             const float4 v = *(const float4*)((char*)tr + row * 256 + ((slot ^ (row & 15)) << 4));
-            nx[it] = make_uint2(0u, 0u);
+            float4 x = xin[it];
+            x.x += v.x; x.y += v.y; x.z += v.z; x.w += v.w;   // x + message
+            nx[it] = make_uint2(cvt_pk_h16(x.x, x.y), cvt_pk_h16(x.z, x.w));
             if (m < a.R) {
-                float* xp = a.x32 + (size_t)m * a.ldx32 + 64 * L.w + 4 * slot;
-                float4 x = *(const float4*)xp;
-                x.x += v.x; x.y += v.y; x.z += v.z; x.w += v.w;   // x + message
-                *(float4*)xp = x;
-                nx[it] = make_uint2(cvt_pk_h16(x.x, x.y), cvt_pk_h16(x.z, x.w));
+                *(float4*)(a.x32 + (size_t)m * a.ldx32 + 64 * L.w + 4 * slot) = x;
                 *(uint2*)(a.xb + (size_t)m * a.ldxb + 64 * L.w + 4 * slot) = nx[it];
             }
         }
     }
-    if (!emask) return;
+    TT(7);
+    if (!emask) { TT(8); TT(9); return; }
     // ---- projection blocks of the new x ---------------------------------------------------------------------------------------
     __syncthreads();   // every wave is done with its transposition tile: the operand tile of the new x overwrites waves 0 / 1's
     {
@@ -367,6 +414,7 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
         }
     }
     __syncthreads();
+    TT(8);
     char* t2 = X + L.w * 4096;   // wave-private [32 rows][64 channels] 16-bit: 16-byte slot s of row r at slot s ^ ((r >> 1) & 7), the
                                  // slot's 8-byte halves swapped for rows 16..31 (32 accumulator rows x 8 B hit 32 distinct bank pairs)
     int b = __ffs(emask) - 1;
@@ -377,10 +425,10 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const char* tile = A + (q >> 1) * 256;
+            W8& w = (q & 1) ? wb : wa;
             if (q == 0) mma_n64<true>(tile, L.a8, 0, 32 * ROWB, w, acc);
             else mma_n64<false>(tile, L.a8, (q & 1) * 4, 32 * ROWB, w, acc);
-            if (q < 3) wload(w, ewp + (size_t)(4 * b + q + 1) * UNIT_U4, L.lane);
-            else if (nb >= 0) wload(w, ewp + (size_t)(4 * nb) * UNIT_U4, L.lane);
+            fetch(w);
         }
         unsigned short* ob = a.eout[b];
         const int ld = a.eld[b];
@@ -409,6 +457,7 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
         }
         b = nb;
     }
+    TT(9);
 }
 
 }  // namespace
@@ -450,6 +499,12 @@ static int token_mlp_launch(const void* msg, void* xb, float* x32, const void* w
     hipLaunchKernelGGL(token_mlp_kernel, dim3((unsigned)((R + ROWS - 1) / ROWS)), dim3(256), SMEM, (hipStream_t)stream, a);
     return gim_check_launch("token_mlp");
 }
+
+#ifdef GIM_TOKEN_TIMING
+extern "C" int GIM_FN(gim_token_mlp_timing)(unsigned long long* host, int n_wg) {   // copies the stamps of the last launch
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tt), (size_t)(n_wg < TT_WG ? n_wg : TT_WG) * 4 * TT_N * 8) == hipSuccess ? GIM_OK : GIM_ERR_LAUNCH;
+}
+#endif
 
 extern "C" int GIM_FN(gim_token_mlp)(const void* msg, void* xb, float* x32, const void* weights, const float* ln_params, const float* kv,
                              const uint8_t* q_mask, int R, int C_, int L, int S, int ldm, int ldxb, int ldx32, float ln_eps,

@@ -466,23 +466,39 @@ __global__ void __launch_bounds__(256, 2) fine_fused_kernel(const FineArgs a) {
     wload(w, a.wts + W_K + L.wn * 8 * 64, L);   // layer 0, Wk: in flight during the gather
     // ---- gather: 2 sides x 4 matches x 32 token slots x 256 B (fine_preprocess.py:40-47; border -> zeros like F.unfold padding)
     {
+        // side and match of a row are uniform per pass (16 rows per pass, 32 token slots per match): the ids come through scalar
+        // loads once, and all 8 window rows of a lane are requested before the first LDS write -- ONE round trip instead of
+        // (ids -> row) x 2 batches of dependent ones
         const int t = threadIdx.x, slot = t & 15;
-#pragma unroll 4
-        for (int pass = 0; pass < 2 * ROWS / 16; ++pass) {
-            const int r = pass * 16 + (t >> 4);   // 0..127
-            const int side = r >> 6, rr = r & 63, mm = rr >> 5, tok = rr & 31;
+        static_assert(2 * ROWS / 16 == 8 && G == 2, "gather schedule: 8 passes = 2 sides x 2 matches x 2 half windows");
+        int bq[G], ci[G], cj[G];
+#pragma unroll
+        for (int mm = 0; mm < G; ++mm) {
             const int m = m_base + mm;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            const bool ok = m < a.M;
+            bq[mm] = ok ? (int)a.b_ids[m] : 0;
+            ci[mm] = ok ? (int)a.i_ids[m] : 0;
+            cj[mm] = ok ? (int)a.j_ids[m] : 0;
+        }
+        uint4 v[8];
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int side = pass >> 2, mm = (pass >> 1) & 1, tok = (pass & 1) * 16 + (t >> 4);
+            const int m = m_base + mm;
+            v[pass] = make_uint4(0u, 0u, 0u, 0u);
             if (tok < WW && m < a.M) {
-                const int b = (int)a.b_ids[m];
-                const int cell = (int)(side ? a.j_ids[m] : a.i_ids[m]);
+                const int cell = side ? cj[mm] : ci[mm];
                 const int wc = side ? a.w1c : a.w0c, hf = side ? a.hf1 : a.hf0, wf = side ? a.wf1 : a.wf0;
                 const int cy = cell / wc, cx = cell - cy * wc;
                 const int y = cy * a.stride - 2 + tok / 5, x = cx * a.stride - 2 + tok % 5;
                 if (y >= 0 && y < hf && x >= 0 && x < wf)
-                    v = *(const uint4*)((side ? a.f1 : a.f0) + (((size_t)b * hf + y) * wf + x) * a.ldf + slot * 8);
+                    v[pass] = *(const uint4*)((side ? a.f1 : a.f0) + (((size_t)bq[mm] * hf + y) * wf + x) * a.ldf + slot * 8);
             }
-            *(uint4*)(smem + (side ? OFF_X1 : OFF_X0) + rr * ROWB + ((slot ^ (rr & 15)) << 4)) = v;
+        }
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int side = pass >> 2, rr = (pass & 3) * 16 + (t >> 4);
+            *(uint4*)(smem + (side ? OFF_X1 : OFF_X0) + rr * ROWB + ((slot ^ (rr & 15)) << 4)) = v[pass];
         }
     }
     FF_SYNC();

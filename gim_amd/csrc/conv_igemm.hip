@@ -275,37 +275,72 @@ struct Epilogue {
                     }
                 // UPS: y += bilinear x2 (align_corners=True) of a.ups, arithmetic of upsample2x_add_kernel (elementwise.hip) on
                 // the rounded conv output.  The 32 pixels of a pass lie in one image row (Wo % 32 == 0, checked at launch).
-                // (Round 3, measured: this epilogue costs 0.23 ms on the 256->196 lateral conv -- 0.49 ms fused against 0.25 ms for the
-                // bare conv -- because every row group's gathers queue behind the previous group's stores (vector memory returns in
-                // order).  Issuing the gathers one pass / half a pass ahead of the stores removes that wait but keeps 32-64 more
-                // VGPRs live across the transposition: 170-450 B of scratch per lane, 1.8 ms.  Not kept; the fix is staging the
-                // half-resolution rows in LDS with half-pass transposition patches.)
-                int ub = 0, uY = 0, uX0 = 0;
-                if constexpr (UPS) {
-                    const int mb = m0 + wm * WTM + j * 32;  // wave-uniform
-                    const int W2 = 2 * a.ups_w, H2 = 2 * a.ups_h;
-                    const int pr = mb / W2;
-                    uX0 = mb - pr * W2; ub = pr / H2; uY = pr - ub * H2;
-                }
+                // Round 3.  The first version gathered the four half-resolution neighbours of a pixel with ordinary loads inside
+                // the store loop: every row group's gathers queued behind the previous group's stores (vector memory returns in
+                // order), 0.23 ms on the 256->196 lateral conv (0.49 ms fused against 0.25 ms for the bare conv), and issuing
+                // them ahead by hand kept 32-64 more VGPRs live across the transposition (170-450 B of scratch, 1.8 ms).
+                // Now the SOURCE PIXELS of half a pass -- 16 output pixels read 2 rows x <= 10 columns of the half-resolution map --
+                // travel by LDS-DMA into a 2.5 KiB patch of this wave (no VGPR destination, invisible to the compiler's waits),
+                // requested BEFORE the stores of the previous half pass; the wait is a counted vmcnt(2) that leaves exactly
+                // those two stores in flight.  Neighbours are then ds_read_b128 from the patch: 20 staged rows instead of 64 gathers.
+                if constexpr (UPS && OUT_BF16) {
+                    static_assert(NI == 4 && RPI == 8 && G::NW * (WAVE_BYTES + 4096) <= G::STAGE, "upsample patch: LDS map");
+                    const int h = a.ups_h, w = a.ups_w;
+                    const float sy = (float)(h - 1) / (float)(2 * h - 1), sx = (float)(w - 1) / (float)(2 * w - 1);
+                    const int pass = j * NH + nh;   // compile-time
+                    char* ul = stage + G::NW * WAVE_BYTES + wave * 4096;                 // [2 rows x 10 columns][128 B]
+                    const unsigned ul_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)ul);
+                    const gim_u32x4_t ur = gim_make_rsrc(a.ups, (unsigned)((size_t)(M / (4 * h * w)) * h * w * a.ups_ld * 2));
+                    // source patch of half pass (jj, hh) of channel half nn: wave-uniform geometry, lane -> (staged row, 16-byte slot)
+                    auto issue = [&](const int jj, const int nn, const int hh) __attribute__((always_inline)) {
+                        const int mb = m0 + wm * WTM + jj * 32;
+                        const int W2 = 2 * w, H2 = 2 * h;
+                        const int pr = mb / W2, X0 = mb - pr * W2 + 16 * hh, ib = pr / H2, Y = pr - ib * H2;
+                        const float fy = sy * Y;
+                        const int y0 = (int)fy, y1 = y0 + (y0 < h - 1 ? 1 : 0);
+                        const int xa = (int)(sx * X0);
+                        const int nc = n0 + wn * WTN + nn * 64 + (threadIdx.x & 7) * 8;
 #pragma unroll
-                for (int k = 0; k < NI; ++k) {
-                    const int row = k * RPI + rrow;
-                    const int m = m0 + wm * WTM + j * 32 + row;
-                    uint4 o = *(const uint4*)(wl + row * RB + ((rslot ^ (row & 7)) << 4));
-                    if constexpr (UPS && OUT_BF16) {
-                        if (ncol_ok && (full || m < M)) {
-                            const int h = a.ups_h, w = a.ups_w;
-                            const float sy = (float)(h - 1) / (float)(2 * h - 1), sx = (float)(w - 1) / (float)(2 * w - 1);
-                            const float fy = sy * uY, fx = sx * (uX0 + row);
-                            const int y0 = (int)fy, x0 = (int)fx;
-                            const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
-                            const float ly1 = fy - y0, ly0 = 1.f - ly1, lx1 = fx - x0, lx0 = 1.f - lx1;
-                            const size_t base = (size_t)ub * h * w;
-                            const unsigned short* up = (const unsigned short*)a.ups + ncol;
-                            const uint4 qa = *(const uint4*)(up + (base + (size_t)y0 * w + x0) * a.ups_ld);
-                            const uint4 qb = *(const uint4*)(up + (base + (size_t)y0 * w + x1) * a.ups_ld);
-                            const uint4 qc = *(const uint4*)(up + (base + (size_t)y1 * w + x0) * a.ups_ld);
-                            const uint4 qd = *(const uint4*)(up + (base + (size_t)y1 * w + x1) * a.ups_ld);
+                        for (int i = 0; i < 3; ++i) {
+                            const int r = i * 8 + ((threadIdx.x & 63) >> 3);             // staged row 0..23 (20 used)
+                            const int sr = r >= 10 ? 1 : 0;
+                            int c = xa + r - 10 * sr;
+                            c = c < w - 1 ? c : w - 1;
+                            const unsigned voff = r < 20 ? (unsigned)((((size_t)ib * h + (sr ? y1 : y0)) * w + c) * a.ups_ld + nc) * 2u : 0xfffffff0u;
+                            gim_dma16(ur, ul_addr + (unsigned)(i * 1024), voff);
+                        }
+                    };
+                    if (pass == 0) issue(0, 0, 0);
+                    const int mb = m0 + wm * WTM + j * 32;  // wave-uniform
+                    const int W2 = 2 * w, H2 = 2 * h;
+                    const int pr = mb / W2, uX0 = mb - pr * W2, uY = pr - (pr / H2) * H2;
+                    const float fy = sy * uY;
+                    const int y0 = (int)fy;
+                    const float ly1 = fy - y0, ly0 = 1.f - ly1;
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        // this half pass's patch has landed; the two stores of the previous half pass (issued behind its request) may still fly
+                        // (counted only when both store instructions of the previous half pass were certainly issued by this wave: all
+                        // its 256 rows inside the tensor and at least the first 16-byte column group of its 64 channels below N --
+                        // wave-uniform; otherwise, where a wave may have skipped a store altogether, the queue is drained)
+                        const int nprev = hh == 1 ? nh : (pass > 0 ? (pass - 1) % NH : 0);
+                        const bool prev_ok = (hh == 1 || pass > 0) && (m0 + G::A_BYTES / KTB <= M) && (n0 + wn * WTN + nprev * 64 < a.N);
+                        if (prev_ok) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        const int xa = (int)(sx * (uX0 + 16 * hh));
+                        uint4 res[2];
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) {
+                            const int row = (2 * hh + kk) * RPI + rrow;
+                            const uint4 o = *(const uint4*)(wl + row * RB + ((rslot ^ (row & 7)) << 4));
+                            const float fx = sx * (uX0 + row);
+                            const int x0 = (int)fx;
+                            const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+                            const float lx1 = fx - x0, lx0 = 1.f - lx1;
+                            const char* q0 = ul + (x0 - xa) * 128 + rslot * 16;
+                            const char* q1 = ul + (x1 - xa) * 128 + rslot * 16;
+                            const uint4 qa = *(const uint4*)q0, qb = *(const uint4*)q1;
+                            const uint4 qc = *(const uint4*)(q0 + 1280), qd = *(const uint4*)(q1 + 1280);
                             const unsigned ov[4] = {o.x, o.y, o.z, o.w}, av[4] = {qa.x, qa.y, qa.z, qa.w}, bv[4] = {qb.x, qb.y, qb.z, qb.w};
                             const unsigned cv[4] = {qc.x, qc.y, qc.z, qc.w}, dv[4] = {qd.x, qd.y, qd.z, qd.w};
                             unsigned rv[4];
@@ -319,10 +354,27 @@ struct Epilogue {
                                 rv[e] = cvt_pk_h16(o0 + (ly0 * (lx0 * a0 + lx1 * b0) + ly1 * (lx0 * c0 + lx1 * d0)),
                                                     o1 + (ly0 * (lx0 * a1 + lx1 * b1) + ly1 * (lx0 * c1 + lx1 * d1)));
                             }
-                            o = make_uint4(rv[0], rv[1], rv[2], rv[3]);
+                            res[kk] = make_uint4(rv[0], rv[1], rv[2], rv[3]);
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the patch is consumed: the next request may overwrite it
+                        // request the next half pass's patch BEFORE this half pass's stores
+                        if (hh == 0) issue(j, nh, 1);
+                        else if (pass + 1 < TM * NH) issue((pass + 1) / NH, (pass + 1) % NH, 0);
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) {
+                            const int row = (2 * hh + kk) * RPI + rrow;
+                            const int m = m0 + wm * WTM + j * 32 + row;
+                            if (ncol_ok && (full || m < M)) *(uint4*)((char*)a.y + ((size_t)m * a.ldy + ncol) * OES) = res[kk];
                         }
                     }
+                } else {
+#pragma unroll
+                for (int k = 0; k < NI; ++k) {
+                    const int row = k * RPI + rrow;
+                    const int m = m0 + wm * WTM + j * 32 + row;
+                    const uint4 o = *(const uint4*)(wl + row * RB + ((rslot ^ (row & 7)) << 4));
                     if (ncol_ok && (full || m < M)) *(uint4*)((char*)a.y + ((size_t)m * a.ldy + ncol) * OES) = o;
+                }
                 }
             }
         }

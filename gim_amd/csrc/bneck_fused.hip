@@ -127,12 +127,23 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // W3
     __syncthreads();   // every wave is done with W2 and T1 (conv1' weights / the patches take their place); W3 is visible
+    // identity rows of the first 64-channel pass (8 lanes x 16 B per pixel, 8 pixels per instruction): requested HERE, a whole conv3
+    // ahead of their use (they used to be requested right in front of it: one exposed HBM round trip per tile, and with one
+    // workgroup per CU nothing else runs meanwhile)
+    const size_t prow0 = ((size_t)(b * a.H + y0 + w) * a.W + x0);   // first pixel of this wave's row
+    const unsigned short* rp = a.res + (prow0 + (lane >> 3)) * C4 + (lane & 7) * 8;
+    uint4 i0 = *(const uint4*)(rp), i1 = *(const uint4*)(rp + 8 * C4), i2 = *(const uint4*)(rp + 16 * C4), i3 = *(const uint4*)(rp + 24 * C4);
     if constexpr (N1 > 0) {
-        const auto rw1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w1n, 0, (int)a.w1n_bytes, 0x00020000);
-        for (int pc = w; pc < N1 * 32 / 64; pc += 8) {              // W1n: N1 rows x 32 slots (512 B), XOR on the low 4 slot bits
+        // W1n by LDS-DMA through inline asm (gim_dma16): a DMA the compiler can see makes the next LDS access -- conv3's first weight
+        // read -- wait vmcnt(0), i.e. for these 32 / 64 KiB and for the identity rows above; the hand-placed wait sits in front of conv1'
+        const gim_u32x4_t rw1 = gim_make_rsrc(a.w1n, a.w1n_bytes);
+        const unsigned w1_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_t*)(smem + OFF_W1));
+#pragma unroll
+        for (int k = 0; k < N1 * 32 / 64 / 8; ++k) {                  // W1n: N1 rows x 32 slots (512 B), XOR on the low 4 slot bits
+            const int pc = w + 8 * k;
             const int idx = pc * 64 + lane, n = idx >> 5, s = idx & 31;
             const unsigned voff = (unsigned)(n * 512 + (((s & 16) | ((s & 15) ^ (n & 15))) << 4));
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw1, (lds_t*)(smem + OFF_W1 + pc * 1024), 16, voff, 0, 0, 0);
+            gim_dma16(rw1, w1_addr + (unsigned)(pc * 1024), voff);
         }
     }
     // ---- relu -> bf16 operand (contraction order = accumulator order) -> conv3 -----------------------------------------
@@ -171,14 +182,10 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
     }
     // ---- + identity, relu; x' out; bf16 operand of conv1' -- in four 64-channel passes through this wave's LDS patch ----
     char* patch = smem + OFF_SCR + w * 4096;          // [32 px][128 B], 16-byte slots XOR (px & 7)
-    const size_t prow0 = ((size_t)(b * a.H + y0 + w) * a.W + x0);   // first pixel of this wave's row
     bf16x8_t xq[16];  // conv1' operand: step s = 2j + t
-    // identity rows (8 lanes x 16 B per pixel, 8 pixels per instruction), fetched one pass ahead.  Four named registers, not an
-    // array: behind the "memory"-clobbering waits below an array was kept in scratch (80 B / lane, a vmcnt(0) around every access:
-    // the kernel ran 1.7x slower)
-    const unsigned short* rp = a.res + (prow0 + (lane >> 3)) * C4 + (lane & 7) * 8;
+    // identity rows are fetched one pass ahead.  Four named registers, not an array: behind the "memory"-clobbering waits below an
+    // array was kept in scratch (80 B / lane, a vmcnt(0) around every access: the kernel ran 1.7x slower)
     const int psl = (lane & 7), ppx = lane >> 3;
-    uint4 i0 = *(const uint4*)(rp), i1 = *(const uint4*)(rp + 8 * C4), i2 = *(const uint4*)(rp + 16 * C4), i3 = *(const uint4*)(rp + 24 * C4);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         *(uint4*)(patch + (ppx) * 128 + ((psl ^ (ppx & 7)) << 4)) = i0;

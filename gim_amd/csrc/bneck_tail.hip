@@ -5,8 +5,8 @@
 //     t1' = relu(bn1'(conv1'_1x1(x')))                4P -> N1          (the NEXT block's resnet.py:109-111)
 //
 // Two implicit-GEMM launches become one: x' (the widest tensor of the block, 315 MB at 16 x 120 x 160 x 512) is written once and
-// NOT read back for conv1'.  Both convolutions are 1x1, so a "tile" is simply 256 consecutive pixel rows; wave w of the
-// 512-thread workgroup owns 32 of them for both products.
+// NOT read back for conv1'.  Both convolutions are 1x1, so a "tile" is simply 256 (128) consecutive pixel rows; wave w of the
+// 8-wave (4-wave: layer 3, see Cfg) workgroup owns 32 of them for both products.
 //
 // The chain stays in registers exactly as in bneck_fused.hip: every MFMA is computed transposed (weights = A operand, pixels = B
 // operand), a lane's accumulator quad is 4 consecutive channels of ONE pixel, and two v_cvt_pk per quad turn it into the next
@@ -25,9 +25,12 @@
 
 namespace {
 
-constexpr int ROWS = 256;            // pixel rows per workgroup (8 waves x 32)
-
-template <int P, int N1> struct Cfg {
+// NW waves per workgroup, 32 pixel rows each: 8 (one workgroup per CU) or 4 (two per CU: layer 3, whose 76 800 rows are 300 tiles of
+// 256 -- 1.17 rounds of 256 CUs -- but 600 tiles of 128 on 512 slots with a short second round; the two co-resident workgroups also
+// run their chunk barriers independently, so one's LDS phase overlaps the other's MFMAs)
+template <int P, int N1, int NW = 8> struct Cfg {
+    static constexpr int ROWS = 32 * NW;
+    static constexpr int LDS_LIMIT = (NW == 8 ? 160 : 80) * 1024;
     static constexpr int C4 = 4 * P;
     static constexpr int CH = P == 128 ? 64 : 32;            // conv3 output channels per chunk
     static constexpr int NCHUNK = C4 / CH;                   // 8 / 32
@@ -38,14 +41,14 @@ template <int P, int N1> struct Cfg {
     static constexpr int BUF = W3C + W1C;
     static constexpr int PROW = CH * 2;                      // bytes of one pixel row of the per-wave patch: 128 / 64
     static constexpr int PATCH = 32 * PROW;                  // [32 px][PROW]
-    static constexpr int NBUF = (3 * BUF + 8 * PATCH + (C4 + N1) * 4 <= 160 * 1024) ? 3 : 2;   // chunk buffers: NBUF - 1 chunks ahead
+    static constexpr int NBUF = (3 * BUF + NW * PATCH + (C4 + N1) * 4 <= LDS_LIMIT) ? 3 : 2;   // chunk buffers: NBUF - 1 chunks ahead
     static constexpr int OFF_PATCH = NBUF * BUF;
-    static constexpr int OFF_BIAS = OFF_PATCH + 8 * PATCH;   // b3 [C4] then b1' [N1], fp32
+    static constexpr int OFF_BIAS = OFF_PATCH + NW * PATCH;  // b3 [C4] then b1' [N1], fp32
     static constexpr int SMEM = OFF_BIAS + (C4 + N1) * 4;
     static constexpr int PIECES = BUF / 1024;                // LDS-DMA instructions per chunk (32 / 48)
-    static constexpr int PPW = PIECES / 8;                   // ... per wave
+    static constexpr int PPW = PIECES / NW;                  // ... per wave
     static constexpr int IPC = PATCH / 1024;                 // identity pieces (= x' stores) per wave and chunk: 4 / 2
-    static_assert(SMEM <= 160 * 1024 && PIECES % 8 == 0 && (P == 128 || P == 256), "LDS map");
+    static_assert(SMEM <= LDS_LIMIT && PIECES % NW == 0 && (P == 128 || P == 256) && (NW == 8 || NW == 4) && NW * 4096 <= NBUF * BUF, "LDS map");
 };
 
 struct Args {
@@ -86,14 +89,14 @@ template <int PROW> __device__ __forceinline__ int pswz(int px, int slot) {
 }
 
 // chunk q -> LDS buffer `buf`: this wave's share of the pieces
-template <int P, int N1>
+template <int P, int N1, int NW>
 __device__ __forceinline__ void issue_chunk(const u32x4_t rw3, const u32x4_t rw1, unsigned smem_addr, int buf, int q, int w, int lane) {
-    typedef Cfg<P, N1> C;
+    typedef Cfg<P, N1, NW> C;
     constexpr int S3 = C::W3ROW / 16, S1 = C::W1ROW / 16;   // slots per row
     const unsigned base = smem_addr + (unsigned)(buf * C::BUF);
 #pragma unroll
     for (int k = 0; k < C::PPW; ++k) {
-        const int pc = w + 8 * k;                          // wave-uniform piece index
+        const int pc = w + NW * k;                         // wave-uniform piece index
         if (pc < C::W3C / 1024) {
             const int idx = pc * 64 + lane, n = idx / S3, d = idx % S3;
             const unsigned voff = (unsigned)((q * C::CH + n) * C::W3ROW + (swz<C::W3ROW>(n, d) << 4));
@@ -111,9 +114,10 @@ __device__ __forceinline__ void issue_chunk(const u32x4_t rw3, const u32x4_t rw1
 // straight into this wave's patch (row layout).  A load hipcc can see beside LDS-DMA makes it wait vmcnt(0); a load hidden in inline
 // asm has its destination registers copied (v_mov) by the register allocator BEFORE the hand-placed wait whenever that wait sits in
 // more than one branch (measured: garbage identity rows in some tiles of launches with more workgroups than CUs).
-template <int P, int N1>
-__global__ void __launch_bounds__(512, 2) bneck_tail_kernel(const Args a) {
-    typedef Cfg<P, N1> C;
+template <int P, int N1, int NW>
+__global__ void __launch_bounds__(NW * 64, 2) bneck_tail_kernel(const Args a) {
+    typedef Cfg<P, N1, NW> C;
+    constexpr int ROWS = C::ROWS;
     constexpr int C4 = C::C4, CH = C::CH, NCHUNK = C::NCHUNK, PROW = C::PROW;
     constexpr int NF = N1 / 32;                            // conv1' output fragments per wave
     constexpr int TF = CH / 32;                            // conv3 output fragments per chunk (2 / 1)
@@ -127,13 +131,12 @@ __global__ void __launch_bounds__(512, 2) bneck_tail_kernel(const Args a) {
 
     const u32x4_t rw3 = make_rsrc(a.w3, a.w3_bytes), rw1 = make_rsrc(a.w1n, a.w1n_bytes);
     const unsigned smem_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_t*)smem);   // LDS byte address of the dynamic array
-    issue_chunk<P, N1>(rw3, rw1, smem_addr, 0, 0, w, lane);
+    issue_chunk<P, N1, NW>(rw3, rw1, smem_addr, 0, 0, w, lane);
     // biases -> LDS (a global bias load inside the chunk loop makes the compiler wait vmcnt(0): it would drain the weight DMA)
     float* bias = (float*)(smem + C::OFF_BIAS);
-    {
-        const int t = threadIdx.x;
+    for (int t = threadIdx.x; t < (C4 + N1) / 4; t += NW * 64) {
         if (t < C4 / 4) *(float4*)(bias + 4 * t) = *(const float4*)(a.b3 + 4 * t);
-        else if (t < (C4 + N1) / 4) *(float4*)(bias + 4 * t) = *(const float4*)(a.b1n + 4 * t - C4);
+        else *(float4*)(bias + 4 * t) = *(const float4*)(a.b1n + 4 * t - C4);
     }
     // conv3's pixel operand: P / 16 k16 steps, lane (pixel l31, half lh) holds channels 16s + 8lh .. + 7
     bf16x8_t t2[P / 16];
@@ -157,7 +160,7 @@ __global__ void __launch_bounds__(512, 2) bneck_tail_kernel(const Args a) {
         for (int k = 0; k < C::IPC; ++k) dma16(rres, patch_addr + (unsigned)(k * 1024), id_voff + (unsigned)(k * PPI * C4 * 2 + q * CH * 2));
     };
     issue_identity(0);
-    if constexpr (C::NBUF == 3) issue_chunk<P, N1>(rw3, rw1, smem_addr, 1, 1, w, lane);   // behind what chunk 0 needs: may stay in flight
+    if constexpr (C::NBUF == 3) issue_chunk<P, N1, NW>(rw3, rw1, smem_addr, 1, 1, w, lane);   // behind what chunk 0 needs: may stay in flight
     __syncthreads();             // biases are in LDS (the compiler knows nothing of the DMA in flight: no drain)
 
     f32x16_t c1[NF];
@@ -237,7 +240,7 @@ __global__ void __launch_bounds__(512, 2) bneck_tail_kernel(const Args a) {
         // in THIS order: identity of chunk q + 1, weights of chunk q + NBUF - 1 (into the buffer chunk q - 1 used, free since this
         // chunk's barrier), and only then this chunk's stores -- nothing the next chunks wait for sits behind a store
         if (q + 1 < NCHUNK) issue_identity(q + 1);
-        if (q + C::NBUF - 1 < NCHUNK) issue_chunk<P, N1>(rw3, rw1, smem_addr, (q + C::NBUF - 1) % C::NBUF, q + C::NBUF - 1, w, lane);
+        if (q + C::NBUF - 1 < NCHUNK) issue_chunk<P, N1, NW>(rw3, rw1, smem_addr, (q + C::NBUF - 1) % C::NBUF, q + C::NBUF - 1, w, lane);
         if (a.xo != nullptr) {
             unsigned short* xp = a.xo + (prow0 + ipx) * C4 + CH * q + isl * 8;
             *(uint4*)(xp) = x0; *(uint4*)(xp + (size_t)PPI * C4) = x1;
@@ -281,24 +284,28 @@ __global__ void __launch_bounds__(512, 2) bneck_tail_kernel(const Args a) {
     }
 }
 
-template <int P, int N1>
+template <int P, int N1, int NW = 8>
 int launch_tail(const Args& a, hipStream_t s) {
-    typedef Cfg<P, N1> C;
+    typedef Cfg<P, N1, NW> C;
     static GimPerDevice attr;
     if (attr.needed()) {
-        hipError_t e = hipFuncSetAttribute((const void*)bneck_tail_kernel<P, N1>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        hipError_t e = hipFuncSetAttribute((const void*)bneck_tail_kernel<P, N1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
         if (e != hipSuccess) { gim_set_error("bneck_tail: hipFuncSetAttribute(%d B LDS): %s", C::SMEM, hipGetErrorString(e)); return GIM_ERR_LAUNCH; }
         attr.done();
     }
-    hipLaunchKernelGGL((bneck_tail_kernel<P, N1>), dim3((unsigned)(a.M / ROWS)), dim3(512), C::SMEM, s, a);
+    hipLaunchKernelGGL((bneck_tail_kernel<P, N1, NW>), dim3((unsigned)(a.M / C::ROWS)), dim3(NW * 64), C::SMEM, s, a);
     return gim_check_launch("bneck_tail");
 }
+
+// GIM_BNECK_TAIL_NW: 0 (default) = 4-wave workgroups for planes 256 when the 256-row tiles would not fill three rounds of the chip;
+// 4 / 8 force one shape (A/B)
+int tail_nw() { static const int v = [] { const char* e = getenv("GIM_BNECK_TAIL_NW"); return e ? atoi(e) : 0; }(); return v; }
 
 int tail_entry(int P, const void* t2, const void* res, void* x_out, void* t1_next, const void* w3, const void* w1n,
                const float* b3, const float* b1n, int M, int n_next, int act_next, gim_stream_t stream) {
     GIM_REQUIRE(t2 && res && t1_next && w3 && w1n && b3 && b1n, "bneck_tail: NULL pointer");
     GIM_REQUIRE(act_next == GIM_ACT_RELU || act_next == GIM_ACT_NONE, "bneck_tail: activation of the next conv1 must be relu or none");
-    GIM_REQUIRE(M > 0 && M % ROWS == 0, "bneck_tail: the pixel row count must be a multiple of %d (got %d)", ROWS, M);
+    GIM_REQUIRE(M > 0 && M % 256 == 0, "bneck_tail: the pixel row count must be a multiple of 256 (got %d)", M);
     GIM_REQUIRE((int64_t)M * 4 * P * 2 < (int64_t)0xFFFFFFF0ll, "bneck_tail: tensor too large for 32-bit buffer offsets");
     Args a;
     a.t2 = (const unsigned short*)t2; a.res = (const unsigned short*)res; a.xo = (unsigned short*)x_out; a.t1n = (unsigned short*)t1_next;
@@ -309,6 +316,8 @@ int tail_entry(int P, const void* t2, const void* res, void* x_out, void* t1_nex
         return n_next == 128 ? launch_tail<128, 128>(a, (hipStream_t)stream) : launch_tail<128, 256>(a, (hipStream_t)stream);
     }
     GIM_REQUIRE(n_next == 256, "bneck_tail256: n_next must be 256 (got %d)", n_next);
+    const int nw = tail_nw();
+    if (nw == 4 || (nw == 0 && M / 256 < 3 * 256)) return launch_tail<256, 256, 4>(a, (hipStream_t)stream);
     return launch_tail<256, 256>(a, (hipStream_t)stream);
 }
 

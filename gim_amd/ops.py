@@ -199,8 +199,8 @@ def _halo_pays(pk, B, H, W):
         return False
     npad = pk.halo[0].shape[0]
     bn = 256 if npad % 256 == 0 else 128
-    if bn == 256 and pk.n_store <= npad - 32:
-        return False
+    if pk.n_store <= npad - 32:     # incl. the 64-channel layers (SuperPoint / VGG19 / ResNet stems) in the 128-wide tile: half of it would be
+        return False                # padding -- the generic 256 x 64 tile is 2x faster there (profiles/r03_lightglue_kernel_stats.txt: 552 vs 280 us)
     return B * (H // 8) * (W // 32) * (npad // bn) >= HALO_MIN_TILES
 
 

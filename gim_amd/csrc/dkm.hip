@@ -407,13 +407,21 @@ __global__ void __launch_bounds__(256) dwconv5x5_tiled_kernel(const void* __rest
 //   * one 16-byte store per output pixel.
 // compiler fence for memory operations (IR level) + scheduling barrier (machine level): pins the software pipeline
 #define ORDER_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-template <bool BF16>
+// PW (bf16, cpad = 32 = 4 channel groups, one chunk): the 1x1 convolution that follows in DKM's / RoMa's ConvRefiner block
+// (create_block, dkm.py:58-73: depthwise 5x5 -> BatchNorm -> ReLU -> 1x1 with bias) runs in the epilogue.  At 24 channels that
+// 1x1 is pure memory traffic -- a 1.77 M-pixel launch of the implicit-GEMM kernel took 284 us for 226 MB (one K slab per tile: all
+// latency) on top of this kernel's 198 us -- so the block's 512 pixels x 32 channels go through LDS instead: bf16 rows [512][64 B],
+// every wave takes the 128 pixels of its own rows as four 32-pixel MFMA fragments (weights = A operand, K = 32 in two k16 steps),
+// writes the results back over them and stores 16 pixels x 64 B per instruction.  The intermediate tensor never exists.
+template <bool BF16, bool PW = false>
 __global__ void __launch_bounds__(256, 2) dwconv5x5_rows2_kernel(const void* __restrict__ x, const float* __restrict__ wgt,
                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
                                                                  void* __restrict__ y, int B, int H, int W, int CG, int CGB, int NCH,
-                                                                 int cpad, int ldx, int ldy, unsigned nblk) {
+                                                                 int cpad, int ldx, int ldy, unsigned nblk,
+                                                                 const unsigned short* __restrict__ pww = nullptr, const float* __restrict__ pwb = nullptr) {
+    static_assert(!PW || BF16, "fused 1x1: bf16 only");
     constexpr int G = BF16 ? 8 : 4, ES = BF16 ? 2 : 4, G2 = G / 2, NP = G / 4;   // NP float4 planes of weights
-    extern __shared__ float4 wl[];                                              // [NP][25][CGB]
+    extern __shared__ float4 wl[];                                              // [NP][25][CGB]  (+ PW: [512 px][64 B] behind it)
     const unsigned lb = xcd_remap(blockIdx.x, nblk);
     const int chunk = (int)(lb % (unsigned)NCH);
     const unsigned sblk = lb / (unsigned)NCH;
@@ -429,9 +437,12 @@ __global__ void __launch_bounds__(256, 2) dwconv5x5_rows2_kernel(const void* __r
     const int cgl = threadIdx.x % CGB, sl = threadIdx.x / CGB;
     const int WS = (W + 3) / 4, HS = (H + 1) / 2;
     const size_t strip = (size_t)sblk * SPB + sl;
-    if (sl >= SPB || cgl >= ncg || strip >= (size_t)B * HS * WS) return;
-    const int xs = (int)(strip % WS) * 4, Y = (int)((strip / WS) % HS) * 2, b = (int)(strip / ((size_t)WS * HS));
-    const int co = (cg0 + cgl) * G;
+    const bool live = !(sl >= SPB || cgl >= ncg || strip >= (size_t)B * HS * WS);
+    if (!PW && !live) return;
+    // (PW: a thread without a strip computes a clamped one and stores nothing -- it has to reach the barriers)
+    const size_t strip_c = live ? strip : 0;
+    const int xs = (int)(strip_c % WS) * 4, Y = (int)((strip_c / WS) % HS) * 2, b = (int)(strip_c / ((size_t)WS * HS));
+    const int co = live ? (cg0 + cgl) * G : 0;
     f32x2_t acc[2][4][G2];
 #pragma unroll
     for (int o = 0; o < 2; ++o)
@@ -517,6 +528,69 @@ __global__ void __launch_bounds__(256, 2) dwconv5x5_rows2_kernel(const void* __r
         const float4 a = *(const float4*)(scale + co + 2 * e), c = *(const float4*)(shift + co + 2 * e);
         sc[e] = (f32x2_t){a.x, a.y}; sc[e + 1] = (f32x2_t){a.z, a.w};
         sh[e] = (f32x2_t){c.x, c.y}; sh[e + 1] = (f32x2_t){c.z, c.w};
+    }
+    if constexpr (PW) {
+        typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
+        typedef __attribute__((ext_vector_type(16))) float f16v_t;
+        char* T = (char*)(wl + NP * 25 * CGB);   // [512 px][4 slots of 16 B], slot s of row r at s ^ ((r >> 2) & 3)
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int p_ = 0; p_ < 4; ++p_) {
+                float rr[8];
+#pragma unroll
+                for (int e = 0; e < G2; ++e) {
+                    const f32x2_t v = acc[o][p_][e] * sc[e] + sh[e];
+                    rr[2 * e] = fmaxf(v.x, 0.f); rr[2 * e + 1] = fmaxf(v.y, 0.f);
+                }
+                const int pi = sl * 8 + o * 4 + p_;
+                // (a channel group beyond the stored width -- 24 stored channels = 3 groups -- must hold exact zeros: it is K of the MFMA)
+                *(uint4*)(T + pi * 64 + ((cgl ^ ((pi >> 2) & 3)) << 4)) = cgl < ncg ?
+                    make_uint4(pack_bf16x2(rr[0], rr[1]), pack_bf16x2(rr[2], rr[3]), pack_bf16x2(rr[4], rr[5]), pack_bf16x2(rr[6], rr[7])) :
+                    make_uint4(0u, 0u, 0u, 0u);
+            }
+        __syncthreads();
+        const int lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+        bf8_t wf[2];   // A operand: row m = output channel l31, k16 step ks: input channels 16 ks + 8 lh .. + 7
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wf[ks] = *(const bf8_t*)(pww + l31 * 32 + (2 * ks + lh) * 8);
+        f16v_t c[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float4 bb = *(const float4*)(pwb + 8 * rg + 4 * lh);
+                c[f][rg * 4] = bb.x; c[f][rg * 4 + 1] = bb.y; c[f][rg * 4 + 2] = bb.z; c[f][rg * 4 + 3] = bb.w;
+            }
+            const int pi = wv * 128 + f * 32 + l31;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf8_t bv = *(const bf8_t*)(T + pi * 64 + (((2 * ks + lh) ^ ((pi >> 2) & 3)) << 4));
+                c[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], bv, c[f], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's rows are consumed (a wave's LDS accesses execute in order)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int pi = wv * 128 + f * 32 + l31;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)   // accumulator quad = output channels 8 rg + 4 lh .. + 3 of pixel pi
+                *(uint2*)(T + pi * 64 + ((rg ^ ((pi >> 2) & 3)) << 4) + lh * 8) =
+                    make_uint2(pack_bf16x2(c[f][rg * 4], c[f][rg * 4 + 1]), pack_bf16x2(c[f][rg * 4 + 2], c[f][rg * 4 + 3]));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int q = wv * 128 + it * 16 + (lane >> 2), sq = lane & 3;
+            const uint4 v = *(const uint4*)(T + q * 64 + ((sq ^ ((q >> 2) & 3)) << 4));
+            const size_t st = (size_t)sblk * SPB + (q >> 3);
+            if (st < (size_t)B * HS * WS) {
+                const int qx = (int)(st % WS) * 4 + (q & 3), qy = (int)((st / WS) % HS) * 2 + ((q >> 2) & 1), qb = (int)(st / ((size_t)WS * HS));
+                if (qx < W && qy < H && sq < CG) *(uint4*)((unsigned short*)y + (((size_t)qb * H + qy) * W + qx) * ldy + sq * 8) = v;
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
@@ -829,6 +903,21 @@ extern "C" int gim_dwconv5x5_bn_relu(const void* x, const float* wgt, const floa
     const dim3 grid(nblocks((size_t)B * H * W * (cpad / 4), 256));
     DISPATCH_BF(dwconv5x5_kernel, dtype == GIM_BF16, grid, x, wgt, scale, shift, y, B, H, W, cpad / 4, Cout / Cin, cpad, ldx, ldy);
     return gim_check_launch("dwconv5x5");
+}
+
+extern "C" int gim_dwconv5x5_pw32(const void* x, const float* wgt, const float* scale, const float* shift, const void* pw_w,
+                                  const float* pw_b, void* y, int B, int H, int W, int cs, int ldx, int ldy, gim_stream_t stream) {
+    GIM_REQUIRE(x && wgt && scale && shift && pw_w && pw_b && y && B > 0 && H > 0 && W > 0, "dwconv5x5_pw32: bad args");
+    GIM_REQUIRE((cs == 24 || cs == 32) && ldx % 8 == 0 && ldx >= cs && ldy % 8 == 0 && ldy >= cs,
+                "dwconv5x5_pw32: stored channels %d (24 or 32), row strides (ldx %d, ldy %d)", cs, ldx, ldy);
+    const int CG = cs / 8, CGB = 4, SPB = 64;
+    const size_t strips = (size_t)B * ((H + 1) / 2) * ((W + 3) / 4);
+    const size_t nblk = (strips + SPB - 1) / SPB;
+    GIM_REQUIRE(nblk < 0x7fffffffull, "dwconv5x5_pw32: grid too large");
+    const size_t shm = (size_t)2 * 25 * CGB * 16 + 512 * 64;
+    hipLaunchKernelGGL((dwconv5x5_rows2_kernel<true, true>), dim3((unsigned)nblk), dim3(256), shm, (hipStream_t)stream, x, wgt, scale, shift, y,
+                       B, H, W, CG, CGB, 1, cs, ldx, ldy, (unsigned)nblk, (const unsigned short*)pw_w, pw_b);
+    return gim_check_launch("dwconv5x5_pw32");
 }
 
 extern "C" int gim_row_norms(const void* x, float* out, int rows, int C, int ld, int dtype, gim_stream_t stream) {

@@ -715,6 +715,20 @@ def dwconv5x5_bn_relu(x, wgt, scale, shift, cin, cout):
     return y
 
 
+def dwconv5x5_pw32(x, wgt, scale, shift, pw_w, pw_b):
+    """One ConvRefiner block at cs = 24 or 32 stored channels in one launch: depthwise 5x5 + BN + ReLU, then the 1x1 conv with bias.
+    x [B,H,W,ldx >= cs] bf16; wgt [25,cs], scale / shift [cs] fp32; pw_w [32,32] bf16 (zero padded), pw_b [32] fp32 -> new [B,H,W,cs]"""
+    _req_cuda(x, wgt, scale, shift, pw_w, pw_b)
+    assert x.dtype == torch.bfloat16 and pw_w.dtype == torch.bfloat16 and tuple(pw_w.shape) == (32, 32) and pw_w.is_contiguous()
+    cs = wgt.shape[1]
+    assert cs in (24, 32) and x.is_contiguous() and pw_b.numel() == 32 and scale.numel() == cs and shift.numel() == cs
+    B, H, W, ldx = x.shape
+    y = torch.empty(B, H, W, cs, dtype=x.dtype, device=x.device)
+    check(lib.gim_dwconv5x5_pw32(_p(x), _p(wgt), _p(scale), _p(shift), _p(pw_w), _p(pw_b), _p(y), B, H, W, cs, ldx, cs, _stream()),
+          "gim_dwconv5x5_pw32")
+    return y
+
+
 def row_norms(x, C):
     """x row view [R, >=C] -> [R] fp32 L2 norms"""
     _req_cuda(x)

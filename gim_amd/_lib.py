@@ -100,6 +100,8 @@ PROTOTYPES = {
     "gim_fine_fused_weight_bytes": (c_int64, []),
     "gim_fine_fused": (c_int, [c_void_p] * 13 + [c_int] * 11 + [c_float, c_float, c_int, c_void_p]),
     "gim_fine_fused_f16": (c_int, [c_void_p] * 13 + [c_int] * 11 + [c_float, c_float, c_int, c_void_p]),
+    "gim_fine_fused_dev": (c_int, [c_void_p] * 11 + [c_int, c_void_p] + [c_int] * 10 + [c_float, c_float, c_int, c_void_p]),
+    "gim_fine_fused_dev_f16": (c_int, [c_void_p] * 11 + [c_int, c_void_p] + [c_int] * 10 + [c_float, c_float, c_int, c_void_p]),
     "gim_copy_segments": (c_int, [ctypes.POINTER(CopySegs), c_void_p]),
     "gim_pack_matches": (c_int, [c_void_p] * 5 + [c_int64, c_void_p, c_int, c_void_p]),
     # gim_lightglue path

@@ -75,6 +75,8 @@ struct FineArgs {
     float* dbg0;                // optional [M, 25, 128] fp32 dumps of the transformer output (tests)
     float* dbg1;
     int M, hf0, wf0, hf1, wf1, ldf, w0c, w1c, stride;
+    const int* count;           // NULL, or the device-side match count: the launch covers M = the capacity of the lists and only the first
+                                // min(M, *count) matches are processed (no host round trip between coarse matching and this kernel)
     float fscale, eps;
     int has_scale0;
     int dbg_stage;
@@ -459,8 +461,10 @@ __global__ void __launch_bounds__(256, 2) fine_fused_kernel(const FineArgs a) {
     L.sw = L.l31 & 15;
     L.tsw = (L.l31 >> 1) & 7;
     const int m_base = blockIdx.x * G;
+    const int Mv = a.count ? min(a.M, *a.count) : a.M;   // block-uniform
+    if (m_base >= Mv) return;
 #ifdef FF_DEBUG_STAGES
-    L.dbg_stage = a.dbg_stage; L.dbg_call = 0; L.dbg_m_base = m_base; L.dbg_M = a.M; L.dbg_out = a.dbg0;
+    L.dbg_stage = a.dbg_stage; L.dbg_call = 0; L.dbg_m_base = m_base; L.dbg_M = Mv; L.dbg_out = a.dbg0;
 #endif
     W8 w;
     wload(w, a.wts + W_K + L.wn * 8 * 64, L);   // layer 0, Wk: in flight during the gather
@@ -475,7 +479,7 @@ __global__ void __launch_bounds__(256, 2) fine_fused_kernel(const FineArgs a) {
 #pragma unroll
         for (int mm = 0; mm < G; ++mm) {
             const int m = m_base + mm;
-            const bool ok = m < a.M;
+            const bool ok = m < Mv;
             bq[mm] = ok ? (int)a.b_ids[m] : 0;
             ci[mm] = ok ? (int)a.i_ids[m] : 0;
             cj[mm] = ok ? (int)a.j_ids[m] : 0;
@@ -486,7 +490,7 @@ __global__ void __launch_bounds__(256, 2) fine_fused_kernel(const FineArgs a) {
             const int side = pass >> 2, mm = (pass >> 1) & 1, tok = (pass & 1) * 16 + (t >> 4);
             const int m = m_base + mm;
             v[pass] = make_uint4(0u, 0u, 0u, 0u);
-            if (tok < WW && m < a.M) {
+            if (tok < WW && m < Mv) {
                 const int cell = side ? cj[mm] : ci[mm];
                 const int wc = side ? a.w1c : a.w0c, hf = side ? a.hf1 : a.hf0, wf = side ? a.wf1 : a.wf0;
                 const int cy = cell / wc, cx = cell - cy * wc;
@@ -534,7 +538,7 @@ __global__ void __launch_bounds__(256, 2) fine_fused_kernel(const FineArgs a) {
                     const int ch = 32 * L.wn + 8 * rg + 4 * L.lh;
                     const float4 v = make_float4(xm[j][rg * 4], xm[j][rg * 4 + 1], xm[j][rg * 4 + 2], xm[j][rg * 4 + 3]);
                     if (L.l31 == WW / 2) *(float4*)(fin0(mq) + ch) = v;
-                    if (a.dbg0 && a.dbg_stage == 0 && m < a.M && L.l31 < WW) *(float4*)(a.dbg0 + ((size_t)m * WW + L.l31) * C + ch) = v;
+                    if (a.dbg0 && a.dbg_stage == 0 && m < Mv && L.l31 < WW) *(float4*)(a.dbg0 + ((size_t)m * WW + L.l31) * C + ch) = v;
                 }
             }
             load_master<true>(xm, X1, LO, L);
@@ -556,12 +560,12 @@ __global__ void __launch_bounds__(256, 2) fine_fused_kernel(const FineArgs a) {
             const int ch = 32 * L.wn + 8 * rg + 4 * L.lh;
             const float4 v = make_float4(xm[j][rg * 4], xm[j][rg * 4 + 1], xm[j][rg * 4 + 2], xm[j][rg * 4 + 3]);
             if (L.l31 < WW) *(float4*)(fin1 + (mq * WW + L.l31) * FIN_LD + ch) = v;   // T1 / T2 are dead: the last call ended with a barrier
-            if (a.dbg1 && m < a.M && L.l31 < WW) *(float4*)(a.dbg1 + ((size_t)m * WW + L.l31) * C + ch) = v;
+            if (a.dbg1 && m < Mv && L.l31 < WW) *(float4*)(a.dbg1 + ((size_t)m * WW + L.l31) * C + ch) = v;
         }
     }
     FF_SYNC();
     const int m = m_base + wave;
-    if (wave >= G || m >= a.M) return;
+    if (wave >= G || m >= Mv) return;
     float s = -INFINITY;
     if (L.lane < WW) {
         const float* kr = fin1 + (wave * WW + L.lane) * FIN_LD;
@@ -600,11 +604,11 @@ __global__ void __launch_bounds__(256, 2) fine_fused_kernel(const FineArgs a) {
 
 extern "C" int64_t GIM_FN(gim_fine_fused_weight_bytes)(void) { return (int64_t)2 * W_LAYER * 16; }
 
-extern "C" int GIM_FN(gim_fine_fused)(const void* feat_f0, const void* feat_f1, const int64_t* b_ids, const int64_t* i_ids,
+static int fine_fused_launch(const void* feat_f0, const void* feat_f1, const int64_t* b_ids, const int64_t* i_ids,
                               const int64_t* j_ids, const float* mkpts1_c, const float* scale1, const void* weights,
                               const float* ln_params, float* expec_f, float* mkpts1_f, float* dbg_fine0, float* dbg_fine1,
                               int M, int hf0, int wf0, int hf1, int wf1, int C_, int ldf, int w0c, int w1c, int stride, int W,
-                              float scale, float ln_eps, int has_scale0, gim_stream_t stream) {
+                              float scale, float ln_eps, int has_scale0, const int* count, gim_stream_t stream) {
     if (M == 0) return GIM_OK;
     GIM_REQUIRE(feat_f0 && feat_f1 && b_ids && i_ids && j_ids && mkpts1_c && weights && ln_params && expec_f && mkpts1_f, "fine_fused: NULL pointer");
     GIM_REQUIRE(C_ == C && W == 5, "fine_fused: built for d_model 128 / 5x5 windows (got C=%d W=%d)", C_, W);
@@ -622,11 +626,30 @@ extern "C" int GIM_FN(gim_fine_fused)(const void* feat_f0, const void* feat_f1, 
     a.b_ids = b_ids; a.i_ids = i_ids; a.j_ids = j_ids; a.mkpts1_c = mkpts1_c; a.scale1 = scale1;
     a.wts = (const uint4*)weights; a.ln = ln_params; a.expec_f = expec_f; a.mkpts1_f = mkpts1_f; a.dbg0 = dbg_fine0; a.dbg1 = dbg_fine1;
     a.M = M; a.hf0 = hf0; a.wf0 = wf0; a.hf1 = hf1; a.wf1 = wf1; a.ldf = ldf; a.w0c = w0c; a.w1c = w1c; a.stride = stride;
-    a.fscale = scale; a.eps = ln_eps; a.has_scale0 = has_scale0;
+    a.fscale = scale; a.eps = ln_eps; a.has_scale0 = has_scale0; a.count = count;
     a.dbg_stage = 0;
 #ifdef FF_DEBUG_STAGES
     if (const char* e = getenv("GIM_FF_STAGE")) a.dbg_stage = atoi(e);
 #endif
     hipLaunchKernelGGL(fine_fused_kernel, dim3((unsigned)((M + G - 1) / G)), dim3(256), SMEM, (hipStream_t)stream, a);
     return gim_check_launch("fine_fused");
+}
+
+extern "C" int GIM_FN(gim_fine_fused)(const void* feat_f0, const void* feat_f1, const int64_t* b_ids, const int64_t* i_ids,
+                              const int64_t* j_ids, const float* mkpts1_c, const float* scale1, const void* weights,
+                              const float* ln_params, float* expec_f, float* mkpts1_f, float* dbg_fine0, float* dbg_fine1,
+                              int M, int hf0, int wf0, int hf1, int wf1, int C_, int ldf, int w0c, int w1c, int stride, int W,
+                              float scale, float ln_eps, int has_scale0, gim_stream_t stream) {
+    return fine_fused_launch(feat_f0, feat_f1, b_ids, i_ids, j_ids, mkpts1_c, scale1, weights, ln_params, expec_f, mkpts1_f, dbg_fine0, dbg_fine1,
+                             M, hf0, wf0, hf1, wf1, C_, ldf, w0c, w1c, stride, W, scale, ln_eps, has_scale0, nullptr, stream);
+}
+
+extern "C" int GIM_FN(gim_fine_fused_dev)(const void* feat_f0, const void* feat_f1, const int64_t* b_ids, const int64_t* i_ids,
+                                  const int64_t* j_ids, const float* mkpts1_c, const float* scale1, const void* weights,
+                                  const float* ln_params, float* expec_f, float* mkpts1_f, int M_cap, const int* count_dev,
+                                  int hf0, int wf0, int hf1, int wf1, int C_, int ldf, int w0c, int w1c, int stride, int W,
+                                  float scale, float ln_eps, int has_scale0, gim_stream_t stream) {
+    GIM_REQUIRE(count_dev, "fine_fused_dev: NULL count");
+    return fine_fused_launch(feat_f0, feat_f1, b_ids, i_ids, j_ids, mkpts1_c, scale1, weights, ln_params, expec_f, mkpts1_f, nullptr, nullptr,
+                             M_cap, hf0, wf0, hf1, wf1, C_, ldf, w0c, w1c, stride, W, scale, ln_eps, has_scale0, count_dev, stream);
 }

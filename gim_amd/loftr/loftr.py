@@ -200,6 +200,9 @@ class LoFTR(nn.Module):
         # bf16 mode, d_model 256: merge -> norm1 -> mlp -> norm2 -> residual of every coarse encoder layer as ONE kernel
         # (token_mlp.hip); GIM_TOKEN_FUSED=0 keeps the five separate launches
         self.token_fused = os.environ.get("GIM_TOKEN_FUSED", "1") != "0"
+        # fused fine kernel launched with the device-side match count (no host round trip in front of it); GIM_FINE_DEV_COUNT=0: sync first
+        self.fine_dev_count = os.environ.get("GIM_FINE_DEV_COUNT", "1") != "0"
+        self._count_pin = None
         # the token tail also computes the q / k / v projections its rows feed next (gim_token_mlp_emit): no projection GEMMs
         self.token_emit = os.environ.get("GIM_TOKEN_EMIT", "1") != "0"
         # bf16 mode, layer1 (planes 64): conv2 -> conv3 (+identity) -> the next block's conv1 chained through registers
@@ -733,12 +736,32 @@ class LoFTR(nn.Module):
         data.update({"hw0_c": torch.Size(hw0_c), "hw1_c": torch.Size(hw1_c),
                      "hw0_f": torch.Size(hw0_f), "hw1_f": torch.Size(hw1_f)})
 
-        M = int(cr.count[0].item())  # the one host sync the reference also has (torch.where, :193)
-        self._generation += 1
-        # 4./5. fine level (fine_preprocess.py:29-47, transformer on [M,25,128], fine_matching.py:15-74): enqueued first, straight
-        # from the coarse stage's buffers, so that the GPU is not left idle while the host hands out the match lists below
+        # 4./5. fine level (fine_preprocess.py:29-47, transformer on [M,25,128], fine_matching.py:15-74).  The reference synchronises on
+        # the match count first (torch.where, coarse_matching.py:193).  With the fused fine kernel the launch goes out BEFORE the host
+        # knows the count: it covers the capacity of the match lists and reads the count on the device, the asynchronous read-back
+        # of the count (pinned host word + event, enqueued in front of it) overlaps the kernel -- the GPU used to idle 60-75 us per
+        # forward between the read-back and the launch (profiles/r03_m kernel trace).
         fine = None
-        if M > 0:
+        dev_count = (self.fine_dev_count and self.fine_fused and self.debug is None and "fine_fused" in self._prepack(dev)
+                     and f0.dtype in ops.HALF)
+        if dev_count:
+            if self._count_pin is None:
+                self._count_pin = torch.empty(1, dtype=torch.int32).pin_memory()
+            self._count_pin.copy_(cr.count[:1], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            cap = cr.b_ids.numel()
+            fine = self._fine_level(f0, f1, cr.b_ids, cr.i_ids, cr.j_ids, cr.mkpts1_c, scale1, "scale0" in data,
+                                    hw0_c, hw1_c, data["hw0_i"], True, count=cr.count)
+            ev.synchronize()
+            M = int(self._count_pin[0])
+            ops.patch_last_fused_flops("fine_fused", 33.6e6 * M)
+            fine = (fine[0][:M], fine[1][:M], None, None) if M > 0 else None
+            assert M <= cap
+        else:
+            M = int(cr.count[0].item())  # the one host sync the reference also has
+        self._generation += 1
+        if not dev_count and M > 0:
             fine = self._fine_level(f0, f1, cr.b_ids[:M], cr.i_ids[:M], cr.j_ids[:M], cr.mkpts1_c[:M], scale1, "scale0" in data,
                                     hw0_c, hw1_c, data["hw0_i"], self.fine_fused)
         # graph replays reuse their output buffers: hand out private copies of the (small) match lists -- one launch for all of
@@ -770,7 +793,7 @@ class LoFTR(nn.Module):
             self.debug.update({"fine0": fine0, "fine1": fine1})
         data.update({"expec_f": expec_f, "mkpts0_f": data["mkpts0_c"], "mkpts1_f": mkpts1_f})
 
-    def _fine_level(self, f0, f1, b_ids, i_ids, j_ids, mkpts1_c, scale1, has_s0, hw0_c, hw1_c, hw0_i, fused):
+    def _fine_level(self, f0, f1, b_ids, i_ids, j_ids, mkpts1_c, scale1, has_s0, hw0_c, hw1_c, hw0_i, fused, count=None):
         """FinePreprocess + loftr_fine + FineMatching (loftr.py:84-91) for M > 0 matches on the NHWC fine maps f0 / f1.
         Returns (expec_f, mkpts1_f, fine0, fine1); fine0/fine1 = fp32 [M, WW, C] transformer outputs (None unless
         self.debug is set on the fused path)."""
@@ -784,7 +807,8 @@ class LoFTR(nn.Module):
         if fused and "fine_fused" in P and f0.dtype in ops.HALF:
             wts, lnp, eps = P["fine_fused"]
             return ops.fine_fused(f0, f1, b_ids, i_ids, j_ids, mkpts1_c, scale1 if has_s0 else None, wts, lnp, M,
-                                  hw0_c[1], hw1_c[1], stride, W, fscale, eps, has_s0, debug=self.debug is not None)
+                                  hw0_c[1], hw1_c[1], stride, W, fscale, eps, has_s0, debug=self.debug is not None, count=count)
+        assert count is None, "the device-side match count needs the fused fine kernel"
         F = self._TfBuffers(2 * M * WW, Cf, torch_dtype(dt), dev)
         ops.fine_gather(f0, f1, b_ids, i_ids, j_ids, M, hw0_c[1], hw1_c[1], stride, W, F.X32, F.CAT[:, :Cf])
         self._transformer(P, "f", self.loftr_fine, F, M, WW, M, WW)

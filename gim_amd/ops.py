@@ -44,6 +44,16 @@ class _Timed:
         return False
 
 
+def patch_last_fused_flops(family, flops):
+    """bench.py's live measurement: a launch that did not know its work when it was enqueued (fine_fused with a device-side count)"""
+    if PROFILE_FUSED:
+        for i in range(len(PROFILE_FUSED) - 1, -1, -1):
+            if PROFILE_FUSED[i][3] == family:
+                e0, e1, _, nm = PROFILE_FUSED[i]
+                PROFILE_FUSED[i] = (e0, e1, flops, nm)
+                return
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
@@ -473,9 +483,25 @@ def linear_attention_state(k, v, nb_kv, S, H, ws=None, kv_mask=None):
 
 
 def fine_fused(feat_f0, feat_f1, b_ids, i_ids, j_ids, mkpts1_c, scale1, weights, ln_params, M, w0c, w1c, stride, W,
-               scale, ln_eps, has_scale0, debug=False):
+               scale, ln_eps, has_scale0, debug=False, count=None):
     """Whole fine level in one launch (bf16 fine maps).  Returns (expec_f [M,3], mkpts1_f [M,2], fine0, fine1) where
-    fine0/fine1 are fp32 [M, W*W, C] dumps of the transformer output when `debug`, else None."""
+    fine0/fine1 are fp32 [M, W*W, C] dumps of the transformer output when `debug`, else None.
+    `count` (device int32 tensor): M is the CAPACITY of the match lists and the kernel processes the first min(M, count[0]) matches --
+    the launch does not wait for the host to learn the count (gim_fine_fused_dev); rows beyond it are left unwritten."""
+    _req_cuda(feat_f0, feat_f1, b_ids, mkpts1_c, weights, ln_params, count)
+    if count is not None:
+        assert not debug and count.dtype == torch.int32 and feat_f0.dtype in HALF and weights.dtype == feat_f0.dtype
+        assert feat_f0.is_contiguous() and feat_f1.is_contiguous() and b_ids.numel() >= M
+        fnd = lib.gim_fine_fused_dev_f16 if feat_f0.dtype == torch.float16 else lib.gim_fine_fused_dev
+        _, hf0, wf0, C = feat_f0.shape
+        _, hf1, wf1, _ = feat_f1.shape
+        expec = torch.empty(M, 3, dtype=torch.float32, device=feat_f0.device)
+        mk1 = torch.empty(M, 2, dtype=torch.float32, device=feat_f0.device)
+        with _Timed("fine_fused", 0.0) as tm:   # the caller fills in the flops once it knows the count (patch_last_fused_flops)
+            check(fnd(_p(feat_f0), _p(feat_f1), _p(b_ids), _p(i_ids), _p(j_ids), _p(mkpts1_c), _p(scale1), _p(weights), _p(ln_params),
+                      _p(expec), _p(mk1), M, _p(count), hf0, wf0, hf1, wf1, C, C, w0c, w1c, stride, W, scale, ln_eps,
+                      1 if has_scale0 else 0, _stream()), "gim_fine_fused_dev")
+        return expec, mk1, None, None
     _req_cuda(feat_f0, feat_f1, b_ids, mkpts1_c, weights, ln_params)
     assert feat_f0.dtype in HALF and feat_f1.dtype == feat_f0.dtype and weights.dtype == feat_f0.dtype
     assert feat_f0.is_contiguous() and feat_f1.is_contiguous()

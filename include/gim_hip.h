@@ -269,6 +269,19 @@ int gim_fine_fused(const void* feat_f0, const void* feat_f1, const int64_t* b_id
                    const float* ln_params, float* expec_f, float* mkpts1_f, float* dbg_fine0, float* dbg_fine1,
                    int M, int hf0, int wf0, int hf1, int wf1, int C, int ldf, int w0c, int w1c, int stride, int W,
                    float scale, float ln_eps, int has_scale0, gim_stream_t stream);
+/* The same launch without the host knowing the match count: it covers M_cap = the capacity of the match lists and processes the first
+ * min(M_cap, *count_dev) of them (count_dev = gim_coarse_match's count[0]); expec_f / mkpts1_f hold M_cap rows.  The reference
+ * synchronises on the count (torch.where, coarse_matching.py:193) before the fine level; here the read-back overlaps this kernel. */
+int gim_fine_fused_dev(const void* feat_f0, const void* feat_f1, const int64_t* b_ids, const int64_t* i_ids,
+                       const int64_t* j_ids, const float* mkpts1_c, const float* scale1, const void* weights,
+                       const float* ln_params, float* expec_f, float* mkpts1_f, int M_cap, const int* count_dev,
+                       int hf0, int wf0, int hf1, int wf1, int C, int ldf, int w0c, int w1c, int stride, int W,
+                       float scale, float ln_eps, int has_scale0, gim_stream_t stream);
+int gim_fine_fused_dev_f16(const void* feat_f0, const void* feat_f1, const int64_t* b_ids, const int64_t* i_ids,
+                           const int64_t* j_ids, const float* mkpts1_c, const float* scale1, const void* weights,
+                           const float* ln_params, float* expec_f, float* mkpts1_f, int M_cap, const int* count_dev,
+                           int hf0, int wf0, int hf1, int wf1, int C, int ldf, int w0c, int w1c, int stride, int W,
+                           float scale, float ln_eps, int has_scale0, gim_stream_t stream);
 /* the same kernel on fp16 fine maps / weights (GIM_F16 mode) */
 int gim_fine_fused_f16(const void* feat_f0, const void* feat_f1, const int64_t* b_ids, const int64_t* i_ids,
                        const int64_t* j_ids, const float* mkpts1_c, const float* scale1, const void* weights,

@@ -112,3 +112,28 @@ def test_end_to_end_bf16_uses_fused_and_agrees_with_unfused(model_sd):
         assert torch.equal(a[k], b[k]), k
     assert (a["expec_f"] - b["expec_f"]).abs().max() < 2e-2
     assert (a["mkpts1_f"] - b["mkpts1_f"]).abs().max() < 8e-2
+
+
+def test_device_side_match_count_equals_host_side(model_sd):
+    """gim_fine_fused_dev (launch over the capacity of the match lists, count read on the device) = the launch that knows the count:
+    bit-identical outputs end to end, incl. the forward without matches (the count is zero, every workgroup leaves at once)"""
+    model, _ = model_sd
+    c0, c1 = S.textured_pairs(2, 192, 256, seed=11)
+    outs = {}
+    try:
+        for dc in (True, False):
+            model.fine_dev_count = dc
+            d = {"image0": c0[:, :1].cuda(), "image1": c1[:, :1].cuda(), "color0": c0.cuda(), "color1": c1.cuda()}
+            model(d)
+            outs[dc] = {k: d[k].clone() for k in ("b_ids", "i_ids", "j_ids", "mconf", "expec_f", "mkpts0_f", "mkpts1_f")}
+        assert outs[True]["b_ids"].numel() > 300
+        for k, v in outs[True].items():
+            assert v.shape == outs[False][k].shape and torch.equal(v, outs[False][k]), k
+        model.fine_dev_count = True
+        z = torch.zeros(1, 1, 192, 256).cuda()   # constant images: no coarse match clears the threshold
+        d = {"image0": z, "image1": z, "color0": z.expand(-1, 3, -1, -1).contiguous(), "color1": z.expand(-1, 3, -1, -1).contiguous()}
+        model(d)
+        if d["b_ids"].numel() == 0:
+            assert d["expec_f"].shape == (0, 3) and d["mkpts1_f"].shape == (0, 2)
+    finally:
+        model.fine_dev_count = True

@@ -41,60 +41,73 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {   // src wav
 // read + 16 broadcast reads feed 16 independent FMAs, nothing waits on a previous result), the 16 panel columns live in
 // registers, and inside the panel pivots / multipliers travel by v_readlane (SGPR broadcast) instead of LDS round trips.
 // The inverse uses the same shape: row panels of 16, batched update from the finished rows, 16 in-register steps.
-__global__ void __launch_bounds__(64) potrf_diag_kernel(double* __restrict__ A, int n, int k0, int nb, size_t bstride, int* __restrict__ info,
-                                                        double* __restrict__ Linv, size_t lstride, int ldl) {
+// Round 3: TWO waves.  The inverse of row panel rb needs rows 16 rb .. 16 rb + 15 of L complete, i.e. factor panels 0 .. rb -- nothing
+// more -- so wave 1 inverts panel rb while wave 0 factors panel rb + 1 (progress word in LDS: a wave's LDS accesses execute in order, so
+// whoever sees the word sees the panel).  The chain shrinks from factor + inverse to factor + the last inverse panel.
+__global__ void __launch_bounds__(128) potrf_diag_kernel(double* __restrict__ A, int n, int k0, int nb, size_t bstride, int* __restrict__ info,
+                                                         double* __restrict__ Linv, size_t lstride, int ldl) {
     __shared__ double T[NB][NB + 1];
     __shared__ double Ti[NB][NB + 1];
     __shared__ double Rinv[NB];
+    __shared__ int prog;          // factor panels finished by wave 0
     double* a = A + blockIdx.x * bstride;
-    const int lane = threadIdx.x;
-    // all loads of a half block are in flight before the first LDS write (a rolled load -> store loop: 64 dependent round trips)
-#pragma unroll 1
-    for (int h = 0; h < NB; h += 32) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0) prog = 0;
+    // all loads of a half block are in flight before the first LDS write (a rolled load -> store loop: 64 dependent round trips);
+    // wave w loads rows 32 w .. 32 w + 31
+    {
+        const int h = wave * 32;
         double tmp[32];
 #pragma unroll
         for (int r = 0; r < 32; ++r) tmp[r] = (h + r < nb && lane <= h + r) ? a[(size_t)(k0 + h + r) * n + k0 + lane] : 0.0;
 #pragma unroll
         for (int r = 0; r < 32; ++r) T[h + r][lane] = tmp[r];
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    const int i = lane;
+    __syncthreads();
+    if (wave == 0) {
+        const int i = lane;
 #pragma unroll 1
-    for (int pb = 0; pb < NB / 16; ++pb) {
-        const int c0 = pb * 16;
-        double p[16];
+        for (int pb = 0; pb < NB / 16; ++pb) {
+            const int c0 = pb * 16;
+            double p[16];
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) p[jj] = T[i][c0 + jj];
+            for (int jj = 0; jj < 16; ++jj) p[jj] = T[i][c0 + jj];
 #pragma unroll 2
-        for (int k = 0; k < c0; ++k) {
-            const double ak = T[i][k];
+            for (int k = 0; k < c0; ++k) {
+                const double ak = T[i][k];
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) p[jj] = fma(-ak, T[c0 + jj][k], p[jj]);
+                for (int jj = 0; jj < 16; ++jj) p[jj] = fma(-ak, T[c0 + jj][k], p[jj]);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const int j = c0 + jj;
+                double d = readlane_f64(p[jj], j);
+                const bool live = j < nb;
+                if (live && !(d > 0.0)) { if (lane == 0) info[blockIdx.x] = k0 + j + 1; d = 1.0; }
+                if (!live) d = 1.0;
+                const double sd = sqrt(d), rinv = 1.0 / sd;
+                const double l = !live ? 0.0 : (i == j ? sd : (i > j ? p[jj] * rinv : 0.0));
+                p[jj] = l;
+                if (i == j) Rinv[j] = live ? rinv : 0.0;
+#pragma unroll
+                for (int kk = jj + 1; kk < 16; ++kk) p[kk] = fma(-l, readlane_f64(l, c0 + kk), p[kk]);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) T[i][c0 + jj] = p[jj];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) *(volatile int*)&prog = pb + 1;
         }
-#pragma unroll
-        for (int jj = 0; jj < 16; ++jj) {
-            const int j = c0 + jj;
-            double d = readlane_f64(p[jj], j);
-            const bool live = j < nb;
-            if (live && !(d > 0.0)) { if (lane == 0) info[blockIdx.x] = k0 + j + 1; d = 1.0; }
-            if (!live) d = 1.0;
-            const double sd = sqrt(d), rinv = 1.0 / sd;
-            const double l = !live ? 0.0 : (i == j ? sd : (i > j ? p[jj] * rinv : 0.0));
-            p[jj] = l;
-            if (i == j) Rinv[j] = live ? rinv : 0.0;
-#pragma unroll
-            for (int kk = jj + 1; kk < 16; ++kk) p[kk] = fma(-l, readlane_f64(l, c0 + kk), p[kk]);
-        }
-#pragma unroll
-        for (int jj = 0; jj < 16; ++jj) T[i][c0 + jj] = p[jj];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int r = 0; r < nb; ++r)
+            if (lane <= r) a[(size_t)(k0 + r) * n + k0 + lane] = T[r][lane];
+        return;
     }
-    for (int r = 0; r < nb; ++r)
-        if (lane <= r) a[(size_t)(k0 + r) * n + k0 + lane] = T[r][lane];
-    // inverse, column j = lane: forward substitution L x = e_j in row panels of 16
+    // wave 1: inverse, column j = lane: forward substitution L x = e_j in row panels of 16
     const int j = lane;
 #pragma unroll 1
     for (int rb = 0; rb < NB / 16; ++rb) {
+        while (*(volatile int*)&prog < rb + 1) __builtin_amdgcn_s_sleep(2);
+        asm volatile("" ::: "memory");
         const int r0 = rb * 16;
         double sacc[16];
 #pragma unroll
@@ -386,7 +399,7 @@ void chol_solve(hipStream_t s, double* A, double* Lf, double* Tb, double* R, dou
     // ---- A = L L^T (lower triangle of A overwritten by L); the inverses of the diagonal blocks land on the diagonal of Lf ----
     for (int k0 = 0; k0 < n; k0 += NB) {
         const int nb = n - k0 < NB ? n - k0 : NB;
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(B), dim3(64), 0, s, A, n, k0, nb, as, info, Lf, as, n);
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(B), dim3(128), 0, s, A, n, k0, nb, as, info, Lf, as, n);
         const int m = n - k0 - nb;
         if (m <= 0) break;
         const int tiles = (m + NB - 1) / NB;

@@ -86,7 +86,15 @@ __global__ void __launch_bounds__(128) potrf_diag_kernel(double* __restrict__ A,
                 const bool live = j < nb;
                 if (live && !(d > 0.0)) { if (lane == 0) info[blockIdx.x] = k0 + j + 1; d = 1.0; }
                 if (!live) d = 1.0;
-                const double sd = sqrt(d), rinv = 1.0 / sd;
+                // 1 / sqrt(d) from v_rsq_f64 + two Newton steps (quadratic: ~1e-8 -> ~1e-16 -> below an ulp), sqrt(d) = d * that + one
+                // correction -- about ten dependent fp64 operations on the critical path of every column instead of the ~60 of the
+                // correctly rounded sqrt() followed by a correctly rounded division
+                const double hd = 0.5 * d;
+                double rinv = __builtin_amdgcn_rsq(d);
+                rinv = rinv * fma(-(hd * rinv), rinv, 1.5);
+                rinv = rinv * fma(-(hd * rinv), rinv, 1.5);
+                double sd = d * rinv;
+                sd = fma(0.5 * rinv, fma(-sd, sd, d), sd);
                 const double l = !live ? 0.0 : (i == j ? sd : (i > j ? p[jj] * rinv : 0.0));
                 p[jj] = l;
                 if (i == j) Rinv[j] = live ? rinv : 0.0;

@@ -1,0 +1,76 @@
+"""The launch plan of the coarse transformer with projections emitted by the token tails (gim_amd/loftr/loftr.py::_emit_plan,
+transformer.py:80-101): every call must find the q projection of its query rows and the k / v projections of its source rows computed
+from the CURRENT value of those rows -- produced exactly once, by the initial GEMMs or by the tail that last updated the rows."""
+import itertools
+
+import pytest
+import torch
+
+import gim_amd.loftr.loftr as L
+
+
+class _Proj:
+    def __init__(self, tag):
+        self.weight = torch.full((256, 256), float(tag))
+
+
+class _Layer:
+    def __init__(self, li):
+        self.q_proj, self.k_proj, self.v_proj = _Proj(3 * li), _Proj(3 * li + 1), _Proj(3 * li + 2)
+
+
+class _TF:
+    def __init__(self, names):
+        self.layer_names = list(names)
+        self.layers = [_Layer(i) for i in range(len(names))]
+
+
+SEQS = [["self", "cross"] * 4, ["cross", "self"] * 2, ["self", "self", "cross", "cross"], ["cross"], ["self"],
+        ["cross", "cross", "cross"], ["self", "cross", "cross", "self", "self"]]
+
+
+@pytest.mark.parametrize("names,same_len", list(itertools.product(SEQS, [True, False])),
+                         ids=[f"{'-'.join(n[0] for n in s)}-{'eq' if e else 'ne'}" for s, e in itertools.product(SEQS, [True, False])])
+def test_every_projection_is_fresh_and_produced_once(monkeypatch, names, same_len):
+    packed = []
+    monkeypatch.setattr(L, "pack_token_emit", lambda ws, dev, tdt: packed.append([int(w[0, 0]) for w in ws]) or len(packed) - 1)
+    calls, per_call, initial = L.LoFTR._emit_plan(_TF(names), same_len, "cpu", torch.float16)
+    version = {0: 0, 1: 0}
+    have = {}          # (layer, block, side) -> version of the rows it was computed from
+    produced = set()
+    for li, blk, sides in initial:
+        for sd in sides:
+            assert (li, blk, sd) not in produced
+            produced.add((li, blk, sd))
+            have[(li, blk, sd)] = 0
+    expect = []
+    for li, kind in enumerate(names):
+        if kind == "self":
+            expect += [(li, (0, 1), (0, 1))] if same_len else [(li, (0,), (0,)), (li, (1,), (1,))]
+        else:
+            expect += [(li, (0,), (1,)), (li, (1,), (0,))]
+    assert calls == expect
+    for (li, xs, ss), em in zip(calls, per_call):
+        for sd in xs:
+            assert have.get((li, 0, sd)) == version[sd], ("stale / missing q", li, sd)
+        for sd in ss:
+            for blk in (1, 2):
+                assert have.get((li, blk, sd)) == version[sd], ("stale / missing k, v", li, blk, sd)
+        for sd in xs:
+            version[sd] += 1
+        if em is None:
+            continue
+        handle, blocks = em
+        assert 0 < len(blocks) <= 6
+        assert packed[handle] == [3 * l2 + blk for l2, blk, _ in blocks]      # the right weight matrix per block, in block order
+        for l2, blk, sides in blocks:
+            assert l2 >= li and set(sides) <= set(xs)
+            for sd in sides:
+                assert (l2, blk, sd) not in produced, ("projection computed twice", l2, blk, sd)
+                produced.add((l2, blk, sd))
+                have[(l2, blk, sd)] = version[sd]
+    # nothing is computed that no call reads
+    used = set()
+    for li, xs, ss in calls:
+        used |= {(li, 0, sd) for sd in xs} | {(li, b, sd) for sd in ss for b in (1, 2)}
+    assert produced == used

@@ -213,3 +213,27 @@ def test_coarse_transformer_emitted_projections_vs_gemms():
         e = (outs[True][k] - outs[False][k]).abs()
         assert e.max().item() < 2e-2 * scale and e.mean().item() < 1e-3 * scale, (k, e.max().item(), e.mean().item(), scale)
     assert outs[True][2] > 0 and abs(outs[True][2] - outs[False][2]) <= 0.05 * outs[False][2] + 2
+
+
+def test_emitted_projections_unequal_image_sizes():
+    """image0 256 x 256 (1024 coarse tokens) against image1 256 x 384 (1536): the self layers run per side, the plan of
+    _emit_plan(same_len=False) -- against the projection-GEMM path on the same inputs"""
+    from tools import synth_loftr as S
+    model, sd = S.synthetic_model("fp16")
+    model = model.cuda()
+    c0, _ = S.textured_pairs(2, 256, 256, seed=5)
+    c1, _ = S.textured_pairs(2, 256, 384, seed=6)
+    outs = {}
+    for emit in (True, False):
+        model.token_emit = emit
+        model.debug = {}
+        d = {"image0": c0[:, :1].cuda(), "image1": c1[:, :1].cuda(), "color0": c0.cuda(), "color1": c1.cuda()}
+        model(d)
+        outs[emit] = (model.debug["feat_c0"].float().cpu(), model.debug["feat_c1"].float().cpu())
+        model.debug = None
+    model.token_emit = True
+    assert outs[True][0].shape[1] == 1024 and outs[True][1].shape[1] == 1536
+    for k in (0, 1):
+        scale = outs[False][k].abs().max().item()
+        e = (outs[True][k] - outs[False][k]).abs()
+        assert e.max().item() < 2e-2 * scale and e.mean().item() < 1e-3 * scale, (k, e.max().item(), e.mean().item(), scale)

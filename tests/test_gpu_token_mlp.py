@@ -237,3 +237,32 @@ def test_emitted_projections_unequal_image_sizes():
         scale = outs[False][k].abs().max().item()
         e = (outs[True][k] - outs[False][k]).abs()
         assert e.max().item() < 2e-2 * scale and e.mean().item() < 1e-3 * scale, (k, e.max().item(), e.mean().item(), scale)
+
+
+def test_emitted_projections_with_padding_masks():
+    """padding masks (mask0 / mask1, coarse resolution) on the 16-bit path with the projections emitted by the token tails: the masks act
+    in the attention state (kv mask) and in the apply step (query mask), the projections are computed for every token as in the
+    reference -- against the projection-GEMM path on the same inputs"""
+    from tools import synth_loftr as S
+    model, sd = S.synthetic_model("fp16")
+    model = model.cuda()
+    c0, c1 = S.textured_pairs(2, 256, 256, seed=8)
+    m0 = torch.zeros(2, 32, 32, dtype=torch.bool); m1 = torch.zeros(2, 32, 32, dtype=torch.bool)
+    for b, ((h0, w0), (h1, w1)) in enumerate([((32, 28), (30, 32)), ((24, 32), (32, 32))]):
+        m0[b, :h0, :w0] = True; m1[b, :h1, :w1] = True
+    outs = {}
+    for emit in (True, False):
+        model.token_emit = emit
+        model.debug = {}
+        d = {"image0": c0[:, :1].cuda(), "image1": c1[:, :1].cuda(), "color0": c0.cuda(), "color1": c1.cuda(),
+             "mask0": m0.cuda(), "mask1": m1.cuda()}
+        model(d)
+        outs[emit] = (model.debug["feat_c0"].float().cpu(), model.debug["feat_c1"].float().cpu(), d["b_ids"].numel())
+        model.debug = None
+    model.token_emit = True
+    for k in (0, 1):
+        scale = outs[False][k].abs().max().item()
+        e = (outs[True][k] - outs[False][k]).abs()
+        assert torch.isfinite(outs[True][k]).all()
+        assert e.max().item() < 2e-2 * scale and e.mean().item() < 1e-3 * scale, (k, e.max().item(), e.mean().item(), scale)
+    assert abs(outs[True][2] - outs[False][2]) <= 0.05 * outs[False][2] + 2

@@ -501,6 +501,11 @@ def main():
         print("per-step ms:", [round(1e3 * (b - a), 2) for a, b in zip([t0] + tstep[:-1], tstep)], file=sys.stderr)
     if rank == 0:
         pairs = world * nb * args.steps
+        if roof is not None:
+            # the whole path priced the same way: SURVEY 8d's algorithmic work (0.7135 TFLOP per pair + 33.6 MFLOP per match) over the timed steps
+            wf = (0.7135e12 * pairs + 33.6e6 * n_matches) / world
+            roof["whole_step"] = {"tflops": round(wf / dt / 1e12, 1), "frac": round(wf / dt / 1e12 / MFMA_PEAK_TFLOPS[args.precision], 4),
+                                  "what": "all kernels of a rank's steps: (0.7135 TFLOP x pairs + 33.6 MFLOP x matches) / time, against the same peak"}
         out = {
             "metric": "image-pairs/sec at 640x480", "value": round(pairs / dt, 2), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -88,6 +88,8 @@ PROTOTYPES = {
     "gim_fine_match": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_float, c_int, c_void_p]),
     "gim_bneck64_fused": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p]),
     "gim_bneck64_fused_f16": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p]),
+    "gim_bneck64_fused_ds": (c_int, [c_void_p] * 11 + [c_int] * 3 + [c_void_p]),
+    "gim_bneck64_fused_ds_f16": (c_int, [c_void_p] * 11 + [c_int] * 3 + [c_void_p]),
     "gim_bneck_tail128": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
     "gim_bneck_tail128_f16": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
     "gim_bneck_tail256": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),

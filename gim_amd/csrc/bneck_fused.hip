@@ -33,12 +33,14 @@ constexpr int OFF_W2 = T1ROWS * 128;                        // [64][1152 B]     
 constexpr int OFF_W1 = OFF_W2;                              // [N1 <= 128][512 B]      (after conv2: replaces W2)
 constexpr int OFF_SCR = OFF_T1;                             // 8 waves x 4 KiB transposition patches (after conv2: replace T1)
 constexpr int OFF_W3 = OFF_W2 + 64 * 1152;                  // [256][128 B]
+constexpr int OFF_WDS = OFF_W1 + 64 * 512;                  // [256][128 B] downsample weights behind W1n (DS variant, N1 = 64: after conv2)
 constexpr int SMEM = OFF_W3 + 256 * 128;
-static_assert(8 * 4096 <= T1ROWS * 128 && 128 * 512 <= 64 * 1152 && SMEM <= 160 * 1024, "LDS map");
+static_assert(8 * 4096 <= T1ROWS * 128 && 128 * 512 <= 64 * 1152 && 64 * 512 + 256 * 128 <= 64 * 1152 && SMEM <= 160 * 1024, "LDS map");
 
 struct Args {
     const unsigned short* t1;    // [B,H,W,64] bf16
-    const unsigned short* res;   // [B,H,W,256] bf16 identity / downsample branch
+    const unsigned short* res;   // [B,H,W,256] bf16 identity / downsample branch -- DS variant: [B,H,W,64], the block's INPUT
+    const unsigned short* wds;   // DS variant: [256][64] bf16 downsample conv (BN folded), K in channel order; its bias is folded into b3
     unsigned short* xo;          // [B,H,W,256] bf16
     unsigned short* t1n;         // [B,H,W,N1] bf16 or NULL
     const unsigned short* w2;    // [64][576] bf16, K = (ky, kx, c)
@@ -50,14 +52,19 @@ struct Args {
     int B, H, W;
     unsigned t1_bytes, w2_bytes, w3_bytes, w1n_bytes;
 };
+// DS (first block of the layer, resnet.py:120-124: identity = bn(conv1x1(x))): the 64 -> 256 downsample convolution is conv3 with its K
+// axis extended -- x' = relu([W3 | Wds] [t2 ; x] + b3 + bds) -- the lane's 32 pixels of x arrive as four MFMA operand fragments straight
+// from global memory (128 B per pixel instead of the identity's 512 B), Wds takes the LDS space conv2's weights leave behind, and the
+// downsample launch (0.17 ms at 640x480 batch 8, HBM-bound) with the 629 MB tensor it wrote disappears.
 
 typedef __attribute__((address_space(3))) void lds_t;
 
 // 8 rows x 128 B per wave instruction, lane i -> row base + (i >> 3), LDS slot i & 7 <- source slot (i & 7) ^ key(row)
 __device__ __forceinline__ int swz_key(int row) { return (row >> 1) & 7; }   // two 128-byte rows share a 256-byte bank row
 
-template <int N1>   // 0: no trailing conv1
+template <int N1, bool DS = false>   // N1 = 0: no trailing conv1
 __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
+    static_assert(!DS || N1 == 64, "downsample variant: first block of layer 1");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -132,7 +139,21 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
     // workgroup per CU nothing else runs meanwhile)
     const size_t prow0 = ((size_t)(b * a.H + y0 + w) * a.W + x0);   // first pixel of this wave's row
     const unsigned short* rp = a.res + (prow0 + (lane >> 3)) * C4 + (lane & 7) * 8;
-    uint4 i0 = *(const uint4*)(rp), i1 = *(const uint4*)(rp + 8 * C4), i2 = *(const uint4*)(rp + 16 * C4), i3 = *(const uint4*)(rp + 24 * C4);
+    uint4 i0 = make_uint4(0u, 0u, 0u, 0u), i1 = i0, i2 = i0, i3 = i0;
+    bf16x8_t xs[4];   // DS: the block's input at this lane's pixel, k16 step s: channels 16 s + 8 lh .. + 7
+    if constexpr (DS) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xs[s] = *(const bf16x8_t*)(a.res + (prow0 + l31) * P + 16 * s + 8 * lh);
+        const gim_u32x4_t rwd = gim_make_rsrc(a.wds, 256 * 128);
+        const unsigned wd_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_t*)(smem + OFF_WDS));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                // Wds: 256 rows x 8 slots, as W3
+            const int pc = w + 8 * k, n = pc * 8 + (lane >> 3);
+            gim_dma16(rwd, wd_addr + (unsigned)(pc * 1024), (unsigned)(n * 128 + (((lane & 7) ^ swz_key(n)) << 4)));
+        }
+    } else {
+        i0 = *(const uint4*)(rp); i1 = *(const uint4*)(rp + 8 * C4); i2 = *(const uint4*)(rp + 16 * C4); i3 = *(const uint4*)(rp + 24 * C4);
+    }
     if constexpr (N1 > 0) {
         // W1n by LDS-DMA through inline asm (gim_dma16): a DMA the compiler can see makes the next LDS access -- conv3's first weight
         // read -- wait vmcnt(0), i.e. for these 32 / 64 KiB and for the identity rows above; the hand-placed wait sits in front of conv1'
@@ -179,6 +200,17 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
                 const bf16x8_t wv = *(const bf16x8_t*)(smem + OFF_W3 + (32 * j + l31) * 128 + (((2 * s + lh) ^ wk) << 4));
                 c3[j] = mfma_h16_32x32x16(wv, t2[s], c3[j]);
             }
+        if constexpr (DS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // Wds (and W1n) pieces of this wave, the xs fragments
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bf16x8_t wv = *(const bf16x8_t*)(smem + OFF_WDS + (32 * j + l31) * 128 + (((2 * s + lh) ^ wk) << 4));
+                    c3[j] = mfma_h16_32x32x16(wv, xs[s], c3[j]);
+                }
+        }
     }
     // ---- + identity, relu; x' out; bf16 operand of conv1' -- in four 64-channel passes through this wave's LDS patch ----
     char* patch = smem + OFF_SCR + w * 4096;          // [32 px][128 B], 16-byte slots XOR (px & 7)
@@ -188,6 +220,12 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
     const int psl = (lane & 7), ppx = lane >> 3;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+        if constexpr (DS) {   // the identity branch is already inside c3
+#pragma unroll
+            for (int ff = 0; ff < 2; ++ff)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c3[2 * q + ff][r] = fmaxf(c3[2 * q + ff][r], 0.f);
+        } else {
         *(uint4*)(patch + (ppx) * 128 + ((psl ^ (ppx & 7)) << 4)) = i0;
         *(uint4*)(patch + (ppx + 8) * 128 + ((psl ^ (ppx & 7)) << 4)) = i1;     // (px + 8k) & 7 == px & 7
         *(uint4*)(patch + (ppx + 16) * 128 + ((psl ^ (ppx & 7)) << 4)) = i2;
@@ -208,6 +246,7 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
                 c3[j][rg * 4 + 2] = fmaxf(c3[j][rg * 4 + 2] + h16_lo(r.y), 0.f);
                 c3[j][rg * 4 + 3] = fmaxf(c3[j][rg * 4 + 3] + h16_hi(r.y), 0.f);
             }
+        }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -278,6 +317,27 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
 
 }  // namespace
 
+extern "C" int GIM_FN(gim_bneck64_fused_ds)(const void* t1, const void* x_in, void* x_out, void* t1_next, const void* w2, const void* w3,
+                                    const void* wds, const void* w1n, const float* b2, const float* b3ds, const float* b1n, int B, int H, int W,
+                                    gim_stream_t stream) {
+    GIM_REQUIRE(t1 && x_in && x_out && t1_next && w2 && w3 && wds && w1n && b2 && b3ds && b1n, "bneck64_fused_ds: NULL pointer");
+    GIM_REQUIRE(B > 0 && H > 0 && W > 0 && H % TH == 0 && W % TW == 0, "bneck64_fused_ds: H %% 8 == 0 and W %% 32 == 0 required (got %d x %d)", H, W);
+    GIM_REQUIRE((int64_t)B * H * W * C4 * 2 < (int64_t)0xFFFFFFF0ll, "bneck64_fused_ds: tensor too large for 32-bit buffer offsets");
+    static GimPerDevice attr;
+    if (attr.needed()) {
+        hipError_t e = hipFuncSetAttribute((const void*)bneck64_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) { gim_set_error("bneck64_fused_ds: hipFuncSetAttribute(%d B LDS): %s", SMEM, hipGetErrorString(e)); return GIM_ERR_LAUNCH; }
+        attr.done();
+    }
+    Args a;
+    a.t1 = (const unsigned short*)t1; a.res = (const unsigned short*)x_in; a.wds = (const unsigned short*)wds; a.xo = (unsigned short*)x_out;
+    a.t1n = (unsigned short*)t1_next; a.w2 = (const unsigned short*)w2; a.w3 = (const unsigned short*)w3; a.w1n = (const unsigned short*)w1n;
+    a.b2 = b2; a.b3 = b3ds; a.b1n = b1n; a.B = B; a.H = H; a.W = W;
+    a.t1_bytes = (unsigned)((size_t)B * H * W * P * 2); a.w2_bytes = 64 * 1152; a.w3_bytes = 256 * 128; a.w1n_bytes = 64 * 512;
+    hipLaunchKernelGGL((bneck64_kernel<64, true>), dim3((unsigned)(B * (H / TH) * (W / TW))), dim3(512), SMEM, (hipStream_t)stream, a);
+    return gim_check_launch("bneck64_fused_ds");
+}
+
 extern "C" int GIM_FN(gim_bneck64_fused)(const void* t1, const void* res, void* x_out, void* t1_next, const void* w2, const void* w3,
                                  const void* w1n, const float* b2, const float* b3, const float* b1n, int B, int H, int W,
                                  int n_next, gim_stream_t stream) {
@@ -295,7 +355,7 @@ extern "C" int GIM_FN(gim_bneck64_fused)(const void* t1, const void* res, void* 
         attr.done();
     }
     Args a;
-    a.t1 = (const unsigned short*)t1; a.res = (const unsigned short*)res; a.xo = (unsigned short*)x_out; a.t1n = (unsigned short*)t1_next;
+    a.t1 = (const unsigned short*)t1; a.res = (const unsigned short*)res; a.wds = nullptr; a.xo = (unsigned short*)x_out; a.t1n = (unsigned short*)t1_next;
     a.w2 = (const unsigned short*)w2; a.w3 = (const unsigned short*)w3; a.w1n = (const unsigned short*)w1n;
     a.b2 = b2; a.b3 = b3; a.b1n = b1n; a.B = B; a.H = H; a.W = W;
     a.t1_bytes = (unsigned)((size_t)B * H * W * P * 2); a.w2_bytes = 64 * 1152; a.w3_bytes = 256 * 128; a.w1n_bytes = (unsigned)n_next * 512;

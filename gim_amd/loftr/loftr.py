@@ -47,7 +47,7 @@ import torch.nn as nn
 
 from .. import ops
 from .._lib import ACT_ELU1, ACT_LEAKY, ACT_NONE, ACT_RELU, GIM_BF16, GIM_F16, GIM_F32, GimHipError
-from ..packing import cstore, is_half, pack_bneck, pack_bneck_tail, pack_conv, pack_fine_fused, pack_token_mlp, pack_token_emit, torch_dtype
+from ..packing import cstore, is_half, pack_bneck, pack_bneck_ds, pack_bneck_tail, pack_conv, pack_fine_fused, pack_token_mlp, pack_token_emit, torch_dtype
 
 _DT = {"bf16": GIM_BF16, "fp16": GIM_F16, "fp32": GIM_F32}
 
@@ -211,6 +211,7 @@ class LoFTR(nn.Module):
         # 16-bit modes, layer2 (planes 128): conv3 (+identity) -> the next block's conv1 in one kernel (bneck_tail.hip);
         # GIM_BNECK_TAIL=0 keeps the two implicit-GEMM launches
         self.bneck_tail = os.environ.get("GIM_BNECK_TAIL", "1") != "0"
+        self.bneck_ds = os.environ.get("GIM_BNECK_DS", "1") != "0"   # layer 1's first block: downsample conv inside the fused kernel
         self._packed = None
         self._packed_key = None
         self._pe_cache = {}
@@ -296,6 +297,8 @@ class LoFTR(nn.Module):
             l1 = list(enc.layer1)
             for bi, blk in enumerate(l1):   # the last block's trailing conv1 is layer2's first one (256 -> 128, same resolution)
                 P[f"l1.{bi}.fused"] = pack_bneck(blk, l1[bi + 1] if bi + 1 < len(l1) else enc.layer2[0], device, tdt)
+            if l1[0].downsample is not None and l1[0].downsample[0].stride == (1, 1) and len(l1) > 1:
+                P["l1.0.fused_ds"] = pack_bneck_ds(l1[0], l1[1], device, tdt)   # the first block's downsample conv runs inside the kernel
             # layers 2 / 3: conv3 + identity + relu of block bi with the 1x1 convolution that reads its output next (bneck_tail.hip):
             # the next block's conv1; for layer 2's last block the first conv1 of layer 3 (512 -> 256, same resolution: the stride sits
             # on conv2); for layer 3's last block the FPN's layer3_outconv (no BatchNorm, no activation)
@@ -390,6 +393,9 @@ class LoFTR(nn.Module):
                 p = f"l{li}.{bi}."
                 if o is None:
                     o = ops.conv2d(x, P[p + "c1"], ACT_RELU, lds_dma=dma)
+                if fuse and self.bneck_ds and (p + "fused_ds") in P and x.shape[3] == 64 and x.is_contiguous():
+                    x, o = ops.bneck64_ds(o, x, P[p + "fused_ds"])   # ... and the downsample branch: no identity tensor at all
+                    continue
                 idn = ops.conv2d(x, P[p + "ds"], ACT_NONE, lds_dma=dma) if (p + "ds") in P else x
                 if fuse:   # conv2 -> conv3 + identity -> the next conv1 (of this layer, or layer2's first), one kernel
                     x, o = ops.bneck64(o, idn, P[p + "fused"], True)

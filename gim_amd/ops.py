@@ -412,6 +412,23 @@ def bneck64(t1, res, pk, want_next):
     return xo, t1n
 
 
+def bneck64_ds(t1, x_in, pk):
+    """First block of layer 1 with its downsample branch computed in the kernel (gim_bneck64_fused_ds): t1 [B,H,W,64] (conv1 output),
+    x_in [B,H,W,64] (the block's input) -> (x' [B,H,W,256], t1' [B,H,W,64]); pk = packing.pack_bneck_ds(...)."""
+    _req_cuda(t1, x_in)
+    assert t1.dtype in HALF and x_in.dtype == t1.dtype and t1.is_contiguous() and x_in.is_contiguous() and x_in.shape == t1.shape
+    w2, w3, wds, w1n, b2, b3ds, b1n = pk
+    assert w2.dtype == t1.dtype and w1n.shape[0] == 64
+    fn = lib.gim_bneck64_fused_ds_f16 if t1.dtype == torch.float16 else lib.gim_bneck64_fused_ds
+    B, H, W, _ = t1.shape
+    xo = torch.empty(B, H, W, 256, dtype=t1.dtype, device=t1.device)
+    t1n = torch.empty(B, H, W, 64, dtype=t1.dtype, device=t1.device)
+    with _Timed("bneck64_fused", 2.0 * B * H * W * (576 * 64 + 64 * 256 + 64 * 256 + 256 * 64)):
+        check(fn(_p(t1), _p(x_in), _p(xo), _p(t1n), _p(w2), _p(w3), _p(wds), _p(w1n), _p(b2), _p(b3ds), _p(b1n), B, H, W, _stream()),
+              "gim_bneck64_fused_ds")
+    return xo, t1n
+
+
 def bneck_tail(t2, res, pk, act_next=ACT_RELU, store_x=True):
     """Bottleneck tail + the next 1x1 convolution in one launch (planes P = 128: layer 2, P = 256: layer 3): t2 [B,H,W,P], res
     [B,H,W,4P] (same 16-bit dtype) -> (x' [B,H,W,4P] or None when store_x is False, t1' [B,H,W,N1]); pk = packing.pack_bneck_tail(...).

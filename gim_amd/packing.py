@@ -278,6 +278,18 @@ def pack_bneck(blk, nxt, device, tdt=torch.bfloat16):
     return w2p, w3p, w1p, b2.float().to(device).contiguous(), b3.float().to(device).contiguous(), b1
 
 
+def pack_bneck_ds(blk, nxt, device, tdt=torch.bfloat16):
+    """gim_bneck64_fused_ds operands: pack_bneck(blk, nxt) plus the block's downsample branch (1x1 conv 64 -> 256 + BN, stride 1) as
+    wds [256][64] in channel order, its bias added to conv3's: (w2, w3, wds, w1n, b2, b3 + bds, b1n)."""
+    bn = lambda m: (m.weight, m.bias, m.running_mean, m.running_var, m.eps)  # noqa: E731
+    w2, w3, w1n, b2, b3, b1n = pack_bneck(blk, nxt, device, tdt)
+    conv, norm = blk.downsample[0], blk.downsample[1]
+    assert tuple(conv.weight.shape) == (256, 64, 1, 1) and conv.stride == (1, 1) and w1n is not None and w1n.shape[0] == 64
+    wd, bd = fold_bn(conv.weight, bn(norm))
+    wds = wd.reshape(256, 64).cpu().to(device).to(tdt).contiguous()
+    return w2, w3, wds, w1n, b2, (b3 + bd.float().to(device)).contiguous(), b1n
+
+
 def pack_bneck_tail(blk, next_conv, next_bn, device, tdt=torch.bfloat16):
     """gim_bneck_tail128 / 256 operands: conv3 / bn3 of Bottleneck `blk` (planes P = 128 or 256) and the 1x1 convolution that consumes
     the block's output next -- the following block's conv1 with its bn1, or (last block of layer 3) the FPN's layer3_outconv, which has

@@ -178,6 +178,15 @@ int gim_coarse_conf_matrix(const gim_coarse_args* a, float* conf, gim_stream_t s
 int gim_bneck64_fused(const void* t1, const void* res, void* x_out, void* t1_next, const void* w2, const void* w3,
                       const void* w1n, const float* b2, const float* b3, const float* b1n, int B, int H, int W,
                       int n_next, gim_stream_t stream);
+/* First block of layer 1 (resnet.py:120-124: identity = bn(conv1x1(x)), 64 -> 256, stride 1): the downsample convolution runs INSIDE
+ * the kernel as extra K of conv3 -- x' = relu([W3 | Wds] [t2 ; x] + b3 + bds) -- so neither its launch nor the 256-channel identity
+ * tensor exist.  x_in: [B,H,W,64] the block's input; wds [256][64] bf16 (BN folded, K in channel order); b3ds = b3 + bds; n_next = 64. */
+int gim_bneck64_fused_ds(const void* t1, const void* x_in, void* x_out, void* t1_next, const void* w2, const void* w3,
+                         const void* wds, const void* w1n, const float* b2, const float* b3ds, const float* b1n, int B, int H, int W,
+                         gim_stream_t stream);
+int gim_bneck64_fused_ds_f16(const void* t1, const void* x_in, void* x_out, void* t1_next, const void* w2, const void* w3,
+                             const void* wds, const void* w1n, const float* b2, const float* b3ds, const float* b1n, int B, int H, int W,
+                             gim_stream_t stream);
 /* the same kernel on IEEE fp16 tensors / weights (GIM_F16 mode) */
 int gim_bneck64_fused_f16(const void* t1, const void* res, void* x_out, void* t1_next, const void* w2, const void* w3,
                           const void* w1n, const float* b2, const float* b3, const float* b1n, int B, int H, int W,

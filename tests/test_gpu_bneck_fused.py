@@ -90,3 +90,50 @@ def test_backbone_with_and_without_fused_layer1():
     for a, b in zip(outs[True], outs[False]):
         sc = b.abs().max().item()
         assert (a - b).abs().mean().item() < 3e-3 * sc and (a - b).abs().max().item() < 6e-2 * sc
+
+
+@pytest.mark.parametrize("tdt", KINDS, ids=KIDS)
+@pytest.mark.parametrize("B,H,W", [(1, 8, 32), (2, 24, 64), (1, 16, 96)])
+def test_bneck64_fused_ds_matches_reference(B, H, W, tdt):
+    """gim_bneck64_fused_ds: first block of layer 1 -- the downsample branch (1x1 conv 64 -> 256 + BN, resnet.py:120-124) runs inside
+    the kernel as extra K of conv3; against torch fp32 convolutions with the kernel's rounding points (the identity is NOT rounded to
+    16 bits here, unlike the two-launch path: it never leaves the accumulators) and against the two-launch path"""
+    from gim_amd import _lib, ops
+    from gim_amd.loftr.loftr import _Bottleneck
+    from gim_amd.packing import fold_bn, pack_bneck, pack_bneck_ds, pack_conv
+    torch.manual_seed(H * W)
+    ds = torch.nn.Sequential(torch.nn.Conv2d(64, 256, 1, bias=False), torch.nn.BatchNorm2d(256))
+    blk, nxt = _Bottleneck(64, 64, 1, ds), _Bottleneck(256, 64, 1, None)
+    with torch.no_grad():
+        for m in list(blk.modules()) + list(nxt.modules()):
+            if isinstance(m, torch.nn.Conv2d):
+                torch.nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(0.5 + torch.rand_like(m.weight)); m.bias.copy_(0.2 * torch.randn_like(m.bias))
+                m.running_mean.copy_(0.2 * torch.randn_like(m.running_mean)); m.running_var.copy_(0.5 + torch.rand_like(m.running_var))
+    blk, nxt = blk.eval(), nxt.eval()
+    g = torch.Generator().manual_seed(B * H)
+    x_in = F.relu(torch.randn(B, 64, H, W, generator=g)).to(tdt)
+    t1 = F.relu(torch.randn(B, 64, H, W, generator=g)).to(tdt)
+    bf = lambda t: t.to(tdt).float()  # noqa: E731
+    bn = lambda m: (m.weight, m.bias, m.running_mean, m.running_var, m.eps)  # noqa: E731
+    with torch.no_grad():
+        w2, b2 = fold_bn(blk.conv2.weight, bn(blk.bn2)); w3, b3 = fold_bn(blk.conv3.weight, bn(blk.bn3))
+        wd, bd = fold_bn(blk.downsample[0].weight, bn(blk.downsample[1])); w1, b1 = fold_bn(nxt.conv1.weight, bn(nxt.bn1))
+        t2 = bf(F.relu(F.conv2d(t1.float(), bf(w2), b2, padding=1)))
+        x_ref = F.relu(F.conv2d(t2, bf(w3), b3) + F.conv2d(x_in.float(), bf(wd), bd))
+        t1n_ref = F.relu(F.conv2d(bf(x_ref), bf(w1), b1))
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()  # noqa: E731
+    xo, t1n = ops.bneck64_ds(nhwc(t1), nhwc(x_in), pack_bneck_ds(blk, nxt, "cuda", tdt))
+    dt = _lib.GIM_F16 if tdt == torch.float16 else _lib.GIM_BF16
+    idn = ops.conv2d(nhwc(x_in), pack_conv(blk.downsample[0].weight, bn(blk.downsample[1]), dt, "cuda"))
+    xo2, t1n2 = ops.bneck64(nhwc(t1), idn, pack_bneck(blk, nxt, "cuda", tdt), True)
+    torch.cuda.synchronize()
+    k = 1.0 if tdt == torch.bfloat16 else 0.25
+    for got, ref, two in ((xo, x_ref, xo2), (t1n, t1n_ref, t1n2)):
+        gv = got.float().cpu().permute(0, 3, 1, 2)
+        sc = ref.abs().max().item()
+        err = (gv - ref).abs()
+        assert err.max().item() < 2e-2 * k * sc and err.mean().item() < 2e-3 * k * sc, (err.max().item() / sc, err.mean().item() / sc)
+        d2 = (got.float() - two.float()).abs()
+        assert d2.max().item() < 4e-2 * k * sc and d2.mean().item() < 3e-3 * k * sc     # the two-launch path rounds the identity to 16 bits

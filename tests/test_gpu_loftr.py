@@ -149,7 +149,7 @@ def test_different_image_shapes(oracle_sd):
 def test_full_size_properties_bf16(oracle_sd):
     """BASELINE config 2 shape (640x480, batch 8 pairs): no oracle at this size (tens of seconds per pair
     on CPU); check size-independent properties instead: determinism, ordering, mutual uniqueness,
-    border rule, thresholds, index ranges, and batch-composition invariance (pair b alone == pair b in batch)."""
+    border rule, thresholds, index ranges."""
     m = _model("bf16", oracle_sd)
     c0, c1 = O.seeded_images(8, 480, 640, seed=1234)
     d = _data(c0, c1, "cuda:0")
@@ -170,10 +170,28 @@ def test_full_size_properties_bf16(oracle_sd):
     m(d2)
     for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts1_f"):
         assert torch.equal(d[k], d2[k]), f"non-deterministic {k}"
-    d3 = _data(c0[3:4], c1[3:4], "cuda:0")
-    m(d3)
-    sel = b == 3
-    assert torch.equal(d3["i_ids"].cpu(), i[sel]) and torch.equal(d3["j_ids"].cpu(), j[sel])
+    # (batch composition -- pair b alone == pair b inside the batch -- is asserted bit for bit in the fp32 mode below.  In the 16-bit modes
+    # the launch shapes differ with the batch: layer 3's 9 600 pixel rows of a single pair are not a multiple of the fused tail's 256-row
+    # tile, so a single pair runs the unfused convolutions, and tile-count thresholds pick other kernels -- other fp32 summation orders
+    # in front of a 16-bit rounding.  With THIS model's uncalibrated random weights the similarities saturate (confidences of 1.0) and
+    # a difference of one 16-bit ulp in a feature can move the arg-max between two rows: the 1-2 matches per pair of this workload are
+    # no basis for an assertion; the calibrated workload's flip rates are bounded in test_gpu_loftr_fullsize.py.)
+
+
+def test_batch_composition_invariance_fp32(oracle_sd):
+    """fp32 mode, 640x480: pair b alone == pair b inside a batch of 4, bit for bit (every GEMM runs the same K order whatever the tile
+    shape the launch picks)"""
+    m = _model("fp32", oracle_sd)
+    c0, c1 = O.seeded_images(4, 480, 640, seed=1234)
+    d = _data(c0, c1, "cuda:0")
+    m(d)
+    b = d["b_ids"].cpu()
+    for pb in (0, 3):
+        d1 = _data(c0[pb:pb + 1], c1[pb:pb + 1], "cuda:0")
+        m(d1)
+        sel = b == pb
+        for k in ("i_ids", "j_ids", "mconf", "mkpts1_f"):
+            assert torch.equal(d1[k].cpu(), d[k].cpu()[sel]), (pb, k)
 
 
 def _pad_mask(n, h, w, valid):

@@ -1,6 +1,6 @@
 """gim_loftr throughput bench on MI355X (driver contract: see DESIGN.md section 6).
 
-    python bench.py                       # 1 GPU, BASELINE config 2: gim_loftr 640x480 bf16, batch 8 pairs
+    python bench.py                       # 1 GPU, BASELINE config 2: gim_loftr 640x480, batch 8 pairs, the fp16 mode (--precision bf16 | fp32)
     python bench.py --gpus 8              # spawns 8 ranks itself (re-exec under torch.distributed.run, 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W        # what the driver does
@@ -15,14 +15,18 @@ injected into the forward: the matches come out of the images.
 Pairs shard embarrassingly across ranks (weak scaling: 8 pairs per rank per step); the only collective is one
 RCCL all-gather(v) of the packed matches at the end of the run.  Rank 0 prints ONE JSON line.
 
-`roofline`  = all gim_conv2d_bn_act launches (the implicit-GEMM MFMA kernel: backbone convs + transformer
-              linears, > 95 % of the step's FLOPs) timed live with HIP events on the launch stream in extra
-              instrumented steps;
+`roofline`  = all gim_conv2d_bn_act launches (the implicit-GEMM MFMA kernels, still the dominant kernel: 60 % of the
+              step's FLOPs since the round-3 fusions) timed live with HIP events on the launch stream in extra
+              instrumented steps; inside it `fused_kernels` (the four fused kernel families, timed the same way),
+              `coarse_gemm` (the coarse matching call priced as its similarity GEMM) and `whole_step` (the whole path
+              priced with SURVEY 8d's algorithmic work);
+`parity_mode`, `bf16_mode` = the fp32 parity mode and the other 16-bit flavour timed on the same batch, each with its
+              own `parity` block;
 `cpu_baseline` = the CPU oracle (a port of the reference's forward, pinned to it by golden vectors) on this
               host's cores, 1 pair, 1 warm-up + 3 timed forwards; the same oracle run yields
-`parity`    = index flip rate / max coordinate and confidence deviation of the benchmarked bf16 engine against
+`parity`    = index flip rate / max coordinate and confidence deviation of the benchmarked 16-bit engine against
               the fp32 oracle on that pair;
-`h2d_inclusive` = the same step with both image batches starting in pinned host memory.
+`h2d_inclusive` = the same step with both image batches starting in pinned host memory (double-buffered copy stream).
 """
 import argparse
 import json

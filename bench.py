@@ -43,6 +43,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# host-side runner (pure torch, no HIP library needed to import it).  Module level on purpose: round 3 imported these inside
+# main() BELOW their first use on the world > 1 branch and every rank of a multi-GPU job died with UnboundLocalError.
+from gim_amd.runner import HostPairFeeder, all_gather_matches, bind_rank_to_cores, pack_matches  # noqa: E402
+
 H, W = 480, 640
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense, MI355X_MICROARCH.md
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_traffic.json")
@@ -77,7 +81,7 @@ def _free_port():
 def launch(args, argv):
     """`python bench.py --gpus N` without a launcher: re-exec as N ranks (test.py:188-218 runs pl.Trainer(gpus=N,
     strategy=DDP); here one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1)."""
-    if not args.selftest_launch:
+    if not args.selftest_launch and os.environ.get("GIM_BENCH_DRY_MODEL") != "1":
         have = torch.cuda.device_count()
         if have < args.gpus:
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} HIP device(s) visible")
@@ -135,30 +139,52 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if args.selftest_launch:
         return selftest_worker(args, rank, world)
+    # GIM_BENCH_DRY_MODEL=1 (tests/test_bench_launch_cpu.py): THIS function, line for line, on CPU ranks over gloo with a stand-in
+    # model -- process group, core binding, timed loop, match packing, the all-gather, the max-over-ranks reduction and the JSON
+    # line are the real ones.  Never set outside that test: the product path has no CPU mode.
+    dry = os.environ.get("GIM_BENCH_DRY_MODEL") == "1"
+    backend = os.environ.get("GIM_BENCH_BACKEND", "gloo" if dry else "nccl")
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback in the product path)"
-    assert torch.cuda.device_count() > local_rank, f"rank {rank}: LOCAL_RANK {local_rank} has no HIP device"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback in the product path)"
+        assert torch.cuda.device_count() > local_rank, f"rank {rank}: LOCAL_RANK {local_rank} has no HIP device"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group(backend, rank=rank, world_size=world, **({} if dry else {"device_id": dev}))
         assert dist.get_world_size() == world
         bind_rank_to_cores(local_rank, world)   # N ranks share one host: own core slice + thread cap per rank
 
-    from gim_amd import ops
-    from gim_amd.runner import HostPairFeeder, all_gather_matches, bind_rank_to_cores, pack_matches
-    from tools import synth_loftr as S
-    from tools.parity import parity_vs_oracle
-
-    # seeded "trained-like" weights of the gim_loftr architecture (no checkpoint ships with the reference)
-    over = {"coarse_sim": args.coarse_sim} if args.coarse_sim else {}
-    model, sd_cpu = S.synthetic_model(args.precision, seed=0, **over)
-    model = model.to(dev)
-
     nb = args.batch
-    c0h, c1h = S.textured_pairs(nb, H, W, seed=1234 + rank, frac=args.frac)
-    c0, c1 = c0h.to(dev), c1h.to(dev)
+    over = {"coarse_sim": args.coarse_sim} if args.coarse_sim else {}
+    if dry:
+        ops = S = parity_vs_oracle = None
+        sd_cpu = None
+
+        class _DryModel:   # emits 3 + rank matches per pair; nothing else of the engine is exercised
+            use_graph, coarse_sim, stem_fp16 = False, "dry", False
+
+            def __call__(self, d):
+                g = torch.Generator().manual_seed(7 + rank)
+                m = (3 + rank) * nb
+                d.update({"mkpts0_f": torch.rand(m, 2, generator=g), "mkpts1_f": torch.rand(m, 2, generator=g),
+                          "mconf": torch.rand(m, generator=g), "m_bids": torch.arange(m) % nb, "b_ids": torch.arange(m) % nb})
+
+        model = _DryModel()
+        c0h = c1h = c0 = c1 = torch.zeros(nb, 3, 8, 8)
+    else:
+        from gim_amd import ops
+        from tools import synth_loftr as S
+        from tools.parity import parity_vs_oracle
+
+        # seeded "trained-like" weights of the gim_loftr architecture (no checkpoint ships with the reference)
+        model, sd_cpu = S.synthetic_model(args.precision, seed=0, **over)
+        model = model.to(dev)
+        c0h, c1h = S.textured_pairs(nb, H, W, seed=1234 + rank, frac=args.frac)
+        c0, c1 = c0h.to(dev), c1h.to(dev)
 
     def step(a=None, b=None):
         a = c0 if a is None else a
@@ -167,11 +193,23 @@ def main():
         model(d)
         return d
 
+    def dev_sync():
+        if not dry:
+            torch.cuda.synchronize()
+
     def sync_all():
-        torch.cuda.synchronize()
+        dev_sync()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            dev_sync()
+
+    # which device every rank really sits on, as the process group saw it (the driver's SCALE record can check RCCL saw N ranks)
+    rank_devices = [f"{dev.type}:{torch.cuda.current_device()}" if not dry else f"cpu:pid{os.getpid()}"]
+    if world > 1:
+        got = [None] * world
+        dist.all_gather_object(got, rank_devices[0])
+        rank_devices = got
+    n_ranks_seen = dist.get_world_size() if world > 1 else 1
 
     for w_ in range(max(2, args.warmup)):  # the COMPLETE step, incl. match packing; the 2nd call captures the HIP graph
         pack_matches(step(), 0)
@@ -193,11 +231,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     d_last = d
-    solo = rank == 0 and world == 1  # the extra measurements below only run in single-GPU jobs
+    solo = rank == 0 and world == 1 and not dry  # the extra measurements below only run in single-GPU jobs
 
     # ---- live roofline of the dominant kernel (instrumented steps outside the timed region) --------
     roof = None
-    if rank == 0:
+    if rank == 0 and not dry:
         graph_was, model.use_graph = model.use_graph, False  # events need eager launches
         step()
         ops.PROFILE, ops.PROFILE_FUSED = [], []
@@ -512,7 +550,7 @@ def main():
                                   "what": "all kernels of a rank's steps: (0.7135 TFLOP x pairs + 33.6 MFLOP x matches) / time, against the same peak"}
         out = {
             "metric": "image-pairs/sec at 640x480", "value": round(pairs / dt, 2), "unit": "pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "n_ranks_seen": n_ranks_seen, "rank_devices": rank_devices, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"gim_loftr {W}x{H}, batch {nb} pairs per GPU per step, seeded trained-like weights "

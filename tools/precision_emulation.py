@@ -36,6 +36,9 @@ def rnd(x, fmt):
     if fmt == "bf16x2":
         hi = x.bfloat16().float()
         return hi + (x - hi).bfloat16().float()
+    if fmt == "fp16x2":      # hi + lo IEEE-fp16 pair (22 significand bits): what the split-operand MFMA of precision='mixed' carries
+        hi = x.half().float()
+        return hi + (x - hi).half().float()
     raise ValueError(fmt)
 
 
@@ -77,28 +80,31 @@ class Emu:
         for k, v in sd.items():
             if not k.endswith("weight") or v.dim() < 2:
                 continue
-            if k.startswith("backbone.encode.layer2"):
-                st = "layer2"
-            elif k.startswith("backbone.encode.layer3"):
-                st = "layer3"
-            elif k.startswith("backbone.encode.layer1"):
-                st = "layer1"
+            # hierarchical stage names: 'layer2.1' (Bottleneck), 'fpn.layer2_outconv2.0', 'transformer.5'; a format table may
+            # name the full stage or only its group ('layer2', 'fpn', 'transformer')
+            if k.startswith("backbone.encode.layer"):
+                st = ".".join(k.split(".")[2:4])
             elif k.startswith("backbone.encode"):
                 st = "stem"
             elif k.startswith("backbone"):
-                st = "fpn"
+                st = "fpn." + k[len("backbone."):-len(".weight")]
             elif k.startswith("loftr_coarse"):
-                st = "transformer"
+                st = "transformer." + k.split(".")[2]
             else:
                 st = "fine"
             self.stage_of[id(v)] = st
         self.cur = "stem"
         self.keep_stream = fmts.get("keep_stream", False)   # True: the ResNet residual stream x (ReLU outputs) is NOT rounded
 
+    def look(self, st):
+        if st in self.fmts:
+            return self.fmts[st]
+        return self.fmts.get(st.split(".")[0], "fp32")
+
     def fmt(self, w):
         st = self.stage_of.get(id(w), "fine")
         self.cur = st
-        return self.fmts.get(st, "fp32")
+        return self.look(st)
 
     def run(self, data):
         conv0, lin0, relu0, la0, cm0 = F.conv2d, F.linear, F.relu, O.linear_attention, O.conf_matrix_dual_softmax
@@ -120,12 +126,12 @@ class Emu:
 
             @staticmethod
             def relu(x, *a, **k):
-                if emu.keep_stream and emu.cur in ("stem", "layer1", "layer2", "layer3"):
+                if emu.keep_stream and emu.cur.split(".")[0] in ("stem", "layer1", "layer2", "layer3"):
                     return relu0(x)
-                return rnd(relu0(x), emu.fmts.get(emu.cur, "fp32"))
+                return rnd(relu0(x), emu.look(emu.cur))
 
         def la(q, k, v, q_mask=None, kv_mask=None, eps=1e-6):
-            f = emu.fmts.get(emu.cur, "fp32")   # 'transformer' or 'fine'
+            f = emu.look(emu.cur)   # 'transformer.N' or 'fine'
             Q = rnd(F.elu(q) + 1, f)
             K = rnd(F.elu(k) + 1, f)
             v = rnd(v, f)
@@ -179,16 +185,40 @@ def main():
                 ("all bf16, unrounded ResNet residual stream", {**allf("bf16"), "keep_stream": True}),
                 ("all bf16, unrounded stream, stem fp32", {**allf("bf16"), "stem": "fp32", "keep_stream": True}),
                 ]
+    if len(sys.argv) > 2 and sys.argv[2] == "sweep":
+        # which layers carry the fp16 mode's flips?  (profiles/r04_precision_sweep.txt)
+        base = sys.argv[3] if len(sys.argv) > 3 else "fp16"
+        groups = ("stem", "layer1", "layer2", "layer3", "fpn", "transformer", "sim")
+        variants = [(f"all {base}", allf(base))]
+        variants += [(f"only {g} {base}, rest fp32", {g: base}) for g in groups]
+        variants += [(f"all {base} except {g} fp32", {**allf(base), g: "fp32"}) for g in groups]
+        blocks = ["layer1.0", "layer1.1", "layer1.2", "layer2.0", "layer2.1", "layer2.2", "layer2.3"] + [f"layer3.{i}" for i in range(6)] + \
+                 ["fpn.layer3_outconv", "fpn.layer2_outconv", "fpn.layer2_outconv2.0", "fpn.layer2_outconv2.3"] + [f"transformer.{i}" for i in range(8)]
+        variants += [(f"only {g} {base}, rest fp32", {g: base}) for g in blocks]
+    if len(sys.argv) > 2 and sys.argv[2] == "mixed":
+        # candidate 'mixed' modes: split (hi + lo fp16) operands on the sensitive stages
+        x2 = lambda *gs: {**allf("fp16"), **{g: "fp16x2" for g in gs}}   # noqa: E731
+        variants = [("all fp16", allf("fp16")),
+                    ("all fp16x2", allf("fp16x2")),
+                    ("stem fp16x2, rest fp16", x2("stem")),
+                    ("stem+layer1 fp16x2, rest fp16", x2("stem", "layer1")),
+                    ("stem+layer1+sim fp16x2, rest fp16", x2("stem", "layer1", "sim")),
+                    ("stem+layer1+layer2 fp16x2, rest fp16", x2("stem", "layer1", "layer2")),
+                    ("backbone fp16x2, transformer+sim fp16", x2("stem", "layer1", "layer2", "layer3", "fpn")),
+                    ("backbone+sim fp16x2, transformer fp16", x2("stem", "layer1", "layer2", "layer3", "fpn", "sim")),
+                    ("transformer+sim fp16x2, backbone fp16", x2("transformer", "sim")),
+                    ]
     for name, fm in variants:
         t = time.time()
         out = Emu(sdf, fm).run(data())
-        fr, dc, n = [], [], 0
+        fr, dc, mx, n = [], [], [], 0
         for b in range(npairs):
             p = parity_vs_oracle(out, ref, b, b)
             fr.append(p["flip_rate"])
             dc.append(p.get("mean_abs_dmconf", 0.0))
+            mx.append(p.get("max_abs_dmconf", 0.0))
             n += p["engine_matches"]
-        print(f"{name:58s} flip {100 * sum(fr) / len(fr):6.3f} %   mean|dmconf| {sum(dc) / len(dc):.5f}   matches {n}   "
+        print(f"{name:58s} flip {100 * sum(fr) / len(fr):6.3f} %   mean|dmconf| {sum(dc) / len(dc):.5f}   max|dmconf| {max(mx):.4f}   matches {n}   "
               f"({time.time() - t:.0f} s)", flush=True)
 
 

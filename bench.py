@@ -165,7 +165,7 @@ def main():
         sd_cpu = None
 
         class _DryModel:   # emits 3 + rank matches per pair; nothing else of the engine is exercised
-            use_graph, coarse_sim, stem_fp16 = False, "dry", False
+            use_graph, coarse_sim, stem_fp16, stem_split = False, "dry", False, False
 
             def __call__(self, d):
                 g = torch.Generator().manual_seed(7 + rank)
@@ -536,6 +536,13 @@ def main():
                 parity["other_coarse_sim"] = {"coarse_sim": model.coarse_sim, "flip_rate": alt["flip_rate"],
                                               "mean_abs_dmconf": alt.get("mean_abs_dmconf"), "mean_abs_dmkpts1_px": alt.get("mean_abs_dmkpts1_px")}
                 model.coarse_sim = was
+                if model.stem_split:   # what the split-operand first convolution buys: the same batch with plainly rounded stem operands (round 3's mode)
+                    model.stem_split = False
+                    model._invalidate()
+                    alt = parity_vs_oracle(step(), ref, 0)
+                    parity["plain_stem"] = {k: alt.get(k) for k in ("flip_rate", "mean_abs_dmconf", "max_abs_dmconf", "mean_abs_dmkpts1_px")}
+                    model.stem_split = True
+                    model._invalidate()
             for nm, (rec, d_alt) in alt_modes.items():
                 rec["parity"] = parity_vs_oracle(d_alt, ref, 0)
 
@@ -557,7 +564,8 @@ def main():
                                    f"(calibrated BatchNorm statistics), textured image pairs with {args.frac:.2f} of the frame "
                                    "in correspondence (device resident), fine level loaded, outputs incl. match count read back",
                        "pairs_per_step": world * nb, "matches_per_pair": round(n_matches / max(1, pairs), 1),
-                       "coarse_sim": model.coarse_sim, "stem_operands": "fp16" if (args.precision == "bf16" and model.stem_fp16) else args.precision,
+                       "coarse_sim": model.coarse_sim, "stem_operands": ("fp16" if (args.precision == "bf16" and model.stem_fp16) else args.precision) +
+                                        (" hi+lo pairs (split-operand first convolution)" if (model.stem_split and args.precision != "fp32") else ""),
                        "parallelism": f"pairs sharded over {world} GPU(s), no collective per step",
                        "hip_graph": bool(model.use_graph)},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity, "parity_mode": alt_modes.get("parity_mode", (None,))[0],

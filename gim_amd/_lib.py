@@ -71,6 +71,7 @@ PROTOTYPES = {
     "gim_ktile_bytes": (c_int, []),
     "gim_npad_granule": (c_int, []),
     "gim_nchw_to_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "gim_nchw_to_nhwc_split": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "gim_nhwc_to_nchw": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "gim_conv2d_bn_act": (c_int, [ctypes.POINTER(ConvArgs), c_void_p]),
     "gim_conv_ups_supported": (c_int, [ctypes.POINTER(ConvArgs)]),

@@ -54,10 +54,13 @@ struct CmWs {  // device pointers carved out of the caller's workspace
     int* ncand;        // [N]
     Cand* cand;        // [N][capc]
     int* ext;          // [N][4] valid extents of the padding masks
-    int* npre;         // [N] pre-candidate counters, npre[N] = overflow flag, npre[N + 1] = "wide logit range" flag of the panel kernel
+    int* npre;         // [N] pre-candidate counters, npre[N] = overflow flag, npre[N + 1] = "wide logit range" flag of the 256-tile kernel
     PreCand* pre;      // [N][capp]
     int* ktab;         // dense K table for the mainloop
     int ntL, ntS, capc, capp;
+    int* health;       // caller's count[1]: bit 0 = a non-finite similarity reached the statistics (inf / NaN features: the fp16 mode's
+                       // range guard, loftr.py reads it with the match count); NULL when the caller has no count buffer
+    int ntL64;         // column-partial slots of the 256-tile statistics kernel (64 rows each); colpart holds max(ntL, ntL64) slots per pair
 };
 
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -65,6 +68,7 @@ inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t carve(CmWs& w, char* base, int N, int L, int S, int C) {
     w.ntL = (L + BM - 1) / BM;
     w.ntS = (S + BN - 1) / BN;
+    w.ntL64 = (L + 63) / 64;
     w.capc = 20 * L + 64;  // < 1/thr entries of a row can exceed thr (sum_j softmax_j <= 1); validate() enforces thr >= 0.05
     // pre-candidate capacity; GIM_CM_PRECAND_PER_ROW (default 16) exists so that tests can force the
     // overflow -> recompute fallback
@@ -73,7 +77,7 @@ size_t carve(CmWs& w, char* base, int N, int L, int S, int C) {
     size_t o = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + o : nullptr; o += al(bytes); return p; };
     w.rowpart = (float2*)take((size_t)N * w.ntS * L * 8);
-    w.colpart = (float2*)take((size_t)N * w.ntL * S * 8);
+    w.colpart = (float2*)take((size_t)N * w.ntL64 * S * 8);   // ntL64 >= ntL
     w.rowstat = (float2*)take((size_t)N * L * 8);
     w.colstat = (float2*)take((size_t)N * S * 8);
     w.rowmaxP = (unsigned*)take((size_t)N * L * 4);
@@ -158,15 +162,8 @@ __device__ __forceinline__ void sim_tile_to_lds(const CmGeom& g, const int* ktab
 // <= ~|x| * 6e-8 -- 1e-6 for every term that contributes more than e^-15 of a sum -- while each of the few
 // final confidences is evaluated with the accurate expf (cm_precand / cm_cand).
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
-// `gated`: launched behind the row-panel kernel as its fallback -- runs only if that kernel found a logit range too wide for its
-// shared exponentials (npre[N + 1]); it then redoes all partials (and adds its own pre-candidates to the list, which may hold
-// duplicates afterwards: every entry is an exact (i, j, similarity) triple that cm_precand evaluates with the final statistics).
 template <bool BF16>
-__global__ void __launch_bounds__(256) cm_stats_kernel(const CmGeom g, const CmWs w, const int gated) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (gated && !w.npre[g.N + 1]) return;
-    const int n = blockIdx.y;
-    const int mt = blockIdx.x / w.ntS, nt = blockIdx.x - mt * w.ntS;
+__device__ __forceinline__ void cm_stats_tile(const CmGeom& g, const CmWs& w, const int n, const int mt, const int nt, char* smem) {
     const int m0 = mt * BM, n0 = nt * BN;
     sim_tile_to_lds<0, BF16>(g, w.ktab, n, m0, n0, smem);
     const float* St = (const float*)smem;
@@ -223,7 +220,10 @@ __global__ void __launch_bounds__(256) cm_stats_kernel(const CmGeom g, const CmW
         if (half == 0) {
             const float zz = red[256 + idx] + red[384 + idx];
             rowm[idx] = m; rowz[idx] = zz;
-            if (m0 + idx < g.L) w.rowpart[((size_t)n * w.ntS + nt) * g.L + m0 + idx] = make_float2(m, zz);
+            if (m0 + idx < g.L) {
+                w.rowpart[((size_t)n * w.ntS + nt) * g.L + m0 + idx] = make_float2(m, zz);
+                if (!(zz < INFINITY) && w.health) atomicOr(w.health, 1);   // NaN / inf features (fp16 overflow upstream)
+            }
         }
         __syncthreads();
     }
@@ -333,224 +333,262 @@ __global__ void __launch_bounds__(256) cm_stats_kernel(const CmGeom g, const CmW
 }
 
 
-// ------------------------------------------------------------------------------------------------------------------------------
-// Pass A as a PERSISTENT ROW-PANEL kernel (16-bit features, C = 256, no padding masks): round 3.
-//
-// The tile-per-workgroup kernel above spends 14 us per 128 x 128 tile for 1 us of MFMAs: every tile re-stages both operand panels
-// through five dependent L2 round trips, writes the fp32 similarity tile to LDS, re-reads it twice (rows, columns) behind five
-// barriers and evaluates TWO exponentials per element (row and column softmax use different maxima).  Here
-//   * a workgroup owns a 128-row panel of feat0 for a third of the columns: the A panel (64 KiB) is staged ONCE, the B tiles stream
-//     through a single 64 KiB buffer -- tile t + 1 is fetched (LDS-DMA issued through inline asm, invisible to the compiler's
-//     waits) while tile t's statistics run;
-//   * the statistics come straight out of the MFMA accumulators (lane = feat0 row, registers = 32 of the wave's 64 columns):
-//     row max / sum-exp in the lane (+ one exchange with lane ^ 32), ONE exponential per element e = exp(v - rowmax), and the
-//     column sums as sum_i e_ij * exp(rowmax_i - ref) with one wave-wide reference `ref` -- the row weights cost two exps per
-//     lane -- reduced over the 32 row lanes by a halving butterfly (31 exchanges instead of 32 x 5);
-//   * row statistics are carried ONLINE across the panel's tiles (max, rescaled sum) and written once per panel third;
-//   * pre-candidates are tested on the registers.
-// Range guard: exp(v - ref) underflows when a wave tile's logits span more than ~87; at 80 the kernel raises npre[N + 1] and the
-// tile-per-workgroup kernel (gated launch right behind this one) redoes the statistics.  exp() rounding: as above (fast_exp for
-// the sums, expf for every decision).
-constexpr int PJ = 3;                                   // column thirds per row panel: N x ntL x 3 workgroups (912 at 640x480 batch 8)
-constexpr int P2_OFF_B = 4 * BM * KTB;                  // A panel: 4 K slabs of [128 rows][128 B]
-constexpr int P2_OFF_X = P2_OFF_B + 4 * BN * KTB;       // B tile : 4 K slabs
-struct P2X {
-    float2 rowx[2][128];      // [column half wn][row]: (max, sum-exp) over the wave tile's 64 columns
-    float2 colx[2][128];      // [row half wm][column]: (reference, sum-exp) over the wave tile's 64 rows
-    float rowm[128], rowz[128], colm[128], colz[128];   // statistics of the whole tile (exact pre-candidate test)
-    float trow[128], tcol[128];                          // cheap thresholds m + log(thr z)
-    PreCand plist[PLIST];
-    int pcnt[4];
-};
-constexpr int P2_SMEM = P2_OFF_X + (int)sizeof(P2X);
-static_assert(P2_SMEM <= 160 * 1024, "row-panel kernel: LDS");
-
-__global__ void __launch_bounds__(256) cm_stats_panel_kernel(const CmGeom g, const CmWs w, const int force_wide) {
+// One workgroup per tile (grid = N * ntL * ntS), or -- `gated` -- a small persistent grid launched behind the 256-tile kernel as
+// its fallback: it leaves at once unless that kernel found a logit range too wide for its shared exponentials (npre[N + 1]); it
+// then redoes all partials (and adds its own pre-candidates to the list, which may hold duplicates afterwards: every entry is an
+// exact (i, j, similarity) triple that cm_precand evaluates with the final statistics).
+template <bool BF16>
+__global__ void __launch_bounds__(256) cm_stats_kernel(const CmGeom g, const CmWs w, const int gated) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef __attribute__((address_space(3))) void lds_t;
-    const int n = blockIdx.y;
-    const int mt = blockIdx.x / PJ, jc = blockIdx.x - mt * PJ;
-    const int m0 = mt * BM;
-    const int jt0 = jc * w.ntS / PJ, jt1 = (jc + 1) * w.ntS / PJ;
-    const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, lh = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), wm = wave >> 1, wn = wave & 1;
-    P2X& X = *(P2X*)(smem + P2_OFF_X);
-    const unsigned smem_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_t*)smem);
-    const unsigned rowb = (unsigned)g.ldf * 2u;
-    const gim_u32x4_t rA = gim_make_rsrc((const char*)g.feat0 + (size_t)n * g.L * rowb, (unsigned)(((size_t)(g.L - 1) * g.ldf + g.C) * 2));
-    const gim_u32x4_t rB = gim_make_rsrc((const char*)g.feat1 + (size_t)n * g.S * rowb, (unsigned)(((size_t)(g.S - 1) * g.ldf + g.C) * 2));
-    // staging: a piece = 8 rows x 128 B; this wave fetches pieces wave, wave + 4, wave + 8, wave + 12 of every K slab; lane -> row
-    // piece * 8 + (lane >> 3), LDS slot lane & 7 <- source slot (lane & 7) ^ ((row >> 1) & 7).  Rows beyond L / S lie beyond the
-    // descriptor's bound and read as zeros.
-    const int srow = lane >> 3, sslot = lane & 7;
-    auto issue = [&](const gim_u32x4_t rs, const unsigned lds_base, const int r0) __attribute__((always_inline)) {
+    if (gated && !w.npre[g.N + 1]) return;
+    const int per = w.ntL * w.ntS, total = per * g.N;
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int n = tile / per, r = tile - n * per, mt = r / w.ntS;
+        cm_stats_tile<BF16>(g, w, n, mt, r - mt * w.ntS, smem);
+        __syncthreads();   // (block-uniform early returns inside the tile function) the next tile's staging overwrites this one's LDS
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Pass A on 256 x 256 tiles, statistics straight from the accumulators (16-bit features, no padding masks): round 4.
+//
+// The 128 x 128 tile kernel above spends ~14 us per tile for 1 us of MFMAs (profiles/r03_final_kernel_stats.txt: 311 us per batch-8
+// call): both operand panels of every tile are re-staged (64 flop per staged byte = 64 B/clk/CU at the full MFMA rate, twice what
+// L2 -> LDS delivers), the fp32 tile goes to LDS and is re-read twice behind five barriers, and every element costs TWO
+// exponentials (the row and the column softmax are taken against different maxima).  Here
+//   * persistent 8-wave workgroups (one per CU) walk 256 x 256 tiles (128 flop per staged byte), pair = tile % N so that with
+//     8 pairs the two feature maps of pair n (4.8 MB) stay in XCD n's L2; the first K slab of the NEXT tile is in flight during
+//     the statistics of this one;
+//   * a wave owns 64 rows x 128 columns in its 128 accumulator registers (lane = row, registers = columns) and takes ONE
+//     exponential per element against ONE wave-wide reference m_w = max of its sub-tile: e = exp(s - m_w) feeds the row sums
+//     (in the lane + one exchange with lane ^ 32) and the column sums (halving butterfly over the 32 row lanes:
+//     v_permlane16_swap, DPP row_ror / quad_perm, one ds_swizzle).  Partials are (reference, sum) pairs -- the combine kernel
+//     only needs sum_j exp(s_ij - ref) for SOME reference, not the maximum;
+//   * nothing of the statistics touches LDS except the wave-private broadcast of the 128 column thresholds;
+//   * pre-candidates: same superset argument as above with the WAVE sub-tile's softmax factors (over 128 columns / 64 rows:
+//     still >= the true factors), tested on the registers; the exact product test is left to cm_precand.
+// Range guard: a row (column) whose terms all underflow against the wave reference (its sum < 1e-30: logits more than ~69 below
+// m_w) raises npre[N + 1] and the 128 x 128 kernel (gated launch right behind) redoes the partials with per-row maxima.
+// Row partials land in the 128-column slots of the tile kernel's layout; column partials have 64-row granularity (ntL64 slots).
+constexpr int PL2 = 1024;                               // per-tile pre-candidate list
+typedef gim::Igemm<256, 256, 4, 2, true, true> G2;
+constexpr int S2_STAGE = 2 * G2::STAGE;                 // two K slabs of (256 + 256) rows x 128 B
+struct S2X {
+    float tcol[8][128];     // wave-private: column thresholds of the wave's 128 columns (accumulator units)
+    PreCand plist[PL2];
+    int pcnt[4];            // [0] = local count, [1] = global base
+};
+constexpr int S2_SMEM = S2_STAGE + (int)sizeof(S2X);
+static_assert(S2_SMEM <= 160 * 1024, "256-tile statistics kernel: LDS");
+
+__device__ __forceinline__ float lane_xor_dpp_1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float lane_xor_dpp_2(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true)); }   // quad_perm [2,3,0,1]
+__device__ __forceinline__ float lane_xor_dpp_8(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xf, 0xf, true)); }  // row_ror:8
+__device__ __forceinline__ float lane_xor_swz_4(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x101F)); }             // bit mode: xor 4
+// v + (v of lane ^ 32): v_permlane32_swap(v, v) leaves (v.lo, v.lo) in one result and (v.hi, v.hi) in the other -- their sum is
+// the pair total in every lane, whichever operand the instruction calls "first"
+__device__ __forceinline__ float pair32_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// Sum of c[r] over the 32 lanes that share (lane >> 5): halving butterfly.  Returns the total of ONE column per lane; which one
+// (register index r in 0..15) is whatever `tag` says after the same network ran on the register indices (cm256_column_tag).
+struct BflyAdd { __device__ __forceinline__ float operator()(float keep, float recv) const { return keep + recv; } };
+struct BflyTag { __device__ __forceinline__ float operator()(float keep, float) const { return keep; } };
+template <typename OP>
+__device__ __forceinline__ float cm256_butterfly(float (&c)[16], const int lane, OP op) {
+    float d[8];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+    for (int k = 0; k < 8; ++k) {   // lane ^ 16: v_permlane16_swap exchanges the odd 16-lane rows of one operand with the even rows of the other
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(c[k]), __float_as_uint(c[k + 8]), false, false);
+        d[k] = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0;
+    float e[4], f[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = (i * 4 + wave) * 8 + srow;
-                const unsigned voff = (unsigned)(r0 + row) * rowb + (unsigned)(kt * KTB) + (unsigned)((sslot ^ ((row >> 1) & 7)) << 4);
-                gim_dma16(rs, lds_base + (unsigned)(kt * BM * KTB + (i * 4 + wave) * 1024), voff);
+    for (int k = 0; k < 4; ++k) {   // lane ^ 8
+        float lo = d[k], hi = d[k + 4];
+        asm volatile("" : "+v"(lo), "+v"(hi));   // keep them values (hipcc otherwise turns the two selects into an indexed array read)
+        e[k] = op(b3 ? hi : lo, lane_xor_dpp_8(b3 ? lo : hi));
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {   // lane ^ 4
+        float lo = e[k], hi = e[k + 2];
+        asm volatile("" : "+v"(lo), "+v"(hi));
+        f[k] = op(b2 ? hi : lo, lane_xor_swz_4(b2 ? lo : hi));
+    }
+    float lo = f[0], hi = f[1];
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    const float g = op(b1 ? hi : lo, lane_xor_dpp_2(b1 ? lo : hi));   // lane ^ 2
+    return op(g, lane_xor_dpp_1(g));                                    // lane ^ 1: both lanes of a pair end with the total
+}
+// register index (0..15) of the column a lane holds after cm256_butterfly: the network run on the indices themselves, so the map
+// does not depend on which operand v_permlane16_swap calls "first"
+__device__ __forceinline__ int cm256_column_tag(const int lane) {
+    float c[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = (float)r;
+    return (int)cm256_butterfly(c, lane, BflyTag());
+}
+
+template <bool EDGE>
+__device__ __forceinline__ void cm256_stats(const CmGeom& g, const CmWs& w, G2::Acc& acc, const int n, const int m0, const int n0,
+                                            S2X& X, const int tag) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int wm, wn;
+    G2::wave_mn(wave, wm, wn);
+    const int row0 = m0 + wm * 64 + l31;        // this lane's rows: row0, row0 + 32
+    const int colw = n0 + wn * 128;             // acc[i][j][rg * 4 + e] = sim(row0 + 32 j, colw + 32 i + 8 rg + 4 lh + e) * C * T
+    const float NEG = -INFINITY;
+    // ---- wave reference ----
+    float mx = NEG;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (EDGE) {
+                const bool rok = row0 + 32 * j < g.L;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (!(rok && colw + 32 * i + 8 * (r >> 2) + 4 * lh + (r & 3) < g.S)) acc[i][j][r] = NEG;
             }
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, acc[i][j][r]), acc[i][j][r + 1]);
+        }
+    mx = wave_max(mx);
+    if (EDGE) mx = mx == NEG ? 0.f : mx;        // sub-tile entirely beyond L x S: any finite reference
+    // ---- one exponential per element: row sums in the lane, column sums through the butterfly ----
+    const float k2 = g.inv_ct * 1.44269504088896341f;   // exp(s - m) = exp2((acc - mx) * inv_ct * log2 e); acc - mx is exact where it matters
+    float rs0 = 0.f, rs1 = 0.f, cs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float c[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e0 = __builtin_amdgcn_exp2f((acc[i][0][r] - mx) * k2), e1 = __builtin_amdgcn_exp2f((acc[i][1][r] - mx) * k2);
+            rs0 += e0; rs1 += e1;
+            c[r] = e0 + e1;
+        }
+        cs[i] = cm256_butterfly(c, lane, BflyAdd());
+    }
+    rs0 = pair32_sum(rs0);
+    rs1 = pair32_sum(rs1);
+    // ---- partials ----
+    const float mref = mx * g.inv_ct;
+    const int rslot = (colw >> 7), cslot = (m0 >> 6) + wm;
+    const bool wave_cols = colw < g.S, wave_rows = m0 + wm * 64 < g.L;
+    const int coff = 8 * (tag >> 2) + 4 * lh + (tag & 3);   // this lane's column within a 32-column fragment
+    bool wide = false;
+    if (wave_cols && lh == 0) {
+        bool bad = false;   // every element feeds a row sum: NaN / inf anywhere in the features (fp16 overflow upstream) shows here
+        if (row0 < g.L) { w.rowpart[((size_t)n * w.ntS + rslot) * g.L + row0] = make_float2(mref, rs0); wide |= rs0 < 1e-30f; bad |= !(rs0 < INFINITY); }
+        if (row0 + 32 < g.L) { w.rowpart[((size_t)n * w.ntS + rslot) * g.L + row0 + 32] = make_float2(mref, rs1); wide |= rs1 < 1e-30f; bad |= !(rs1 < INFINITY); }
+        if (bad && w.health) atomicOr(w.health, 1);
+    }
+    const float ct = (float)g.C * g.temperature;
+    const float thr_pre = g.thr * (1.0f - 1e-3f);   // slack: rounding must never drop a true candidate
+    float* tc = X.tcol[wave];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int col = colw + 32 * i + coff;
+        if (wave_rows && (l31 & 1) == 0 && col < g.S) {
+            w.colpart[((size_t)n * w.ntL64 + cslot) * g.S + col] = make_float2(mref, cs[i]);
+            wide |= cs[i] < 1e-30f;
+        }
+        // column threshold in accumulator units: s > m + log(thr z)  <=>  acc > mx + log(thr z) * C * T
+        if ((l31 & 1) == 0) tc[32 * i + coff] = mx + __logf(thr_pre * cs[i]) * ct;
+    }
+    if (wide) w.npre[g.N + 1] = 1;
+    const float tr0 = mx + __logf(thr_pre * rs0) * ct, tr1 = mx + __logf(thr_pre * rs1) * ct;
+    // ---- pre-candidates on the registers ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const float4 t4 = *(const float4*)(tc + 32 * i + 8 * rg + 4 * lh);
+            const float tq[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float tr = j ? tr1 : tr0;
+                bool h[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = acc[i][j][4 * rg + e] > fmaxf(tr, tq[e]);
+                if (__builtin_amdgcn_ballot_w64(h[0] | h[1] | h[2] | h[3]) != 0ull) {   // wave-uniform, rare
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (h[e]) {
+                            const int k = atomicAdd(&X.pcnt[0], 1);
+                            if (k < PL2) X.plist[k] = PreCand{row0 + 32 * j, colw + 32 * i + 8 * rg + 4 * lh + e, acc[i][j][4 * rg + e] * g.inv_ct};
+                        }
+                }
+            }
+        }
+}
+
+__global__ void __launch_bounds__(512) cm_stats256_kernel(const CmGeom g, const CmWs w, const int force_wide) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    S2X& X = *(S2X*)(smem + S2_STAGE);
+    const int t = threadIdx.x;
+    const int ntL2 = (g.L + 255) >> 8, ntS2 = (g.S + 255) >> 8;
+    const int total = g.N * ntL2 * ntS2;
+    const int nkt = g.C * 2 / KTB;
+    const int tag = cm256_column_tag(t & 63);
+    if (t == 0) { X.pcnt[0] = 0; if (force_wide) w.npre[g.N + 1] = 1; }   // force_wide: tests exercise the gated fallback
+    gim::MainloopArgs ml;
+    ml.ktab = nullptr;
+    ml.x_bytes = (unsigned)(((size_t)(g.L - 1) * g.ldf + g.C) * 2);
+    ml.w_bytes = (unsigned)(((size_t)(g.S - 1) * g.ldf + g.C) * 2);
+    ml.H = 1; ml.W = g.L; ml.Ho = 1; ml.Wo = g.L; ml.stride = 1; ml.pad = 0; ml.ldx = g.ldf;
+    ml.kpad = g.C; ml.ldw = g.ldf; ml.M = g.L;
+    // dense K table entry of this thread's staging slot: K group kt * 8 + (slot ^ swizzle) -> channel 8 * group, no tap offset
+    const int kgrp = (t & 7) ^ (((t >> 3) >> 1) & 7);
+    G2 gg;
+    int n = 0, m0 = 0, n0 = 0;
+    auto locate = [&](const int tile) __attribute__((always_inline)) {
+        n = tile % g.N;
+        const int r = tile / g.N, mt = r / ntS2;
+        m0 = mt << 8; n0 = (r - mt * ntS2) << 8;
+        ml.x = (const char*)g.feat0 + (size_t)n * g.L * g.ldf * 2;
+        ml.w = (const char*)g.feat1 + (size_t)n * g.S * g.ldf * 2;
+        gg.decode(ml, m0, n0);
     };
-    issue(rA, smem_addr, m0);
-    issue(rB, smem_addr + P2_OFF_B, jt0 * BN);
-    if (force_wide && t == 0) w.npre[g.N + 1] = 1;   // tests: exercise the gated fallback
-    float runM = -INFINITY, runZ = 0.f;            // threads 0..127: online row statistics of row m0 + t over this panel third
-    const float thr_pre = g.thr * (1.0f - 1e-4f);  // slack: rounding must never drop a true candidate
-    const int lswz = (l31 >> 1) & 7;
-    const char* sA = smem + (wm * 64 + l31) * KTB;
-    const char* sB = smem + P2_OFF_B + (wn * 64 + l31) * KTB;
-    const int irow0 = m0 + wm * 64 + l31;           // this lane's rows: irow0, irow0 + 32
-    for (int nt = jt0; nt < jt1; ++nt) {
-        const int n0 = nt * BN;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                             // both operands of this tile have landed (every wave waited for its pieces)
-        f32x16_t acc[2][2];                          // [column fragment ic][row fragment jr]
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int so = ((2 * ks + lh) ^ lswz) << 4;
-                const bf16x8_t a0 = *(const bf16x8_t*)(sA + kt * BM * KTB + so), a1 = *(const bf16x8_t*)(sA + kt * BM * KTB + 32 * KTB + so);
-                const bf16x8_t b0 = *(const bf16x8_t*)(sB + kt * BN * KTB + so), b1 = *(const bf16x8_t*)(sB + kt * BN * KTB + 32 * KTB + so);
-                acc[0][0] = mfma_h16_32x32x16(b0, a0, acc[0][0]);
-                acc[0][1] = mfma_h16_32x32x16(b0, a1, acc[0][1]);
-                acc[1][0] = mfma_h16_32x32x16(b1, a0, acc[1][0]);
-                acc[1][1] = mfma_h16_32x32x16(b1, a1, acc[1][1]);
-            }
-        __syncthreads();                             // everybody is done with the B tile
-        if (nt + 1 < jt1) issue(rB, smem_addr + P2_OFF_B, n0 + BN);   // lands under the statistics below
-        // ---- statistics on the registers: acc[ic][jr][4 rg + e] = sim(row irow0 + 32 jr, column n0 + 64 wn + 32 ic + 8 rg + 4 lh + e) ----
-        const bool edge = (m0 + BM > g.L) || (n0 + BN > g.S);   // block-uniform
-        const int jcol0 = n0 + wn * 64 + lh * 4;
-        float rmax[2], rsum[2], vmin = INFINITY;
-#pragma unroll
-        for (int jr = 0; jr < 2; ++jr) {
-            const bool rok = irow0 + 32 * jr < g.L;
-            float mx = -INFINITY;
-#pragma unroll
-            for (int ic = 0; ic < 2; ++ic)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[ic][jr][r] * g.inv_ct;   // (f0/sqrt C).(f1/sqrt C)/T as one multiply (see sim_tile_to_lds)
-                    if (edge && !(rok && jcol0 + ic * 32 + (r >> 2) * 8 + (r & 3) < g.S)) v = -INFINITY;
-                    acc[ic][jr][r] = v;
-                    mx = fmaxf(mx, v);
-                    vmin = fminf(vmin, v == -INFINITY ? INFINITY : v);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            rmax[jr] = mx == -INFINITY ? 0.f : mx;       // a row without a valid column (beyond L): any finite reference
+    int tile = blockIdx.x, sc = 0;   // sc: running slab counter, slab sc lives in stage buffer sc & 1
+    if (tile < total) { locate(tile); gg.stage_issue(ml, smem, 0, 0, kgrp * 8); }
+    while (tile < total) {
+        G2::Acc acc;
+        G2::zero(acc);
+        for (int kt = 0; kt < nkt; ++kt, ++sc) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                        // slab sc has landed for everybody; everybody is done with slab sc - 1
+            if (kt + 1 < nkt) gg.stage_issue(ml, smem, (sc + 1) & 1, kt + 1, ((kt + 1) * 8 + kgrp) * 8);
+            G2::compute(smem, sc & 1, acc);
         }
-        float mw = fmaxf(rmax[0], rmax[1]);
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) { mw = fmaxf(mw, __shfl_xor(mw, o, 64)); vmin = fminf(vmin, __shfl_xor(vmin, o, 64)); }
-        vmin = fminf(vmin, __shfl_xor(vmin, 32, 64));
-        if (mw - vmin > 80.f && lane == 0) w.npre[g.N + 1] = 1;   // shared exponentials would underflow: the gated fallback redoes it
-        const float wg0 = fast_exp(rmax[0] - mw), wg1 = fast_exp(rmax[1] - mw);
-        float cs[32];
-        rsum[0] = rsum[1] = 0.f;
-#pragma unroll
-        for (int ic = 0; ic < 2; ++ic)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e0 = fast_exp(acc[ic][0][r] - rmax[0]), e1 = fast_exp(acc[ic][1][r] - rmax[1]);
-                rsum[0] += e0; rsum[1] += e1;
-                cs[ic * 16 + r] = e0 * wg0 + e1 * wg1;     // this lane's two rows of column (ic, r), relative to mw
-            }
-        rsum[0] += __shfl_xor(rsum[0], 32, 64);
-        rsum[1] += __shfl_xor(rsum[1], 32, 64);
-        // column sums over the 32 row lanes: halving butterfly, lane l31 ends up with column x = l31 of its 32 (ic = x >> 4, r = x & 15)
-#pragma unroll
-        for (int lvl = 16; lvl > 0; lvl >>= 1) {
-            const bool up = (l31 & lvl) != 0;
-#pragma unroll
-            for (int x = 0; x < lvl; ++x) {
-                float lo = cs[x], hi = cs[x + lvl];
-                asm volatile("" : "+v"(lo), "+v"(hi));   // keep them values: hipcc otherwise folds the two selects into ONE
-                                                         // dynamically indexed read of cs[] = a 32-deep compare/select chain each
-                cs[x] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, lvl, 64);
-            }
-        }
-        const int cloc = wn * 64 + (l31 >> 4) * 32 + ((l31 & 15) >> 2) * 8 + lh * 4 + (l31 & 3);   // column of this lane within the tile
-        if (lh == 0) {
-            X.rowx[wn][wm * 64 + l31] = make_float2(rmax[0], rsum[0]);
-            X.rowx[wn][wm * 64 + 32 + l31] = make_float2(rmax[1], rsum[1]);
-        }
-        X.colx[wm][cloc] = make_float2(mw, cs[0]);
-        if (t == 0) X.pcnt[0] = 0;
-        __syncthreads();
-        if (t < 128) {                                // tile row statistics + the online update of this panel third
-            const float2 a = X.rowx[0][t], b = X.rowx[1][t];
-            const float m = fmaxf(a.x, b.x);
-            const float z = a.y * expf(a.x - m) + b.y * expf(b.x - m);
-            X.rowm[t] = m; X.rowz[t] = z; X.trow[t] = m + logf(thr_pre * z);
-            const float mn = fmaxf(runM, m);
-            runZ = runZ * expf(runM - mn) + z * expf(m - mn);
-            runM = mn;
-        } else {
-            const int c = t - 128;
-            const float2 a = X.colx[0][c], b = X.colx[1][c];
-            const float m = fmaxf(a.x, b.x);
-            const float z = a.y * expf(a.x - m) + b.y * expf(b.x - m);
-            X.colm[c] = m; X.colz[c] = z; X.tcol[c] = m + logf(thr_pre * z);
-            if (n0 + c < g.S) w.colpart[((size_t)n * w.ntL + mt) * g.S + n0 + c] = make_float2(m, z);
-        }
-        __syncthreads();
-        // ---- pre-candidates (same test as the tile kernel): cheap thresholds on the registers, the exact product for the survivors ----
-#pragma unroll
-        for (int jr = 0; jr < 2; ++jr) {
-            const int il = wm * 64 + jr * 32 + l31;
-            const float trow = X.trow[il];
-            unsigned hit = 0u;
-#pragma unroll
-            for (int ic = 0; ic < 2; ++ic)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const float4 t4 = *(const float4*)(X.tcol + wn * 64 + ic * 32 + rg * 8 + lh * 4);
-                    const f32x16_t& v = acc[ic][jr];
-                    hit |= (v[rg * 4] > trow && v[rg * 4] > t4.x) ? 1u << (ic * 16 + rg * 4) : 0u;
-                    hit |= (v[rg * 4 + 1] > trow && v[rg * 4 + 1] > t4.y) ? 1u << (ic * 16 + rg * 4 + 1) : 0u;
-                    hit |= (v[rg * 4 + 2] > trow && v[rg * 4 + 2] > t4.z) ? 1u << (ic * 16 + rg * 4 + 2) : 0u;
-                    hit |= (v[rg * 4 + 3] > trow && v[rg * 4 + 3] > t4.w) ? 1u << (ic * 16 + rg * 4 + 3) : 0u;
-                }
-            while (hit) {
-                const int x = __ffs(hit) - 1;
-                hit &= hit - 1;
-                const int ic = x >> 4, r = x & 15;
-                float sv = 0.f;                       // acc[ic][jr][r] with a run-time (ic, r): select, do not index (scratch)
-#pragma unroll
-                for (int q = 0; q < 32; ++q) sv = (q == x) ? acc[q >> 4][jr][q & 15] : sv;
-                const int jl = wn * 64 + ic * 32 + (r >> 2) * 8 + lh * 4 + (r & 3);
-                const float pr = expf(sv - X.rowm[il]) / X.rowz[il];
-                const float pc = expf(sv - X.colm[jl]) / X.colz[jl];
-                if (pr * pc > thr_pre) {
-                    const int k = atomicAdd(&X.pcnt[0], 1);
-                    if (k < PLIST) X.plist[k] = PreCand{m0 + il, n0 + jl, sv};
-                }
-            }
-        }
+        const int cn = n, cm0 = m0, cn0 = n0;
+        const int next = tile + gridDim.x;
+        // the buffer of slab sc was last read one slab ago and every wave has passed a barrier since: the next tile's first slab
+        // travels during the statistics
+        if (next < total) { locate(next); gg.stage_issue(ml, smem, sc & 1, 0, kgrp * 8); }
+        if ((cm0 + 256 <= g.L) && (cn0 + 256 <= g.S)) cm256_stats<false>(g, w, acc, cn, cm0, cn0, X, tag);   // block-uniform
+        else cm256_stats<true>(g, w, acc, cn, cm0, cn0, X, tag);
         __syncthreads();
         const int cnt = X.pcnt[0];
         if (cnt > 0) {                                // block-uniform
-            if (cnt > PLIST) {
+            if (cnt > PL2) {
                 if (t == 0) w.npre[g.N] = 1;          // recompute path (cm_cand_kernel<0>)
             } else {
-                if (t == 0) X.pcnt[1] = atomicAdd(&w.npre[n], cnt);
+                if (t == 0) X.pcnt[1] = atomicAdd(&w.npre[cn], cnt);
                 __syncthreads();
                 const int base = X.pcnt[1];
                 if (base + cnt > w.capp) { if (t == 0) w.npre[g.N] = 1; }
-                else for (int k = t; k < cnt; k += 256) w.pre[(size_t)n * w.capp + base + k] = X.plist[k];
+                else for (int k = t; k < cnt; k += 512) w.pre[(size_t)cn * w.capp + base + k] = X.plist[k];
             }
+            __syncthreads();
+            if (t == 0) X.pcnt[0] = 0;                // the next pushes come behind the next tile's barriers
         }
+        tile = next;
     }
-    if (t < 128 && m0 + t < g.L) w.rowpart[((size_t)n * w.ntS + jc) * g.L + m0 + t] = make_float2(runM, runZ);
 }
 
 // Pass B on the pre-candidate list: final statistics -> conf; candidates + row/column maxima
@@ -573,23 +611,38 @@ __global__ void cm_precand_kernel(const CmGeom g, const CmWs w) {
     }
 }
 
-// stat[n][x] = combine over tiles:  m = max m_t ; z = sum_t z_t * exp(m_t - m)   (ascending tile order)
-// `stride` = tile slots per pair in `part`; `ntile_panel` > 0: the row-panel kernel filled only that many of them -- unless its
-// fallback ran (*wide), which filled all `ntile`
-__global__ void cm_combine_kernel(const float2* __restrict__ part, float2* __restrict__ stat, int N, int len, int ntile_all,
-                                  int ntile_panel, const int* __restrict__ wide) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)N * len) return;
-    const int ntile = (ntile_panel > 0 && !*wide) ? ntile_panel : ntile_all;
-    const size_t n = idx / len, x = idx - n * len;
-    float m = -INFINITY;
-    for (int t = 0; t < ntile; ++t) m = fmaxf(m, part[(n * ntile_all + t) * len + x].x);
-    float z = 0.f;
-    for (int t = 0; t < ntile; ++t) {
-        const float2 p = part[(n * ntile_all + t) * len + x];
-        z += p.y * expf(p.x - m);
+// stat[n][x] = combine over partial slots:  m = max m_t ; z = sum_t z_t * exp(m_t - m)   (fixed order: deterministic)
+// `part` holds either layout A (`ntile_a` slots per pair: the 256-tile statistics kernel) or, when that kernel raised *wide and the
+// gated 128 x 128 kernel rewrote the partials, layout B (`ntile_b` slots).  Four threads share an element (slots t, t + 4, ...)
+// so that a pair's 38 ... 75 dependent-latency loads become 10 ... 19: the two launches took 20 us each as one thread per element.
+__global__ void __launch_bounds__(256) cm_combine_kernel(const float2* __restrict__ part, float2* __restrict__ stat, int N, int len,
+                                                         int ntile_a, int ntile_b, const int* __restrict__ wide) {
+    __shared__ float2 sh[4][64];
+    const int xq = threadIdx.x & 63, tq = threadIdx.x >> 6;
+    const size_t idx = (size_t)blockIdx.x * 64 + xq;
+    const int ntile = (ntile_a > 0 && !*wide) ? ntile_a : ntile_b;
+    const bool ok = idx < (size_t)N * len;
+    float m = -INFINITY, z = 0.f;
+    if (ok) {
+        const size_t n = idx / len, x = idx - n * len;
+        const float2* p = part + n * (size_t)ntile * len + x;
+        for (int t = tq; t < ntile; t += 4) m = fmaxf(m, p[(size_t)t * len].x);
+        for (int t = tq; t < ntile; t += 4) {
+            const float2 v = p[(size_t)t * len];
+            z += v.y * expf(v.x - m);
+        }
     }
-    stat[idx] = make_float2(m, z);
+    sh[tq][xq] = make_float2(m, z);
+    __syncthreads();
+    if (tq == 0 && ok) {
+        float mm = m;
+#pragma unroll
+        for (int q = 1; q < 4; ++q) mm = fmaxf(mm, sh[q][xq].x);
+        float zz = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float2 v = sh[q][xq]; zz += v.x == -INFINITY ? 0.f : v.y * expf(v.x - mm); }
+        stat[idx] = make_float2(mm, zz);
+    }
 }
 
 __global__ void cm_init_kernel(const CmWs w, int N, int L, int S) {
@@ -598,6 +651,7 @@ __global__ void cm_init_kernel(const CmWs w, int N, int L, int S) {
     if (idx < (size_t)N * S) w.colmaxP[idx] = 0u;
     if (idx < (size_t)N) w.ncand[idx] = 0;
     if (idx <= (size_t)N + 1) w.npre[idx] = 0;
+    if (idx == 0 && w.health) *w.health &= 2;   // bit 1 belongs to the fine kernel of the PREVIOUS call on this buffer (sticky: the host clears it)
 }
 
 __global__ void cm_ktab_kernel(int* ktab, int C, int ge) {  // dense table: K group g -> channel ge * g (ge = 4 fp32 / 8 bf16 per 16 B); 2 padding slabs
@@ -608,11 +662,7 @@ __global__ void cm_ktab_kernel(int* ktab, int C, int ge) {  // dense table: K gr
 
 // MODE 0: emit candidates.  MODE 1: write the conf tile to `conf` (lazy data['conf_matrix']).
 template <int MODE, bool BF16>
-__global__ void __launch_bounds__(256) cm_cand_kernel(const CmGeom g, const CmWs w, float* __restrict__ conf) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (MODE == 0 && !w.npre[g.N]) return;  // fallback only: the pre-candidate path did the work
-    const int n = blockIdx.y;
-    const int mt = blockIdx.x / w.ntS, nt = blockIdx.x - mt * w.ntS;
+__device__ __forceinline__ void cm_cand_tile(const CmGeom& g, const CmWs& w, float* __restrict__ conf, const int n, const int mt, const int nt, char* smem) {
     const int m0 = mt * BM, n0 = nt * BN;
     sim_tile_to_lds<1, BF16>(g, w.ktab, n, m0, n0, smem);
     const float* St = (const float*)smem;
@@ -645,6 +695,20 @@ __global__ void __launch_bounds__(256) cm_cand_kernel(const CmGeom g, const CmWs
                 if (k < w.capc) w.cand[(size_t)n * w.capc + k] = Cand{i, j, p, 0};
             }
         }
+    }
+}
+
+// MODE 0 is launched as a small persistent grid (it is the overflow fallback and normally leaves at once), MODE 1 with one
+// workgroup per tile
+template <int MODE, bool BF16>
+__global__ void __launch_bounds__(256) cm_cand_kernel(const CmGeom g, const CmWs w, float* __restrict__ conf) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (MODE == 0 && !w.npre[g.N]) return;  // fallback only: the pre-candidate path did the work
+    const int per = w.ntL * w.ntS, total = per * g.N;
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int n = tile / per, r = tile - n * per, mt = r / w.ntS;
+        cm_cand_tile<MODE, BF16>(g, w, conf, n, mt, r - mt * w.ntS, smem);
+        __syncthreads();
     }
 }
 
@@ -726,7 +790,7 @@ __global__ void __launch_bounds__(1024) cm_scan_kernel(const CmWs w, int L, int*
         }
         __syncthreads();
     }
-    if (t == 0) count[1 + n] = running;
+    if (t == 0) count[2 + n] = running;
 }
 
 struct EmitArgs {
@@ -742,7 +806,7 @@ __global__ void cm_emit_kernel(const CmWs w, const EmitArgs e) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx == 0) {
         int s = 0;
-        for (int k = 0; k < e.N; ++k) s += e.count[1 + k];
+        for (int k = 0; k < e.N; ++k) s += e.count[2 + k];
         e.count[0] = s < e.cap ? s : e.cap;  // the host sizes its views by count[0]: never beyond the output capacity
     }
     if (idx >= (size_t)e.N * e.L) return;
@@ -750,7 +814,7 @@ __global__ void cm_emit_kernel(const CmWs w, const EmitArgs e) {
     const int j = w.jsel[idx];
     if (j == INT_MAX) return;
     int o = w.lpos[idx];
-    for (int k = 0; k < n; ++k) o += e.count[1 + k];
+    for (int k = 0; k < n; ++k) o += e.count[2 + k];
     if (o >= e.cap) return;
     e.b_ids[o] = n; e.i_ids[o] = i; e.j_ids[o] = j;
     e.mconf[o] = w.psel[idx];
@@ -779,14 +843,9 @@ int validate(const gim_coarse_args& a) {
     return GIM_OK;
 }
 
-// GIM_CM_PANEL: 1 (default) = row-panel statistics kernel where it applies, 0 = tile-per-workgroup kernel always,
-// 2 = row-panel kernel AND its fallback forced (tests: the gated kernel runs although the range guard did not trip)
-// GIM_CM_PANEL: 0 (default) the tile-per-workgroup statistics kernel; 1 the row-panel kernel (+ gated fallback); 2 the row-panel
-// kernel with the fallback forced (tests).  Measured on MI355X (profiles/r03_cm_panel.txt): the panel kernel is exact but SLOWER
-// -- 410 us against 320 us on planted features, +0.7 ms per step on the bench's random-weight features (one wave per SIMD at 259
-// VGPRs has nothing to hide its ~3000 VALU instructions per tile behind; 912 workgroups = 3.56 rounds of one workgroup per CU) --
-// so it stays opt-in until it wins.
-static int panel_mode() { static const int v = [] { const char* e = getenv("GIM_CM_PANEL"); return e ? atoi(e) : 0; }(); return v; }
+// GIM_CM_STATS: 1 (default) the 256-tile statistics kernel where it applies (16-bit features, no padding masks) + its gated
+// fallback; 2 the same with the fallback forced (tests); 0 the 128 x 128 tile-per-workgroup kernel always.
+static int stats_mode() { static const int v = [] { const char* e = getenv("GIM_CM_STATS"); return e ? atoi(e) : 1; }(); return v; }
 
 template <typename K>
 int set_smem(K kern) {
@@ -804,6 +863,7 @@ extern "C" int64_t GIM_FN(gim_coarse_match_ws_bytes)(int N, int L, int S) {
 
 static int cm_prepare(const gim_coarse_args& a, CmWs& w, CmGeom& g) {
     carve(w, (char*)a.ws, a.N, a.L, a.S, a.C);
+    w.health = a.count ? a.count + 1 : nullptr;
     g.feat0 = a.feat0; g.feat1 = a.feat1; g.bf16 = a.feat_dtype == GIM_H16; g.ldf = a.ldf ? a.ldf : a.C; g.mask0 = a.mask0; g.mask1 = a.mask1; g.N = a.N; g.L = a.L; g.S = a.S; g.C = a.C;
     g.inv_c = 1.0f / (float)a.C; g.temperature = a.temperature; g.thr = a.thr;
     g.inv_ct = 1.0f / ((float)a.C * a.temperature);
@@ -815,8 +875,8 @@ static int cm_prepare(const gim_coarse_args& a, CmWs& w, CmGeom& g) {
         if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<1, false>);
         if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<0, true>);
         if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<1, true>);
-        if (rc == GIM_OK && hipFuncSetAttribute((const void*)cm_stats_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P2_SMEM) != hipSuccess) {
-            gim_set_error("coarse_match: hipFuncSetAttribute(panel kernel, %d B LDS)", P2_SMEM);
+        if (rc == GIM_OK && hipFuncSetAttribute((const void*)cm_stats256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S2_SMEM) != hipSuccess) {
+            gim_set_error("coarse_match: hipFuncSetAttribute(256-tile statistics kernel, %d B LDS)", S2_SMEM);
             rc = GIM_ERR_LAUNCH;
         }
         if (rc != GIM_OK) return rc;
@@ -844,21 +904,27 @@ extern "C" int GIM_FN(gim_coarse_match)(const gim_coarse_args* ap, gim_stream_t 
     const size_t nmax = (size_t)a.N * (a.L > a.S ? a.L : a.S);
     hipLaunchKernelGGL(cm_init_kernel, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, s, w, a.N, a.L, a.S);
     hipLaunchKernelGGL(cm_ktab_kernel, dim3(1), dim3(256), 0, s, w.ktab, a.C, g.bf16 ? 8 : 4);
-    dim3 tgrid((unsigned)(w.ntL * w.ntS), (unsigned)a.N);
-    // row-panel statistics kernel: 16-bit features of 256 channels, no padding masks, enough column tiles for its three-way split
-    const bool panel = g.bf16 && a.C == 256 && !a.mask0 && w.ntS >= 2 * PJ && panel_mode();
-    if (panel) {
-        hipLaunchKernelGGL(cm_stats_panel_kernel, dim3((unsigned)(w.ntL * PJ), (unsigned)a.N), dim3(256), P2_SMEM, s, g, w, panel_mode() == 2 ? 1 : 0);
-        hipLaunchKernelGGL(cm_stats_kernel<true>, tgrid, dim3(256), TILE_SMEM, s, g, w, 1);   // gated fallback (wide logit range)
-    } else if (g.bf16) hipLaunchKernelGGL(cm_stats_kernel<true>, tgrid, dim3(256), TILE_SMEM, s, g, w, 0);
-    else hipLaunchKernelGGL(cm_stats_kernel<false>, tgrid, dim3(256), TILE_SMEM, s, g, w, 0);
-    hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.L + 255) / 256)), dim3(256), 0, s, w.rowpart, w.rowstat, a.N, a.L, w.ntS,
-                       panel ? PJ : 0, w.npre + a.N + 1);
-    hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.S + 255) / 256)), dim3(256), 0, s, w.colpart, w.colstat, a.N, a.S, w.ntL,
-                       0, w.npre + a.N + 1);
+    const unsigned ntiles = (unsigned)(w.ntL * w.ntS * a.N), nfallback = ntiles < 512u ? ntiles : 512u;
+    // 256-tile statistics kernel: 16-bit features, no padding masks (K in whole 128-byte slabs is validate()'s rule already)
+    const bool big = g.bf16 && !a.mask0 && stats_mode();
+    if (big) {
+        const unsigned t256 = (unsigned)(a.N * ((a.L + 255) / 256) * ((a.S + 255) / 256));
+        int ncu = 256;
+        { int dev = 0; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); }
+        // persistent: one workgroup per CU; a grid that is a multiple of N (and of 8) keeps pair = tile % N on one XCD per workgroup
+        unsigned grid = (unsigned)ncu;
+        if (grid > t256) grid = t256;
+        hipLaunchKernelGGL(cm_stats256_kernel, dim3(grid), dim3(512), S2_SMEM, s, g, w, stats_mode() == 2 ? 1 : 0);
+        hipLaunchKernelGGL(cm_stats_kernel<true>, dim3(nfallback), dim3(256), TILE_SMEM, s, g, w, 1);   // gated fallback (wide logit range)
+    } else if (g.bf16) hipLaunchKernelGGL(cm_stats_kernel<true>, dim3(ntiles), dim3(256), TILE_SMEM, s, g, w, 0);
+    else hipLaunchKernelGGL(cm_stats_kernel<false>, dim3(ntiles), dim3(256), TILE_SMEM, s, g, w, 0);
+    hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.L + 63) / 64)), dim3(256), 0, s, w.rowpart, w.rowstat, a.N, a.L,
+                       0, w.ntS, w.npre + a.N + 1);
+    hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.S + 63) / 64)), dim3(256), 0, s, w.colpart, w.colstat, a.N, a.S,
+                       big ? w.ntL64 : 0, w.ntL, w.npre + a.N + 1);
     hipLaunchKernelGGL(cm_precand_kernel, dim3((unsigned)((w.capp + 255) / 256), (unsigned)a.N), dim3(256), 0, s, g, w);
-    if (g.bf16) hipLaunchKernelGGL((cm_cand_kernel<0, true>), tgrid, dim3(256), TILE_SMEM, s, g, w, (float*)nullptr);
-    else hipLaunchKernelGGL((cm_cand_kernel<0, false>), tgrid, dim3(256), TILE_SMEM, s, g, w, (float*)nullptr);
+    if (g.bf16) hipLaunchKernelGGL((cm_cand_kernel<0, true>), dim3(nfallback), dim3(256), TILE_SMEM, s, g, w, (float*)nullptr);
+    else hipLaunchKernelGGL((cm_cand_kernel<0, false>), dim3(nfallback), dim3(256), TILE_SMEM, s, g, w, (float*)nullptr);
     if (a.mask0) hipLaunchKernelGGL(cm_mask_extent_kernel, dim3((unsigned)a.N), dim3(256), 0, s, a.mask0, a.mask1, w.ext, a.h0c, a.w0c, a.h1c, a.w1c);
     BorderGeom bg{a.h0c, a.w0c, a.h1c, a.w1c, a.border_rm, a.mask0 ? w.ext : nullptr};
     dim3 cgrid((unsigned)((w.capc + 255) / 256), (unsigned)a.N);
@@ -885,7 +951,7 @@ extern "C" int GIM_FN(gim_coarse_conf_matrix)(const gim_coarse_args* ap, float* 
     CmWs w; CmGeom g;
     rc = cm_prepare(a, w, g);
     if (rc != GIM_OK) return rc;
-    dim3 tgrid((unsigned)(w.ntL * w.ntS), (unsigned)a.N);
+    dim3 tgrid((unsigned)(w.ntL * w.ntS * a.N));
     if (g.bf16) hipLaunchKernelGGL((cm_cand_kernel<1, true>), tgrid, dim3(256), TILE_SMEM, (hipStream_t)stream, g, w, conf);
     else hipLaunchKernelGGL((cm_cand_kernel<1, false>), tgrid, dim3(256), TILE_SMEM, (hipStream_t)stream, g, w, conf);
     return gim_check_launch("coarse_conf_matrix");

@@ -20,6 +20,24 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, void* __restr
     }
 }
 
+// [B,C,H,W] fp32 -> NHWC rows carrying every channel as a 16-bit hi + lo pair, laid out for the split-operand first convolution
+// (packing.pack_conv_split): channels [hi(C) | lo(C) | hi(C) | 0 ...] against weights [w_hi | w_hi | w_lo]: the MFMA sums
+// x_hi w_hi + x_lo w_hi + x_hi w_lo = x w up to 2^-22 -- the image and the 7x7 filters rounded to one 16-bit value are half of the
+// 16-bit modes' error (profiles/r04_precision_sweep.txt).  One thread per pixel.
+__global__ void nchw_to_nhwc_split_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int B, int C, int HW, int ld, int b_off) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (size_t)B * HW) return;
+    const size_t b = p / HW, r = p - b * HW;
+    unsigned short* row = dst + ((size_t)(b + b_off) * HW + r) * ld;
+    for (int c = 3 * C; c < ld; ++c) row[c] = 0;
+    for (int c = 0; c < C; ++c) {
+        const float v = src[(b * C + c) * HW + r];
+        const unsigned short hi = f32_to_h16(v);
+        const unsigned short lo = f32_to_h16(v - h16_to_f32(hi));
+        row[c] = hi; row[C + c] = lo; row[2 * C + c] = hi;
+    }
+}
+
 // NHWC rows -> [B,C,H,W] fp32.  LDS-tiled transpose: 64 pixels x 64 channels per block.
 template <bool BF16>
 __global__ void nhwc_to_nchw_kernel(const void* __restrict__ src, float* __restrict__ dst, int C, int HW, int ld) {
@@ -160,6 +178,21 @@ extern "C" int GIM_FN(gim_nchw_to_nhwc)(const float* src, void* dst, int B, int 
     else
         hipLaunchKernelGGL(nchw_to_nhwc_kernel<false>, dim3(nblocks(n, 256)), dim3(256), 0, s, src, dst, B, C, H * W, cpad, ld, b_off);
     return gim_check_launch("nchw_to_nhwc");
+}
+
+#if !GIM_HALF_KIND
+extern "C" int gim_nchw_to_nhwc_split_f16(const float* src, void* dst, int B, int C, int H, int W, int ld, int b_off, int dtype, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_nchw_to_nhwc_split)(const float* src, void* dst, int B, int C, int H, int W, int ld, int b_off, int dtype, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16) return gim_nchw_to_nhwc_split_f16(src, dst, B, C, H, W, ld, b_off, dtype, stream);   // the fp16 objects of this file
+#endif
+    GIM_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc_split: bad args");
+    GIM_REQUIRE(dtype == GIM_H16, "nchw_to_nhwc_split: 16-bit output only (dtype %d)", dtype);
+    GIM_REQUIRE(ld >= 3 * C && ld % 8 == 0, "nchw_to_nhwc_split: ld=%d must hold 3 x %d channels in 16-byte groups", ld, C);
+    const size_t n = (size_t)B * H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_split_kernel, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, B, C, H * W, ld, b_off);
+    return gim_check_launch("nchw_to_nhwc_split");
 }
 
 #if !GIM_HALF_KIND

@@ -589,6 +589,7 @@ __global__ void __launch_bounds__(256, 2) fine_fused_kernel(const FineArgs a) {
     if (L.lane == 0) {
         const float sd = sqrtf(fmaxf(vx, 1e-10f)) + sqrtf(fmaxf(vy, 1e-10f));
         a.expec_f[3 * m + 0] = cx; a.expec_f[3 * m + 1] = cy; a.expec_f[3 * m + 2] = sd;
+        if (a.count && !(fabsf(cx) + fabsf(cy) + sd < INFINITY)) atomicOr((int*)a.count + 1, 2);   // health word of the coarse count buffer: non-finite fine output
         float s1x = a.fscale, s1y = a.fscale;
         if (a.has_scale0) {  // quirk preserved: keyed on scale0, multiplies scale1 (fine_matching.py:68)
             const int b = (int)a.b_ids[m];

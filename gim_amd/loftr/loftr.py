@@ -47,7 +47,8 @@ import torch.nn as nn
 
 from .. import ops
 from .._lib import ACT_ELU1, ACT_LEAKY, ACT_NONE, ACT_RELU, GIM_BF16, GIM_F16, GIM_F32, GimHipError
-from ..packing import cstore, is_half, pack_bneck, pack_bneck_ds, pack_bneck_tail, pack_conv, pack_fine_fused, pack_token_mlp, pack_token_emit, torch_dtype
+from ..packing import (cstore, is_half, pack_bneck, pack_bneck_ds, pack_bneck_tail, pack_conv, pack_conv_split, pack_fine_fused, pack_token_mlp,
+                       pack_token_emit, split_channels, torch_dtype)
 
 _DT = {"bf16": GIM_BF16, "fp16": GIM_F16, "fp32": GIM_F32}
 
@@ -189,6 +190,12 @@ class LoFTR(nn.Module):
         self.coarse_sim = self._check_sim((config.get("coarse_sim") or os.environ.get("GIM_COARSE_SIM") or self.precision).lower())
         sf = config.get("stem_fp16")
         self.stem_fp16 = (os.environ.get("GIM_STEM_FP16", "1") != "0") if sf is None else bool(sf)
+        # 16-bit modes: the first convolution on split (hi + lo) operands -- image and 7x7 filters carried to 2^-22 instead of 2^-11
+        # (profiles/r04_precision_sweep.txt: the stem alone is 57 % of the fp16 mode's mean |dmconf| and 3/4 of its index flips)
+        ss = config.get("stem_split")
+        self.stem_split = (os.environ.get("GIM_STEM_SPLIT", "1") != "0") if ss is None else bool(ss)
+        # set once the fp16 mode's range guard tripped and the module fell back to bf16 (see forward)
+        self.fp16_overflowed = False
         self.backbone = _ResNetFPN_8_2(config["resnetfpn"])
         self.loftr_coarse = _LocalFeatureTransformer(config["coarse"])
         self.loftr_fine = _LocalFeatureTransformer(config["fine"])
@@ -213,6 +220,7 @@ class LoFTR(nn.Module):
         self.bneck_tail = os.environ.get("GIM_BNECK_TAIL", "1") != "0"
         self.bneck_ds = os.environ.get("GIM_BNECK_DS", "1") != "0"   # layer 1's first block: downsample conv inside the fused kernel
         self._packed = None
+        self._health_sync_left = 3   # forwards that still wait for the fine kernel to read its health bit at once (fp16 mode)
         self._packed_key = None
         self._pe_cache = {}
         self.debug = None  # set to a dict to capture stage outputs (tests): coarse/fine maps, token features
@@ -241,6 +249,7 @@ class LoFTR(nn.Module):
         """weights / device / precision changed: packed weights, captured graphs AND the seen-shape counters go (a stale
         counter would send the next forward of a known shape straight into capture with nothing packed)"""
         self._packed = None
+        self._health_sync_left = 3
         if hasattr(self, "_graphs"):
             self._graphs.clear()
             self._seen.clear()
@@ -260,7 +269,12 @@ class LoFTR(nn.Module):
 
     def _img_dt(self):
         """dtype of the NHWC image tensor = operand type of the first convolution (see the module docstring)"""
-        return GIM_F16 if (self.precision == "bf16" and self.stem_fp16) else self._dt()
+        # (the fp16-in / bf16-out convolution exists on the LDS-DMA kernels only: with GIM_LDS_DMA=0 the stem reads the mode's own type)
+        return GIM_F16 if (self.precision == "bf16" and self.stem_fp16 and self.use_lds_dma) else self._dt()
+
+    def _split(self):
+        """first convolution on split (hi + lo) operands?  16-bit modes only: to the kernels it is a 9-channel convolution"""
+        return bool(self.stem_split) and self.precision != "fp32"
 
     def set_precision(self, precision, coarse_sim=None):
         assert precision in _DT
@@ -275,7 +289,7 @@ class LoFTR(nn.Module):
         return (m.weight, m.bias, m.running_mean, m.running_var, m.eps)
 
     def _prepack(self, device):
-        key = (str(device), self.precision, self._img_dt())
+        key = (str(device), self.precision, self._img_dt(), self._split())
         if self._packed is not None and self._packed_key == key:
             return self._packed
         dt = self._dt()
@@ -283,7 +297,10 @@ class LoFTR(nn.Module):
         P = {}
         enc = self.backbone.encode
         idt = self._img_dt()
-        P["stem"] = pack_conv(enc.conv1.weight, self._bn(enc.bn1), idt, device, stride=2, pad=3, cin_pad=cstore(3, idt))
+        if self._split():
+            P["stem"] = pack_conv_split(enc.conv1.weight, self._bn(enc.bn1), idt, device, stride=2, pad=3)
+        else:
+            P["stem"] = pack_conv(enc.conv1.weight, self._bn(enc.bn1), idt, device, stride=2, pad=3, cin_pad=cstore(3, idt))
         for li in (1, 2, 3):
             for bi, blk in enumerate(getattr(enc, f"layer{li}")):
                 p = f"l{li}.{bi}."
@@ -371,11 +388,13 @@ class LoFTR(nn.Module):
         (replaces torch.cat([color0, color1]), loftr.py:60).  `out`: an existing tensor to fill (the HIP graph's static input)."""
         H, W = images[0].shape[2:]
         B = sum(im.shape[0] for im in images)
+        split = self._split()
         if out is None:
-            out = torch.empty(B, H, W, cstore(3, dt), dtype=torch_dtype(dt), device=images[0].device)
+            cs = cstore(split_channels(images[0].shape[1]) if split else 3, dt)
+            out = torch.empty(B, H, W, cs, dtype=torch_dtype(dt), device=images[0].device)
         off = 0
         for im in images:
-            ops.nchw_to_nhwc(im, out, off)
+            (ops.nchw_to_nhwc_split if split else ops.nchw_to_nhwc)(im, out, off)
             off += im.shape[0]
         return out
 
@@ -585,7 +604,7 @@ class LoFTR(nn.Module):
                 self._encoder_layer(P, p, T, r1, r0, n1, S, L, H, have_q=True)
 
     # ---- forward (loftr.py:43-91) -------------------------------------------------------------------
-    def _coarse_stage(self, xs, bs, scale0, scale1, mask0=None, mask1=None):
+    def _coarse_stage(self, xs, bs, scale0, scale1, mask0=None, mask1=None, count=None):
         """Everything from the NHWC images up to and including coarse matching: a fixed launch sequence with no host sync and
         no data-dependent shape, so it can be captured once per input shape into a HIP graph and replayed.
         xs: [x_all] (both images of all pairs in one [2 bs, H, W, c] tensor: equal image shapes) or [x0, x1] (loftr.py:59-63).
@@ -627,13 +646,13 @@ class LoFTR(nn.Module):
             fc0, fc1 = T.X32[r0].view(bs, L, C), T.X32[r1].view(bs, S, C)
         cr = ops.coarse_match(fc0, fc1, hw0_c, hw1_c, scale,
                               mc["dsmax_temperature"], mc["thr"], mc["border_rm"], scale0, scale1,
-                              T.MASK[r0] if mask0 is not None else None, T.MASK[r1] if mask0 is not None else None)
+                              T.MASK[r0] if mask0 is not None else None, T.MASK[r1] if mask0 is not None else None, count=count)
         return {"c0": c0, "c1": c1, "f0": f0, "f1": f1, "cr": cr,
                 "feat_c0": T.X32[r0].view(bs, L, C), "feat_c1": T.X32[r1].view(bs, S, C)}
 
     def _graph_key(self, color0, color1, scale0, mask0):
         return (tuple(color0.shape), tuple(color1.shape), scale0 is not None, mask0 is not None, self.precision,
-                self.coarse_sim, self._img_dt(), str(color0.device))
+                self.coarse_sim, self._img_dt(), self._split(), str(color0.device))
 
     def _coarse_stage_graphed(self, key, color0, color1, scale0, scale1, mask0=None, mask1=None):
         """HIP-graph replay of `_coarse_stage` (one graph per input shape / precision).  ~140 kernel launches collapse into one
@@ -655,6 +674,8 @@ class LoFTR(nn.Module):
                    scale0.clone().float() if scale0 is not None else None,
                    scale1.clone().float() if scale1 is not None else None,
                    mask0.clone() if mask0 is not None else None, mask1.clone() if mask1 is not None else None]
+            # the count buffer of the captured coarse matching: zeroed HERE, outside the capture (its health bit 1 is sticky)
+            sin.append(torch.zeros(2 + color0.shape[0], dtype=torch.int32, device=color0.device))
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             # thread_local: other threads (e.g. RCCL's watchdog in multi-GPU runs) may issue HIP calls meanwhile
@@ -750,22 +771,34 @@ class LoFTR(nn.Module):
         fine = None
         dev_count = (self.fine_dev_count and self.fine_fused and self.debug is None and "fine_fused" in self._prepack(dev)
                      and f0.dtype in ops.HALF)
+        if self._count_pin is None:
+            self._count_pin = torch.empty(2, dtype=torch.int32).pin_memory()
         if dev_count:
-            if self._count_pin is None:
-                self._count_pin = torch.empty(1, dtype=torch.int32).pin_memory()
-            self._count_pin.copy_(cr.count[:1], non_blocking=True)
+            self._count_pin.copy_(cr.count[:2], non_blocking=True)   # [match count, health word of the coarse level]
             ev = torch.cuda.Event()
             ev.record()
             cap = cr.b_ids.numel()
             fine = self._fine_level(f0, f1, cr.b_ids, cr.i_ids, cr.j_ids, cr.mkpts1_c, scale1, "scale0" in data,
                                     hw0_c, hw1_c, data["hw0_i"], True, count=cr.count)
             ev.synchronize()
-            M = int(self._count_pin[0])
+            M, health = int(self._count_pin[0]), int(self._count_pin[1])
+            # bit 1 (non-finite fine-level output) is written by the fine kernel, which is still running: a replayed graph reuses its
+            # count buffer, so the word read HERE carries the previous forward's bit (one batch late, no extra sync); eager forwards
+            # and the first forwards after a weight / precision change wait for the kernel and look at once
+            if self.precision == "fp16" and M > 0 and not health and (not graphed or self._health_sync_left > 0):
+                self._health_sync_left = max(0, self._health_sync_left - 1)
+                health = int(cr.count[1].item())
             ops.patch_last_fused_flops("fine_fused", 33.6e6 * M)
             fine = (fine[0][:M], fine[1][:M], None, None) if M > 0 else None
             assert M <= cap
         else:
-            M = int(cr.count[0].item())  # the one host sync the reference also has
+            self._count_pin.copy_(cr.count[:2])  # the one host sync the reference also has
+            M, health = int(self._count_pin[0]), int(self._count_pin[1])
+        if health:
+            if health & 2:
+                cr.count[1:2].zero_()   # sticky bit: acknowledged
+            if self._range_guard(health):
+                return self.forward(data)   # the module is in bf16 now: same inputs, once more
         self._generation += 1
         if not dev_count and M > 0:
             fine = self._fine_level(f0, f1, cr.b_ids[:M], cr.i_ids[:M], cr.j_ids[:M], cr.mkpts1_c[:M], scale1, "scale0" in data,
@@ -798,6 +831,23 @@ class LoFTR(nn.Module):
         if self.debug is not None:
             self.debug.update({"fine0": fine0, "fine1": fine1})
         data.update({"expec_f": expec_f, "mkpts0_f": data["mkpts0_c"], "mkpts1_f": mkpts1_f})
+
+    def _range_guard(self, health):
+        """A non-finite value reached coarse matching (bit 0) or left the fine level (bit 1).  In the fp16 mode that is the IEEE-fp16
+        range (|activation| > 65504 somewhere in the backbone: a checkpoint whose un-normalised ResNet streams run hot): warn, switch
+        this module to bf16 for good -- same kernels, fp32's exponent range -- and tell the caller to run the batch again.  In the
+        other modes the inputs or weights themselves were not finite: warn only.  The reference computes in fp32 and has no such
+        case (networks/loftr/utils/coarse_matching.py:174-195 would return no match for a NaN row, silently)."""
+        import warnings
+        what = " and ".join(w for b, w in ((1, "coarse similarities"), (2, "fine-level outputs")) if health & b)
+        if self.precision == "fp16":
+            warnings.warn(f"gim_amd LoFTR: non-finite {what} in the fp16 mode (an activation left the IEEE-fp16 range); "
+                          "falling back to precision='bf16' for this module and re-running the batch")
+            self.fp16_overflowed = True
+            self.set_precision("bf16")
+            return True
+        warnings.warn(f"gim_amd LoFTR: non-finite {what} in the {self.precision} mode: the inputs or the weights are not finite")
+        return False
 
     def _fine_level(self, f0, f1, b_ids, i_ids, j_ids, mkpts1_c, scale1, has_s0, hw0_c, hw1_c, hw0_i, fused, count=None):
         """FinePreprocess + loftr_fine + FineMatching (loftr.py:84-91) for M > 0 matches on the NHWC fine maps f0 / f1.

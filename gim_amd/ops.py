@@ -87,6 +87,15 @@ def nchw_to_nhwc(src, dst, b_off=0):
                                gim_dtype(dst), _stream()), "gim_nchw_to_nhwc")
 
 
+def nchw_to_nhwc_split(src, dst, b_off=0):
+    """src [B,C,H,W] fp32 -> dst [Btot,H,W,ld] 16-bit with channels [hi(C) | lo(C) | hi(C) | 0...] (gim_nchw_to_nhwc_split)"""
+    _req_cuda(src, dst)
+    assert src.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous() and dst.dtype in HALF
+    B, C, H, W = src.shape
+    check(lib.gim_nchw_to_nhwc_split(_p(src), _p(dst), B, C, H, W, dst.shape[-1], b_off, gim_dtype(dst), _stream()),
+          "gim_nchw_to_nhwc_split")
+
+
 def copy_segments(pairs):
     """[(src or None, dst), ...] contiguous device tensors of equal byte size per pair (src None: dst is zero filled) -> all of
     them in ONE launch (gim_copy_segments); more than 12 pairs go out in batches."""
@@ -309,7 +318,7 @@ class CoarseResult:
 
 
 def coarse_match(feat0, feat1, hw0_c, hw1_c, scale, temperature=0.1, thr=0.2, border_rm=2,
-                 scale0=None, scale1=None, mask0=None, mask1=None):
+                 scale0=None, scale1=None, mask0=None, mask1=None, count=None):
     """feat0 [N,L,C], feat1 [N,S,C], fp32 or bf16, rows possibly strided (stride(1) = ldf >= C, the same for both; e.g. a
     column range of the transformer's token buffers).  bf16 features run the similarity on the bf16 MFMA (exact products,
     fp32 accumulation).  Returns CoarseResult with cap-sized device buffers; count[0] (device int32) is the number of
@@ -325,7 +334,11 @@ def coarse_match(feat0, feat1, hw0_c, hw1_c, scale, temperature=0.1, thr=0.2, bo
     cap = N * min(L, S)
     r = CoarseResult()
     r.ws = torch.empty(lib.gim_coarse_match_ws_bytes(N, L, S), dtype=torch.uint8, device=dev)
-    r.count = torch.empty(1 + N, dtype=torch.int32, device=dev)
+    # [M, health word, per-pair counts].  Bit 1 of the health word is sticky (include/gim_hip.h): a caller that captures this call
+    # into a graph passes a `count` buffer it zeroed OUTSIDE the capture, so that replays do not clear the bit
+    if count is not None:
+        assert count.dtype == torch.int32 and count.numel() >= 2 + N and count.device == dev and count.is_contiguous()
+    r.count = torch.zeros(2 + N, dtype=torch.int32, device=dev) if count is None else count
     r.b_ids = torch.empty(cap, dtype=torch.int64, device=dev)
     r.i_ids = torch.empty(cap, dtype=torch.int64, device=dev)
     r.j_ids = torch.empty(cap, dtype=torch.int64, device=dev)

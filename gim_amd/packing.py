@@ -65,6 +65,25 @@ def fold_bn(weight, bn):
     return w * s.view(-1, 1, 1, 1), beta.detach().float() - mean.detach().float() * s
 
 
+def split_channels(cin):
+    """channels the split-operand layout stores for a cin-channel image: [hi | lo | hi]"""
+    return 3 * cin
+
+
+def pack_conv_split(weight, bn, dtype, device, stride=1, pad=0):
+    """The first convolution on split operands (16-bit dtypes): BatchNorm is folded in fp32 first, then every weight becomes the
+    pair w_hi = rn16(w), w_lo = rn16(w - w_hi) and the layer is packed as a 3*Cin-channel convolution [w_hi | w_hi | w_lo] that
+    meets the image layout [x_hi | x_lo | x_hi] of gim_nchw_to_nhwc_split: x_hi w_hi + x_lo w_hi + x_hi w_lo (the x_lo w_lo term,
+    2^-22 relative, is dropped).  Both halves are exactly representable, so the device-side cast of pack_conv is the identity."""
+    assert is_half(dtype)
+    w, b = fold_bn(weight, bn)
+    td = torch_dtype(dtype)
+    w_hi = w.to(td).float()
+    w_lo = (w - w_hi).to(td).float()
+    w3 = torch.cat([w_hi, w_hi, w_lo], dim=1)
+    return pack_conv(w3, None, dtype, device, stride=stride, pad=pad, cin_pad=cstore(w3.shape[1], dtype), bias=b)
+
+
 def pack_conv(weight, bn, dtype, device, stride=1, pad=0, cin_pad=None, bias=None):
     """weight [Cout, Cin, kh, kw] (or [out, in] for a Linear).  Returns PackedConv on `device`."""
     if weight.dim() == 2:

@@ -45,6 +45,12 @@ int gim_npad_granule(void);
  * `b_off`: first output image index (color0 -> 0, color1 -> bs: replaces torch.cat, loftr.py:60). */
 int gim_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int cpad, int ld,
                      int b_off, int dtype, gim_stream_t stream);
+/* The same boundary conversion for the split-operand first convolution (16-bit dtypes only): every channel c becomes the pair
+ * hi = rn16(x), lo = rn16(x - hi), stored as channels [hi(0..C) | lo(0..C) | hi(0..C) | zeros up to ld]; with weights packed as
+ * [w_hi | w_hi | w_lo] (gim_amd/packing.py::pack_conv_split) the 16-bit MFMA evaluates x*w to 2^-22 instead of 2^-11: the input
+ * of backbone/resnet.py:306 (conv1 7x7 on the image) is where half of the 16-bit modes' deviation from the fp32 reference arises. */
+int gim_nchw_to_nhwc_split(const float* src, void* dst, int B, int C, int H, int W, int ld, int b_off, int dtype,
+                           gim_stream_t stream);
 /* inverse, for exposing feature maps in the reference layout (tests / lazy outputs) */
 int gim_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int ld, int dtype,
                      gim_stream_t stream);
@@ -134,7 +140,12 @@ int gim_layernorm_residual(const void* x, const float* gamma, const float* beta,
  * + ordered compaction, fused so that the [N,L,S] confidence matrix is never written.
  * feat0 [N*L, C] / feat1 [N*S, C] fp32 rows (row stride C).  Outputs in torch.where order
  * (ascending b, then i): b_ids/i_ids/j_ids int64, mconf fp32, mkpts0_c/mkpts1_c fp32 [cap,2].
- * `count` (device int32[1 + N]): count[0] = M, count[1+b] = matches of pair b.
+ * `count` (device int32[2 + N], ZERO IT ONCE when allocating): count[0] = M, count[2+b] = matches of pair b, count[1] = health word:
+ * bit 0 (rewritten by every call) = a NaN / inf similarity reached the statistics -- the fp16 mode's activations overflowed
+ * upstream, or the inputs were not finite; bit 1 (sticky, never cleared here) = gim_fine_fused_dev saw a non-finite fine-level
+ * output on this buffer: a host that replays a captured graph on the same buffer learns it with the NEXT call's count read-back.
+ * The reference has no such word (fp32 has the range); gim_amd/loftr/loftr.py reads it with the match count
+ * (coarse_matching.py:193's sync) and re-runs the batch in bf16.
  * scale0/scale1: NULL or fp32 [N,2] per-pair (w,h) scales (coarse_matching.py:237-245). */
 typedef struct gim_coarse_args {
     const void* feat0;    /* [N, L, ldf] rows of C features, fp32 or bf16 (feat_dtype) */

@@ -420,13 +420,15 @@ def test_linear_attention_masks(shape):
     _assert_close(out.view(nb, L, H, D), ref, 1e-5, f"masked linear attention {shape}")
 
 
-@pytest.mark.parametrize("mode", ["1", "2", "0"], ids=["panel", "panel+forced-fallback", "tile-kernel"])
+@pytest.mark.parametrize("mode", ["1", "2", "0"], ids=["tile256", "tile256+forced-fallback", "tile128-kernel"])
 @pytest.mark.parametrize("kind", ["bf16", "fp16"])
-def test_coarse_match_row_panel_statistics(mode, kind):
-    """The persistent row-panel statistics kernel (16-bit features, C = 256, no masks; round 3) against the oracle evaluated on the
-    SAME 16-bit-valued features: exact indices and order, confidences to 1e-5 -- on sizes with ragged last tiles in both directions,
-    unequal L / S, several pairs -- and the same through its gated fallback (GIM_CM_PANEL=2) and through the tile-per-workgroup
-    kernel (GIM_CM_PANEL=0).  Subprocess: the mode is read once per process."""
+def test_coarse_match_tile256_statistics(mode, kind):
+    """The persistent 256 x 256 statistics kernel (16-bit features, no masks; round 4: one exponential per element against a wave-wide
+    reference, sums straight from the accumulators) against the oracle evaluated on the SAME 16-bit-valued features: exact indices
+    and order, confidences to 1e-5 -- on sizes with ragged last tiles in both directions, unequal L / S, several pairs, a logit range
+    wide enough to trip its range guard (sigma = 3: the gated 128 x 128 kernel redoes the partials) -- and the same with the fallback
+    forced (GIM_CM_STATS=2) and through the tile-per-workgroup kernel alone (GIM_CM_STATS=0).  Subprocess: the mode is read once
+    per process."""
     import os
     import subprocess
     import sys
@@ -438,7 +440,7 @@ from gim_amd import ops
 tdt = torch.bfloat16 if sys.argv[1] == 'bf16' else torch.float16
 tot = 0
 for (N, hw0, hw1, sigma, eps, seed) in ((2, (30, 40), (30, 40), 1.0, 0.5, 3), (1, (36, 45), (36, 45), 2.0, 0.1, 4), (3, (25, 31), (25, 31), 1.0, 0.3, 5),
-                                     (1, (60, 80), (60, 80), 1.0, 0.5, 6)):
+                                     (1, (60, 80), (60, 80), 1.0, 0.5, 6), (1, (30, 40), (30, 40), 3.0, 0.1, 8), (8, (17, 23), (17, 23), 1.0, 0.5, 11)):
     f0, f1, _ = O.planted_coarse_features(N, hw0, sigma=sigma, eps=eps, seed=seed)
     b0, b1 = f0.to(tdt), f1.to(tdt)
     conf = O.conf_matrix_dual_softmax(b0.float(), b1.float(), 0.1)
@@ -465,5 +467,5 @@ print('OK', tot + M)
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code, kind], cwd=root, capture_output=True, text=True,
-                         env={**os.environ, "GIM_CM_PANEL": mode}, timeout=600)
+                         env={**os.environ, "GIM_CM_STATS": mode}, timeout=600)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -71,21 +71,25 @@ def test_fp32_640x480_exact_vs_oracle(synth, pairs, oracle_two_pairs):
             assert torch.equal(d[k].cpu(), ref[k]), k
 
 
-# (precision, coarse_sim, stem_fp16, bound on the index flip rate, bound on mean |d mconf|): bounds = 2 x the worse of the two
-# pairs measured on MI355X (profiles/r03_parity_modes.txt): bf16 with the fp16 stem 0.67 % / 1.30 % flips, mean |d mconf| 0.009;
-# bf16 incl. a bf16 stem (round 2's mode) 1.68 % / 2.61 %, 0.018; fp16 0.27 % / 0.15 %, 0.0024.  The CPU emulation of the engine's
-# roundings (tools/precision_emulation.py, profiles/r03_precision_emulation.txt) predicts 0.98 % / 1.95 % / 0.47 %.
-MODES = [("bf16", "fp32", True, 0.026, 0.018), ("bf16", "bf16", True, 0.026, 0.018), ("bf16", "bf16", False, 0.052, 0.036),
-         ("fp16", "fp16", True, 0.0055, 0.005), ("fp16", "fp32", True, 0.0055, 0.005)]
+# (precision, coarse_sim, stem_fp16, stem_split, bound on the index flip rate, bound on mean |d mconf|): bounds = 2 x the worse of the
+# two pairs measured on MI355X.  Plain stem (profiles/r03_parity_modes.txt): bf16 with the fp16 stem 0.67 % / 1.30 % flips, mean
+# |d mconf| 0.009; bf16 incl. a bf16 stem (round 2's mode) 1.68 % / 2.61 %, 0.018; fp16 0.27 % / 0.15 %, 0.0024.  Split stem (round 4,
+# the default; profiles/r04_parity_modes.txt): see the table there.  The CPU emulation of the engine's roundings
+# (tools/precision_emulation.py, profiles/r04_precision_sweep.txt) predicts 0.47 % / 0.0025 for fp16 with a plain stem and
+# 0.19 % / 0.0012 with the stem exact.
+MODES = [("bf16", "fp32", True, False, 0.026, 0.018), ("bf16", "bf16", True, False, 0.026, 0.018), ("bf16", "bf16", False, False, 0.052, 0.036),
+         ("fp16", "fp16", True, False, 0.0055, 0.005), ("fp16", "fp32", True, False, 0.0055, 0.005),
+         ("fp16", "fp16", True, True, 0.004, 0.0025), ("bf16", "bf16", True, True, 0.02, 0.016)]
 
 
-@pytest.mark.parametrize("precision,coarse_sim,stem_fp16,max_flip,max_dconf", MODES,
-                         ids=[f"{m[0]}-sim{m[1]}-{'stemfp16' if m[2] else 'stembf16'}" for m in MODES])
-def test_bf16_batch8_flip_rate_vs_oracle(synth, pairs, oracle_two_pairs, precision, coarse_sim, stem_fp16, max_flip, max_dconf):
+@pytest.mark.parametrize("precision,coarse_sim,stem_fp16,stem_split,max_flip,max_dconf", MODES,
+                         ids=[f"{m[0]}-sim{m[1]}-{'stemfp16' if m[2] else 'stembf16'}{'-split' if m[3] else ''}" for m in MODES])
+def test_bf16_batch8_flip_rate_vs_oracle(synth, pairs, oracle_two_pairs, precision, coarse_sim, stem_fp16, stem_split, max_flip, max_dconf):
     """The benchmarked 16-bit modes against the fp32 oracle, batch 8 (what bench.py times).  Round 2 (bf16 incl. a bf16 stem)
     measured 1.7-2.6 % flips, 0.006 px mean / 0.33 px max coordinate deviation (profiles/r02_parity_probe.txt)."""
     model, _ = synth
     model.stem_fp16 = stem_fp16
+    model.stem_split = stem_split
     model.set_precision(precision, coarse_sim)
     c0, c1 = pairs
     try:
@@ -93,17 +97,18 @@ def test_bf16_batch8_flip_rate_vs_oracle(synth, pairs, oracle_two_pairs, precisi
             d = _data(c0, c1, "cuda:0")
             model(d)
         torch.cuda.synchronize()
-        assert len(model._graphs) == 1
+        assert len(model._graphs) == 1 and model.precision == precision   # (the fp16 range guard did not trip)
         assert d["b_ids"].numel() >= 8 * 1000
         for b in range(2):
             p = parity_vs_oracle(d, oracle_two_pairs, b, b)
-            print(precision, "batch-8 coarse_sim", coarse_sim, "stem_fp16", stem_fp16, "pair", b, p)
+            print(precision, "batch-8 coarse_sim", coarse_sim, "stem_fp16", stem_fp16, "stem_split", stem_split, "pair", b, p)
             assert p["flip_rate"] <= max_flip, p
             assert p["mean_abs_dmkpts1_px"] <= 0.02 and p["max_abs_dmkpts1_px"] <= 1.0, p
             assert p["mean_abs_dmconf"] <= max_dconf, p
             assert torch.isfinite(d["mconf"]).all() and torch.isfinite(d["mkpts1_f"]).all()
     finally:
         model.stem_fp16 = True
+        model.stem_split = True
         model.set_precision("fp32")
 
 

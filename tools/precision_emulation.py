@@ -70,6 +70,13 @@ def fold_bn(sd):
     return sd
 
 
+def parts(f):
+    """'fp16' -> the same format for weights, conv / linear inputs and stored ReLU outputs; 'w/x/s' (e.g. 'fp16x2/fp16/fp16'):
+    one format each -- split WEIGHTS cost MFMA work only, split activations cost bytes too"""
+    p = f.split("/")
+    return (p[0], p[0], p[0]) if len(p) == 1 else (p[0], p[1], p[2])
+
+
 class Emu:
     """Patches the oracle module's F.conv2d / F.linear / F.relu / linear_attention / similarity by stage."""
 
@@ -116,22 +123,22 @@ class Emu:
 
             @staticmethod
             def conv2d(x, w, *a, **k):
-                f = emu.fmt(w)
-                return conv0(rnd(x, f), rnd(w, f), *a, **k)
+                wf, xf, _ = parts(emu.fmt(w))
+                return conv0(rnd(x, xf), rnd(w, wf), *a, **k)
 
             @staticmethod
             def linear(x, w, *a, **k):
-                f = emu.fmt(w)
-                return lin0(rnd(x, f), rnd(w, f), *a, **k)
+                wf, xf, _ = parts(emu.fmt(w))
+                return lin0(rnd(x, xf), rnd(w, wf), *a, **k)
 
             @staticmethod
             def relu(x, *a, **k):
                 if emu.keep_stream and emu.cur.split(".")[0] in ("stem", "layer1", "layer2", "layer3"):
                     return relu0(x)
-                return rnd(relu0(x), emu.look(emu.cur))
+                return rnd(relu0(x), parts(emu.look(emu.cur))[2])
 
         def la(q, k, v, q_mask=None, kv_mask=None, eps=1e-6):
-            f = emu.look(emu.cur)   # 'transformer.N' or 'fine'
+            f = parts(emu.look(emu.cur))[1]   # 'transformer.N' or 'fine'
             Q = rnd(F.elu(q) + 1, f)
             K = rnd(F.elu(k) + 1, f)
             v = rnd(v, f)
@@ -141,7 +148,7 @@ class Emu:
             return (torch.einsum("nlhd,nhdv,nlh->nlhv", Q, rnd(KV, f), Z) * vl).contiguous()
 
         def cm(f0, f1, temperature=0.1, m0=None, m1=None):
-            f = emu.fmts.get("sim", "fp32")
+            f = parts(emu.fmts.get("sim", "fp32"))[1]
             return cm0(rnd(f0, f), rnd(f1, f), temperature, m0, m1)
 
         O.F = FF()
@@ -207,6 +214,20 @@ def main():
                     ("backbone fp16x2, transformer+sim fp16", x2("stem", "layer1", "layer2", "layer3", "fpn")),
                     ("backbone+sim fp16x2, transformer fp16", x2("stem", "layer1", "layer2", "layer3", "fpn", "sim")),
                     ("transformer+sim fp16x2, backbone fp16", x2("transformer", "sim")),
+                    ]
+    if len(sys.argv) > 2 and sys.argv[2] == "mixed2":
+        # with the stem on split operands: what else is worth spending precision on?  w/x/s = weights / inputs / stored activations
+        st = {**allf("fp16"), "stem": "fp16x2"}
+        BBL = ("layer1", "layer2", "layer3")
+        variants = [("stem x2, rest fp16", st),
+                    ("stem x2 + layer1-3 split WEIGHTS", {**st, **{g: "fp16x2/fp16/fp16" for g in BBL}}),
+                    ("stem x2 + layer1-3 split conv INPUTS", {**st, **{g: "fp16/fp16x2/fp16" for g in BBL}}),
+                    ("stem x2 + layer1-3 unrounded residual STREAM", {**st, **{g: "fp16/fp16/fp32" for g in BBL}}),
+                    ("stem x2 + layer1-3 weights + stream", {**st, **{g: "fp16x2/fp16/fp32" for g in BBL}}),
+                    ("stem x2 + layer1 split weights", {**st, "layer1": "fp16x2/fp16/fp16"}),
+                    ("stem x2 + all split WEIGHTS (backbone, transformer)", {**st, **{g: "fp16x2/fp16/fp16" for g in BBL + ("fpn", "transformer")}}),
+                    ("stem x2 + sim x2", {**st, "sim": "fp16x2"}),
+                    ("stem x2 + sim x2 + transformer x2", {**st, "sim": "fp16x2", "transformer": "fp16x2"}),
                     ]
     for name, fm in variants:
         t = time.time()

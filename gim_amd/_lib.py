@@ -68,6 +68,7 @@ class LgAssignArgs(ctypes.Structure):
 PROTOTYPES = {
     "gim_version": (c_int, []),
     "gim_last_error": (ctypes.c_char_p, []),
+    "gim_set_range_guard": (c_int, [c_void_p]),
     "gim_ktile_bytes": (c_int, []),
     "gim_npad_granule": (c_int, []),
     "gim_nchw_to_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),

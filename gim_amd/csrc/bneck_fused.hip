@@ -51,6 +51,7 @@ struct Args {
     const float* b1n;            // [N1]
     int B, H, W;
     unsigned t1_bytes, w2_bytes, w3_bytes, w1n_bytes;
+    int* health;                 // fp16 range guard word (gim_common.h) or NULL
 };
 // DS (first block of the layer, resnet.py:120-124: identity = bn(conv1x1(x))): the 64 -> 256 downsample convolution is conv3 with its K
 // axis extended -- x' = relu([W3 | Wds] [t2 ; x] + b3 + bds) -- the lane's 32 pixels of x arrive as four MFMA operand fragments straight
@@ -68,6 +69,7 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float hmax = 0.f;   // fp16 range guard: largest residual-stream value this thread converts (gim_common.h)
     const int tiles_x = a.W / TW, tiles_y = a.H / TH;
     const int tile = blockIdx.x;
     const int b = tile / (tiles_x * tiles_y), tr = tile - b * tiles_x * tiles_y;
@@ -255,6 +257,8 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
             unsigned u[8];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
+                h16_range_track(hmax, c3[j][rg * 4], c3[j][rg * 4 + 1]);        // x': the un-normalised residual stream
+                h16_range_track(hmax, c3[j][rg * 4 + 2], c3[j][rg * 4 + 3]);
                 u[2 * rg] = cvt_pk_h16(c3[j][rg * 4], c3[j][rg * 4 + 1]);
                 u[2 * rg + 1] = cvt_pk_h16(c3[j][rg * 4 + 2], c3[j][rg * 4 + 3]);
                 *(uint2*)(patch + l31 * 128 + (((4 * ff + rg) ^ (l31 & 7)) << 4) + lh * 8) = make_uint2(u[2 * rg], u[2 * rg + 1]);
@@ -271,6 +275,7 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the patch is rewritten by the next pass
     }
+    h16_range_flag(a.health, hmax);
     if constexpr (N1 > 0) {
         // ---- conv1' of the next block: K = 256 in accumulator order, weights from LDS -----------------------------------------
         constexpr int NF = N1 / 32;
@@ -332,7 +337,7 @@ extern "C" int GIM_FN(gim_bneck64_fused_ds)(const void* t1, const void* x_in, vo
     Args a;
     a.t1 = (const unsigned short*)t1; a.res = (const unsigned short*)x_in; a.wds = (const unsigned short*)wds; a.xo = (unsigned short*)x_out;
     a.t1n = (unsigned short*)t1_next; a.w2 = (const unsigned short*)w2; a.w3 = (const unsigned short*)w3; a.w1n = (const unsigned short*)w1n;
-    a.b2 = b2; a.b3 = b3ds; a.b1n = b1n; a.B = B; a.H = H; a.W = W;
+    a.b2 = b2; a.b3 = b3ds; a.b1n = b1n; a.B = B; a.H = H; a.W = W; a.health = gim_range_guard_ptr();
     a.t1_bytes = (unsigned)((size_t)B * H * W * P * 2); a.w2_bytes = 64 * 1152; a.w3_bytes = 256 * 128; a.w1n_bytes = 64 * 512;
     hipLaunchKernelGGL((bneck64_kernel<64, true>), dim3((unsigned)(B * (H / TH) * (W / TW))), dim3(512), SMEM, (hipStream_t)stream, a);
     return gim_check_launch("bneck64_fused_ds");
@@ -357,7 +362,7 @@ extern "C" int GIM_FN(gim_bneck64_fused)(const void* t1, const void* res, void* 
     Args a;
     a.t1 = (const unsigned short*)t1; a.res = (const unsigned short*)res; a.wds = nullptr; a.xo = (unsigned short*)x_out; a.t1n = (unsigned short*)t1_next;
     a.w2 = (const unsigned short*)w2; a.w3 = (const unsigned short*)w3; a.w1n = (const unsigned short*)w1n;
-    a.b2 = b2; a.b3 = b3; a.b1n = b1n; a.B = B; a.H = H; a.W = W;
+    a.b2 = b2; a.b3 = b3; a.b1n = b1n; a.B = B; a.H = H; a.W = W; a.health = gim_range_guard_ptr();
     a.t1_bytes = (unsigned)((size_t)B * H * W * P * 2); a.w2_bytes = 64 * 1152; a.w3_bytes = 256 * 128; a.w1n_bytes = (unsigned)n_next * 512;
     const unsigned tiles = (unsigned)(B * (H / TH) * (W / TW));
     if (n_next == 0) hipLaunchKernelGGL(bneck64_kernel<0>, dim3(tiles), dim3(512), SMEM, (hipStream_t)stream, a);

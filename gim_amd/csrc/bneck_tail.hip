@@ -63,6 +63,7 @@ struct Args {
     int M;
     int act1;                    // activation of conv1': GIM_ACT_RELU (next block's conv1) or GIM_ACT_NONE
     unsigned w3_bytes, w1n_bytes;
+    int* health;                 // fp16 range guard word (gim_common.h) or NULL
 };
 
 typedef __attribute__((address_space(3))) void lds_t;
@@ -126,6 +127,7 @@ __global__ void __launch_bounds__(NW * 64, 2) bneck_tail_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float hmax = 0.f;   // fp16 range guard: largest residual-stream value this thread converts (gim_common.h)
     const size_t prow0 = (size_t)blockIdx.x * ROWS + w * 32;   // first pixel row of this wave
     char* patch = smem + C::OFF_PATCH + w * C::PATCH;
 
@@ -224,6 +226,8 @@ __global__ void __launch_bounds__(NW * 64, 2) bneck_tail_kernel(const Args a) {
             unsigned u[8];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
+                h16_range_track(hmax, c3[f][rg * 4], c3[f][rg * 4 + 1]);        // x': the un-normalised residual stream
+                h16_range_track(hmax, c3[f][rg * 4 + 2], c3[f][rg * 4 + 3]);
                 u[2 * rg] = cvt_pk_h16(c3[f][rg * 4], c3[f][rg * 4 + 1]);
                 u[2 * rg + 1] = cvt_pk_h16(c3[f][rg * 4 + 2], c3[f][rg * 4 + 3]);
                 *(uint2*)(patch + l31 * PROW + (pswz<PROW>(l31, 4 * f + rg) << 4) + lh * 8) = make_uint2(u[2 * rg], u[2 * rg + 1]);
@@ -282,6 +286,7 @@ __global__ void __launch_bounds__(NW * 64, 2) bneck_tail_kernel(const Args a) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    h16_range_flag(a.health, hmax);
 }
 
 template <int P, int N1, int NW = 8>
@@ -310,7 +315,7 @@ int tail_entry(int P, const void* t2, const void* res, void* x_out, void* t1_nex
     Args a;
     a.t2 = (const unsigned short*)t2; a.res = (const unsigned short*)res; a.xo = (unsigned short*)x_out; a.t1n = (unsigned short*)t1_next;
     a.w3 = (const unsigned short*)w3; a.w1n = (const unsigned short*)w1n; a.b3 = b3; a.b1n = b1n; a.M = M; a.act1 = act_next;
-    a.w3_bytes = (unsigned)(4 * P * P * 2); a.w1n_bytes = (unsigned)(n_next * 4 * P * 2);
+    a.w3_bytes = (unsigned)(4 * P * P * 2); a.w1n_bytes = (unsigned)(n_next * 4 * P * 2); a.health = gim_range_guard_ptr();
     if (P == 128) {
         GIM_REQUIRE(n_next == 128 || n_next == 256, "bneck_tail128: n_next must be 128 or 256 (got %d)", n_next);
         return n_next == 128 ? launch_tail<128, 128>(a, (hipStream_t)stream) : launch_tail<128, 256>(a, (hipStream_t)stream);

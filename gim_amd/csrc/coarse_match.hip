@@ -54,7 +54,7 @@ struct CmWs {  // device pointers carved out of the caller's workspace
     int* ncand;        // [N]
     Cand* cand;        // [N][capc]
     int* ext;          // [N][4] valid extents of the padding masks
-    int* npre;         // [N] pre-candidate counters, npre[N] = overflow flag, npre[N + 1] = "wide logit range" flag of the 256-tile kernel
+    int* npre;         // [N] pre-candidate counters, npre[N] = overflow flag
     PreCand* pre;      // [N][capp]
     int* ktab;         // dense K table for the mainloop
     int ntL, ntS, capc, capp;
@@ -88,7 +88,7 @@ size_t carve(CmWs& w, char* base, int N, int L, int S, int C) {
     w.ncand = (int*)take((size_t)N * 4);
     w.cand = (Cand*)take((size_t)N * w.capc * sizeof(Cand));
     w.ext = (int*)take((size_t)N * 16);
-    w.npre = (int*)take((size_t)(N + 2) * 4);
+    w.npre = (int*)take((size_t)(N + 1) * 4);
     w.pre = (PreCand*)take((size_t)N * w.capp * sizeof(PreCand));
     w.ktab = (int*)take((size_t)(C / 32 + 2) * 8 * 4);
     return o;
@@ -333,14 +333,10 @@ __device__ __forceinline__ void cm_stats_tile(const CmGeom& g, const CmWs& w, co
 }
 
 
-// One workgroup per tile (grid = N * ntL * ntS), or -- `gated` -- a small persistent grid launched behind the 256-tile kernel as
-// its fallback: it leaves at once unless that kernel found a logit range too wide for its shared exponentials (npre[N + 1]); it
-// then redoes all partials (and adds its own pre-candidates to the list, which may hold duplicates afterwards: every entry is an
-// exact (i, j, similarity) triple that cm_precand evaluates with the final statistics).
+// One workgroup per tile (grid = N * ntL * ntS)
 template <bool BF16>
-__global__ void __launch_bounds__(256) cm_stats_kernel(const CmGeom g, const CmWs w, const int gated) {
+__global__ void __launch_bounds__(256) cm_stats_kernel(const CmGeom g, const CmWs w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (gated && !w.npre[g.N + 1]) return;
     const int per = w.ntL * w.ntS, total = per * g.N;
     for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
         const int n = tile / per, r = tile - n * per, mt = r / w.ntS;
@@ -359,16 +355,16 @@ __global__ void __launch_bounds__(256) cm_stats_kernel(const CmGeom g, const CmW
 //   * persistent 8-wave workgroups (one per CU) walk 256 x 256 tiles (128 flop per staged byte), pair = tile % N so that with
 //     8 pairs the two feature maps of pair n (4.8 MB) stay in XCD n's L2; the first K slab of the NEXT tile is in flight during
 //     the statistics of this one;
-//   * a wave owns 64 rows x 128 columns in its 128 accumulator registers (lane = row, registers = columns) and takes ONE
-//     exponential per element against ONE wave-wide reference m_w = max of its sub-tile: e = exp(s - m_w) feeds the row sums
-//     (in the lane + one exchange with lane ^ 32) and the column sums (halving butterfly over the 32 row lanes:
-//     v_permlane16_swap, DPP row_ror / quad_perm, one ds_swizzle).  Partials are (reference, sum) pairs -- the combine kernel
-//     only needs sum_j exp(s_ij - ref) for SOME reference, not the maximum;
-//   * nothing of the statistics touches LDS except the wave-private broadcast of the 128 column thresholds;
+//   * a wave owns 64 rows x 128 columns in its 128 accumulator registers (lane = row, registers = columns) and takes the
+//     statistics straight from them: row maxima / sums in the lane (+ one exchange with lane ^ 32), column maxima / sums by a
+//     halving butterfly over the 32 row lanes (v_permlane16_swap, DPP row_ror / quad_perm, one ds_swizzle level) -- the exact
+//     (max, sum-exp) pairs of the wave's sub-tile, the same arithmetic as the 128 x 128 kernel on a different partition.
+//     (A first version took ONE exponential per element against a wave-wide reference: 253 us per call on narrow logits, but the
+//     bench's features span > 69 between a wave tile's matches and its weakest rows -- shared exponentials underflow there, its
+//     range guard sent every call to the fallback and the step got slower; profiles/r04_cm_stats.txt.)
+//   * nothing of the statistics touches shared LDS: the column maxima / thresholds are broadcast through a wave-private buffer;
 //   * pre-candidates: same superset argument as above with the WAVE sub-tile's softmax factors (over 128 columns / 64 rows:
 //     still >= the true factors), tested on the registers; the exact product test is left to cm_precand.
-// Range guard: a row (column) whose terms all underflow against the wave reference (its sum < 1e-30: logits more than ~69 below
-// m_w) raises npre[N + 1] and the 128 x 128 kernel (gated launch right behind) redoes the partials with per-row maxima.
 // Row partials land in the 128-column slots of the tile kernel's layout; column partials have 64-row granularity (ntL64 slots).
 constexpr int PL2 = 1024;                               // per-tile pre-candidate list
 typedef gim::Igemm<256, 256, 4, 2, true, true> G2;
@@ -391,10 +387,15 @@ __device__ __forceinline__ float pair32_sum(float v) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+__device__ __forceinline__ float pair32_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 
 // Sum of c[r] over the 32 lanes that share (lane >> 5): halving butterfly.  Returns the total of ONE column per lane; which one
 // (register index r in 0..15) is whatever `tag` says after the same network ran on the register indices (cm256_column_tag).
 struct BflyAdd { __device__ __forceinline__ float operator()(float keep, float recv) const { return keep + recv; } };
+struct BflyMax { __device__ __forceinline__ float operator()(float keep, float recv) const { return fmaxf(keep, recv); } };
 struct BflyTag { __device__ __forceinline__ float operator()(float keep, float) const { return keep; } };
 template <typename OP>
 __device__ __forceinline__ float cm256_butterfly(float (&c)[16], const int lane, OP op) {
@@ -442,66 +443,77 @@ __device__ __forceinline__ void cm256_stats(const CmGeom& g, const CmWs& w, G2::
     const int row0 = m0 + wm * 64 + l31;        // this lane's rows: row0, row0 + 32
     const int colw = n0 + wn * 128;             // acc[i][j][rg * 4 + e] = sim(row0 + 32 j, colw + 32 i + 8 rg + 4 lh + e) * C * T
     const float NEG = -INFINITY;
-    // ---- wave reference ----
-    float mx = NEG;
+    const int coff = 8 * (tag >> 2) + 4 * lh + (tag & 3);   // the column (within a 32-column fragment) this lane owns after a butterfly
+    float* tc = X.tcol[wave];                   // wave-private broadcast buffer: 128 floats, written and read by this wave only
+    // ---- references: exact maxima of the wave's sub-tile, per row (in the lane) and per column (butterfly over the row lanes) ----
+    float rm0 = NEG, rm1 = NEG, cml[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+        if (EDGE) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (EDGE) {
+            for (int j = 0; j < 2; ++j) {
                 const bool rok = row0 + 32 * j < g.L;
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (!(rok && colw + 32 * i + 8 * (r >> 2) + 4 * lh + (r & 3) < g.S)) acc[i][j][r] = NEG;
             }
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, acc[i][j][r]), acc[i][j][r + 1]);
         }
-    mx = wave_max(mx);
-    if (EDGE) mx = mx == NEG ? 0.f : mx;        // sub-tile entirely beyond L x S: any finite reference
-    // ---- one exponential per element: row sums in the lane, column sums through the butterfly ----
-    const float k2 = g.inv_ct * 1.44269504088896341f;   // exp(s - m) = exp2((acc - mx) * inv_ct * log2 e); acc - mx is exact where it matters
+        float c[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            rm0 = fmaxf(rm0, acc[i][0][r]);
+            rm1 = fmaxf(rm1, acc[i][1][r]);
+            c[r] = fmaxf(acc[i][0][r], acc[i][1][r]);
+        }
+        cml[i] = cm256_butterfly(c, lane, BflyMax());
+        if (EDGE) cml[i] = cml[i] == NEG ? 0.f : cml[i];   // column beyond S (or no valid row): any finite reference
+        if ((l31 & 1) == 0) tc[32 * i + coff] = cml[i];
+    }
+    rm0 = pair32_max(rm0);
+    rm1 = pair32_max(rm1);
+    if (EDGE) { rm0 = rm0 == NEG ? 0.f : rm0; rm1 = rm1 == NEG ? 0.f : rm1; }
+    // ---- two exponentials per element (row softmax against the row maximum, column softmax against the column maximum) ----
+    const float k2 = g.inv_ct * 1.44269504088896341f;   // exp(s - m) = exp2((acc - macc) * inv_ct * log2 e); acc - macc is exact where it matters
     float rs0 = 0.f, rs1 = 0.f, cs[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float c[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float e0 = __builtin_amdgcn_exp2f((acc[i][0][r] - mx) * k2), e1 = __builtin_amdgcn_exp2f((acc[i][1][r] - mx) * k2);
-            rs0 += e0; rs1 += e1;
-            c[r] = e0 + e1;
+        for (int rg = 0; rg < 4; ++rg) {
+            const float4 m4 = *(const float4*)(tc + 32 * i + 8 * rg + 4 * lh);
+            const float mq[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * rg + e;
+                rs0 += __builtin_amdgcn_exp2f((acc[i][0][r] - rm0) * k2);
+                rs1 += __builtin_amdgcn_exp2f((acc[i][1][r] - rm1) * k2);
+                c[r] = __builtin_amdgcn_exp2f((acc[i][0][r] - mq[e]) * k2) + __builtin_amdgcn_exp2f((acc[i][1][r] - mq[e]) * k2);
+            }
         }
         cs[i] = cm256_butterfly(c, lane, BflyAdd());
     }
     rs0 = pair32_sum(rs0);
     rs1 = pair32_sum(rs1);
-    // ---- partials ----
-    const float mref = mx * g.inv_ct;
+    // ---- partials: (maximum, sum) in similarity units, the layout of the 128 x 128 kernel for rows, 64-row slots for columns ----
     const int rslot = (colw >> 7), cslot = (m0 >> 6) + wm;
     const bool wave_cols = colw < g.S, wave_rows = m0 + wm * 64 < g.L;
-    const int coff = 8 * (tag >> 2) + 4 * lh + (tag & 3);   // this lane's column within a 32-column fragment
-    bool wide = false;
     if (wave_cols && lh == 0) {
         bool bad = false;   // every element feeds a row sum: NaN / inf anywhere in the features (fp16 overflow upstream) shows here
-        if (row0 < g.L) { w.rowpart[((size_t)n * w.ntS + rslot) * g.L + row0] = make_float2(mref, rs0); wide |= rs0 < 1e-30f; bad |= !(rs0 < INFINITY); }
-        if (row0 + 32 < g.L) { w.rowpart[((size_t)n * w.ntS + rslot) * g.L + row0 + 32] = make_float2(mref, rs1); wide |= rs1 < 1e-30f; bad |= !(rs1 < INFINITY); }
+        if (row0 < g.L) { w.rowpart[((size_t)n * w.ntS + rslot) * g.L + row0] = make_float2(rm0 * g.inv_ct, rs0); bad |= !(rs0 < INFINITY); }
+        if (row0 + 32 < g.L) { w.rowpart[((size_t)n * w.ntS + rslot) * g.L + row0 + 32] = make_float2(rm1 * g.inv_ct, rs1); bad |= !(rs1 < INFINITY); }
         if (bad && w.health) atomicOr(w.health, 1);
     }
     const float ct = (float)g.C * g.temperature;
     const float thr_pre = g.thr * (1.0f - 1e-3f);   // slack: rounding must never drop a true candidate
-    float* tc = X.tcol[wave];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int col = colw + 32 * i + coff;
-        if (wave_rows && (l31 & 1) == 0 && col < g.S) {
-            w.colpart[((size_t)n * w.ntL64 + cslot) * g.S + col] = make_float2(mref, cs[i]);
-            wide |= cs[i] < 1e-30f;
-        }
-        // column threshold in accumulator units: s > m + log(thr z)  <=>  acc > mx + log(thr z) * C * T
-        if ((l31 & 1) == 0) tc[32 * i + coff] = mx + __logf(thr_pre * cs[i]) * ct;
+        if (wave_rows && (l31 & 1) == 0 && col < g.S) w.colpart[((size_t)n * w.ntL64 + cslot) * g.S + col] = make_float2(cml[i] * g.inv_ct, cs[i]);
+        // column threshold in accumulator units: s > m + log(thr z)  <=>  acc > macc + log(thr z) * C * T   (tc: the maxima were
+        // consumed above; LDS operations of one wave execute in order)
+        if ((l31 & 1) == 0) tc[32 * i + coff] = cml[i] + __logf(thr_pre * cs[i]) * ct;
     }
-    if (wide) w.npre[g.N + 1] = 1;
-    const float tr0 = mx + __logf(thr_pre * rs0) * ct, tr1 = mx + __logf(thr_pre * rs1) * ct;
+    const float tr0 = rm0 + __logf(thr_pre * rs0) * ct, tr1 = rm1 + __logf(thr_pre * rs1) * ct;
     // ---- pre-candidates on the registers ----
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -527,7 +539,7 @@ __device__ __forceinline__ void cm256_stats(const CmGeom& g, const CmWs& w, G2::
         }
 }
 
-__global__ void __launch_bounds__(512) cm_stats256_kernel(const CmGeom g, const CmWs w, const int force_wide) {
+__global__ void __launch_bounds__(512) cm_stats256_kernel(const CmGeom g, const CmWs w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     S2X& X = *(S2X*)(smem + S2_STAGE);
     const int t = threadIdx.x;
@@ -535,7 +547,7 @@ __global__ void __launch_bounds__(512) cm_stats256_kernel(const CmGeom g, const 
     const int total = g.N * ntL2 * ntS2;
     const int nkt = g.C * 2 / KTB;
     const int tag = cm256_column_tag(t & 63);
-    if (t == 0) { X.pcnt[0] = 0; if (force_wide) w.npre[g.N + 1] = 1; }   // force_wide: tests exercise the gated fallback
+    if (t == 0) X.pcnt[0] = 0;
     gim::MainloopArgs ml;
     ml.ktab = nullptr;
     ml.x_bytes = (unsigned)(((size_t)(g.L - 1) * g.ldf + g.C) * 2);
@@ -611,16 +623,13 @@ __global__ void cm_precand_kernel(const CmGeom g, const CmWs w) {
     }
 }
 
-// stat[n][x] = combine over partial slots:  m = max m_t ; z = sum_t z_t * exp(m_t - m)   (fixed order: deterministic)
-// `part` holds either layout A (`ntile_a` slots per pair: the 256-tile statistics kernel) or, when that kernel raised *wide and the
-// gated 128 x 128 kernel rewrote the partials, layout B (`ntile_b` slots).  Four threads share an element (slots t, t + 4, ...)
-// so that a pair's 38 ... 75 dependent-latency loads become 10 ... 19: the two launches took 20 us each as one thread per element.
-__global__ void __launch_bounds__(256) cm_combine_kernel(const float2* __restrict__ part, float2* __restrict__ stat, int N, int len,
-                                                         int ntile_a, int ntile_b, const int* __restrict__ wide) {
+// stat[n][x] = combine over the `ntile` partial slots of a pair:  m = max m_t ; z = sum_t z_t * exp(m_t - m)   (fixed order:
+// deterministic).  Four threads share an element (slots t, t + 4, ...) so that a pair's 38 ... 75 dependent-latency loads become
+// 10 ... 19: the two launches took 20 us each as one thread per element.
+__global__ void __launch_bounds__(256) cm_combine_kernel(const float2* __restrict__ part, float2* __restrict__ stat, int N, int len, int ntile) {
     __shared__ float2 sh[4][64];
     const int xq = threadIdx.x & 63, tq = threadIdx.x >> 6;
     const size_t idx = (size_t)blockIdx.x * 64 + xq;
-    const int ntile = (ntile_a > 0 && !*wide) ? ntile_a : ntile_b;
     const bool ok = idx < (size_t)N * len;
     float m = -INFINITY, z = 0.f;
     if (ok) {
@@ -650,8 +659,8 @@ __global__ void cm_init_kernel(const CmWs w, int N, int L, int S) {
     if (idx < (size_t)N * L) { w.rowmaxP[idx] = 0u; w.jsel[idx] = INT_MAX; w.psel[idx] = 0.f; }
     if (idx < (size_t)N * S) w.colmaxP[idx] = 0u;
     if (idx < (size_t)N) w.ncand[idx] = 0;
-    if (idx <= (size_t)N + 1) w.npre[idx] = 0;
-    if (idx == 0 && w.health) *w.health &= 2;   // bit 1 belongs to the fine kernel of the PREVIOUS call on this buffer (sticky: the host clears it)
+    if (idx <= (size_t)N) w.npre[idx] = 0;
+    if (idx == 0 && w.health) *w.health &= ~1;   // bits 1 (fine kernel of the PREVIOUS call on this buffer) and 2 (range guard of the kernels in front of this call) are sticky: the host clears them
 }
 
 __global__ void cm_ktab_kernel(int* ktab, int C, int ge) {  // dense table: K group g -> channel ge * g (ge = 4 fp32 / 8 bf16 per 16 B); 2 padding slabs
@@ -843,8 +852,8 @@ int validate(const gim_coarse_args& a) {
     return GIM_OK;
 }
 
-// GIM_CM_STATS: 1 (default) the 256-tile statistics kernel where it applies (16-bit features, no padding masks) + its gated
-// fallback; 2 the same with the fallback forced (tests); 0 the 128 x 128 tile-per-workgroup kernel always.
+// GIM_CM_STATS: 1 (default) the 256-tile statistics kernel where it applies (16-bit features, no padding masks); 0 the 128 x 128
+// tile-per-workgroup kernel always (tests compare the two).
 static int stats_mode() { static const int v = [] { const char* e = getenv("GIM_CM_STATS"); return e ? atoi(e) : 1; }(); return v; }
 
 template <typename K>
@@ -914,14 +923,12 @@ extern "C" int GIM_FN(gim_coarse_match)(const gim_coarse_args* ap, gim_stream_t 
         // persistent: one workgroup per CU; a grid that is a multiple of N (and of 8) keeps pair = tile % N on one XCD per workgroup
         unsigned grid = (unsigned)ncu;
         if (grid > t256) grid = t256;
-        hipLaunchKernelGGL(cm_stats256_kernel, dim3(grid), dim3(512), S2_SMEM, s, g, w, stats_mode() == 2 ? 1 : 0);
-        hipLaunchKernelGGL(cm_stats_kernel<true>, dim3(nfallback), dim3(256), TILE_SMEM, s, g, w, 1);   // gated fallback (wide logit range)
-    } else if (g.bf16) hipLaunchKernelGGL(cm_stats_kernel<true>, dim3(ntiles), dim3(256), TILE_SMEM, s, g, w, 0);
-    else hipLaunchKernelGGL(cm_stats_kernel<false>, dim3(ntiles), dim3(256), TILE_SMEM, s, g, w, 0);
-    hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.L + 63) / 64)), dim3(256), 0, s, w.rowpart, w.rowstat, a.N, a.L,
-                       0, w.ntS, w.npre + a.N + 1);
+        hipLaunchKernelGGL(cm_stats256_kernel, dim3(grid), dim3(512), S2_SMEM, s, g, w);
+    } else if (g.bf16) hipLaunchKernelGGL(cm_stats_kernel<true>, dim3(ntiles), dim3(256), TILE_SMEM, s, g, w);
+    else hipLaunchKernelGGL(cm_stats_kernel<false>, dim3(ntiles), dim3(256), TILE_SMEM, s, g, w);
+    hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.L + 63) / 64)), dim3(256), 0, s, w.rowpart, w.rowstat, a.N, a.L, w.ntS);
     hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.S + 63) / 64)), dim3(256), 0, s, w.colpart, w.colstat, a.N, a.S,
-                       big ? w.ntL64 : 0, w.ntL, w.npre + a.N + 1);
+                       big ? w.ntL64 : w.ntL);
     hipLaunchKernelGGL(cm_precand_kernel, dim3((unsigned)((w.capp + 255) / 256), (unsigned)a.N), dim3(256), 0, s, g, w);
     if (g.bf16) hipLaunchKernelGGL((cm_cand_kernel<0, true>), dim3(nfallback), dim3(256), TILE_SMEM, s, g, w, (float*)nullptr);
     else hipLaunchKernelGGL((cm_cand_kernel<0, false>), dim3(nfallback), dim3(256), TILE_SMEM, s, g, w, (float*)nullptr);

@@ -165,6 +165,24 @@ template <> struct ElemIO<false> {
     static __device__ __forceinline__ void st4(void* p, size_t i, float4 v) { *(float4*)((float*)p + i) = v; }
 };
 
+// ---- fp16 range guard ---------------------------------------------------------------------------------------------------------------
+// IEEE fp16 ends at 65504.  The un-normalised ResNet residual streams are the values of the path that can get there (every other
+// stored activation sits behind a BatchNorm or a LayerNorm), and downstream ReLUs scrub the evidence: fmaxf(NaN, 0) = 0, so an
+// overflow rarely survives to the outputs as a NaN.  The kernels that STORE a residual stream (bneck_fused.hip, bneck_tail.hip) track
+// the largest value they convert -- one v_max3 per packed pair, fp16 flavour only -- and OR 4 into the caller's health word
+// (gim_set_range_guard(): the coarse count buffer's word [1], read back with the match count) when it is beyond the range.
+int* gim_range_guard_ptr();   // runtime.hip: the device word registered for the calling thread's current device, or NULL
+__device__ __forceinline__ void h16_range_track(float& m, float a, float b) {
+#if GIM_HALF_KIND
+    m = fmaxf(fmaxf(m, a), b);    // callers pass post-ReLU values (>= 0); +inf included, NaN ignored (it comes from an inf flagged earlier)
+#endif
+}
+__device__ __forceinline__ void h16_range_flag(int* health, float m) {
+#if GIM_HALF_KIND
+    if (health != nullptr && m > 65504.f) atomicOr(health, 4);
+#endif
+}
+
 // ---- LDS-DMA through inline asm (invisible to hipcc's s_waitcnt bookkeeping) --------------------------------------------------
 // hipcc makes the first LDS access behind an LDS-DMA it can see (__builtin_amdgcn_raw_ptr_buffer_load_lds) wait vmcnt(0): it assumes
 // every ds_read / ds_write may alias the DMA's destination.  Kernels that keep a DMA in flight ACROSS other LDS work (bneck_tail.hip,

@@ -359,6 +359,16 @@ class LoFTR(nn.Module):
         fl = self.loftr_fine
         if is_half(dt) and fl.d_model == 128 and fl.nhead == 8 and fl.layer_names == ["self", "cross"] and self.W == 5:
             P["fine_fused"] = pack_fine_fused(fl.layers, device, tdt) + (fl.layers[0].norm1.eps,)
+        if self.precision == "fp16":
+            # range guard, weight side: a BatchNorm-folded weight beyond the IEEE-fp16 range became inf when it was packed
+            bad = [k for k, v in P.items() if hasattr(v, "w") and torch.is_tensor(v.w) and not bool(torch.isfinite(v.w).all())]
+            if bad:
+                import warnings
+                warnings.warn(f"gim_amd LoFTR: folded weights of {bad[:4]}{' ...' if len(bad) > 4 else ''} exceed the IEEE-fp16 range; "
+                              "falling back to precision='bf16' for this module")
+                self.fp16_overflowed = True
+                self.set_precision("bf16")
+                return self._prepack(device)
         self._packed, self._packed_key = P, key
         return P
 
@@ -611,6 +621,11 @@ class LoFTR(nn.Module):
         Returns a dict of device tensors (graph-owned when captured)."""
         dev = xs[0].device
         dt = self._dt()
+        # [match count, health word, per-pair counts] of this forward's coarse matching.  The health word doubles as the fp16 range
+        # guard of the kernels in front of it (registered here, read back with the count): allocated before the first launch
+        if count is None:
+            count = torch.zeros(2 + bs, dtype=torch.int32, device=dev)
+        ops.set_range_guard(count[1:2] if self.precision == "fp16" else None)
         tdt = torch_dtype(dt)
         P = self._prepack(dev)
         cfg = self.config
@@ -647,6 +662,7 @@ class LoFTR(nn.Module):
         cr = ops.coarse_match(fc0, fc1, hw0_c, hw1_c, scale,
                               mc["dsmax_temperature"], mc["thr"], mc["border_rm"], scale0, scale1,
                               T.MASK[r0] if mask0 is not None else None, T.MASK[r1] if mask0 is not None else None, count=count)
+        ops.set_range_guard(None)   # the launches above carry the pointer; nothing later may write through it
         return {"c0": c0, "c1": c1, "f0": f0, "f1": f1, "cr": cr,
                 "feat_c0": T.X32[r0].view(bs, L, C), "feat_c1": T.X32[r1].view(bs, S, C)}
 
@@ -708,6 +724,7 @@ class LoFTR(nn.Module):
             raise GimHipError("gim_amd LoFTR runs on the HIP device only (no CPU fallback): move the inputs "
                               "and the module to 'cuda'")
         dev = color0.device
+        self._prepack(dev)   # first: packing may still change the mode (fp16 weights out of range -> bf16, see _prepack)
         dt = self._dt()
         tdt = torch_dtype(dt)
         cfg = self.config
@@ -795,8 +812,8 @@ class LoFTR(nn.Module):
             self._count_pin.copy_(cr.count[:2])  # the one host sync the reference also has
             M, health = int(self._count_pin[0]), int(self._count_pin[1])
         if health:
-            if health & 2:
-                cr.count[1:2].zero_()   # sticky bit: acknowledged
+            if health & 6:
+                cr.count[1:2].zero_()   # sticky bits: acknowledged
             if self._range_guard(health):
                 return self.forward(data)   # the module is in bf16 now: same inputs, once more
         self._generation += 1
@@ -839,14 +856,15 @@ class LoFTR(nn.Module):
         other modes the inputs or weights themselves were not finite: warn only.  The reference computes in fp32 and has no such
         case (networks/loftr/utils/coarse_matching.py:174-195 would return no match for a NaN row, silently)."""
         import warnings
-        what = " and ".join(w for b, w in ((1, "coarse similarities"), (2, "fine-level outputs")) if health & b)
+        what = " and ".join(w for b, w in ((4, "a residual-stream value beyond 65504"), (1, "non-finite coarse similarities"),
+                                           (2, "non-finite fine-level outputs")) if health & b)
         if self.precision == "fp16":
-            warnings.warn(f"gim_amd LoFTR: non-finite {what} in the fp16 mode (an activation left the IEEE-fp16 range); "
+            warnings.warn(f"gim_amd LoFTR: {what} in the fp16 mode (an activation left the IEEE-fp16 range); "
                           "falling back to precision='bf16' for this module and re-running the batch")
             self.fp16_overflowed = True
             self.set_precision("bf16")
             return True
-        warnings.warn(f"gim_amd LoFTR: non-finite {what} in the {self.precision} mode: the inputs or the weights are not finite")
+        warnings.warn(f"gim_amd LoFTR: {what} in the {self.precision} mode: the inputs or the weights are not finite")
         return False
 
     def _fine_level(self, f0, f1, b_ids, i_ids, j_ids, mkpts1_c, scale1, has_s0, hw0_c, hw1_c, hw0_i, fused, count=None):

@@ -87,6 +87,14 @@ def nchw_to_nhwc(src, dst, b_off=0):
                                gim_dtype(dst), _stream()), "gim_nchw_to_nhwc")
 
 
+def set_range_guard(word):
+    """int32 device tensor (one element) the fp16 residual-stream kernels OR 4 into on overflow, or None (gim_set_range_guard)"""
+    if word is not None:
+        _req_cuda(word)
+        assert word.dtype == torch.int32 and word.numel() >= 1
+    check(lib.gim_set_range_guard(_p(word)), "gim_set_range_guard")
+
+
 def nchw_to_nhwc_split(src, dst, b_off=0):
     """src [B,C,H,W] fp32 -> dst [Btot,H,W,ld] 16-bit with channels [hi(C) | lo(C) | hi(C) | 0...] (gim_nchw_to_nhwc_split)"""
     _req_cuda(src, dst)

@@ -34,6 +34,11 @@ enum { GIM_ACT_NONE = 0, GIM_ACT_RELU = 1, GIM_ACT_LEAKY = 2, GIM_ACT_ELU1 = 3 /
 enum { GIM_OK = 0, GIM_ERR_INVALID = -1, GIM_ERR_LAUNCH = -2, GIM_ERR_UNSUPPORTED = -3 };
 
 int gim_version(void);
+/* fp16 range guard.  Registers (NULL: removes) the device word into which the fp16 flavour of the kernels that store residual
+ * streams (gim_bneck64_fused*, gim_bneck_tail*) OR 4 when a converted value exceeds the IEEE-fp16 range -- ReLUs downstream turn the
+ * resulting NaNs into zeros, so the outputs alone do not show it.  One registration per device, process-wide; launches read it when
+ * they are enqueued (a captured graph keeps the word registered at capture).  gim_amd registers count[1] of gim_coarse_match. */
+int gim_set_range_guard(int32_t* device_word);
 const char* gim_last_error(void);
 /* compile-time facts the host packer needs: K-tile bytes (128) and the N padding granule (64). */
 int gim_ktile_bytes(void);
@@ -141,11 +146,12 @@ int gim_layernorm_residual(const void* x, const float* gamma, const float* beta,
  * feat0 [N*L, C] / feat1 [N*S, C] fp32 rows (row stride C).  Outputs in torch.where order
  * (ascending b, then i): b_ids/i_ids/j_ids int64, mconf fp32, mkpts0_c/mkpts1_c fp32 [cap,2].
  * `count` (device int32[2 + N], ZERO IT ONCE when allocating): count[0] = M, count[2+b] = matches of pair b, count[1] = health word:
- * bit 0 (rewritten by every call) = a NaN / inf similarity reached the statistics -- the fp16 mode's activations overflowed
- * upstream, or the inputs were not finite; bit 1 (sticky, never cleared here) = gim_fine_fused_dev saw a non-finite fine-level
- * output on this buffer: a host that replays a captured graph on the same buffer learns it with the NEXT call's count read-back.
- * The reference has no such word (fp32 has the range); gim_amd/loftr/loftr.py reads it with the match count
- * (coarse_matching.py:193's sync) and re-runs the batch in bf16.
+ * bit 0 (rewritten by every call) = a NaN / inf similarity reached the statistics -- the inputs or weights were not finite, or an
+ * overflow survived the ReLUs in between; bit 1 (sticky, never cleared here) = gim_fine_fused_dev saw a non-finite fine-level
+ * output on this buffer: a host that replays a captured graph on the same buffer learns it with the NEXT call's count read-back;
+ * bit 2 (sticky) = the fp16 range guard: a kernel that stores an un-normalised residual stream converted a value beyond 65504
+ * while this word was registered through gim_set_range_guard().  The reference has no such word (fp32 has the range);
+ * gim_amd/loftr/loftr.py reads it with the match count (coarse_matching.py:193's sync) and re-runs the batch in bf16.
  * scale0/scale1: NULL or fp32 [N,2] per-pair (w,h) scales (coarse_matching.py:237-245). */
 typedef struct gim_coarse_args {
     const void* feat0;    /* [N, L, ldf] rows of C features, fp32 or bf16 (feat_dtype) */

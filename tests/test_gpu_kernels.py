@@ -259,7 +259,8 @@ def test_coarse_match(case):
     M = int(cnt[0])
     assert ref["b_ids"].numel() > 20, "test input produced too few matches"
     assert M == ref["b_ids"].numel(), f"M={M} ref={ref['b_ids'].numel()}"
-    assert cnt[1:].tolist() == torch.bincount(ref["b_ids"], minlength=N).tolist()
+    assert int(cnt[1]) == 0                                                             # health word: finite similarities
+    assert cnt[2:].tolist() == torch.bincount(ref["b_ids"], minlength=N).tolist()
     for k in ("b_ids", "i_ids", "j_ids"):
         got = getattr(r, k)[:M].cpu()
         assert got.dtype == torch.int64
@@ -420,15 +421,14 @@ def test_linear_attention_masks(shape):
     _assert_close(out.view(nb, L, H, D), ref, 1e-5, f"masked linear attention {shape}")
 
 
-@pytest.mark.parametrize("mode", ["1", "2", "0"], ids=["tile256", "tile256+forced-fallback", "tile128-kernel"])
+@pytest.mark.parametrize("mode", ["1", "0"], ids=["tile256", "tile128-kernel"])
 @pytest.mark.parametrize("kind", ["bf16", "fp16"])
 def test_coarse_match_tile256_statistics(mode, kind):
-    """The persistent 256 x 256 statistics kernel (16-bit features, no masks; round 4: one exponential per element against a wave-wide
-    reference, sums straight from the accumulators) against the oracle evaluated on the SAME 16-bit-valued features: exact indices
-    and order, confidences to 1e-5 -- on sizes with ragged last tiles in both directions, unequal L / S, several pairs, a logit range
-    wide enough to trip its range guard (sigma = 3: the gated 128 x 128 kernel redoes the partials) -- and the same with the fallback
-    forced (GIM_CM_STATS=2) and through the tile-per-workgroup kernel alone (GIM_CM_STATS=0).  Subprocess: the mode is read once
-    per process."""
+    """The persistent 256 x 256 statistics kernel (16-bit features, no masks; round 4: row / column maxima and sums straight from the
+    accumulators) against the oracle evaluated on the SAME 16-bit-valued features: exact indices and order, confidences to 1e-5 --
+    on sizes with ragged last tiles in both directions, unequal L / S, several pairs (8: pair = tile % N walks every pair), a wide
+    logit range (sigma = 3: similarities of ~90 beside rows that peak at ~15) -- and the same through the 128 x 128
+    tile-per-workgroup kernel (GIM_CM_STATS=0).  Subprocess: the mode is read once per process."""
     import os
     import subprocess
     import sys

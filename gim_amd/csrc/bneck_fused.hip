@@ -69,7 +69,6 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float hmax = 0.f;   // fp16 range guard: largest residual-stream value this thread converts (gim_common.h)
     const int tiles_x = a.W / TW, tiles_y = a.H / TH;
     const int tile = blockIdx.x;
     const int b = tile / (tiles_x * tiles_y), tr = tile - b * tiles_x * tiles_y;
@@ -257,8 +256,6 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
             unsigned u[8];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                h16_range_track(hmax, c3[j][rg * 4], c3[j][rg * 4 + 1]);        // x': the un-normalised residual stream
-                h16_range_track(hmax, c3[j][rg * 4 + 2], c3[j][rg * 4 + 3]);
                 u[2 * rg] = cvt_pk_h16(c3[j][rg * 4], c3[j][rg * 4 + 1]);
                 u[2 * rg + 1] = cvt_pk_h16(c3[j][rg * 4 + 2], c3[j][rg * 4 + 3]);
                 *(uint2*)(patch + l31 * 128 + (((4 * ff + rg) ^ (l31 & 7)) << 4) + lh * 8) = make_uint2(u[2 * rg], u[2 * rg + 1]);
@@ -267,15 +264,17 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
             xq[2 * j + 1] = __builtin_bit_cast(bf16x8_t, make_uint4(u[4], u[5], u[6], u[7]));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        unsigned hm = 0u;   // fp16 range guard (gim_common.h): packed maximum of the x' halves this lane stores in this pass
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int px = it * 8 + (lane >> 3), sl = lane & 7;
             const uint4 v = *(const uint4*)(patch + px * 128 + ((sl ^ (px & 7)) << 4));
             *(uint4*)(a.xo + (prow0 + px) * C4 + 64 * q + sl * 8) = v;
+            hm = h16_range_fold(hm, v);
         }
+        h16_range_check(a.health, hm);   // x': the un-normalised residual stream
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the patch is rewritten by the next pass
     }
-    h16_range_flag(a.health, hmax);
     if constexpr (N1 > 0) {
         // ---- conv1' of the next block: K = 256 in accumulator order, weights from LDS -----------------------------------------
         constexpr int NF = N1 / 32;

@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(NW * 64, 2) bneck_tail_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float hmax = 0.f;   // fp16 range guard: largest residual-stream value this thread converts (gim_common.h)
+    bool hbig = false;  // fp16 range guard: a residual-stream value this thread converts is beyond the fp16 range (gim_common.h)
     const size_t prow0 = (size_t)blockIdx.x * ROWS + w * 32;   // first pixel row of this wave
     char* patch = smem + C::OFF_PATCH + w * C::PATCH;
 
@@ -226,8 +226,6 @@ __global__ void __launch_bounds__(NW * 64, 2) bneck_tail_kernel(const Args a) {
             unsigned u[8];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                h16_range_track(hmax, c3[f][rg * 4], c3[f][rg * 4 + 1]);        // x': the un-normalised residual stream
-                h16_range_track(hmax, c3[f][rg * 4 + 2], c3[f][rg * 4 + 3]);
                 u[2 * rg] = cvt_pk_h16(c3[f][rg * 4], c3[f][rg * 4 + 1]);
                 u[2 * rg + 1] = cvt_pk_h16(c3[f][rg * 4 + 2], c3[f][rg * 4 + 3]);
                 *(uint2*)(patch + l31 * PROW + (pswz<PROW>(l31, 4 * f + rg) << 4) + lh * 8) = make_uint2(u[2 * rg], u[2 * rg + 1]);
@@ -241,6 +239,8 @@ __global__ void __launch_bounds__(NW * 64, 2) bneck_tail_kernel(const Args a) {
         uint4 x0 = *(const uint4*)(prd), x1 = *(const uint4*)(prd + PPI * PROW), x2 = x0, x3 = x0;
         if constexpr (C::IPC == 4) { x2 = *(const uint4*)(prd + 2 * PPI * PROW); x3 = *(const uint4*)(prd + 3 * PPI * PROW); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the patch is free: the next chunk's identity rows may land in it
+        h16_range_track(hbig, x0); h16_range_track(hbig, x1);   // x': the un-normalised residual stream
+        if constexpr (C::IPC == 4) { h16_range_track(hbig, x2); h16_range_track(hbig, x3); }
         // in THIS order: identity of chunk q + 1, weights of chunk q + NBUF - 1 (into the buffer chunk q - 1 used, free since this
         // chunk's barrier), and only then this chunk's stores -- nothing the next chunks wait for sits behind a store
         if (q + 1 < NCHUNK) issue_identity(q + 1);
@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(NW * 64, 2) bneck_tail_kernel(const Args a) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    h16_range_flag(a.health, hmax);
+    h16_range_flag(a.health, hbig);
 }
 
 template <int P, int N1, int NW = 8>

@@ -366,16 +366,25 @@ __global__ void __launch_bounds__(256) cm_stats_kernel(const CmGeom g, const CmW
 //   * pre-candidates: same superset argument as above with the WAVE sub-tile's softmax factors (over 128 columns / 64 rows:
 //     still >= the true factors), tested on the registers; the exact product test is left to cm_precand.
 // Row partials land in the 128-column slots of the tile kernel's layout; column partials have 64-row granularity (ntL64 slots).
-constexpr int PL2 = 1024;                               // per-tile pre-candidate list
-typedef gim::Igemm<256, 256, 4, 2, true, true> G2;
-constexpr int S2_STAGE = 2 * G2::STAGE;                 // two K slabs of (256 + 256) rows x 128 B
+// Two workgroup shapes of the same kernel (GIM_CM_TILE selects; measured in profiles/r04_cm_stats.txt):
+//   WN2 = 2: 256 x 256 tile, 8 waves, K slabs double-buffered, one workgroup per CU (128 flop per staged byte).  The two waves of a
+//            SIMD run the same phase: MFMA pipe and VALU take turns.
+//   WN2 = 1: 256 x 128 tile, 4 waves, ONE stage buffer, two workgroups per CU (85 flop per staged byte).  A workgroup cannot hide its
+//            own staging, but its neighbour is in another phase: one wave of every SIMD multiplies while the other runs statistics.
+constexpr int PL2 = 512;                                // per-tile pre-candidate list
+template <int WN2> struct Cm2 {
+    static constexpr int BN2 = 128 * WN2, NT = 256 * WN2, NBUF = WN2;   // tile columns, threads, stage buffers
+    typedef gim::Igemm<256, BN2, 4, WN2, true, true> G;
+    static constexpr int STAGE = NBUF * G::STAGE;
+};
 struct S2X {
-    float tcol[8][128];     // wave-private: column thresholds of the wave's 128 columns (accumulator units)
+    float tcol[8][128];     // wave-private: column maxima, then column thresholds of the wave's 128 columns (accumulator units)
     PreCand plist[PL2];
     int pcnt[4];            // [0] = local count, [1] = global base
 };
-constexpr int S2_SMEM = S2_STAGE + (int)sizeof(S2X);
-static_assert(S2_SMEM <= 160 * 1024, "256-tile statistics kernel: LDS");
+template <int WN2> constexpr int s2_smem() { return Cm2<WN2>::STAGE + (int)sizeof(S2X); }
+static_assert(s2_smem<2>() <= 160 * 1024 && 2 * s2_smem<1>() <= 160 * 1024, "256-row statistics kernel: LDS");
+typedef f32x16_t Acc2[4][2];                            // [column fragment][row fragment] of a wave's 64 x 128 sub-tile
 
 __device__ __forceinline__ float lane_xor_dpp_1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)); }   // quad_perm [1,0,3,2]
 __device__ __forceinline__ float lane_xor_dpp_2(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true)); }   // quad_perm [2,3,0,1]
@@ -433,13 +442,13 @@ __device__ __forceinline__ int cm256_column_tag(const int lane) {
     return (int)cm256_butterfly(c, lane, BflyTag());
 }
 
-template <bool EDGE>
-__device__ __forceinline__ void cm256_stats(const CmGeom& g, const CmWs& w, G2::Acc& acc, const int n, const int m0, const int n0,
+template <bool EDGE, int WN2>
+__device__ __forceinline__ void cm256_stats(const CmGeom& g, const CmWs& w, Acc2& acc, const int n, const int m0, const int n0,
                                             S2X& X, const int tag) {
     const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int wm, wn;
-    G2::wave_mn(wave, wm, wn);
+    Cm2<WN2>::G::wave_mn(wave, wm, wn);
     const int row0 = m0 + wm * 64 + l31;        // this lane's rows: row0, row0 + 32
     const int colw = n0 + wn * 128;             // acc[i][j][rg * 4 + e] = sim(row0 + 32 j, colw + 32 i + 8 rg + 4 lh + e) * C * T
     const float NEG = -INFINITY;
@@ -503,47 +512,52 @@ __device__ __forceinline__ void cm256_stats(const CmGeom& g, const CmWs& w, G2::
         if (row0 + 32 < g.L) { w.rowpart[((size_t)n * w.ntS + rslot) * g.L + row0 + 32] = make_float2(rm1 * g.inv_ct, rs1); bad |= !(rs1 < INFINITY); }
         if (bad && w.health) atomicOr(w.health, 1);
     }
-    const float ct = (float)g.C * g.temperature;
-    const float thr_pre = g.thr * (1.0f - 1e-3f);   // slack: rounding must never drop a true candidate
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int col = colw + 32 * i + coff;
         if (wave_rows && (l31 & 1) == 0 && col < g.S) w.colpart[((size_t)n * w.ntL64 + cslot) * g.S + col] = make_float2(cml[i] * g.inv_ct, cs[i]);
-        // column threshold in accumulator units: s > m + log(thr z)  <=>  acc > macc + log(thr z) * C * T   (tc: the maxima were
-        // consumed above; LDS operations of one wave execute in order)
-        if ((l31 & 1) == 0) tc[32 * i + coff] = cml[i] + __logf(thr_pre * cs[i]) * ct;
     }
-    const float tr0 = rm0 + __logf(thr_pre * rs0) * ct, tr1 = rm1 + __logf(thr_pre * rs1) * ct;
-    // ---- pre-candidates on the registers ----
+    // ---- pre-candidates.  A row can only hold one if its LARGEST element passes the row test, i.e. if the wave-local softmax of
+    // its maximum, 1 / rs, exceeds thr: two compares per lane screen the whole sub-tile.  Rows of tiles the matches do not run
+    // through have rs >> 1 / thr; only the wave tiles that do hold a peaked row run the scan that names the elements ----
+    const float thr_pre = g.thr * (1.0f - 1e-3f);   // slack: rounding must never drop a true candidate
+    const bool hot0 = thr_pre * rs0 < 1.0f, hot1 = thr_pre * rs1 < 1.0f;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(hot0 | hot1) != 0ull, 0)) {
+        const float ct = (float)g.C * g.temperature;
+        // thresholds in accumulator units: s > m + log(thr z)  <=>  acc > macc + log(thr z) * C * T; the column ones are broadcast
+        // through the wave's buffer (the maxima in it were consumed above; LDS operations of one wave execute in order)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
+            if ((l31 & 1) == 0) tc[32 * i + coff] = cml[i] + __logf(thr_pre * cs[i]) * ct;
+        const float tr0 = hot0 ? rm0 + __logf(thr_pre * rs0) * ct : INFINITY, tr1 = hot1 ? rm1 + __logf(thr_pre * rs1) * ct : INFINITY;
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const float4 t4 = *(const float4*)(tc + 32 * i + 8 * rg + 4 * lh);
-            const float tq[4] = {t4.x, t4.y, t4.z, t4.w};
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float tr = j ? tr1 : tr0;
-                bool h[4];
+            for (int rg = 0; rg < 4; ++rg) {
+                const float4 t4 = *(const float4*)(tc + 32 * i + 8 * rg + 4 * lh);
+                const float tq[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = acc[i][j][4 * rg + e] > fmaxf(tr, tq[e]);
-                if (__builtin_amdgcn_ballot_w64(h[0] | h[1] | h[2] | h[3]) != 0ull) {   // wave-uniform, rare
+                for (int j = 0; j < 2; ++j) {
+                    const float tr = j ? tr1 : tr0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (h[e]) {
+                        if (acc[i][j][4 * rg + e] > fmaxf(tr, tq[e])) {
                             const int k = atomicAdd(&X.pcnt[0], 1);
                             if (k < PL2) X.plist[k] = PreCand{row0 + 32 * j, colw + 32 * i + 8 * rg + 4 * lh + e, acc[i][j][4 * rg + e] * g.inv_ct};
                         }
                 }
             }
-        }
+    }
 }
 
-__global__ void __launch_bounds__(512) cm_stats256_kernel(const CmGeom g, const CmWs w) {
+template <int WN2>
+__global__ void __launch_bounds__(256 * WN2, 2) cm_stats256_kernel(const CmGeom g, const CmWs w) {
+    typedef Cm2<WN2> K;
+    typedef typename K::G G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    S2X& X = *(S2X*)(smem + S2_STAGE);
+    S2X& X = *(S2X*)(smem + K::STAGE);
     const int t = threadIdx.x;
-    const int ntL2 = (g.L + 255) >> 8, ntS2 = (g.S + 255) >> 8;
+    const int ntL2 = (g.L + 255) >> 8, ntS2 = (g.S + K::BN2 - 1) / K::BN2;
     const int total = g.N * ntL2 * ntS2;
     const int nkt = g.C * 2 / KTB;
     const int tag = cm256_column_tag(t & 63);
@@ -556,34 +570,38 @@ __global__ void __launch_bounds__(512) cm_stats256_kernel(const CmGeom g, const 
     ml.kpad = g.C; ml.ldw = g.ldf; ml.M = g.L;
     // dense K table entry of this thread's staging slot: K group kt * 8 + (slot ^ swizzle) -> channel 8 * group, no tap offset
     const int kgrp = (t & 7) ^ (((t >> 3) >> 1) & 7);
-    G2 gg;
+    G gg;
     int n = 0, m0 = 0, n0 = 0;
     auto locate = [&](const int tile) __attribute__((always_inline)) {
         n = tile % g.N;
         const int r = tile / g.N, mt = r / ntS2;
-        m0 = mt << 8; n0 = (r - mt * ntS2) << 8;
+        m0 = mt << 8; n0 = (r - mt * ntS2) * K::BN2;
         ml.x = (const char*)g.feat0 + (size_t)n * g.L * g.ldf * 2;
         ml.w = (const char*)g.feat1 + (size_t)n * g.S * g.ldf * 2;
         gg.decode(ml, m0, n0);
     };
-    int tile = blockIdx.x, sc = 0;   // sc: running slab counter, slab sc lives in stage buffer sc & 1
+    int tile = blockIdx.x, sc = 0;   // sc: running slab counter, slab sc lives in stage buffer sc & (NBUF - 1)
     if (tile < total) { locate(tile); gg.stage_issue(ml, smem, 0, 0, kgrp * 8); }
     while (tile < total) {
-        G2::Acc acc;
-        G2::zero(acc);
+        Acc2 acc;
+        G::zero(acc);
         for (int kt = 0; kt < nkt; ++kt, ++sc) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                        // slab sc has landed for everybody; everybody is done with slab sc - 1
-            if (kt + 1 < nkt) gg.stage_issue(ml, smem, (sc + 1) & 1, kt + 1, ((kt + 1) * 8 + kgrp) * 8);
-            G2::compute(smem, sc & 1, acc);
+            __syncthreads();                        // slab sc has landed for everybody (two buffers: and everybody is done with slab sc - 1)
+            if (K::NBUF == 2 && kt + 1 < nkt) gg.stage_issue(ml, smem, (sc + 1) & 1, kt + 1, ((kt + 1) * 8 + kgrp) * 8);
+            G::compute(smem, sc & (K::NBUF - 1), acc);
+            if (K::NBUF == 1) {
+                __syncthreads();                    // one buffer: everybody is done with it before the next slab overwrites it
+                if (kt + 1 < nkt) gg.stage_issue(ml, smem, 0, kt + 1, ((kt + 1) * 8 + kgrp) * 8);
+            }
         }
         const int cn = n, cm0 = m0, cn0 = n0;
         const int next = tile + gridDim.x;
-        // the buffer of slab sc was last read one slab ago and every wave has passed a barrier since: the next tile's first slab
-        // travels during the statistics
-        if (next < total) { locate(next); gg.stage_issue(ml, smem, sc & 1, 0, kgrp * 8); }
-        if ((cm0 + 256 <= g.L) && (cn0 + 256 <= g.S)) cm256_stats<false>(g, w, acc, cn, cm0, cn0, X, tag);   // block-uniform
-        else cm256_stats<true>(g, w, acc, cn, cm0, cn0, X, tag);
+        // the target buffer is free (two buffers: last read one slab ago, a barrier since; one buffer: the barrier above): the next
+        // tile's first slab travels during the statistics
+        if (next < total) { locate(next); gg.stage_issue(ml, smem, sc & (K::NBUF - 1), 0, kgrp * 8); }
+        if ((cm0 + 256 <= g.L) && (cn0 + K::BN2 <= g.S)) cm256_stats<false, WN2>(g, w, acc, cn, cm0, cn0, X, tag);   // block-uniform
+        else cm256_stats<true, WN2>(g, w, acc, cn, cm0, cn0, X, tag);
         __syncthreads();
         const int cnt = X.pcnt[0];
         if (cnt > 0) {                                // block-uniform
@@ -594,7 +612,7 @@ __global__ void __launch_bounds__(512) cm_stats256_kernel(const CmGeom g, const 
                 __syncthreads();
                 const int base = X.pcnt[1];
                 if (base + cnt > w.capp) { if (t == 0) w.npre[g.N] = 1; }
-                else for (int k = t; k < cnt; k += 512) w.pre[(size_t)cn * w.capp + base + k] = X.plist[k];
+                else for (int k = t; k < cnt; k += K::NT) w.pre[(size_t)cn * w.capp + base + k] = X.plist[k];
             }
             __syncthreads();
             if (t == 0) X.pcnt[0] = 0;                // the next pushes come behind the next tile's barriers
@@ -884,8 +902,9 @@ static int cm_prepare(const gim_coarse_args& a, CmWs& w, CmGeom& g) {
         if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<1, false>);
         if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<0, true>);
         if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<1, true>);
-        if (rc == GIM_OK && hipFuncSetAttribute((const void*)cm_stats256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S2_SMEM) != hipSuccess) {
-            gim_set_error("coarse_match: hipFuncSetAttribute(256-tile statistics kernel, %d B LDS)", S2_SMEM);
+        if (rc == GIM_OK && (hipFuncSetAttribute((const void*)cm_stats256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, s2_smem<2>()) != hipSuccess ||
+                             hipFuncSetAttribute((const void*)cm_stats256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, s2_smem<1>()) != hipSuccess)) {
+            gim_set_error("coarse_match: hipFuncSetAttribute(256-row statistics kernels, %d / %d B LDS)", s2_smem<2>(), s2_smem<1>());
             rc = GIM_ERR_LAUNCH;
         }
         if (rc != GIM_OK) return rc;
@@ -917,13 +936,15 @@ extern "C" int GIM_FN(gim_coarse_match)(const gim_coarse_args* ap, gim_stream_t 
     // 256-tile statistics kernel: 16-bit features, no padding masks (K in whole 128-byte slabs is validate()'s rule already)
     const bool big = g.bf16 && !a.mask0 && stats_mode();
     if (big) {
-        const unsigned t256 = (unsigned)(a.N * ((a.L + 255) / 256) * ((a.S + 255) / 256));
+        static const int wn2 = [] { const char* e = getenv("GIM_CM_TILE"); return (e && atoi(e) == 256) ? 2 : 1; }();   // tile columns: 128 (default) / 256
         int ncu = 256;
         { int dev = 0; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); }
-        // persistent: one workgroup per CU; a grid that is a multiple of N (and of 8) keeps pair = tile % N on one XCD per workgroup
-        unsigned grid = (unsigned)ncu;
-        if (grid > t256) grid = t256;
-        hipLaunchKernelGGL(cm_stats256_kernel, dim3(grid), dim3(512), S2_SMEM, s, g, w);
+        // persistent: one (two) workgroup(s) per CU; a grid that is a multiple of N (and of 8) keeps pair = tile % N on one XCD per workgroup
+        const unsigned tiles2 = (unsigned)(a.N * ((a.L + 255) / 256) * ((a.S + 128 * wn2 - 1) / (128 * wn2)));
+        unsigned grid = (unsigned)ncu * (wn2 == 1 ? 2u : 1u);
+        if (grid > tiles2) grid = tiles2;
+        if (wn2 == 2) hipLaunchKernelGGL(cm_stats256_kernel<2>, dim3(grid), dim3(512), s2_smem<2>(), s, g, w);
+        else hipLaunchKernelGGL(cm_stats256_kernel<1>, dim3(grid), dim3(256), s2_smem<1>(), s, g, w);
     } else if (g.bf16) hipLaunchKernelGGL(cm_stats_kernel<true>, dim3(ntiles), dim3(256), TILE_SMEM, s, g, w);
     else hipLaunchKernelGGL(cm_stats_kernel<false>, dim3(ntiles), dim3(256), TILE_SMEM, s, g, w);
     hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.L + 63) / 64)), dim3(256), 0, s, w.rowpart, w.rowstat, a.N, a.L, w.ntS);

@@ -169,17 +169,42 @@ template <> struct ElemIO<false> {
 // IEEE fp16 ends at 65504.  The un-normalised ResNet residual streams are the values of the path that can get there (every other
 // stored activation sits behind a BatchNorm or a LayerNorm), and downstream ReLUs scrub the evidence: fmaxf(NaN, 0) = 0, so an
 // overflow rarely survives to the outputs as a NaN.  The kernels that STORE a residual stream (bneck_fused.hip, bneck_tail.hip) track
-// the largest value they convert -- one v_max3 per packed pair, fp16 flavour only -- and OR 4 into the caller's health word
+// whether a value they write became inf -- six VALU operations per 16-byte row piece, fp16 flavour only -- and OR 4 into the caller's health word
 // (gim_set_range_guard(): the coarse count buffer's word [1], read back with the match count) when it is beyond the range.
 int* gim_range_guard_ptr();   // runtime.hip: the device word registered for the calling thread's current device, or NULL
-__device__ __forceinline__ void h16_range_track(float& m, float a, float b) {
+// The check runs on the PACKED row (16 bytes = 8 stored halves) the kernel is about to write, not on the fp32 values: packed
+// fp16 maxima fold it into one word with transient registers only, and the verdict is a bool, i.e. a lane mask in two SGPRs.
+// (A float running maximum -- or any test on the accumulators -- costs registers where bneck_tail's 256-channel variants have none:
+// they sit at 253-256 VGPRs and spilled 12-17 of them, +0.8 ms per step.)  Values are post-ReLU (>= 0): inf is the largest half;
+// v_pk_max_f16 drops a NaN operand, which can only come from an inf that was flagged where it was stored.
+typedef _Float16 gim_h2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned h16_pk_max(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(gim_h2_t, a), __builtin_bit_cast(gim_h2_t, b)));
+}
+__device__ __forceinline__ void h16_range_track(bool& any, const uint4 v) {
 #if GIM_HALF_KIND
-    m = fmaxf(fmaxf(m, a), b);    // callers pass post-ReLU values (>= 0); +inf included, NaN ignored (it comes from an inf flagged earlier)
+    const unsigned m = h16_pk_max(h16_pk_max(v.x, v.y), h16_pk_max(v.z, v.w));
+    any |= (((m & 0x7FFF7FFFu) + 0x04000400u) & 0x80008000u) != 0u;   // a half with all exponent bits set (inf / NaN)
 #endif
 }
-__device__ __forceinline__ void h16_range_flag(int* health, float m) {
+// the same in two steps: fold rows into a packed maximum, test it once and write the flag on the spot (a rare wave-level branch,
+// no state carried through the kernel)
+__device__ __forceinline__ unsigned h16_range_fold(unsigned m, const uint4 v) {
 #if GIM_HALF_KIND
-    if (health != nullptr && m > 65504.f) atomicOr(health, 4);
+    return h16_pk_max(h16_pk_max(m, v.x), h16_pk_max(h16_pk_max(v.y, v.z), v.w));
+#else
+    return m;
+#endif
+}
+__device__ __forceinline__ void h16_range_check(int* health, unsigned m) {
+#if GIM_HALF_KIND
+    if (__builtin_expect((((m & 0x7FFF7FFFu) + 0x04000400u) & 0x80008000u) != 0u, 0))
+        if (health != nullptr) atomicOr(health, 4);
+#endif
+}
+__device__ __forceinline__ void h16_range_flag(int* health, bool any) {
+#if GIM_HALF_KIND
+    if (health != nullptr && any) atomicOr(health, 4);
 #endif
 }
 

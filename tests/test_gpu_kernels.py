@@ -421,13 +421,14 @@ def test_linear_attention_masks(shape):
     _assert_close(out.view(nb, L, H, D), ref, 1e-5, f"masked linear attention {shape}")
 
 
-@pytest.mark.parametrize("mode", ["1", "0"], ids=["tile256", "tile128-kernel"])
+@pytest.mark.parametrize("mode", ["128", "256", "off"], ids=["rows256x128-2wg", "rows256x256-1wg", "tile128-kernel"])
 @pytest.mark.parametrize("kind", ["bf16", "fp16"])
 def test_coarse_match_tile256_statistics(mode, kind):
     """The persistent 256 x 256 statistics kernel (16-bit features, no masks; round 4: row / column maxima and sums straight from the
     accumulators) against the oracle evaluated on the SAME 16-bit-valued features: exact indices and order, confidences to 1e-5 --
     on sizes with ragged last tiles in both directions, unequal L / S, several pairs (8: pair = tile % N walks every pair), a wide
-    logit range (sigma = 3: similarities of ~90 beside rows that peak at ~15) -- and the same through the 128 x 128
+    logit range (sigma = 3: similarities of ~90 beside rows that peak at ~15) -- in both workgroup shapes (GIM_CM_TILE = 128: two
+    4-wave workgroups per CU on 256 x 128 tiles, the default; 256: one 8-wave workgroup on 256 x 256) and through the 128 x 128
     tile-per-workgroup kernel (GIM_CM_STATS=0).  Subprocess: the mode is read once per process."""
     import os
     import subprocess
@@ -467,5 +468,5 @@ print('OK', tot + M)
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code, kind], cwd=root, capture_output=True, text=True,
-                         env={**os.environ, "GIM_CM_STATS": mode}, timeout=600)
+                         env={**os.environ, "GIM_CM_STATS": "0" if mode == "off" else "1", "GIM_CM_TILE": mode}, timeout=600)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -20,19 +20,20 @@ pytestmark = pytest.mark.gpu
 KINDS = [torch.float16, torch.bfloat16]
 
 
+@pytest.mark.parametrize("C,ld", [(3, 16), (1, 8), (2, 8), (5, 16)], ids=["rgb", "gray", "c2-generic", "c5-generic"])
 @pytest.mark.parametrize("td", KINDS, ids=["fp16", "bf16"])
-def test_nchw_to_nhwc_split_layout(td):
+def test_nchw_to_nhwc_split_layout(td, C, ld):
     from gim_amd import ops
     g = torch.Generator().manual_seed(3)
-    a, b = torch.rand(2, 3, 20, 24, generator=g), torch.rand(1, 3, 20, 24, generator=g) * 255.0
-    out = torch.full((3, 20, 24, 16), 7.0, dtype=td, device="cuda")
+    a, b = torch.rand(2, C, 20, 24, generator=g), torch.rand(1, C, 20, 24, generator=g) * 255.0
+    out = torch.full((3, 20, 24, ld), 7.0, dtype=td, device="cuda")
     ops.nchw_to_nhwc_split(a.cuda(), out, 0)
     ops.nchw_to_nhwc_split(b.cuda(), out, 2)
     torch.cuda.synchronize()
     x = torch.cat([a, b]).permute(0, 2, 3, 1)
     hi = x.to(td)
     lo = (x - hi.float()).to(td)
-    ref = torch.cat([hi, lo, hi, torch.zeros(3, 20, 24, 7, dtype=td)], dim=-1)
+    ref = torch.cat([hi, lo, hi, torch.zeros(3, 20, 24, ld - 3 * C, dtype=td)], dim=-1)
     assert torch.equal(out.cpu(), ref)
 
 

@@ -229,6 +229,15 @@ def main():
                     ("stem x2 + sim x2", {**st, "sim": "fp16x2"}),
                     ("stem x2 + sim x2 + transformer x2", {**st, "sim": "fp16x2", "transformer": "fp16x2"}),
                     ]
+    if len(sys.argv) > 2 and sys.argv[2] == "stem":
+        # which half of the stem's split matters: the image (x) or the filters (w)?  (6 channels [x_hi | x_lo] x [w_hi | w_hi] fit the
+        # 8-channel image layout of the plain stem; the full split needs 9 -> 16 channels and twice the K of the first convolution)
+        f = allf("fp16")
+        variants = [("stem plain fp16", f),
+                    ("stem split IMAGE only (w fp16, x hi+lo)", {**f, "stem": "fp16/fp16x2/fp16"}),
+                    ("stem split WEIGHTS only (w hi+lo, x fp16)", {**f, "stem": "fp16x2/fp16/fp16"}),
+                    ("stem split both (stored output fp16)", {**f, "stem": "fp16x2/fp16x2/fp16"}),
+                    ]
     for name, fm in variants:
         t = time.time()
         out = Emu(sdf, fm).run(data())

@@ -22,6 +22,8 @@ import math
 import os
 
 import torch
+
+from ..precision import resolve as resolve_precision
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -158,7 +160,7 @@ class RegressionMatcher(nn.Module):
         self.sample_thresh = 0.05
         self.upsample_res = (1152, 1536)
         self.use_soft_mutual_nearest_neighbours = use_soft_mutual_nearest_neighbours
-        self.precision = precision or os.environ.get("GIM_PRECISION", "bf16")
+        self.precision = resolve_precision(precision, "gim_dkm")
         # GP posterior entirely in fp64 (kernel entries, Cholesky, products; csrc/gp_solve.hip: gim_gp_posterior_f64).  None = in
         # the fp32 parity mode only: the system's condition number (~2e4) turns fp32 rounding of the kernel ENTRIES into ~1e-4 of mu,
         # the one term of the engine's deviation that is not the reference's own (tests/test_gpu_gp_pins.py)

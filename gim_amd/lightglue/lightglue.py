@@ -21,6 +21,8 @@ No CPU / eager fallback.
 import os
 
 import torch
+
+from ..precision import resolve as resolve_precision
 import torch.nn as nn
 
 from .. import ops
@@ -115,7 +117,7 @@ class LightGlue(nn.Module):
             raise NotImplementedError("early stopping / point pruning are disabled in gim (demo.py:345-349) and not built")
         if c["add_scale_ori"] or c["input_dim"] != c["descriptor_dim"] or c["descriptor_dim"] != 256 or c["num_heads"] != 4:
             raise NotImplementedError("only the SuperPoint configuration (256-d, 4 heads, no scale/orientation) is built")
-        self.precision = c.get("precision") or os.environ.get("GIM_PRECISION", "bf16")
+        self.precision = resolve_precision(c.get("precision"), "LightGlue")
         d, n = c["descriptor_dim"], c["n_layers"]
         self.input_proj = nn.Identity()
         self.posenc = _PosEnc(2, d // c["num_heads"])

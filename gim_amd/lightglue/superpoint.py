@@ -18,6 +18,8 @@ through ctypes.  No CPU / eager fallback.
 import os
 
 import torch
+
+from ..precision import resolve as resolve_precision
 import torch.nn as nn
 
 from .. import ops
@@ -43,7 +45,7 @@ class SuperPoint(nn.Module):
             raise NotImplementedError("gim_lightglue uses the sparse detector+descriptor outputs")
         if not c["legacy_sampling"] or c["refinement_radius"] != 0 or c["descriptor_dim"] != 256:
             raise NotImplementedError("only the gim configuration (legacy_sampling, no refinement, 256-d) is built")
-        self.precision = c.get("precision") or os.environ.get("GIM_PRECISION", "bf16")
+        self.precision = resolve_precision(c.get("precision"), "SuperPoint")
         c1, c2, c3, c4, c5 = 64, 64, 128, 128, 256
         for name, ci, co, k in (("conv1a", 1, c1, 3), ("conv1b", c1, c1, 3), ("conv2a", c1, c2, 3), ("conv2b", c2, c2, 3),
                                 ("conv3a", c2, c3, 3), ("conv3b", c3, c3, 3), ("conv4a", c3, c4, 3), ("conv4b", c4, c4, 3),

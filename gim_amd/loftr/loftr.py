@@ -169,10 +169,8 @@ class LazyConfMatrix:
 
 
 def _precision_from(config):
-    p = (config.get("precision") or os.environ.get("GIM_PRECISION") or "fp16").lower()
-    if p not in _DT:
-        raise ValueError(f"precision must be 'bf16', 'fp16' or 'fp32', got {p!r}")
-    return p
+    from ..precision import resolve
+    return resolve(config.get("precision"), "loftr", default="fp16")
 
 
 class LoFTR(nn.Module):
@@ -320,14 +318,19 @@ class LoFTR(nn.Module):
             # the next block's conv1; for layer 2's last block the first conv1 of layer 3 (512 -> 256, same resolution: the stride sits
             # on conv2); for layer 3's last block the FPN's layer3_outconv (no BatchNorm, no activation)
             l2, l3 = list(enc.layer2), list(enc.layer3)
+
+            def tail_fits(blk, nconv):   # the shapes gim_bneck_tail128 / 256 are built for; any other block_dims keeps conv3 + conv1 launches
+                pl, c4, n1 = blk.conv3.weight.shape[1], blk.conv3.weight.shape[0], nconv.weight.shape[0]
+                return pl in (128, 256) and c4 == 4 * pl and tuple(nconv.weight.shape[1:]) == (c4, 1, 1) and n1 in ((128, 256) if pl == 128 else (256,))
+
             for bi in range(len(l2)):
-                nx = l2[bi + 1] if bi + 1 < len(l2) else l3[0]
-                P[f"l2.{bi}.tail"] = pack_bneck_tail(l2[bi], nx.conv1, nx.bn1, device, tdt)
+                nx = l2[bi + 1] if bi + 1 < len(l2) else (l3[0] if l3 else None)
+                if nx is not None and tail_fits(l2[bi], nx.conv1):
+                    P[f"l2.{bi}.tail"] = pack_bneck_tail(l2[bi], nx.conv1, nx.bn1, device, tdt)
             for bi in range(len(l3)):
-                if bi + 1 < len(l3):
-                    P[f"l3.{bi}.tail"] = pack_bneck_tail(l3[bi], l3[bi + 1].conv1, l3[bi + 1].bn1, device, tdt)
-                else:
-                    P[f"l3.{bi}.tail"] = pack_bneck_tail(l3[bi], self.backbone.layer3_outconv, None, device, tdt)
+                nconv, nbn = (l3[bi + 1].conv1, l3[bi + 1].bn1) if bi + 1 < len(l3) else (self.backbone.layer3_outconv, None)
+                if tail_fits(l3[bi], nconv):
+                    P[f"l3.{bi}.tail"] = pack_bneck_tail(l3[bi], nconv, nbn, device, tdt)
         bb = self.backbone
         P["l3o"] = pack_conv(bb.layer3_outconv.weight, None, dt, device)
         P["l2o"] = pack_conv(bb.layer2_outconv.weight, None, dt, device)
@@ -430,7 +433,9 @@ class LoFTR(nn.Module):
                     x, o = ops.bneck64(o, idn, P[p + "fused"], True)
                     continue
                 o = ops.conv2d(o, P[p + "c2"], ACT_RELU, lds_dma=dma)
-                if self.bneck_tail and (p + "tail") in P and (o.shape[0] * o.shape[1] * o.shape[2]) % 256 == 0:
+                rows = o.shape[0] * o.shape[1] * o.shape[2]
+                # the tail kernel walks 256-row tiles with 32-bit byte offsets into the [rows, 4 P] tensors (its own REQUIREs)
+                if self.bneck_tail and (p + "tail") in P and rows % 256 == 0 and rows * 4 * o.shape[3] * 2 < (1 << 32) - 16:
                     if li == 3 and bi == nblk - 1:   # last block: t1' IS x3_out (layer3_outconv), x3 itself is read by nothing else
                         x, x3_out = ops.bneck_tail(o, idn.contiguous(), P[p + "tail"], ACT_NONE, store_x=self.debug is not None)
                         o = None

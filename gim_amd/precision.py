@@ -1,0 +1,26 @@
+"""One place that resolves the `precision` of an engine (config value > GIM_PRECISION > the engine's default).
+
+gim_loftr has three modes -- 'fp16' (its default), 'bf16', 'fp32'.  The secondary engines (SuperPoint, LightGlue, DKMv3, RoMa)
+have two, 'bf16' and 'fp32': a process-wide GIM_PRECISION=fp16 (gim_loftr's spelling of "the fast mode") means 'bf16' to
+them, and an unknown value raises instead of silently selecting the fp32 path (five times slower)."""
+import os
+
+LOFTR_MODES = ("fp16", "bf16", "fp32")
+
+
+def resolve(value, engine, default="bf16", env=True):
+    """engine: 'loftr' (three modes) or anything else (two modes).  Returns the mode string."""
+    explicit = value is not None
+    p = value if explicit else (os.environ.get("GIM_PRECISION") if env else None)
+    p = (p or default).lower()
+    if engine == "loftr":
+        if p not in LOFTR_MODES:
+            raise ValueError(f"precision must be 'bf16', 'fp16' or 'fp32', got {p!r}")
+        return p
+    if p == "fp16":
+        if explicit:
+            raise ValueError(f"{engine}: precision must be 'bf16' or 'fp32' (the IEEE-fp16 flavour exists for gim_loftr only), got 'fp16'")
+        return "bf16"      # GIM_PRECISION=fp16 set for gim_loftr: this engine's 16-bit mode
+    if p not in ("bf16", "fp32"):
+        raise ValueError(f"{engine}: precision must be 'bf16' or 'fp32', got {p!r}")
+    return p

@@ -69,8 +69,10 @@ def test_dkm_672x896_vs_oracle(monkeypatch):
     m.load_state_dict(sd)
     m = m.eval()
     warp, cert = m.match(im0.to("cuda:0"), im1.to("cuda:0"))
-    _close(warp, ref_warp, 2e-3, "dkm warp 672x896 vs the reference arithmetic")
-    _close(cert, ref_cert, 5e-3, "dkm certainty 672x896 vs the reference arithmetic")
+    # (a) against the PINNED reference arithmetic: bounds = 2 x measured (profiles/r03_dense_parity.txt: warp max 2.9e-4 / mean
+    # 2.5e-5 of scale, certainty max 8.8e-5 / mean 1.8e-5 -- the distance the reference's own fp32 GP arithmetic keeps from its formula)
+    _close(warp, ref_warp, 6e-4, "dkm warp 672x896 vs the reference arithmetic", frac=1.0, mean_tol=5e-5)
+    _close(cert, ref_cert, 2e-4, "dkm certainty 672x896 vs the reference arithmetic", frac=1.0, mean_tol=4e-5)
     # (b) against the exact-GP oracle: EVERY value within 2e-5 of scale (north_star: 1e-4; measured max 3.0e-6 / 1.1e-6,
     # profiles/r03_dense_parity.txt)
     _close(warp, x_warp, 2e-5, "dkm warp 672x896 vs the fp64-GP oracle", frac=1.0, mean_tol=2e-6)
@@ -98,8 +100,10 @@ def test_roma_672_vs_oracle(monkeypatch):
     warp, cert = m.match(im0.to("cuda:0"), im1.to("cuda:0"))
     # RoMa's coarse flow is an arg-max over 64 x 64 anchor classes (roma.py:94-136): with random weights ~0.7 % of the values sit
     # behind a decision that the GP's 1e-4 noise flips
-    _close(warp, ref_warp, 2e-3, "roma warp 672x672 vs the reference arithmetic", frac=0.99, mean_tol=2e-3)
-    _close(cert, ref_cert, 5e-3, "roma certainty 672x672 vs the reference arithmetic", frac=0.99, mean_tol=5e-3)
+    # (a) against the PINNED reference arithmetic, 2 x measured (profiles/r03_dense_parity.txt): 99.75 % of the warp values within
+    # 2e-3 (the rest: arg-max flips caused by the reference's own GP noise, max 1.1 of scale), mean 3.6e-4; certainty max 7.5e-4
+    _close(warp, ref_warp, 2e-3, "roma warp 672x672 vs the reference arithmetic", frac=0.995, mean_tol=7.5e-4)
+    _close(cert, ref_cert, 1.5e-3, "roma certainty 672x672 vs the reference arithmetic", frac=1.0, mean_tol=1.1e-4)
     # (b) against the exact-GP oracle: the anchor arg-max no longer sees GP noise, so the flipped decisions go away: EVERY value
     # within 2e-5 of scale (measured max 3.6e-7 / 3.0e-6); a flipped arg-max at an isolated pixel would show as a value of O(1)
     _close(warp, x_warp, 2e-5, "roma warp 672x672 vs the fp64-GP oracle", frac=1.0, mean_tol=2e-6)

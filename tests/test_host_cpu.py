@@ -147,3 +147,19 @@ def test_lightglue_state_dict_surface_and_qkv_permutation():
         assert torch.equal(got[:, s * d:(s + 1) * d].reshape(5, H, dh), ref[..., s])
     with pytest.raises(NotImplementedError):
         LightGlue({"depth_confidence": 0.95})
+
+
+def test_precision_resolver(monkeypatch):
+    """GIM_PRECISION=fp16 (gim_loftr's default spelling) must not silently put the secondary engines on the fp32 path"""
+    from gim_amd.precision import resolve
+    monkeypatch.delenv("GIM_PRECISION", raising=False)
+    assert resolve(None, "loftr", default="fp16") == "fp16" and resolve(None, "gim_dkm") == "bf16"
+    monkeypatch.setenv("GIM_PRECISION", "fp16")
+    assert resolve(None, "loftr", default="fp16") == "fp16" and resolve(None, "gim_roma") == "bf16" and resolve(None, "SuperPoint") == "bf16"
+    assert resolve("fp32", "LightGlue") == "fp32"
+    with pytest.raises(ValueError):
+        resolve("fp16", "gim_dkm")          # explicit request for a mode the engine does not have
+    monkeypatch.setenv("GIM_PRECISION", "fp64")
+    for eng in ("loftr", "gim_dkm"):
+        with pytest.raises(ValueError):
+            resolve(None, eng)

@@ -442,7 +442,7 @@ __device__ __forceinline__ int cm256_column_tag(const int lane) {
     return (int)cm256_butterfly(c, lane, BflyTag());
 }
 
-template <bool EDGE, int WN2>
+template <bool EDGE, int WN2, bool PK>
 __device__ __forceinline__ void cm256_stats(const CmGeom& g, const CmWs& w, Acc2& acc, const int n, const int m0, const int n0,
                                             S2X& X, const int tag) {
     const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
@@ -484,22 +484,54 @@ __device__ __forceinline__ void cm256_stats(const CmGeom& g, const CmWs& w, Acc2
     // ---- two exponentials per element (row softmax against the row maximum, column softmax against the column maximum) ----
     const float k2 = g.inv_ct * 1.44269504088896341f;   // exp(s - m) = exp2((acc - macc) * inv_ct * log2 e); acc - macc is exact where it matters
     float rs0 = 0.f, rs1 = 0.f, cs[4];
+    if constexpr (PK) {
+        // the same arithmetic on PAIRS of neighbouring columns: v_pk_add_f32 / v_pk_mul_f32 form two exponents per instruction, the
+        // row sums run as two partial sums per row (summation order differs from the scalar form in the last bits)
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 k22 = {k2, k2}, r0 = {rm0, rm0}, r1 = {rm1, rm1};
+        f2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float c[16];
+        for (int i = 0; i < 4; ++i) {
+            float c[16];
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const float4 m4 = *(const float4*)(tc + 32 * i + 8 * rg + 4 * lh);
-            const float mq[4] = {m4.x, m4.y, m4.z, m4.w};
+            for (int rg = 0; rg < 4; ++rg) {
+                const float4 m4 = *(const float4*)(tc + 32 * i + 8 * rg + 4 * lh);
+                const f2 mq[2] = {{m4.x, m4.y}, {m4.z, m4.w}};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * rg + e;
-                rs0 += __builtin_amdgcn_exp2f((acc[i][0][r] - rm0) * k2);
-                rs1 += __builtin_amdgcn_exp2f((acc[i][1][r] - rm1) * k2);
-                c[r] = __builtin_amdgcn_exp2f((acc[i][0][r] - mq[e]) * k2) + __builtin_amdgcn_exp2f((acc[i][1][r] - mq[e]) * k2);
+                for (int h = 0; h < 2; ++h) {
+                    const int r = 4 * rg + 2 * h;
+                    const f2 a0 = {acc[i][0][r], acc[i][0][r + 1]}, a1 = {acc[i][1][r], acc[i][1][r + 1]};
+                    const f2 x0 = (a0 - r0) * k22, x1 = (a1 - r1) * k22, y0 = (a0 - mq[h]) * k22, y1 = (a1 - mq[h]) * k22;
+                    const f2 e0 = {__builtin_amdgcn_exp2f(x0[0]), __builtin_amdgcn_exp2f(x0[1])};
+                    const f2 e1 = {__builtin_amdgcn_exp2f(x1[0]), __builtin_amdgcn_exp2f(x1[1])};
+                    const f2 g0 = {__builtin_amdgcn_exp2f(y0[0]), __builtin_amdgcn_exp2f(y0[1])};
+                    const f2 g1 = {__builtin_amdgcn_exp2f(y1[0]), __builtin_amdgcn_exp2f(y1[1])};
+                    s0 += e0; s1 += e1;
+                    const f2 cc = g0 + g1;
+                    c[r] = cc[0]; c[r + 1] = cc[1];
+                }
             }
+            cs[i] = cm256_butterfly(c, lane, BflyAdd());
         }
-        cs[i] = cm256_butterfly(c, lane, BflyAdd());
+        rs0 = s0[0] + s0[1]; rs1 = s1[0] + s1[1];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float c[16];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float4 m4 = *(const float4*)(tc + 32 * i + 8 * rg + 4 * lh);
+                const float mq[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * rg + e;
+                    rs0 += __builtin_amdgcn_exp2f((acc[i][0][r] - rm0) * k2);
+                    rs1 += __builtin_amdgcn_exp2f((acc[i][1][r] - rm1) * k2);
+                    c[r] = __builtin_amdgcn_exp2f((acc[i][0][r] - mq[e]) * k2) + __builtin_amdgcn_exp2f((acc[i][1][r] - mq[e]) * k2);
+                }
+            }
+            cs[i] = cm256_butterfly(c, lane, BflyAdd());
+        }
     }
     rs0 = pair32_sum(rs0);
     rs1 = pair32_sum(rs1);
@@ -550,7 +582,7 @@ __device__ __forceinline__ void cm256_stats(const CmGeom& g, const CmWs& w, Acc2
     }
 }
 
-template <int WN2>
+template <int WN2, bool PK>
 __global__ void __launch_bounds__(256 * WN2, 2) cm_stats256_kernel(const CmGeom g, const CmWs w) {
     typedef Cm2<WN2> K;
     typedef typename K::G G;
@@ -600,8 +632,8 @@ __global__ void __launch_bounds__(256 * WN2, 2) cm_stats256_kernel(const CmGeom 
         // the target buffer is free (two buffers: last read one slab ago, a barrier since; one buffer: the barrier above): the next
         // tile's first slab travels during the statistics
         if (next < total) { locate(next); gg.stage_issue(ml, smem, sc & (K::NBUF - 1), 0, kgrp * 8); }
-        if ((cm0 + 256 <= g.L) && (cn0 + K::BN2 <= g.S)) cm256_stats<false, WN2>(g, w, acc, cn, cm0, cn0, X, tag);   // block-uniform
-        else cm256_stats<true, WN2>(g, w, acc, cn, cm0, cn0, X, tag);
+        if ((cm0 + 256 <= g.L) && (cn0 + K::BN2 <= g.S)) cm256_stats<false, WN2, PK>(g, w, acc, cn, cm0, cn0, X, tag);   // block-uniform
+        else cm256_stats<true, WN2, PK>(g, w, acc, cn, cm0, cn0, X, tag);
         __syncthreads();
         const int cnt = X.pcnt[0];
         if (cnt > 0) {                                // block-uniform
@@ -902,8 +934,10 @@ static int cm_prepare(const gim_coarse_args& a, CmWs& w, CmGeom& g) {
         if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<1, false>);
         if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<0, true>);
         if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<1, true>);
-        if (rc == GIM_OK && (hipFuncSetAttribute((const void*)cm_stats256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, s2_smem<2>()) != hipSuccess ||
-                             hipFuncSetAttribute((const void*)cm_stats256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, s2_smem<1>()) != hipSuccess)) {
+        if (rc == GIM_OK && (hipFuncSetAttribute((const void*)cm_stats256_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s2_smem<2>()) != hipSuccess ||
+                             hipFuncSetAttribute((const void*)cm_stats256_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s2_smem<1>()) != hipSuccess ||
+                             hipFuncSetAttribute((const void*)cm_stats256_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, s2_smem<2>()) != hipSuccess ||
+                             hipFuncSetAttribute((const void*)cm_stats256_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, s2_smem<1>()) != hipSuccess)) {
             gim_set_error("coarse_match: hipFuncSetAttribute(256-row statistics kernels, %d / %d B LDS)", s2_smem<2>(), s2_smem<1>());
             rc = GIM_ERR_LAUNCH;
         }
@@ -943,8 +977,11 @@ extern "C" int GIM_FN(gim_coarse_match)(const gim_coarse_args* ap, gim_stream_t 
         const unsigned tiles2 = (unsigned)(a.N * ((a.L + 255) / 256) * ((a.S + 128 * wn2 - 1) / (128 * wn2)));
         unsigned grid = (unsigned)ncu * (wn2 == 1 ? 2u : 1u);
         if (grid > tiles2) grid = tiles2;
-        if (wn2 == 2) hipLaunchKernelGGL(cm_stats256_kernel<2>, dim3(grid), dim3(512), s2_smem<2>(), s, g, w);
-        else hipLaunchKernelGGL(cm_stats256_kernel<1>, dim3(grid), dim3(256), s2_smem<1>(), s, g, w);
+        static const int pk = [] { const char* e = getenv("GIM_CM_PK"); return e ? atoi(e) : 1; }();   // packed-f32 exponent arithmetic (A/B knob)
+        if (wn2 == 2) { if (pk) hipLaunchKernelGGL((cm_stats256_kernel<2, true>), dim3(grid), dim3(512), s2_smem<2>(), s, g, w);
+                        else hipLaunchKernelGGL((cm_stats256_kernel<2, false>), dim3(grid), dim3(512), s2_smem<2>(), s, g, w); }
+        else { if (pk) hipLaunchKernelGGL((cm_stats256_kernel<1, true>), dim3(grid), dim3(256), s2_smem<1>(), s, g, w);
+               else hipLaunchKernelGGL((cm_stats256_kernel<1, false>), dim3(grid), dim3(256), s2_smem<1>(), s, g, w); }
     } else if (g.bf16) hipLaunchKernelGGL(cm_stats_kernel<true>, dim3(ntiles), dim3(256), TILE_SMEM, s, g, w);
     else hipLaunchKernelGGL(cm_stats_kernel<false>, dim3(ntiles), dim3(256), TILE_SMEM, s, g, w);
     hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.L + 63) / 64)), dim3(256), 0, s, w.rowpart, w.rowstat, a.N, a.L, w.ntS);

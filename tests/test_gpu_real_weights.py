@@ -28,8 +28,17 @@ def _check(rep):
 
 
 def test_hook_selftest_on_a_seeded_checkpoint(tmp_path):
+    import numpy as np
+    from PIL import Image
     from tools import real_weights_check as R
-    rep = R.main(["--synthetic", str(tmp_path / "w")])
+    from tools import synth_loftr as S
+    # the seeded weights only "see" the synthetic textures they were calibrated on: the pair is written as two PNG files
+    c0, c1 = S.textured_pairs(1, 480, 640, seed=21, frac=0.6)
+    paths = []
+    for name, img in (("a.png", c0[0]), ("b.png", c1[0])):
+        paths.append(str(tmp_path / name))
+        Image.fromarray((img.permute(1, 2, 0).numpy() * 255).round().astype(np.uint8)).save(paths[-1])
+    rep = R.main(["--synthetic", str(tmp_path / "w"), "--pair", *paths])
     assert rep is not None and os.path.exists(tmp_path / "w" / "gim_loftr_50h.ckpt")
     _check(rep)
 

@@ -442,22 +442,22 @@ __device__ __forceinline__ int cm256_column_tag(const int lane) {
     return (int)cm256_butterfly(c, lane, BflyTag());
 }
 
-template <bool EDGE, int WN2, bool PK>
-__device__ __forceinline__ void cm256_stats(const CmGeom& g, const CmWs& w, Acc2& acc, const int n, const int m0, const int n0,
-                                            S2X& X, const int tag) {
+// Statistics of one wave sub-tile of 64 rows x 32 NI columns held in the accumulators (lane = row, registers = columns):
+//   acc[i][j][4 rg + e] = sim(row0 + 32 j, colw + 32 i + 8 rg + 4 lh + e) * C * T.
+// Column partials (64-row slot `cslot`) are stored here; the row partials are stored into slot `rslot` (ROWSTORE) or handed back
+// (rmax[j], rsum[j]: maximum in accumulator units and sum-exp of this lane's two rows, valid in both lanes of a pair) for the
+// caller's online merge across tiles.  `tc`: wave-private LDS buffer of 32 NI floats.
+template <bool EDGE, int NI, bool ROWSTORE>
+__device__ __forceinline__ void cm_wave_stats(const CmGeom& g, const CmWs& w, f32x16_t (&acc)[NI][2], const int n, const int row0, const int colw,
+                                              const int rslot, const int cslot, const bool wave_rows, float* tc, PreCand* plist, int* pcnt,
+                                              const int tag, float (&rmax)[2], float (&rsum)[2]) {
     const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int wm, wn;
-    Cm2<WN2>::G::wave_mn(wave, wm, wn);
-    const int row0 = m0 + wm * 64 + l31;        // this lane's rows: row0, row0 + 32
-    const int colw = n0 + wn * 128;             // acc[i][j][rg * 4 + e] = sim(row0 + 32 j, colw + 32 i + 8 rg + 4 lh + e) * C * T
     const float NEG = -INFINITY;
     const int coff = 8 * (tag >> 2) + 4 * lh + (tag & 3);   // the column (within a 32-column fragment) this lane owns after a butterfly
-    float* tc = X.tcol[wave];                   // wave-private broadcast buffer: 128 floats, written and read by this wave only
     // ---- references: exact maxima of the wave's sub-tile, per row (in the lane) and per column (butterfly over the row lanes) ----
-    float rm0 = NEG, rm1 = NEG, cml[4];
+    float rm0 = NEG, rm1 = NEG, cml[NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         if (EDGE) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -483,69 +483,37 @@ __device__ __forceinline__ void cm256_stats(const CmGeom& g, const CmWs& w, Acc2
     if (EDGE) { rm0 = rm0 == NEG ? 0.f : rm0; rm1 = rm1 == NEG ? 0.f : rm1; }
     // ---- two exponentials per element (row softmax against the row maximum, column softmax against the column maximum) ----
     const float k2 = g.inv_ct * 1.44269504088896341f;   // exp(s - m) = exp2((acc - macc) * inv_ct * log2 e); acc - macc is exact where it matters
-    float rs0 = 0.f, rs1 = 0.f, cs[4];
-    if constexpr (PK) {
-        // the same arithmetic on PAIRS of neighbouring columns: v_pk_add_f32 / v_pk_mul_f32 form two exponents per instruction, the
-        // row sums run as two partial sums per row (summation order differs from the scalar form in the last bits)
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        const f2 k22 = {k2, k2}, r0 = {rm0, rm0}, r1 = {rm1, rm1};
-        f2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f};
+    float rs0 = 0.f, rs1 = 0.f, cs[NI];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float c[16];
+    for (int i = 0; i < NI; ++i) {
+        float c[16];
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const float4 m4 = *(const float4*)(tc + 32 * i + 8 * rg + 4 * lh);
-                const f2 mq[2] = {{m4.x, m4.y}, {m4.z, m4.w}};
+        for (int rg = 0; rg < 4; ++rg) {
+            const float4 m4 = *(const float4*)(tc + 32 * i + 8 * rg + 4 * lh);
+            const float mq[4] = {m4.x, m4.y, m4.z, m4.w};
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int r = 4 * rg + 2 * h;
-                    const f2 a0 = {acc[i][0][r], acc[i][0][r + 1]}, a1 = {acc[i][1][r], acc[i][1][r + 1]};
-                    const f2 x0 = (a0 - r0) * k22, x1 = (a1 - r1) * k22, y0 = (a0 - mq[h]) * k22, y1 = (a1 - mq[h]) * k22;
-                    const f2 e0 = {__builtin_amdgcn_exp2f(x0[0]), __builtin_amdgcn_exp2f(x0[1])};
-                    const f2 e1 = {__builtin_amdgcn_exp2f(x1[0]), __builtin_amdgcn_exp2f(x1[1])};
-                    const f2 g0 = {__builtin_amdgcn_exp2f(y0[0]), __builtin_amdgcn_exp2f(y0[1])};
-                    const f2 g1 = {__builtin_amdgcn_exp2f(y1[0]), __builtin_amdgcn_exp2f(y1[1])};
-                    s0 += e0; s1 += e1;
-                    const f2 cc = g0 + g1;
-                    c[r] = cc[0]; c[r + 1] = cc[1];
-                }
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * rg + e;
+                rs0 += __builtin_amdgcn_exp2f((acc[i][0][r] - rm0) * k2);
+                rs1 += __builtin_amdgcn_exp2f((acc[i][1][r] - rm1) * k2);
+                c[r] = __builtin_amdgcn_exp2f((acc[i][0][r] - mq[e]) * k2) + __builtin_amdgcn_exp2f((acc[i][1][r] - mq[e]) * k2);
             }
-            cs[i] = cm256_butterfly(c, lane, BflyAdd());
         }
-        rs0 = s0[0] + s0[1]; rs1 = s1[0] + s1[1];
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float c[16];
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const float4 m4 = *(const float4*)(tc + 32 * i + 8 * rg + 4 * lh);
-                const float mq[4] = {m4.x, m4.y, m4.z, m4.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * rg + e;
-                    rs0 += __builtin_amdgcn_exp2f((acc[i][0][r] - rm0) * k2);
-                    rs1 += __builtin_amdgcn_exp2f((acc[i][1][r] - rm1) * k2);
-                    c[r] = __builtin_amdgcn_exp2f((acc[i][0][r] - mq[e]) * k2) + __builtin_amdgcn_exp2f((acc[i][1][r] - mq[e]) * k2);
-                }
-            }
-            cs[i] = cm256_butterfly(c, lane, BflyAdd());
-        }
+        cs[i] = cm256_butterfly(c, lane, BflyAdd());
     }
     rs0 = pair32_sum(rs0);
     rs1 = pair32_sum(rs1);
-    // ---- partials: (maximum, sum) in similarity units, the layout of the 128 x 128 kernel for rows, 64-row slots for columns ----
-    const int rslot = (colw >> 7), cslot = (m0 >> 6) + wm;
-    const bool wave_cols = colw < g.S, wave_rows = m0 + wm * 64 < g.L;
+    rmax[0] = rm0; rmax[1] = rm1; rsum[0] = rs0; rsum[1] = rs1;
+    // ---- partials: (maximum, sum) in similarity units ----
+    const bool wave_cols = colw < g.S;
     if (wave_cols && lh == 0) {
         bool bad = false;   // every element feeds a row sum: NaN / inf anywhere in the features (fp16 overflow upstream) shows here
-        if (row0 < g.L) { w.rowpart[((size_t)n * w.ntS + rslot) * g.L + row0] = make_float2(rm0 * g.inv_ct, rs0); bad |= !(rs0 < INFINITY); }
-        if (row0 + 32 < g.L) { w.rowpart[((size_t)n * w.ntS + rslot) * g.L + row0 + 32] = make_float2(rm1 * g.inv_ct, rs1); bad |= !(rs1 < INFINITY); }
+        if (row0 < g.L) { if (ROWSTORE) w.rowpart[((size_t)n * w.ntS + rslot) * g.L + row0] = make_float2(rm0 * g.inv_ct, rs0); bad |= !(rs0 < INFINITY); }
+        if (row0 + 32 < g.L) { if (ROWSTORE) w.rowpart[((size_t)n * w.ntS + rslot) * g.L + row0 + 32] = make_float2(rm1 * g.inv_ct, rs1); bad |= !(rs1 < INFINITY); }
         if (bad && w.health) atomicOr(w.health, 1);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int col = colw + 32 * i + coff;
         if (wave_rows && (l31 & 1) == 0 && col < g.S) w.colpart[((size_t)n * w.ntL64 + cslot) * g.S + col] = make_float2(cml[i] * g.inv_ct, cs[i]);
     }
@@ -559,11 +527,11 @@ __device__ __forceinline__ void cm256_stats(const CmGeom& g, const CmWs& w, Acc2
         // thresholds in accumulator units: s > m + log(thr z)  <=>  acc > macc + log(thr z) * C * T; the column ones are broadcast
         // through the wave's buffer (the maxima in it were consumed above; LDS operations of one wave execute in order)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
             if ((l31 & 1) == 0) tc[32 * i + coff] = cml[i] + __logf(thr_pre * cs[i]) * ct;
         const float tr0 = hot0 ? rm0 + __logf(thr_pre * rs0) * ct : INFINITY, tr1 = hot1 ? rm1 + __logf(thr_pre * rs1) * ct : INFINITY;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const float4 t4 = *(const float4*)(tc + 32 * i + 8 * rg + 4 * lh);
@@ -574,15 +542,27 @@ __device__ __forceinline__ void cm256_stats(const CmGeom& g, const CmWs& w, Acc2
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (acc[i][j][4 * rg + e] > fmaxf(tr, tq[e])) {
-                            const int k = atomicAdd(&X.pcnt[0], 1);
-                            if (k < PL2) X.plist[k] = PreCand{row0 + 32 * j, colw + 32 * i + 8 * rg + 4 * lh + e, acc[i][j][4 * rg + e] * g.inv_ct};
+                            const int k = atomicAdd(&pcnt[0], 1);
+                            if (k < PL2) plist[k] = PreCand{row0 + 32 * j, colw + 32 * i + 8 * rg + 4 * lh + e, acc[i][j][4 * rg + e] * g.inv_ct};
                         }
                 }
             }
     }
 }
 
-template <int WN2, bool PK>
+template <bool EDGE, int WN2>
+__device__ __forceinline__ void cm256_stats(const CmGeom& g, const CmWs& w, Acc2& acc, const int n, const int m0, const int n0,
+                                            S2X& X, const int tag) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int wm, wn;
+    Cm2<WN2>::G::wave_mn(wave, wm, wn);
+    const int colw = n0 + wn * 128;
+    float rmax[2], rsum[2];
+    cm_wave_stats<EDGE, 4, true>(g, w, acc, n, m0 + wm * 64 + (threadIdx.x & 31), colw, colw >> 7, (m0 >> 6) + wm, m0 + wm * 64 < g.L,
+                                 X.tcol[wave], X.plist, X.pcnt, tag, rmax, rsum);
+}
+
+template <int WN2>
 __global__ void __launch_bounds__(256 * WN2, 2) cm_stats256_kernel(const CmGeom g, const CmWs w) {
     typedef Cm2<WN2> K;
     typedef typename K::G G;
@@ -632,8 +612,8 @@ __global__ void __launch_bounds__(256 * WN2, 2) cm_stats256_kernel(const CmGeom 
         // the target buffer is free (two buffers: last read one slab ago, a barrier since; one buffer: the barrier above): the next
         // tile's first slab travels during the statistics
         if (next < total) { locate(next); gg.stage_issue(ml, smem, sc & (K::NBUF - 1), 0, kgrp * 8); }
-        if ((cm0 + 256 <= g.L) && (cn0 + K::BN2 <= g.S)) cm256_stats<false, WN2, PK>(g, w, acc, cn, cm0, cn0, X, tag);   // block-uniform
-        else cm256_stats<true, WN2, PK>(g, w, acc, cn, cm0, cn0, X, tag);
+        if ((cm0 + 256 <= g.L) && (cn0 + K::BN2 <= g.S)) cm256_stats<false, WN2>(g, w, acc, cn, cm0, cn0, X, tag);   // block-uniform
+        else cm256_stats<true, WN2>(g, w, acc, cn, cm0, cn0, X, tag);
         __syncthreads();
         const int cnt = X.pcnt[0];
         if (cnt > 0) {                                // block-uniform
@@ -673,10 +653,10 @@ __global__ void cm_precand_kernel(const CmGeom g, const CmWs w) {
     }
 }
 
-// stat[n][x] = combine over the `ntile` partial slots of a pair:  m = max m_t ; z = sum_t z_t * exp(m_t - m)   (fixed order:
+// stat[n][x] = combine over the first `ntile` of a pair's `stride` partial slots:  m = max m_t ; z = sum_t z_t * exp(m_t - m)   (fixed order:
 // deterministic).  Four threads share an element (slots t, t + 4, ...) so that a pair's 38 ... 75 dependent-latency loads become
 // 10 ... 19: the two launches took 20 us each as one thread per element.
-__global__ void __launch_bounds__(256) cm_combine_kernel(const float2* __restrict__ part, float2* __restrict__ stat, int N, int len, int ntile) {
+__global__ void __launch_bounds__(256) cm_combine_kernel(const float2* __restrict__ part, float2* __restrict__ stat, int N, int len, int ntile, int stride) {
     __shared__ float2 sh[4][64];
     const int xq = threadIdx.x & 63, tq = threadIdx.x >> 6;
     const size_t idx = (size_t)blockIdx.x * 64 + xq;
@@ -684,7 +664,7 @@ __global__ void __launch_bounds__(256) cm_combine_kernel(const float2* __restric
     float m = -INFINITY, z = 0.f;
     if (ok) {
         const size_t n = idx / len, x = idx - n * len;
-        const float2* p = part + n * (size_t)ntile * len + x;
+        const float2* p = part + n * (size_t)stride * len + x;   // `stride` slots per pair, the first `ntile` of them filled
         for (int t = tq; t < ntile; t += 4) m = fmaxf(m, p[(size_t)t * len].x);
         for (int t = tq; t < ntile; t += 4) {
             const float2 v = p[(size_t)t * len];
@@ -902,8 +882,9 @@ int validate(const gim_coarse_args& a) {
     return GIM_OK;
 }
 
-// GIM_CM_STATS: 1 (default) the 256-tile statistics kernel where it applies (16-bit features, no padding masks); 0 the 128 x 128
-// tile-per-workgroup kernel always (tests compare the two).
+// GIM_CM_STATS: 1 (default) the 256-row statistics kernel takes 16-bit features without padding masks (GIM_CM_TILE = 128 / 256 selects
+// its workgroup shape); 0 the 128 x 128 tile-per-workgroup kernel always -- it also serves fp32 features and padding masks (tests
+// compare them).
 static int stats_mode() { static const int v = [] { const char* e = getenv("GIM_CM_STATS"); return e ? atoi(e) : 1; }(); return v; }
 
 template <typename K>
@@ -934,10 +915,8 @@ static int cm_prepare(const gim_coarse_args& a, CmWs& w, CmGeom& g) {
         if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<1, false>);
         if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<0, true>);
         if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<1, true>);
-        if (rc == GIM_OK && (hipFuncSetAttribute((const void*)cm_stats256_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s2_smem<2>()) != hipSuccess ||
-                             hipFuncSetAttribute((const void*)cm_stats256_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s2_smem<1>()) != hipSuccess ||
-                             hipFuncSetAttribute((const void*)cm_stats256_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, s2_smem<2>()) != hipSuccess ||
-                             hipFuncSetAttribute((const void*)cm_stats256_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, s2_smem<1>()) != hipSuccess)) {
+        if (rc == GIM_OK && (hipFuncSetAttribute((const void*)cm_stats256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, s2_smem<2>()) != hipSuccess ||
+                             hipFuncSetAttribute((const void*)cm_stats256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, s2_smem<1>()) != hipSuccess)) {
             gim_set_error("coarse_match: hipFuncSetAttribute(256-row statistics kernels, %d / %d B LDS)", s2_smem<2>(), s2_smem<1>());
             rc = GIM_ERR_LAUNCH;
         }
@@ -977,16 +956,13 @@ extern "C" int GIM_FN(gim_coarse_match)(const gim_coarse_args* ap, gim_stream_t 
         const unsigned tiles2 = (unsigned)(a.N * ((a.L + 255) / 256) * ((a.S + 128 * wn2 - 1) / (128 * wn2)));
         unsigned grid = (unsigned)ncu * (wn2 == 1 ? 2u : 1u);
         if (grid > tiles2) grid = tiles2;
-        static const int pk = [] { const char* e = getenv("GIM_CM_PK"); return e ? atoi(e) : 1; }();   // packed-f32 exponent arithmetic (A/B knob)
-        if (wn2 == 2) { if (pk) hipLaunchKernelGGL((cm_stats256_kernel<2, true>), dim3(grid), dim3(512), s2_smem<2>(), s, g, w);
-                        else hipLaunchKernelGGL((cm_stats256_kernel<2, false>), dim3(grid), dim3(512), s2_smem<2>(), s, g, w); }
-        else { if (pk) hipLaunchKernelGGL((cm_stats256_kernel<1, true>), dim3(grid), dim3(256), s2_smem<1>(), s, g, w);
-               else hipLaunchKernelGGL((cm_stats256_kernel<1, false>), dim3(grid), dim3(256), s2_smem<1>(), s, g, w); }
+        if (wn2 == 2) hipLaunchKernelGGL(cm_stats256_kernel<2>, dim3(grid), dim3(512), s2_smem<2>(), s, g, w);
+        else hipLaunchKernelGGL(cm_stats256_kernel<1>, dim3(grid), dim3(256), s2_smem<1>(), s, g, w);
     } else if (g.bf16) hipLaunchKernelGGL(cm_stats_kernel<true>, dim3(ntiles), dim3(256), TILE_SMEM, s, g, w);
     else hipLaunchKernelGGL(cm_stats_kernel<false>, dim3(ntiles), dim3(256), TILE_SMEM, s, g, w);
-    hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.L + 63) / 64)), dim3(256), 0, s, w.rowpart, w.rowstat, a.N, a.L, w.ntS);
+    hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.L + 63) / 64)), dim3(256), 0, s, w.rowpart, w.rowstat, a.N, a.L, w.ntS, w.ntS);
     hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.S + 63) / 64)), dim3(256), 0, s, w.colpart, w.colstat, a.N, a.S,
-                       big ? w.ntL64 : w.ntL);
+                       big ? w.ntL64 : w.ntL, big ? w.ntL64 : w.ntL);
     hipLaunchKernelGGL(cm_precand_kernel, dim3((unsigned)((w.capp + 255) / 256), (unsigned)a.N), dim3(256), 0, s, g, w);
     if (g.bf16) hipLaunchKernelGGL((cm_cand_kernel<0, true>), dim3(nfallback), dim3(256), TILE_SMEM, s, g, w, (float*)nullptr);
     else hipLaunchKernelGGL((cm_cand_kernel<0, false>), dim3(nfallback), dim3(256), TILE_SMEM, s, g, w, (float*)nullptr);

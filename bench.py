@@ -27,6 +27,9 @@ RCCL all-gather(v) of the packed matches at the end of the run.  Rank 0 prints O
 `parity`    = index flip rate / max coordinate and confidence deviation of the benchmarked 16-bit engine against
               the fp32 oracle on that pair;
 `h2d_inclusive` = the same step with both image batches starting in pinned host memory (double-buffered copy stream).
+Round 4: `n_ranks_seen` / `rank_devices` (what the process group and every rank's device really were), `config.stem_operands`
+(the first convolution runs on hi + lo operand pairs by default) and `parity.plain_stem` (the same batch with plainly rounded
+stem operands, round 3's arithmetic).  GIM_BENCH_DRY_MODEL=1 walks main() on CPU ranks with a stand-in model (tests only).
 """
 import argparse
 import json
@@ -49,9 +52,7 @@ from gim_amd.runner import HostPairFeeder, all_gather_matches, bind_rank_to_core
 
 H, W = 480, 640
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense, MI355X_MICROARCH.md
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_traffic.json")
-if not os.path.exists(TRAFFIC_JSON):
-    TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_traffic.json") for r in (4, 3, 2)) if os.path.exists(p)), "")
 
 
 def parse_args(argv=None):
@@ -260,7 +261,7 @@ def main():
             coarse_gemm = {"us": round(1e3 * v[0] / v[2], 1), "tflops": cg["tflops"],
                            "frac": round(cg["tflops"] / MFMA_PEAK_TFLOPS[args.precision], 4),
                            "what": "whole gim_coarse_match call (init + statistics + combine + selection + emit kernels; the "
-                                   "statistics kernel is ~80 % of it: profiles/)"}
+                                   "statistics kernel is ~80 % of it: profiles/r04_cm_stats.txt)"}
         tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in prof)
         tot_fl = sum(f for _, _, f, _ in prof)
         nlaunch = len(prof)

@@ -414,6 +414,12 @@ class LoFTR(nn.Module):
     def _backbone(self, P, x, dt):
         """x: NHWC [B,H,W,cstore(3)] images in the compute dtype.  Returns (x3_out NHWC [B,h8,w8,256], feat_f NHWC [B,h2,w2,128])
         in the compute dtype.  (resnet.py:230-235, 306-329)"""
+        x1, x2, x3_out = self._backbone_trunk(P, x, dt)
+        return x3_out, self._fpn_fine(P, x1, x2, x3_out)
+
+    def _backbone_trunk(self, P, x, dt):
+        """stem + layer1-3 + layer3_outconv (resnet.py:306-320): returns (x1, x2, x3_out) -- the coarse features x3_out are complete
+        here; the fine head only needs x1, x2 and x3_out (see _fpn_fine)"""
         dma = self.use_lds_dma
         x = ops.conv2d(x, P["stem"], ACT_RELU, out_dtype=torch_dtype(dt), lds_dma=dma)   # image dtype may be fp16 in bf16 mode
         feats = []
@@ -448,13 +454,19 @@ class LoFTR(nn.Module):
         x1, x2, x3 = feats
         if x3_out is None:
             x3_out = ops.conv2d(x3, P["l3o"], lds_dma=dma)
+        return x1, x2, x3_out
+
+    def _fpn_fine(self, P, x1, x2, x3_out):
+        """the FPN's top-down path to the 1/2-resolution fine features (resnet.py:321-329): six convolutions that nothing of the coarse
+        level (position encoding, transformer, coarse matching) depends on"""
+        dma = self.use_lds_dma
         # lateral 1x1 conv + F.interpolate(scale_factor=2, bilinear, align_corners=True) of the coarser level + add (resnet.py:
         # 321-327): the upsample-add runs in the conv's epilogue when the launch takes it, else as a second pass over the output
         x2_out = ops.conv2d(x2, P["l2o"], lds_dma=dma, ups=x3_out)
         x2_out = ops.conv2d(ops.conv2d(x2_out, P["l2o2a"], ACT_LEAKY, lds_dma=dma), P["l2o2b"], lds_dma=dma)
         x1_out = ops.conv2d(x1, P["l1o"], lds_dma=dma, ups=x2_out)
         x1_out = ops.conv2d(ops.conv2d(x1_out, P["l1o2a"], ACT_LEAKY, lds_dma=dma), P["l1o2b"], lds_dma=dma)
-        return x3_out, x1_out
+        return x1_out
 
     class _TfBuffers:
         """Row buffers of one LocalFeatureTransformer run over R rows of width C."""
@@ -635,6 +647,9 @@ class LoFTR(nn.Module):
         P = self._prepack(dev)
         cfg = self.config
         if len(xs) == 1:
+            # (round 4: the fine head on a second stream beside the coarse level -- a graph with two branches, the head's persistent
+            # workgroups filling the CUs the transformer's 600-tile launches leave idle -- measured SLOWER, 10.96 vs 10.70 ms per step:
+            # the two branches fight over L2 and LDS instead of complementing each other; one stream it is)
             c_all, f_all = self._backbone(P, xs[0], dt)
             c0, c1 = c_all[:bs], c_all[bs:]
             f0, f1 = f_all[:bs], f_all[bs:]

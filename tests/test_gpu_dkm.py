@@ -27,6 +27,7 @@ def _close(got, ref, tol, what=""):
     assert torch.isfinite(got).all(), f"{what}: non-finite output"
     scale = max(1e-6, ref.abs().max().item())
     err = (got - ref).abs().max().item()
+    print(f"[close] {what}: {err / scale:.3e} of scale (tol {tol:g})")   # pytest -s: the measured value the tolerance is set from
     assert err <= tol * scale, f"{what}: max|err|={err:.3e} scale={scale:.3e} tol={tol}"
 
 
@@ -68,7 +69,7 @@ def test_grid_sample(dt):
     ref = F.grid_sample(feat, grid, align_corners=False).permute(0, 2, 3, 1)
     out = torch.zeros(2 * 7 * 11, 32, dtype=_tdt(dt), device=dev)
     ops.grid_sample(_nhwc(feat, dt, dev), grid.to(dev), out[:, 16:])
-    _close(out[:, 16:].view(2, 7, 11, 16), ref, 1e-2 if dt == "bf16" else 2e-6, "grid_sample")
+    _close(out[:, 16:].view(2, 7, 11, 16), ref, 5e-3 if dt == "bf16" else 2e-6, "grid_sample")
     assert (out[:, :16] == 0).all()
 
 
@@ -128,7 +129,7 @@ def test_dwconv5x5_bn_relu(dt, cin, mult, hw):
     sc = torch.zeros(cpad); sc[:cout] = s
     sh = torch.zeros(cpad); sh[:cout] = bet + (bias - mean) * s
     y = ops.dwconv5x5_bn_relu(xin.to(dev), W.to(dev), sc.to(dev), sh.to(dev), cin, cout)
-    _close(y[..., :cout], ref, 1e-2 if dt == "bf16" else 2e-6, "dwconv")
+    _close(y[..., :cout], ref, 6e-3 if dt == "bf16" else 2e-6, "dwconv")
     assert (y[..., cout:] == 0).all()
 
 
@@ -160,7 +161,7 @@ def test_dwconv5x5_pw32_fused_block(hw, cs):
     b32 = torch.zeros(32); b32[:c] = pw_b
     y = ops.dwconv5x5_pw32(xin.to(dev), W.to(dev), sc.to(dev), sh.to(dev), w32.to(dev).to(torch.bfloat16), b32.to(dev))
     assert y.shape[3] == cs
-    _close(y[..., :c], ref, 1e-2, "dwconv5x5_pw32")
+    _close(y[..., :c], ref, 4.5e-3, "dwconv5x5_pw32")
     assert (y[..., c:] == 0).all()
     mid2 = ops.dwconv5x5_bn_relu(xin.to(dev), W.to(dev), sc.to(dev), sh.to(dev), c, c)
     y2 = ops.conv2d(mid2, pack_conv(pw_w, None, _lib.GIM_BF16, dev, cin_pad=cs, bias=pw_b))
@@ -303,7 +304,9 @@ def test_match_bf16_and_sample():
     m = _model("bf16", 128, 160, None)
     warp, cert = m.match(im0.to(dev), im1.to(dev))
     assert torch.isfinite(warp).all() and torch.isfinite(cert).all()
-    assert (warp.cpu() - warp_ref).abs().mean().item() < 0.02 and (cert.cpu() - cert_ref).abs().mean().item() < 0.05
+    e_w, e_c = (warp.cpu() - warp_ref).abs().mean().item(), (cert.cpu() - cert_ref).abs().mean().item()
+    print(f"[measured] dkm bf16 vs fp32 oracle: mean |warp err| {e_w:.4f}, mean |certainty err| {e_c:.4f}")
+    assert e_w < 0.02 and e_c < 0.05
     torch.manual_seed(0)
     sm, sc = m.sample(warp, cert, 300)
     assert sm.shape == (300, 4) and sc.shape == (300,) and sm.abs().max() <= 1

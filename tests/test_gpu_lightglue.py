@@ -3,7 +3,8 @@ oracle/lightglue_oracle.py on the same seeded inputs and against the golden vect
 reference's own modules (tests/golden/lg_*.npz).
 
 Bars: keypoint coordinates, arg-max / match indices: exact in fp32 mode (fp32 MFMA); floats 2e-5 of the
-output scale in fp32 mode (summation order only), 2.5e-2 in bf16 mode."""
+output scale in fp32 mode (summation order only); bf16 mode: 6.5e-3 = 2 x the largest value measured on MI355X (3.2e-3 of scale, one
+bf16 output rounding; profiles/r04_secondary_measured.txt -- the bound was 1.5e-2 ... 2.5e-2 through round 3)."""
 import os
 
 import numpy as np
@@ -27,7 +28,7 @@ def _tdt(dt):
 
 
 def _tol(dt):
-    return 2.5e-2 if dt == "bf16" else 2e-5
+    return 6.5e-3 if dt == "bf16" else 2e-5
 
 
 def _close(got, ref, tol, what=""):
@@ -36,6 +37,7 @@ def _close(got, ref, tol, what=""):
     assert torch.isfinite(got).all(), f"{what}: non-finite output"
     scale = max(1e-6, ref.abs().max().item())
     err = (got - ref).abs().max().item()
+    print(f"[close] {what}: {err / scale:.3e} of scale (tol {tol:g})")   # pytest -s: the measured value the tolerance is set from
     assert err <= tol * scale, f"{what}: max|err|={err:.3e} scale={scale:.3e} tol={tol}"
 
 
@@ -196,7 +198,7 @@ def test_sdpa(dt, L, S, cross):
     kk = kv.double()[:, 256:512].reshape(nb, S, H, 64).transpose(1, 2).roll(-shift, 0)
     vv = kv.double()[:, 512:].reshape(nb, S, H, 64).transpose(1, 2).roll(-shift, 0)
     ref = (torch.softmax(qq @ kk.transpose(-1, -2) / 8.0, -1) @ vv).transpose(1, 2).reshape(nb * L, 256)
-    _close(out, ref.float(), 1e-5 if dt == "fp32" else 1.5e-2, f"sdpa L={L} S={S}")
+    _close(out, ref.float(), 1e-5 if dt == "fp32" else 6.5e-3, f"sdpa L={L} S={S}")
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -212,7 +214,7 @@ def test_layernorm_gelu(dt):
         ops.layernorm_act(x.to(dev), gamma.to(dev), beta.to(dev), out, act)
         ref = F.layer_norm(x, (512,), gamma, beta)
         ref = F.gelu(ref) if act == ACT_GELU else ref
-        _close(out, ref, 1e-2 if dt == "bf16" else 2e-6, "layernorm_act")
+        _close(out, ref, 5e-3 if dt == "bf16" else 2e-6, "layernorm_act")
 
 
 def _assign_inputs(B, M, N, seed):
@@ -356,10 +358,11 @@ def test_lightglue_unequal_counts_and_bf16():
     rs = torch.tensor([[480, 640]])
     data = {"keypoints0": kp0, "keypoints1": kp1, "descriptors0": d0, "descriptors1": d1, "resize0": rs, "resize1": rs}
     ref = O.lightglue_forward(lg_sd, data)
-    for prec, need in (("fp32", 1.0), ("bf16", 0.8)):
+    for prec, need in (("fp32", 1.0), ("bf16", 0.985)):   # bf16 measured 0.9948 (one of 192 keypoints differs): 2 x the disagreement
         _, lg, _, _ = _models(prec, 128)
         pred = lg({k: v.to(dev) for k, v in data.items()})
         agree = (pred["matches0"].cpu() == ref["matches0"]).float().mean().item()
+        print(f"[agree] lightglue {prec} matches0 agreement with the fp32 oracle: {agree:.4f}")
         assert agree >= need, (prec, agree)
         assert pred["matches1"].shape == (1, 150)
     assert (ref["matches0"] > -1).sum() > 50

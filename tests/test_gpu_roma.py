@@ -2,7 +2,7 @@
 inputs and against the golden vectors recorded from the reference's own modules (tests/golden/roma_*.npz).
 
 Bars: fp32 mode 2e-5 of the output scale for single kernels (summation order only), 1e-4 for the stages of the
-whole pipeline; bf16 mode 3e-2."""
+whole pipeline; bf16 kernels 6.5e-3 = 2 x the largest measured error (profiles/r04_secondary_measured.txt)."""
 import math
 import os
 
@@ -32,6 +32,7 @@ def _close(got, ref, tol, what=""):
     assert torch.isfinite(got).all(), f"{what}: non-finite output"
     scale = max(1e-6, ref.abs().max().item())
     err = (got - ref).abs().max().item()
+    print(f"[close] {what}: {err / scale:.3e} of scale (tol {tol:g})")   # pytest -s: the measured value the tolerance is set from
     assert err <= tol * scale, f"{what}: max|err|={err:.3e} scale={scale:.3e} tol={tol}"
 
 
@@ -58,7 +59,7 @@ def test_sdpa_head_dim_128(dt, L, S):
     kk = q.double()[:, C:2 * C].reshape(nb, S, H, D).transpose(1, 2)
     vv = q.double()[:, 2 * C:].reshape(nb, S, H, D).transpose(1, 2)
     ref = (torch.softmax(qq @ kk.transpose(-1, -2) / math.sqrt(D), -1) @ vv).transpose(1, 2).reshape(nb * L, C)
-    _close(out, ref.float(), 1e-5 if dt == "fp32" else 1.5e-2, f"sdpa D=128 L={L}")
+    _close(out, ref.float(), 1e-5 if dt == "fp32" else 6.5e-3, f"sdpa D=128 L={L}")
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -71,7 +72,7 @@ def test_layernorm_1024(dt):
     gamma, beta = 1 + 0.1 * torch.randn(1024, generator=g), 0.1 * torch.randn(1024, generator=g)
     out = torch.empty(77, 1024, dtype=_tdt(dt), device=dev)
     ops.layernorm_act(x.to(dev), gamma.to(dev), beta.to(dev), out, ACT_NONE, eps=1e-6)
-    _close(out, F.layer_norm(x, (1024,), gamma, beta, 1e-6), 1e-2 if dt == "bf16" else 2e-6, "layernorm 1024")
+    _close(out, F.layer_norm(x, (1024,), gamma, beta, 1e-6), 6.5e-3 if dt == "bf16" else 2e-6, "layernorm 1024")
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -90,7 +91,7 @@ def test_linear_gelu_epilogue(dt):
     y = torch.empty(333, pk.n_store, dtype=tdt, device=dev)
     ops.linear(x.to(dev), pk, y, ACT_GELU)
     ref = F.gelu(x.double() @ w.double().t() + b.double()).float()
-    _close(y[:, :512], ref, 1e-2 if dt == "bf16" else 2e-5, "linear+gelu")
+    _close(y[:, :512], ref, 5.5e-3 if dt == "bf16" else 2e-5, "linear+gelu")
 
 
 def test_cls_to_flow():
@@ -232,7 +233,7 @@ def test_match_bf16_batch_and_sample(golden_dir):
     e_w = (warp[::2, ::2].cpu() - torch.as_tensor(g["warp"])).abs().mean().item()
     e_c = (cert[::2, ::2].cpu() - torch.as_tensor(g["certainty"])).abs().mean().item()
     print(f"bf16 vs fp32 reference: mean |warp err| {e_w:.4f}, mean |certainty err| {e_c:.4f}")
-    assert e_w < 0.05 and e_c < 0.1
+    assert e_w < 0.02 and e_c < 0.001   # measured 0.0091 / 0.0004 on MI355X: 2 x
     wb, cb = m.match_batch(torch.cat((a, b)), torch.cat((b, a)))
     assert torch.equal(wb[0], warp) and torch.equal(cb[0], cert)
     w2, c2 = m.match(b, a)

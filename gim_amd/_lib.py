@@ -74,6 +74,9 @@ PROTOTYPES = {
     "gim_nchw_to_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "gim_nchw_to_nhwc_split": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "gim_nhwc_to_nchw": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "gim_stem7x7_weight_bytes": (c_int64, [c_int]),
+    "gim_stem7x7": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
+    "gim_stem7x7_f16": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
     "gim_conv2d_bn_act": (c_int, [ctypes.POINTER(ConvArgs), c_void_p]),
     "gim_conv_ups_supported": (c_int, [ctypes.POINTER(ConvArgs)]),
     "gim_upsample2x_add": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),

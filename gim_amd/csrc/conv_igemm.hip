@@ -686,6 +686,144 @@ igemm_ring3_kernel(const gim_conv_args a, const int mtiles, const int ntiles, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Loader-wave variant of the 256 x 256 tile (16-bit operands and output, no residual / upsample operand): round 4.
+//
+// tools/microbench_mainloop.hip runs this library's main loop one ingredient at a time (profiles/r04_microbench.txt).  On CUs that
+// are not power-limited the bare MFMA stream of the tile runs at the peak rate; fragment reads from LDS cost 12 %, the LDS-DMA
+// instructions of the next slab ISSUED BY THE MFMA WAVES another 20 %: a wave that issues a buffer_load ... lds holds its own MFMA
+// stream for ~60 cycles per instruction (in-order issue), and all eight waves do so together right behind the slab barrier --
+// wherever in the slab the instructions are placed.  Four extra waves (one per SIMD) that do nothing but stage bring the same
+// loop from 0.73 to 0.86 of the peak rate -- on 32 of the 256 CUs.  With all CUs busy the chip is power-limited (the bare MFMA stream
+// reaches 0.68 of the nominal peak on random operands, 0.97 on all-zero ones) and the same change is worth 3-4 %; in the real
+// layers, where the loaders also carry the tap arithmetic and first touches come from HBM with ONE slab of lookahead, the forward got
+// 0.33 ms slower (10.83 vs 10.50 ms, same box).  EXPERIMENTAL, off by default (GIM_IGEMM_LW=1), kept with its test as the measured
+// answer to "dedicated loader waves" (VERDICT r3 item 4 iii).  Structure:
+//   waves 0-7  : MFMA waves, 4 x 2 over the tile, 64 px x 128 ch each (gim::Igemm<256,256,4,2>::compute + the shared Epilogue):
+//                ds_read_b128, MFMA, one barrier per slab -- no address arithmetic, no vector-memory instruction in the K loop;
+//   waves 8-11 : loader waves.  Each plays two of the eight staging waves of the plain kernel (same LDS image, same source-side
+//                swizzle): tap decode, bounds checks, 16 LDS-DMA instructions per slab, vmcnt(0), barrier.
+// The barrier that ends slab k tells the MFMA waves that slab k + 1 has landed and the loaders that the stage of slab k is free.
+// 12 waves = 3 per SIMD: 168 VGPRs per wave (128 accumulator registers + 24 fragment registers + addresses in the MFMA waves).
+template <bool SKIP>
+__global__ void __launch_bounds__(768, 3)
+igemm_lw_kernel(const gim_conv_args a, const int mtiles, const int ntiles, const int M) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 256, BN = 256;
+    typedef gim::Igemm<BM, BN, 4, 2, true, true> G;
+    typedef Epilogue<G, true, false> E;
+
+    unsigned first, step, end;
+    tile_list((unsigned)(mtiles * ntiles), first, step, end);
+    if (first >= end) return;
+    const gim::MainloopArgs ml = mainloop_args(a, M, G::ES);
+    const int nkt = a.kpad * G::ES / KTB;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    if (wave >= 8) {
+        // ---- loader waves ---------------------------------------------------------------------------------------------------
+        const int sw0 = 2 * (wave - 8);                          // the two staging waves this wave plays
+        const int vt0 = sw0 * 64 + (int)(threadIdx.x & 63), vt1 = vt0 + 64;
+        G g0, g1, gn0, gn1;
+        int m0 = (int)(first / ntiles) * BM, n0 = (int)(first % ntiles) * BN;
+        g0.decode(ml, m0, n0, vt0);
+        g1.decode(ml, m0, n0, vt1);
+        g0.stage_issue(ml, smem, 0, 0, a.ktab[G::ktab_index(0, vt0)], sw0);
+        g1.stage_issue(ml, smem, 0, 0, a.ktab[G::ktab_index(0, vt1)], sw0 + 1);
+        int e0 = a.ktab[G::ktab_index(nkt > 1 ? 1 : 0, vt0)], e1 = a.ktab[G::ktab_index(nkt > 1 ? 1 : 0, vt1)];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                          // slab 0 of the first tile has landed
+        int buf = 0;
+        for (unsigned tile = first; tile < end; tile += step) {
+            const unsigned tile_n = tile + step;
+            const bool has_next = tile_n < end;
+            if (has_next) {
+                const int m0n = (int)(tile_n / ntiles) * BM, n0n = (int)(tile_n % ntiles) * BN;
+                gn0.decode(ml, m0n, n0n, vt0);
+                gn1.decode(ml, m0n, n0n, vt1);
+            }
+            if (tile != first) __syncthreads();                   // the previous tile's epilogue has left the stage buf ^ 1
+            for (int kt = 0; kt < nkt; ++kt) {
+                const bool last = kt + 1 == nkt;
+                int k2 = kt + 2;
+                if (k2 >= nkt) k2 -= nkt;
+                if (k2 >= nkt) k2 = 0;                            // nkt == 1
+                const int f0 = a.ktab[G::ktab_index(k2, vt0)], f1 = a.ktab[G::ktab_index(k2, vt1)];
+                if (!last) {
+                    g0.stage_issue(ml, smem, buf ^ 1, kt + 1, e0, sw0);
+                    g1.stage_issue(ml, smem, buf ^ 1, kt + 1, e1, sw0 + 1);
+                } else if (has_next) {
+                    gn0.stage_issue(ml, smem, buf ^ 1, 0, e0, sw0);
+                    gn1.stage_issue(ml, smem, buf ^ 1, 0, e1, sw0 + 1);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                                  // slab kt + 1 has landed; the MFMA waves are done with slab kt
+                buf ^= 1;
+                e0 = f0; e1 = f1;
+            }
+            g0 = gn0; g1 = gn1;
+        }
+        return;
+    }
+
+    // ---- MFMA waves -----------------------------------------------------------------------------------------------------------
+    E epi;
+    typename G::Acc acc;
+    typename E::Res rres;
+    int m0 = (int)(first / ntiles) * BM, n0 = (int)(first % ntiles) * BN;
+    epi.init_acc(a, acc, n0);
+    __syncthreads();                                              // slab 0 of the first tile has landed
+    int buf = 0;
+    for (unsigned tile = first; tile < end; tile += step) {
+        const unsigned tile_n = tile + step;
+        const bool has_next = tile_n < end;
+        auto kloop = [&](auto live) __attribute__((always_inline)) {
+            for (int kt = 0; kt < nkt; ++kt) {
+                G::template compute<decltype(live)::value>(smem, buf, acc);
+                __syncthreads();
+                buf ^= 1;
+            }
+        };
+        if constexpr (SKIP) {
+            // the wave's last channel fragment holds only padding channels (wave-uniform)
+            if (n0 + epi.wn * G::WTN + (G::TN - 1) * 32 >= a.N) kloop(IntC<G::TN - 1>());
+            else kloop(IntC<G::TN>());
+        } else {
+            kloop(IntC<G::TN>());
+        }
+        epi.run(a, acc, rres, smem + (buf ^ 1) * G::STAGE, m0, n0, M);   // buf ^ 1: the stage of the tile's last slab
+        m0 = (int)(tile_n / ntiles) * BM; n0 = (int)(tile_n % ntiles) * BN;
+        epi.init_acc(a, acc, n0 < a.npad ? n0 : 0);
+        if (has_next) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();                                      // the transposition tiles are consumed: the loaders may refill that stage
+        }
+    }
+}
+
+int launch_lw(const gim_conv_args& a, hipStream_t stream, const bool skip) {
+    constexpr int smem = 2 * (256 + 256) * KTB;
+    static GimPerDevice attr_done;
+    if (attr_done.needed()) {
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_lw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_lw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) {
+            gim_set_error("hipFuncSetAttribute(%d B LDS): %s", smem, hipGetErrorString(e));
+            return GIM_ERR_LAUNCH;
+        }
+        attr_done.done();
+    }
+    const int M = a.B * a.Ho * a.Wo;
+    const int mtiles = (M + 255) / 256, ntiles = a.npad / 256;
+    const int T = mtiles * ntiles;
+    constexpr int RESIDENT = 256;  // one workgroup per CU
+    const int rounds = (T + RESIDENT - 1) / RESIDENT;
+    const int grid = (T + rounds - 1) / rounds;
+    if (skip) hipLaunchKernelGGL(igemm_lw_kernel<true>, dim3((unsigned)grid), dim3(768), smem, stream, a, mtiles, ntiles, M);
+    else hipLaunchKernelGGL(igemm_lw_kernel<false>, dim3((unsigned)grid), dim3(768), smem, stream, a, mtiles, ntiles, M);
+    return gim_check_launch("igemm_lw_kernel");
+}
+
 template <int BM, int BN, int WM, int WN, bool BF16, bool OUT_BF16, bool HAS_RES, bool SKIP = false, bool UPS = false>
 int launch_persistent(const gim_conv_args& a, hipStream_t stream) {
     constexpr int smem = 2 * (BM + BN) * KTB;
@@ -983,6 +1121,9 @@ static int skip_mode() { static const int v = env_int("GIM_IGEMM_SKIP", 1); retu
 // GIM_IGEMM_PP: ping-pong variant of the 256 x 256 tile: 0 = never (default), 1 = for K loops of at least GIM_IGEMM_PP_MIN_NKT slabs, 2 = always
 static int pp_mode() { static const int v = env_int("GIM_IGEMM_PP", 0); return v; }
 static int pp_min_nkt() { static const int v = env_int("GIM_IGEMM_PP_MIN_NKT", 8); return v; }
+// GIM_IGEMM_LW: loader-wave variant of the 256 x 256 tile (16-bit, no residual / upsample operand): 0 = never (default: measured
+// 0.33 ms per forward SLOWER than the plain kernel on the full chip, see igemm_lw_kernel), 1 = wherever the plain 256 x 256 kernel would run
+static int lw_mode() { static const int v = env_int("GIM_IGEMM_LW", 0); return v; }
 static int big_min_tiles() { static const int v = env_int("GIM_IGEMM_BIG_MIN_TILES", 1024); return v; }   // round-3 sweep (profiles/r03_knob_sweep.txt)
 static int big_min_nkt() { static const int v = env_int("GIM_IGEMM_BIG_MIN_NKT", 4); return v; }
 
@@ -1021,6 +1162,9 @@ int dispatch_persistent(const gim_conv_args& a, hipStream_t s) {
             if constexpr (BF16) {
                 if (a.ups) return skip ? launch_persistent<256, 256, 4, 2, true, true, false, true, true>(a, s)
                                        : launch_persistent<256, 256, 4, 2, true, true, false, false, true>(a, s);
+            }
+            if constexpr (BF16) {
+                if (lw_mode()) return launch_lw(a, s, skip);
             }
             if (skip) return launch_persistent<256, 256, 4, 2, BF16, true, false, true>(a, s);
             return launch_persistent<256, 256, 4, 2, BF16, true, false>(a, s);

@@ -24,24 +24,25 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, void* __restr
 // (packing.pack_conv_split): channels [hi(C) | lo(C) | hi(C) | 0 ...] against weights [w_hi | w_hi | w_lo]: the MFMA sums
 // x_hi w_hi + x_lo w_hi + x_hi w_lo = x w up to 2^-22 -- the image and the 7x7 filters rounded to one 16-bit value are half of the
 // 16-bit modes' error (profiles/r04_precision_sweep.txt).  One thread per pixel.
-__global__ void nchw_to_nhwc_split_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int B, int C, int HW, int ld, int b_off) {
+__global__ void nchw_to_nhwc_split_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int B, int C, int HW, int ld, int b_off, int third) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= (size_t)B * HW) return;
     const size_t b = p / HW, r = p - b * HW;
     unsigned short* row = dst + ((size_t)(b + b_off) * HW + r) * ld;
-    for (int c = 3 * C; c < ld; ++c) row[c] = 0;
+    for (int c = (third ? 3 : 2) * C; c < ld; ++c) row[c] = 0;
     for (int c = 0; c < C; ++c) {
         const float v = src[(b * C + c) * HW + r];
         const unsigned short hi = f32_to_h16(v);
         const unsigned short lo = f32_to_h16(v - h16_to_f32(hi));
-        row[c] = hi; row[C + c] = lo; row[2 * C + c] = hi;
+        row[c] = hi; row[C + c] = lo;
+        if (third) row[2 * C + c] = hi;
     }
 }
 // the same for C and ld known at compile time (RGB -> 16 stored channels, gray -> 8): the row is built in registers and leaves in
 // 16-byte stores (the generic kernel writes 2 bytes at a time: 0.1 ms per batch-8 step)
-template <int C, int LD>
+template <int C, int LD, bool THIRD>
 __global__ void nchw_to_nhwc_split_fixed_kernel(const float* __restrict__ src, uint4* __restrict__ dst, int B, int HW, int b_off) {
-    static_assert(3 * C <= LD && LD % 8 == 0, "split layout");
+    static_assert((THIRD ? 3 : 2) * C <= LD && LD % 8 == 0, "split layout");
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= (size_t)B * HW) return;
     const size_t b = p / HW, r = p - b * HW;
@@ -52,7 +53,8 @@ __global__ void nchw_to_nhwc_split_fixed_kernel(const float* __restrict__ src, u
     for (int c = 0; c < C; ++c) {
         const float v = src[(b * C + c) * HW + r];
         const unsigned short hi = f32_to_h16(v);
-        h[c] = hi; h[C + c] = f32_to_h16(v - h16_to_f32(hi)); h[2 * C + c] = hi;
+        h[c] = hi; h[C + c] = f32_to_h16(v - h16_to_f32(hi));
+        if (THIRD) h[2 * C + c] = hi;
     }
     uint4* row = dst + ((size_t)(b + b_off) * HW + r) * (LD / 8);
 #pragma unroll
@@ -212,14 +214,18 @@ extern "C" int GIM_FN(gim_nchw_to_nhwc_split)(const float* src, void* dst, int B
 #endif
     GIM_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc_split: bad args");
     GIM_REQUIRE(dtype == GIM_H16, "nchw_to_nhwc_split: 16-bit output only (dtype %d)", dtype);
-    GIM_REQUIRE(ld >= 3 * C && ld % 8 == 0, "nchw_to_nhwc_split: ld=%d must hold 3 x %d channels in 16-byte groups", ld, C);
+    // ld >= 3 C: [hi | lo | hi | 0 ...] (the implicit-GEMM form of the split convolution); 2 C <= ld < 3 C: [hi | lo | 0 ...] (gim_stem7x7)
+    GIM_REQUIRE(ld >= 2 * C && ld % 8 == 0, "nchw_to_nhwc_split: ld=%d must hold 2 or 3 x %d channels in 16-byte groups", ld, C);
+    const int third = ld >= 3 * C;
     const size_t n = (size_t)B * H * W;
     if (C == 3 && ld == 16)
-        hipLaunchKernelGGL((nchw_to_nhwc_split_fixed_kernel<3, 16>), dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, src, (uint4*)dst, B, H * W, b_off);
+        hipLaunchKernelGGL((nchw_to_nhwc_split_fixed_kernel<3, 16, true>), dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, src, (uint4*)dst, B, H * W, b_off);
+    else if (C == 3 && ld == 8)
+        hipLaunchKernelGGL((nchw_to_nhwc_split_fixed_kernel<3, 8, false>), dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, src, (uint4*)dst, B, H * W, b_off);
     else if (C == 1 && ld == 8)
-        hipLaunchKernelGGL((nchw_to_nhwc_split_fixed_kernel<1, 8>), dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, src, (uint4*)dst, B, H * W, b_off);
+        hipLaunchKernelGGL((nchw_to_nhwc_split_fixed_kernel<1, 8, true>), dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, src, (uint4*)dst, B, H * W, b_off);
     else
-        hipLaunchKernelGGL(nchw_to_nhwc_split_kernel, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, B, C, H * W, ld, b_off);
+        hipLaunchKernelGGL(nchw_to_nhwc_split_kernel, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, B, C, H * W, ld, b_off, third);
     return gim_check_launch("nchw_to_nhwc_split");
 }
 

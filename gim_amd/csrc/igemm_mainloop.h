@@ -47,9 +47,11 @@ struct Igemm {
     unsigned wrow;
     uint4 ra[LDSDMA ? 1 : PA], rb[LDSDMA ? 1 : PB];
 
-    // pixel coordinates of this thread's staging rows for the tile at (m0, n0)
-    __device__ __forceinline__ void decode(const MainloopArgs& a, int m0, int n0) {
-        const int t = threadIdx.x, srow = t >> 3, sslot = t & 7;
+    // pixel coordinates of this thread's staging rows for the tile at (m0, n0).  `t`: the staging thread this lane stands in for
+    // (its own index in the kernels whose waves stage and compute; a loader wave of igemm_lw_kernel plays two of them)
+    __device__ __forceinline__ void decode(const MainloopArgs& a, int m0, int n0) { decode(a, m0, n0, (int)threadIdx.x); }
+    __device__ __forceinline__ void decode(const MainloopArgs& a, int m0, int n0, const int t) {
+        const int srow = t >> 3, sslot = t & 7;
         const int sgrp = sslot ^ ((srow >> 1) & 7);
         const bool flat = (a.Ho == 1) && (a.H == 1) && (a.stride == 1) && (a.pad == 0);  // pixel index == row index
         const int HoWo = a.Ho * a.Wo;
@@ -72,16 +74,19 @@ struct Igemm {
         wrow = (unsigned)(n0 + srow) * (unsigned)a.ldw * ES + sgrp * 16;
     }
 
-    static __device__ __forceinline__ int ktab_index(int kt) {
-        const int t = threadIdx.x;
+    static __device__ __forceinline__ int ktab_index(int kt) { return ktab_index(kt, (int)threadIdx.x); }
+    static __device__ __forceinline__ int ktab_index(int kt, const int t) {
         return kt * 8 + ((t & 7) ^ (((t >> 3) >> 1) & 7));
     }
 
     // issue the loads of slab kt into LDS stage `buf`.  `e` = ktab[ktab_index(kt)], fetched by the caller
     // one slab ahead so that no dependent global load sits in front of the DMA issue.
     __device__ __forceinline__ void stage_issue(const MainloopArgs& a, char* smem, int buf, int kt, int e) {
+        stage_issue(a, smem, buf, kt, e, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+    }
+    // (`wave`: the staging wave whose 8-row groups this call fills -- wave-uniform)
+    __device__ __forceinline__ void stage_issue(const MainloopArgs& a, char* smem, int buf, int kt, int e, const int wave) {
         // `buf` selects the stage at smem + buf * STAGE (2-stage double buffer or a deeper ring)
-        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
         const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.w_bytes, 0x00020000);
         const int c = e & 0xffff, dx = (e >> 16) & 0xff;

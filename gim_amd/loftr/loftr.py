@@ -47,8 +47,8 @@ import torch.nn as nn
 
 from .. import ops
 from .._lib import ACT_ELU1, ACT_LEAKY, ACT_NONE, ACT_RELU, GIM_BF16, GIM_F16, GIM_F32, GimHipError
-from ..packing import (cstore, is_half, pack_bneck, pack_bneck_ds, pack_bneck_tail, pack_conv, pack_conv_split, pack_fine_fused, pack_token_mlp,
-                       pack_token_emit, split_channels, torch_dtype)
+from ..packing import (PackedStem, cstore, is_half, pack_bneck, pack_bneck_ds, pack_bneck_tail, pack_conv, pack_conv_split, pack_fine_fused,
+                       pack_stem7x7, pack_token_mlp, pack_token_emit, split_channels, torch_dtype)
 
 _DT = {"bf16": GIM_BF16, "fp16": GIM_F16, "fp32": GIM_F32}
 
@@ -192,6 +192,10 @@ class LoFTR(nn.Module):
         # (profiles/r04_precision_sweep.txt: the stem alone is 57 % of the fp16 mode's mean |dmconf| and 3/4 of its index flips)
         ss = config.get("stem_split")
         self.stem_split = (os.environ.get("GIM_STEM_SPLIT", "1") != "0") if ss is None else bool(ss)
+        # 16-bit modes: the first convolution on its own kernel (gim_stem7x7: filter bank resident in LDS, every input patch staged
+        # once) instead of the implicit-GEMM kernel; GIM_STEM_KERNEL=0 / config['stem_kernel']=False keep the latter
+        sk = config.get("stem_kernel")
+        self.stem_kernel = (os.environ.get("GIM_STEM_KERNEL", "1") != "0") if sk is None else bool(sk)
         # set once the fp16 mode's range guard tripped and the module fell back to bf16 (see forward)
         self.fp16_overflowed = False
         self.backbone = _ResNetFPN_8_2(config["resnetfpn"])
@@ -271,8 +275,13 @@ class LoFTR(nn.Module):
         return GIM_F16 if (self.precision == "bf16" and self.stem_fp16 and self.use_lds_dma) else self._dt()
 
     def _split(self):
-        """first convolution on split (hi + lo) operands?  16-bit modes only: to the kernels it is a 9-channel convolution"""
+        """first convolution on split (hi + lo) operands?  16-bit modes only: to the implicit-GEMM kernel it is a 9-channel
+        convolution, to gim_stem7x7 one MFMA per tap on [hi | lo] pixels"""
         return bool(self.stem_split) and self.precision != "fp32"
+
+    def _stem_k(self):
+        """first convolution through gim_stem7x7?  (16-bit modes; the kernel stages by LDS-DMA, so GIM_LDS_DMA=0 turns it off too)"""
+        return bool(self.stem_kernel) and self.precision != "fp32" and self.use_lds_dma
 
     def set_precision(self, precision, coarse_sim=None):
         assert precision in _DT
@@ -287,7 +296,7 @@ class LoFTR(nn.Module):
         return (m.weight, m.bias, m.running_mean, m.running_var, m.eps)
 
     def _prepack(self, device):
-        key = (str(device), self.precision, self._img_dt(), self._split())
+        key = (str(device), self.precision, self._img_dt(), self._split(), self._stem_k())
         if self._packed is not None and self._packed_key == key:
             return self._packed
         dt = self._dt()
@@ -295,7 +304,9 @@ class LoFTR(nn.Module):
         P = {}
         enc = self.backbone.encode
         idt = self._img_dt()
-        if self._split():
+        if self._stem_k():
+            P["stem"] = pack_stem7x7(enc.conv1.weight, self._bn(enc.bn1), idt, device, split=self._split())
+        elif self._split():
             P["stem"] = pack_conv_split(enc.conv1.weight, self._bn(enc.bn1), idt, device, stride=2, pad=3)
         else:
             P["stem"] = pack_conv(enc.conv1.weight, self._bn(enc.bn1), idt, device, stride=2, pad=3, cin_pad=cstore(3, idt))
@@ -403,7 +414,8 @@ class LoFTR(nn.Module):
         B = sum(im.shape[0] for im in images)
         split = self._split()
         if out is None:
-            cs = cstore(split_channels(images[0].shape[1]) if split else 3, dt)
+            # gim_stem7x7 reads one 16-byte piece per pixel ([hi | lo | 0] when split); the implicit-GEMM form of the split needs 3 C
+            cs = 8 if self._stem_k() else cstore(split_channels(images[0].shape[1]) if split else 3, dt)
             out = torch.empty(B, H, W, cs, dtype=torch_dtype(dt), device=images[0].device)
         off = 0
         for im in images:
@@ -421,7 +433,10 @@ class LoFTR(nn.Module):
         """stem + layer1-3 + layer3_outconv (resnet.py:306-320): returns (x1, x2, x3_out) -- the coarse features x3_out are complete
         here; the fine head only needs x1, x2 and x3_out (see _fpn_fine)"""
         dma = self.use_lds_dma
-        x = ops.conv2d(x, P["stem"], ACT_RELU, out_dtype=torch_dtype(dt), lds_dma=dma)   # image dtype may be fp16 in bf16 mode
+        if isinstance(P["stem"], PackedStem):
+            x = ops.stem7x7(x, P["stem"], out_dtype=torch_dtype(dt))
+        else:
+            x = ops.conv2d(x, P["stem"], ACT_RELU, out_dtype=torch_dtype(dt), lds_dma=dma)   # image dtype may be fp16 in bf16 mode
         feats = []
         x3_out = None   # produced by the last block's fused tail when that path is taken
         o = None   # conv1 output of the upcoming block when the previous fused kernel already produced it
@@ -688,7 +703,7 @@ class LoFTR(nn.Module):
 
     def _graph_key(self, color0, color1, scale0, mask0):
         return (tuple(color0.shape), tuple(color1.shape), scale0 is not None, mask0 is not None, self.precision,
-                self.coarse_sim, self._img_dt(), self._split(), str(color0.device))
+                self.coarse_sim, self._img_dt(), self._split(), self._stem_k(), str(color0.device))
 
     def _coarse_stage_graphed(self, key, color0, color1, scale0, scale1, mask0=None, mask1=None):
         """HIP-graph replay of `_coarse_stage` (one graph per input shape / precision).  ~140 kernel launches collapse into one

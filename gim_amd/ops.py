@@ -96,12 +96,28 @@ def set_range_guard(word):
 
 
 def nchw_to_nhwc_split(src, dst, b_off=0):
-    """src [B,C,H,W] fp32 -> dst [Btot,H,W,ld] 16-bit with channels [hi(C) | lo(C) | hi(C) | 0...] (gim_nchw_to_nhwc_split)"""
+    """src [B,C,H,W] fp32 -> dst [Btot,H,W,ld] 16-bit with channels [hi(C) | lo(C) | hi(C) | 0...] when ld >= 3 C, [hi(C) | lo(C) |
+    0...] when 2 C <= ld < 3 C (gim_nchw_to_nhwc_split)"""
     _req_cuda(src, dst)
     assert src.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous() and dst.dtype in HALF
     B, C, H, W = src.shape
     check(lib.gim_nchw_to_nhwc_split(_p(src), _p(dst), B, C, H, W, dst.shape[-1], b_off, gim_dtype(dst), _stream()),
           "gim_nchw_to_nhwc_split")
+
+
+def stem7x7(x, ps, out_dtype=None):
+    """x [B,H,W,8] 16-bit pixels ([r g b 0...] or, ps.split, [hi(3) lo(3) 0 0]) -> relu(bn1(conv1(x))) [B,Ho,Wo,64] (gim_stem7x7;
+    ps = packing.pack_stem7x7)"""
+    _req_cuda(x, ps.w, ps.bias)
+    assert x.dtype in HALF and x.dtype == ps.w.dtype and x.is_contiguous() and x.shape[-1] == 8
+    assert ps.w.numel() * 2 == lib.gim_stem7x7_weight_bytes(int(ps.split))
+    B, H, W, _ = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(B, Ho, Wo, 64, dtype=out_dtype or x.dtype, device=x.device)
+    with _Timed("stem7x7", 2.0 * B * Ho * Wo * 64 * 49 * ps.cin):   # the layer's algorithmic flops
+        check(lib.gim_stem7x7(_p(x), _p(ps.w), _p(ps.bias), _p(y), B, H, W, int(ps.split), gim_dtype(x), gim_dtype(y), _stream()),
+              "gim_stem7x7")
+    return y
 
 
 def copy_segments(pairs):

@@ -84,6 +84,56 @@ def pack_conv_split(weight, bn, dtype, device, stride=1, pad=0):
     return pack_conv(w3, None, dtype, device, stride=stride, pad=pad, cin_pad=cstore(w3.shape[1], dtype), bias=b)
 
 
+class PackedStem:
+    """The first convolution for gim_stem7x7: `w` = the kernel's LDS image of the (BatchNorm-folded) filter bank, `bias` fp32 [64]."""
+
+    def __init__(self, w, bias, split, dtype, cin):
+        self.w, self.bias, self.split, self.dtype, self.cin = w, bias, bool(split), dtype, cin
+        self.cout, self.kh, self.kw, self.stride, self.pad = 64, 7, 7, 2, 3
+
+
+def stem7x7_image(weight, bn, dtype, split):
+    """The filter bank of conv1 (backbone/resnet.py:306, + bn1 folded in fp32) as gim_stem7x7 reads it from LDS, as an fp32 tensor
+    [NVT, 64, 2, 8] of values exactly representable in `dtype` (NVT "virtual taps" = MFMAs per accumulator, 64 output channels, 2 K
+    halves of 8 channels), BEFORE the half-slot swizzle:
+      split: virtual tap = tap (49); half 0 = [w_hi(C) | w_hi(C) | 0], half 1 = [w_lo(C) | 0] against the pixel [x_hi | x_lo | 0] that
+             both halves read: x_hi w_hi + x_lo w_hi + x_hi w_lo (the 2^-22 relative x_lo w_lo term is dropped, as in pack_conv_split);
+      plain: virtual tap v = taps 2 v (half 0) and 2 v + 1 (half 1; tap 49 does not exist: zeros), each [w(C) | 0].
+    Returns (image, bias)."""
+    assert is_half(dtype)
+    w, b = fold_bn(weight, bn)
+    cout, cin, kh, kw = w.shape
+    assert (cout, kh, kw) == (64, 7, 7) and 2 * cin <= 8, "gim_stem7x7 is the 7x7, <= 4 -> 64 channel first convolution"
+    td = torch_dtype(dtype)
+    wt = w.float().cpu().permute(2, 3, 0, 1).reshape(49, 64, cin)          # [tap][cout][cin]
+    w_hi = wt.to(td).float()
+    if split:
+        w_lo = (wt - w_hi).to(td).float()
+        img = torch.zeros(49, 64, 2, 8)
+        img[:, :, 0, :cin] = w_hi
+        img[:, :, 0, cin:2 * cin] = w_hi
+        img[:, :, 1, :cin] = w_lo
+    else:
+        img = torch.zeros(50, 64, 8)
+        img[:49, :, :cin] = w_hi
+        img = img.reshape(25, 2, 64, 8).permute(0, 2, 1, 3).contiguous()
+    bias = b.float().cpu() if b is not None else torch.zeros(64)
+    return img, bias
+
+
+def pack_stem7x7(weight, bn, dtype, device, split=True):
+    """-> PackedStem: stem7x7_image with K half h of output channel n stored at half slot h ^ ((n >> 3) & 1) (the kernel's
+    conflict-free ds_read_b128 of a 32-row filter fragment), in the 16-bit kind of `dtype`, on `device`."""
+    img, bias = stem7x7_image(weight, bn, dtype, split)
+    n = torch.arange(64)
+    sw = (n >> 3) & 1
+    out = torch.empty_like(img)
+    out[:, n, sw, :] = img[:, :, 0, :]
+    out[:, n, 1 - sw, :] = img[:, :, 1, :]
+    cin = weight.shape[1]
+    return PackedStem(out.to(torch_dtype(dtype)).contiguous().to(device), bias.to(device), split, dtype, cin)
+
+
 def pack_conv(weight, bn, dtype, device, stride=1, pad=0, cin_pad=None, bias=None):
     """weight [Cout, Cin, kh, kw] (or [out, in] for a Linear).  Returns PackedConv on `device`."""
     if weight.dim() == 2:

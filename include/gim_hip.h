@@ -56,6 +56,20 @@ int gim_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, in
  * of backbone/resnet.py:306 (conv1 7x7 on the image) is where half of the 16-bit modes' deviation from the fp32 reference arises. */
 int gim_nchw_to_nhwc_split(const float* src, void* dst, int B, int C, int H, int W, int ld, int b_off, int dtype,
                            gim_stream_t stream);
+/* (ld >= 3 C: the layout above.  2 C <= ld < 3 C: [hi(0..C) | lo(0..C) | zeros] -- one 16-byte piece per RGB pixel, the input of gim_stem7x7.) */
+
+/* --------------------------------------------------------------------------------------------
+ * The first convolution of the backbone as its own kernel: conv1 7x7 / stride 2 / pad 3, 3 -> 64, + bn1 (folded) + relu
+ * (backbone/resnet.py:306).  x [B,H,W,8] 16-bit pixels (one 16-byte piece each: gim_nchw_to_nhwc with cpad 8 for split = 0,
+ * gim_nchw_to_nhwc_split with ld 8 for split = 1), w = the LDS image of the filter bank (gim_stem7x7_weight_bytes(split) bytes,
+ * gim_amd/packing.py::pack_stem7x7: split = 1 carries every filter as a hi + lo pair), bias [64] fp32, y [B,Ho,Wo,64] of out_dtype
+ * (bf16 / fp16; Ho = (H - 1) / 2 + 1).  dtype = the operands' 16-bit kind.  The implicit-GEMM entry computes the same layer
+ * (split: on 16 channels per pixel) and remains the fp32 mode's path. */
+int64_t gim_stem7x7_weight_bytes(int split);
+int gim_stem7x7(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int split, int dtype, int out_dtype,
+                gim_stream_t stream);
+int gim_stem7x7_f16(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int split, int dtype, int out_dtype,
+                    gim_stream_t stream);
 /* inverse, for exposing feature maps in the reference layout (tests / lazy outputs) */
 int gim_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int ld, int dtype,
                      gim_stream_t stream);

@@ -384,11 +384,12 @@ print('OK', M)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
 
-@pytest.mark.parametrize("env", [{"GIM_IGEMM_BIG": "2"}, {"GIM_IGEMM_RING3": "2", "GIM_IGEMM_BIG": "0"},
-                                 {"GIM_IGEMM_BIG": "2", "GIM_IGEMM_PP": "2"}],
-                         ids=["big256x256", "ring3", "pingpong"])
+@pytest.mark.parametrize("env", [{"GIM_IGEMM_BIG": "2", "GIM_IGEMM_LW": "0"}, {"GIM_IGEMM_BIG": "2", "GIM_IGEMM_LW": "1"},
+                                 {"GIM_IGEMM_RING3": "2", "GIM_IGEMM_BIG": "0"}, {"GIM_IGEMM_BIG": "2", "GIM_IGEMM_PP": "2"}],
+                         ids=["big256x256", "loaderwaves", "ring3", "pingpong"])
 def test_conv_kernel_variants_forced(env):
-    """the 256x256 / 8-wave tile, the 3-stage ring variant and the (experimental) ping-pong schedule are picked by shape
+    """the 256x256 / 8-wave tile (its waves stage and compute), its loader-wave form (round 4: 8 MFMA waves + 4 staging waves), the
+    3-stage ring variant and the (experimental) ping-pong schedule are picked by shape
     heuristics / environment switches; force each
     of them onto every eligible conv / linear case (the choice is read once per process -> subprocess)"""
     import os

@@ -2,8 +2,8 @@
 // + bn1 + relu) as its own kernel for gfx950: round 4.
 //
 // Through the implicit-GEMM kernel this layer stages 49 taps x 16 B (32 B with split operands) per OUTPUT pixel and K slab after K
-// slab of a [64 x 392 / 784] filter bank for 23 GFLOP of work: 0.12 ms per batch-8 step, 0.25 ms on split operands, bound by the
-// ~13 B per clock a CU stages from L2 into LDS (DESIGN "Round 4: what the counters said").  Here
+// slab of a [64 x 392 / 784] filter bank for 23 GFLOP of work: 0.12 ms per batch-8 step, 0.25 ms on split operands -- 14 x more
+// staged bytes than the layer has input (DESIGN "Round 4: what the counters said").  Here
 //   * a persistent 8-wave workgroup (one per CU) keeps the WHOLE filter bank in LDS (98 KiB, loaded once) and walks 4 x 32-pixel
 //     output tiles; the (2 * 4 + 5) x (2 * 32 + 5) = 13 x 69 input pixels a tile touches are staged ONCE (14 KiB instead of 196 KiB of
 //     per-tap gathers), double-buffered by LDS-DMA so that tile t + 1 travels under the MFMAs of tile t;

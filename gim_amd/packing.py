@@ -9,6 +9,8 @@
 
 This is layout plumbing in torch on the host; no matching arithmetic happens here.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -134,6 +136,19 @@ def pack_stem7x7(weight, bn, dtype, device, split=True):
     return PackedStem(out.to(torch_dtype(dtype)).contiguous().to(device), bias.to(device), split, dtype, cin)
 
 
+NPAD128 = os.environ.get("GIM_NPAD128", "1") != "0"
+
+
+def npad_for(cout):
+    """rows of the packed weight matrix = what the kernels tile over N.  The granule is 64 (the 256 x 64 tile); a wide layer whose
+    64-granule count is odd is padded to the next multiple of 128 when that costs at most 1/8 more tiles, so that it runs on the
+    128 x 128 tile (DKM's 569-channel refiner: 576 -> 640 rows; ~725 instead of ~510 TFLOP/s on the layers' useful work)"""
+    npad = _round_up(cout, NPAD)
+    if NPAD128 and npad % 128 and npad >= 512:
+        npad += 64
+    return npad
+
+
 def pack_conv(weight, bn, dtype, device, stride=1, pad=0, cin_pad=None, bias=None):
     """weight [Cout, Cin, kh, kw] (or [out, in] for a Linear).  Returns PackedConv on `device`."""
     if weight.dim() == 2:
@@ -149,7 +164,7 @@ def pack_conv(weight, bn, dtype, device, stride=1, pad=0, cin_pad=None, bias=Non
     kslab = KTILE_BYTES // es
     k = kh * kw * cin_pad
     kpad = _round_up(k, kslab)
-    npad = _round_up(cout, NPAD)
+    npad = npad_for(cout)
     wk = torch.zeros(npad, kpad, dtype=torch.float32)
     if kh == 1 and kw == 1:          # Linear / 1x1 conv: one pass (the 300 M-parameter ViT packs in seconds)
         wk[:cout, :cin] = w.reshape(cout, cin).cpu()

@@ -1177,6 +1177,13 @@ int dispatch_persistent(const gim_conv_args& a, hipStream_t s) {
             return a.res ? launch_ring3<BF16, true>(a, s) : launch_ring3<BF16, false>(a, s);
         return dispatch_res<128, 128, 2, 2, BF16>(a, s);
     }
+    // N = 129 ... 192 on the 256 x 64 tile reads every pixel panel three times (one tile per 64 channels); these layers are memory-bound
+    // (DKM's 144-channel refiner blocks at 0.9 M pixels: 510 MB per launch at 2.8 TB/s).  A 256 x 192 tile on 8 waves of 32 px x 192 ch
+    // stages the panel once.  GIM_IGEMM_N192=0 keeps the 64-wide tiles.
+    if constexpr (BF16) {
+        static const int n192 = env_int("GIM_IGEMM_N192", 1);
+        if (n192 && a.npad == 192 && out_is16(a) && !a.res && !a.ups) return launch_persistent<256, 192, 8, 1, true, true, false>(a, s);
+    }
     return dispatch_res<256, 64, 4, 1, BF16>(a, s);
 }
 

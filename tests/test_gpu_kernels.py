@@ -72,6 +72,8 @@ CONV_CASES = [
     (1, 196, 10, 14, 196, 3, 1, True, "leaky", False),   # 196 inputs (cin_pad 196/200)
     (1, 196, 9, 11, 128, 3, 1, False, "none", False),
     (1, 1024, 6, 8, 256, 1, 1, False, "none", False),    # long K
+    (2, 144, 37, 45, 144, 1, 1, False, "relu", False),   # npad 192: the 256 x 192 tile (16-bit, round 4), ragged M
+    (1, 96, 20, 28, 160, 3, 1, True, "leaky", False),    # npad 192 again, 3x3, N = 160 (the last 32-channel fragment empty)
 ]
 
 

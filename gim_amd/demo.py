@@ -11,8 +11,8 @@ Mirrors the reference entry point step by step (reference file:line):
                                             rules; without a checkpoint the seeded init of the modules is kept -- plumbing runs)
   * `match_pair`         demo.py:405-511  (dense: pad / match / sample 5000 / pixels / un-pad / in-bounds mask; gim_loftr: the
                                             module's dict; gim_lightglue: detector x2 + matcher + per-pair gather)
-  * robust fitting       demo.py:514-517  cv2.findFundamentalMat(USAC_MAGSAC, 1.0 px, 0.999999, 10000) stays on the host and
-                                            runs only when OpenCV is importable (north_star: RANSAC stays on the host)
+  * robust fitting       demo.py:514-517  cv2.findFundamentalMat(USAC_MAGSAC, 1.0 px, 0.999999, 10000) stays on the host (north_star);
+                                            without OpenCV: seven-point RANSAC of gim_amd/pose.py with the same parameters
 Returns / prints `{mkpts0_f, mkpts1_f, mconf, m_bids}` in pixels of the ORIGINAL images (kpts * scale, demo.py:499-500 and
 the `scale0/scale1` the other models get through their own adapters).
 """
@@ -161,14 +161,19 @@ def match_pair(model_name, model, detector, path0, path1, device="cuda", resize_
         kpts0, kpts1, b_ids, mconf = d["mkpts0_f"], d["mkpts1_f"], d["m_bids"], d["mconf"]
     out = {"mkpts0_f": kpts0, "mkpts1_f": kpts1, "m_bids": b_ids, "mconf": mconf,
            "hw0_i": image0.shape[2:], "hw1_i": image1.shape[2:], "scale0": scale0, "scale1": scale1}
-    try:   # robust fitting on the host (demo.py:514-517)
-        import cv2
-        if len(kpts0) >= 8:
-            _, mask = cv2.findFundamentalMat(kpts0.cpu().numpy(), kpts1.cpu().numpy(), cv2.USAC_MAGSAC, ransacReprojThreshold=1.0,
-                                             confidence=0.999999, maxIters=10000)
-            out["inliers"] = mask.ravel() > 0
-    except ImportError:
-        pass
+    # robust fitting on the host (demo.py:514-517): OpenCV's USAC_MAGSAC when cv2 imports, else plain seven-point RANSAC with the
+    # same threshold / confidence / iteration bound (gim_amd/pose.py; `backend` says which one produced the mask)
+    if len(kpts0) >= 8:
+        from . import pose
+        p0, p1 = kpts0.float().cpu().numpy(), kpts1.float().cpu().numpy()
+        out["ransac_backend"] = pose.backend()
+        if out["ransac_backend"] == "cv2":
+            import cv2
+            _, mask = cv2.findFundamentalMat(p0, p1, cv2.USAC_MAGSAC, ransacReprojThreshold=1.0, confidence=0.999999, maxIters=10000)
+            out["inliers"] = mask.ravel() > 0 if mask is not None else np.zeros(len(p0), dtype=bool)
+        else:
+            _, mask = pose.find_fundamental_mat(p0, p1, threshold=1.0, prob=0.999999, max_iters=10000)
+            out["inliers"] = mask
     return out
 
 
@@ -190,7 +195,7 @@ def main(argv=None):
     model, detector = build(args.model, weights, args.precision, dinov2_weights=args.dinov2_weights)
     out = match_pair(args.model, model, detector, args.image0, args.image1, resize_max=args.resize_max)
     n = len(out["mconf"])
-    print(f"{args.model}: {n} matches" + (f", {int(out['inliers'].sum())} inliers" if "inliers" in out else " (OpenCV not installed: no RANSAC)"))
+    print(f"{args.model}: {n} matches" + (f", {int(out['inliers'].sum())} inliers ({out['ransac_backend']} RANSAC)" if "inliers" in out else " (fewer than 8: no RANSAC)"))
     for k in range(min(n, 5)):
         a, b = out["mkpts0_f"][k].tolist(), out["mkpts1_f"][k].tolist()
         print(f"  ({a[0]:8.2f}, {a[1]:8.2f}) <-> ({b[0]:8.2f}, {b[1]:8.2f})  conf {float(out['mconf'][k]):.4f}")

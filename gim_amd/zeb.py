@@ -7,8 +7,9 @@ Restates, without Lightning:
     ("identifiers covisible0 covisible1 R_errs t_errs t_errs2 Bef.Prec Bef.Num Aft.Prec Aft.Num",
     file name "[T] <weight> <scene:>15> <version>.txt"), so `check.py` / `analysis.py` of the reference keep
     working on dumps produced by this engine;
-  * `tools/metrics.py:28-53,107-168` relative pose error and the RANSAC call -- RANSAC stays on the host with
-    OpenCV as north_star prescribes (imported lazily; not available in the build container).
+  * `tools/metrics.py:28-53,107-168` relative pose error and the RANSAC call -- RANSAC stays on the host as north_star
+    prescribes: OpenCV when it imports (it does not in the build container), else gim_amd/pose.py (numpy five-point RANSAC +
+    recoverPose, the published algorithms behind the two cv2 calls).
 Pinned by `tests/test_zeb_cpu.py` against AUC values computed by the reference's own `analysis.py` on a
 sample of its shipped dumps (`oracle/make_golden_zeb.py`).
 """
@@ -123,17 +124,21 @@ def relative_pose_error(T_0to1, R, t, ignore_gt_t_thr=0.0):
 
 
 def estimate_pose(kpts0, kpts1, K0, K1, thresh=0.5, conf=0.99999):
-    """tools/metrics.py:77-103 (cv2.findEssentialMat RANSAC + recoverPose).  Host only; needs OpenCV."""
-    try:
-        import cv2
-    except ImportError as e:  # pragma: no cover
-        raise ImportError("ZEB pose estimation runs cv2 RANSAC on the host (tools/metrics.py:88-98); "
-                          "install opencv-python on the evaluation machine") from e
+    """tools/metrics.py:77-103 (findEssentialMat RANSAC + recoverPose).  Host only.  OpenCV when it imports (the reference's own
+    call), otherwise the numpy restatement of the same two OpenCV routines in gim_amd/pose.py (`GIM_POSE_BACKEND` forces one)."""
+    from . import pose
     if len(kpts0) < 5:
         return None
     kpts0 = (kpts0 - K0[[0, 1], [2, 2]][None]) / K0[[0, 1], [0, 1]][None]
     kpts1 = (kpts1 - K1[[0, 1], [2, 2]][None]) / K1[[0, 1], [0, 1]][None]
     ransac_thr = thresh / np.mean([K0[0, 0], K1[1, 1], K0[0, 0], K1[1, 1]])
+    if pose.backend() == "numpy":
+        E, mask = pose.find_essential_mat(kpts0, kpts1, ransac_thr, prob=conf)
+        if E is None:
+            return None
+        n, R, t, _ = pose.recover_pose(E, kpts0, kpts1, 1e9, mask=mask)
+        return (R, t, mask) if n > 0 else None
+    import cv2
     E, mask = cv2.findEssentialMat(kpts0, kpts1, np.eye(3), threshold=ransac_thr, prob=conf, method=cv2.RANSAC)
     if E is None:
         return None

@@ -271,6 +271,115 @@ la_kv_mfma_kernel(const void* __restrict__ k, const void* __restrict__ v, const 
     if (lh == 0) out[D * D + l31] = kt;
 }
 
+// Round 4, second shape of the same reduction (GIM_LA_KV2=1).  The kernel above runs 304 / 608 workgroups per coarse-level call, each a
+// serial chain of four (global load -> barrier -> LDS -> barrier -> 32 MFMAs) steps: ~1.2 - 2.4 workgroups per CU cannot hide a chain
+// of four memory round trips (25 us per call for 39 - 79 MB that sit in L2 / MALL behind the token kernel that wrote them).  Here
+//   * 8 waves per workgroup = (head, half of the 256-row chunk): twice the waves, half the MFMA chain per wave;
+//   * every wave streams ITS OWN head slice (64 / 128 B per row) of its 128 rows: ALL of its global loads are issued before the
+//     first one is consumed (16 / 32 x 16 B per lane and operand pair: one memory round trip per wave instead of four);
+//   * the slices go through a wave-private LDS region (lane = (row, 16-byte piece) on the way in, lane = channel on the way out: the
+//     fp32 MFMA wants one scalar per lane and row) -- no workgroup barrier in the loop, a wave's own LDS accesses execute in order;
+//   * the two halves of a head are added in a fixed order through LDS at the end (lower half + upper half): deterministic, same
+//     partial layout, same finalize pass.
+// Arithmetic per row as above (K exact, V * 1/S or V / S in fp32, fp32 MFMA); only the association of the 256-row sum differs.
+template <bool BF16>
+__global__ void __launch_bounds__(512)
+la_kv_mfma2_kernel(const void* __restrict__ k, const void* __restrict__ v, const uint8_t* __restrict__ kv_mask,
+                   float* __restrict__ part, int S, int ldk, int ldv, int nchunk) {
+    constexpr int D = 32, H = 8, HG = 4, ES = BF16 ? 2 : 4, PER = D * D + D;
+    constexpr int SEG = D * ES;                   // bytes of one head's slice of a row (64 / 128)
+    constexpr int STROWS = 64, NST = CHM / 2 / STROWS;   // a wave's 128 rows go through its LDS region in two stages of 64
+    constexpr int PPR = SEG / 16, RPI = 64 / PPR, LPS = STROWS / RPI;   // 16-byte pieces per row, rows per wave load, loads per stage and operand
+    constexpr int WREG = 2 * STROWS * SEG;        // a wave's LDS region: K slice, V slice (8 / 16 KiB)
+    static_assert(17 * 64 * 4 <= WREG, "the combine tile (16 accumulator registers + Ksum, per lane) lives in the upper wave's region");
+    extern __shared__ __attribute__((aligned(16))) char la_smem[];
+    const int b = blockIdx.x, chunk = blockIdx.y, hg = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31, lh = lane >> 5;
+    const int hf = wave >> 2, h = hg * HG + (wave & 3);
+    const int s0 = chunk * CHM + hf * (CHM / 2);
+    char* Kw = la_smem + wave * WREG;
+    char* Vw = Kw + STROWS * SEG;
+    const float slen = (float)S, inv_s = 1.0f / slen;
+    const int prow = lane / PPR, ppc = lane % PPR;
+    const char* kb = (const char*)k + (size_t)h * SEG + ppc * 16;
+    const char* vb = (const char*)v + (size_t)h * SEG + ppc * 16;
+    // which of this lane's rows hold data: inside the sequence and not masked (K * kv_mask, values * kv_mask, attentions.py:38-39).
+    // All mask bytes are requested before the first K / V load (a mask byte in front of every load would drain the queue each time).
+    unsigned okm = 0u;
+#pragma unroll
+    for (int st = 0; st < NST; ++st)
+#pragma unroll
+        for (int i = 0; i < LPS; ++i)
+            okm |= (s0 + st * STROWS + i * RPI + prow < S ? 1u : 0u) << (st * LPS + i);
+    if (kv_mask) {
+        unsigned mm = 0u;
+#pragma unroll
+        for (int st = 0; st < NST; ++st)
+#pragma unroll
+            for (int i = 0; i < LPS; ++i)
+                mm |= (kv_mask[(size_t)b * S + min(s0 + st * STROWS + i * RPI + prow, S - 1)] ? 1u : 0u) << (st * LPS + i);
+        okm &= mm;
+    }
+    // straight-line loads: a row without data reads a clamped address and is zeroed on its way into LDS (behind a branch around
+    // every load pair the register allocator parks loaded values in other registers -- and waits for them in the middle of the sequence)
+    uint4 rk[NST][LPS], rv[NST][LPS];
+#pragma unroll
+    for (int st = 0; st < NST; ++st)
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) {
+            const size_t srow = (size_t)b * S + min(s0 + st * STROWS + i * RPI + prow, S - 1);
+            rk[st][i] = *(const uint4*)(kb + srow * ldk * ES);
+            rv[st][i] = *(const uint4*)(vb + srow * ldv * ES);
+        }
+    __builtin_amdgcn_sched_barrier(0);   // every load is issued before the first one is waited for (left alone, the scheduler waits for
+                                         // the first stage's rows in front of the second stage's requests: two round trips)
+    f32x16_t acc;
+    float ks = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) {   // lane (row, piece) of load i sits at byte i * 1024 + lane * 16 of the [64 rows][SEG] slice
+            const unsigned m = ((okm >> (st * LPS + i)) & 1u) ? 0xffffffffu : 0u;
+            *(uint4*)(Kw + i * 1024 + lane * 16) = make_uint4(rk[st][i].x & m, rk[st][i].y & m, rk[st][i].z & m, rk[st][i].w & m);
+            *(uint4*)(Vw + i * 1024 + lane * 16) = make_uint4(rv[st][i].x & m, rv[st][i].y & m, rv[st][i].z & m, rv[st][i].w & m);
+        }
+        // (no barrier: the region is this wave's own, and LDS executes a wave's accesses in order)
+#pragma unroll 8
+        for (int x = 0; x < STROWS / 2; ++x) {
+            const int row = 2 * x + lh;
+            float a, bv;
+            if constexpr (BF16) {
+                a = h16_to_f32(*(const unsigned short*)(Kw + row * SEG + l31 * ES));
+                bv = h16_to_f32(*(const unsigned short*)(Vw + row * SEG + l31 * ES)) * inv_s;
+            } else {
+                a = *(const float*)(Kw + row * SEG + l31 * ES);
+                bv = *(const float*)(Vw + row * SEG + l31 * ES) / slen;  // values / v_length (attentions.py:42)
+            }
+            ks += a;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+        }
+    }
+    // upper half -> LDS (its own region: its reads are done), lower half adds and stores
+    float* comb = (float*)(la_smem + (wave | 4) * WREG);
+    if (hf == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) comb[r * 64 + lane] = acc[r];
+        comb[16 * 64 + lane] = ks;
+    }
+    __syncthreads();
+    if (hf == 1) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += comb[r * 64 + lane];
+    ks += comb[16 * 64 + lane];
+    float* out = part + ((size_t)(b * H + h) * nchunk + chunk) * PER;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[((r >> 2) * 8 + lh * 4 + (r & 3)) * D + l31] = acc[r];
+    const float kt = ks + __shfl_xor(ks, 32, 64);
+    if (lh == 0) out[D * D + l31] = kt;
+}
+
 template <bool BF16, bool OUT_BF16>
 __global__ void __launch_bounds__(256)
 la_apply_mfma_kernel(const void* __restrict__ q, const uint8_t* __restrict__ q_mask, const float* __restrict__ kvfin,
@@ -370,7 +479,20 @@ extern "C" int GIM_FN(gim_linear_attention_kv)(const void* k, const void* v, con
             attr.done();
         }
         const dim3 g2((unsigned)nb, (unsigned)nc, 2u);
-        if (bf) hipLaunchKernelGGL(la_kv_mfma_kernel<true>, g2, dim3(256), smem, s, k, v, kv_mask, part, S, ldk, ldv, nc);
+        // GIM_LA_KV2=1: 8-wave workgroups, wave-private streaming (la_kv_mfma2_kernel); 0 (default): the 4-wave kernel
+        static const int kv2 = [] { const char* e = getenv("GIM_LA_KV2"); return e ? atoi(e) : 0; }();
+        if (kv2) {
+            const int smem2 = 8 * 2 * 64 * 32 * (bf ? 2 : 4);
+            static GimPerDevice attr2;
+            if (attr2.needed()) {
+                hipError_t e = hipFuncSetAttribute((const void*)la_kv_mfma2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 64 * 32 * 2);
+                if (e == hipSuccess) e = hipFuncSetAttribute((const void*)la_kv_mfma2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 64 * 32 * 4);
+                if (e != hipSuccess) { gim_set_error("linear_attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return GIM_ERR_LAUNCH; }
+                attr2.done();
+            }
+            if (bf) hipLaunchKernelGGL(la_kv_mfma2_kernel<true>, g2, dim3(512), smem2, s, k, v, kv_mask, part, S, ldk, ldv, nc);
+            else hipLaunchKernelGGL(la_kv_mfma2_kernel<false>, g2, dim3(512), smem2, s, k, v, kv_mask, part, S, ldk, ldv, nc);
+        } else if (bf) hipLaunchKernelGGL(la_kv_mfma_kernel<true>, g2, dim3(256), smem, s, k, v, kv_mask, part, S, ldk, ldv, nc);
         else hipLaunchKernelGGL(la_kv_mfma_kernel<false>, g2, dim3(256), smem, s, k, v, kv_mask, part, S, ldk, ldv, nc);
     } else if (D == 32) {
         if (bf) hipLaunchKernelGGL((la_kv_kernel<32, true>), grid, dim3(256), 0, s, k, v, kv_mask, part, S, H, ldk, ldv, nc);

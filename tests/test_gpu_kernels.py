@@ -424,6 +424,51 @@ def test_linear_attention_masks(shape):
     _assert_close(out.view(nb, L, H, D), ref, 1e-5, f"masked linear attention {shape}")
 
 
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape", [(16, 4800, True, False), (3, 1000, False, True), (2, 257, True, True)],
+                         ids=["coarse16x4800-strided", "3x1000-masked", "2x257-strided-masked"])
+def test_linear_attention_state(dt, shape):
+    """gim_linear_attention_kv alone (the MFMA kernels of the coarse level: D = 32, H = 8): the final KV / Ksum state against a float64
+    einsum on the rounded operands -- at the benchmark's size with K / V as column blocks of a [rows, 3C] projection buffer (the
+    layout gim_token_mlp_emit writes), on ragged last chunks, and with kv_mask (attentions.py:38-43)."""
+    from gim_amd import ops
+    dev = _dev()
+    nb, S, strided, masked = shape
+    H, D, C = 8, 32, 256
+    g = torch.Generator().manual_seed(23)
+    k = _rnd(F.elu(torch.randn(nb * S, C, generator=g)) + 1, dt)
+    v = _rnd(torch.randn(nb * S, C, generator=g), dt)
+    km = (torch.rand(nb * S, generator=g) > 0.25) if masked else None
+    buf = torch.zeros(nb * S, 3 * C if strided else 2 * C, dtype=_tdt(dt))
+    buf[:, -2 * C:-C], buf[:, -C:] = k.to(_tdt(dt)), v.to(_tdt(dt))
+    bd = buf.to(dev)
+    ws, need = ops.linear_attention_state(bd[:, -2 * C:-C], bd[:, -C:], nb, S, H,
+                                          kv_mask=km.to(torch.uint8).to(dev) if masked else None)
+    torch.cuda.synchronize()
+    got = ws[:nb * H * (D * D + D)].view(nb, H, D * D + D).cpu().double()
+    kd, vd = k.double().view(nb, S, H, D), v.double().view(nb, S, H, D)
+    if masked:
+        kd, vd = kd * km.view(nb, S, 1, 1), vd * km.view(nb, S, 1, 1)
+    KV = torch.einsum("nshd,nshv->nhdv", kd, vd / S)
+    ref = torch.cat([KV.reshape(nb, H, D * D), kd.sum(1)], -1)
+    # fp32 accumulation of S products: error ~ sqrt(S) * 2^-24 of the running sums (a wrong row, mask or head shows at 1e-2)
+    _assert_close(got[..., :D * D], ref[..., :D * D], 1e-5, f"KV state {shape}")
+    _assert_close(got[..., D * D:], ref[..., D * D:], 1e-5, f"Ksum {shape}")
+
+
+def test_linear_attention_kv2_variant_forced():
+    """GIM_LA_KV2=1: the 8-wave / wave-private-streaming shape of the KV reduction (la_kv_mfma2_kernel) under every linear-attention
+    test of this file and the token kernel's fused-apply tests (the choice is read once per process -> subprocess)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_kernels.py", "tests/test_gpu_token_mlp.py", "-m", "gpu", "-q", "-x",
+                          "-k", "linear_attention and not forced or token_mlp", "-p", "no:cacheprovider"],
+                         cwd=root, capture_output=True, text=True, env={**os.environ, "GIM_LA_KV2": "1"}, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+
+
 @pytest.mark.parametrize("mode", ["128", "256", "off"], ids=["rows256x128-2wg", "rows256x256-1wg", "tile128-kernel"])
 @pytest.mark.parametrize("kind", ["bf16", "fp16"])
 def test_coarse_match_tile256_statistics(mode, kind):

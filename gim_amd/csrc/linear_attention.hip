@@ -282,13 +282,13 @@ la_kv_mfma_kernel(const void* __restrict__ k, const void* __restrict__ v, const 
 //   * the two halves of a head are added in a fixed order through LDS at the end (lower half + upper half): deterministic, same
 //     partial layout, same finalize pass.
 // Arithmetic per row as above (K exact, V * 1/S or V / S in fp32, fp32 MFMA); only the association of the 256-row sum differs.
-template <bool BF16>
+template <bool BF16, int CHK>   // CHK rows per workgroup (256: the partial count of the kernel above; 128: twice the workgroups, one stage per wave)
 __global__ void __launch_bounds__(512)
 la_kv_mfma2_kernel(const void* __restrict__ k, const void* __restrict__ v, const uint8_t* __restrict__ kv_mask,
                    float* __restrict__ part, int S, int ldk, int ldv, int nchunk) {
     constexpr int D = 32, H = 8, HG = 4, ES = BF16 ? 2 : 4, PER = D * D + D;
     constexpr int SEG = D * ES;                   // bytes of one head's slice of a row (64 / 128)
-    constexpr int STROWS = 64, NST = CHM / 2 / STROWS;   // a wave's 128 rows go through its LDS region in two stages of 64
+    constexpr int STROWS = 64, NST = CHK / 2 / STROWS;   // a wave's CHK / 2 rows go through its LDS region in stages of 64
     constexpr int PPR = SEG / 16, RPI = 64 / PPR, LPS = STROWS / RPI;   // 16-byte pieces per row, rows per wave load, loads per stage and operand
     constexpr int WREG = 2 * STROWS * SEG;        // a wave's LDS region: K slice, V slice (8 / 16 KiB)
     static_assert(17 * 64 * 4 <= WREG, "the combine tile (16 accumulator registers + Ksum, per lane) lives in the upper wave's region");
@@ -296,7 +296,7 @@ la_kv_mfma2_kernel(const void* __restrict__ k, const void* __restrict__ v, const
     const int b = blockIdx.x, chunk = blockIdx.y, hg = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31, lh = lane >> 5;
     const int hf = wave >> 2, h = hg * HG + (wave & 3);
-    const int s0 = chunk * CHM + hf * (CHM / 2);
+    const int s0 = chunk * CHK + hf * (CHK / 2);
     char* Kw = la_smem + wave * WREG;
     char* Vw = Kw + STROWS * SEG;
     const float slen = (float)S, inv_s = 1.0f / slen;
@@ -462,7 +462,9 @@ extern "C" int GIM_FN(gim_linear_attention_kv)(const void* k, const void* v, con
     hipStream_t s = (hipStream_t)stream;
     const bool mfma_path = D == 32 && H == 8 && (ldk * (dtype == GIM_H16 ? 2 : 4)) % 16 == 0 &&
                            (ldv * (dtype == GIM_H16 ? 2 : 4)) % 16 == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0;
-    const int nc = mfma_path ? (S + CHM - 1) / CHM : nchunks(S);
+    static const int kv2 = [] { const char* e = getenv("GIM_LA_KV2"); return e ? atoi(e) : 0; }();
+    const int chm = kv2 == 2 ? 128 : CHM;
+    const int nc = mfma_path ? (S + chm - 1) / chm : nchunks(S);
     const int per = D * D + D;
     float* fin = kv_ws;
     float* part = nc > 1 ? kv_ws + (size_t)nb * H * per : kv_ws;
@@ -479,19 +481,25 @@ extern "C" int GIM_FN(gim_linear_attention_kv)(const void* k, const void* v, con
             attr.done();
         }
         const dim3 g2((unsigned)nb, (unsigned)nc, 2u);
-        // GIM_LA_KV2=1: 8-wave workgroups, wave-private streaming (la_kv_mfma2_kernel); 0 (default): the 4-wave kernel
-        static const int kv2 = [] { const char* e = getenv("GIM_LA_KV2"); return e ? atoi(e) : 0; }();
+        // GIM_LA_KV2 = 1 / 2: 8-wave workgroups, wave-private streaming (la_kv_mfma2_kernel) on 256- / 128-row chunks; 0 (default): the 4-wave kernel
         if (kv2) {
             const int smem2 = 8 * 2 * 64 * 32 * (bf ? 2 : 4);
             static GimPerDevice attr2;
             if (attr2.needed()) {
-                hipError_t e = hipFuncSetAttribute((const void*)la_kv_mfma2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 64 * 32 * 2);
-                if (e == hipSuccess) e = hipFuncSetAttribute((const void*)la_kv_mfma2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 64 * 32 * 4);
+                hipError_t e = hipFuncSetAttribute((const void*)la_kv_mfma2_kernel<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 64 * 32 * 2);
+                if (e == hipSuccess) e = hipFuncSetAttribute((const void*)la_kv_mfma2_kernel<true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 64 * 32 * 2);
+                if (e == hipSuccess) e = hipFuncSetAttribute((const void*)la_kv_mfma2_kernel<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 64 * 32 * 4);
+                if (e == hipSuccess) e = hipFuncSetAttribute((const void*)la_kv_mfma2_kernel<false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 64 * 32 * 4);
                 if (e != hipSuccess) { gim_set_error("linear_attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return GIM_ERR_LAUNCH; }
                 attr2.done();
             }
-            if (bf) hipLaunchKernelGGL(la_kv_mfma2_kernel<true>, g2, dim3(512), smem2, s, k, v, kv_mask, part, S, ldk, ldv, nc);
-            else hipLaunchKernelGGL(la_kv_mfma2_kernel<false>, g2, dim3(512), smem2, s, k, v, kv_mask, part, S, ldk, ldv, nc);
+            if (kv2 == 2) {
+                if (bf) hipLaunchKernelGGL((la_kv_mfma2_kernel<true, 128>), g2, dim3(512), smem2, s, k, v, kv_mask, part, S, ldk, ldv, nc);
+                else hipLaunchKernelGGL((la_kv_mfma2_kernel<false, 128>), g2, dim3(512), smem2, s, k, v, kv_mask, part, S, ldk, ldv, nc);
+            } else {
+                if (bf) hipLaunchKernelGGL((la_kv_mfma2_kernel<true, 256>), g2, dim3(512), smem2, s, k, v, kv_mask, part, S, ldk, ldv, nc);
+                else hipLaunchKernelGGL((la_kv_mfma2_kernel<false, 256>), g2, dim3(512), smem2, s, k, v, kv_mask, part, S, ldk, ldv, nc);
+            }
         } else if (bf) hipLaunchKernelGGL(la_kv_mfma_kernel<true>, g2, dim3(256), smem, s, k, v, kv_mask, part, S, ldk, ldv, nc);
         else hipLaunchKernelGGL(la_kv_mfma_kernel<false>, g2, dim3(256), smem, s, k, v, kv_mask, part, S, ldk, ldv, nc);
     } else if (D == 32) {

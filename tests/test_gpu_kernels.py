@@ -456,8 +456,9 @@ def test_linear_attention_state(dt, shape):
     _assert_close(got[..., D * D:], ref[..., D * D:], 1e-5, f"Ksum {shape}")
 
 
-def test_linear_attention_kv2_variant_forced():
-    """GIM_LA_KV2=1: the 8-wave / wave-private-streaming shape of the KV reduction (la_kv_mfma2_kernel) under every linear-attention
+@pytest.mark.parametrize("mode", ["1", "2"], ids=["chunks256", "chunks128"])
+def test_linear_attention_kv2_variant_forced(mode):
+    """GIM_LA_KV2=1 / 2: the 8-wave / wave-private-streaming shape of the KV reduction (la_kv_mfma2_kernel) under every linear-attention
     test of this file and the token kernel's fused-apply tests (the choice is read once per process -> subprocess)"""
     import os
     import subprocess
@@ -465,7 +466,7 @@ def test_linear_attention_kv2_variant_forced():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_kernels.py", "tests/test_gpu_token_mlp.py", "-m", "gpu", "-q", "-x",
                           "-k", "linear_attention and not forced or token_mlp", "-p", "no:cacheprovider"],
-                         cwd=root, capture_output=True, text=True, env={**os.environ, "GIM_LA_KV2": "1"}, timeout=900)
+                         cwd=root, capture_output=True, text=True, env={**os.environ, "GIM_LA_KV2": mode}, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
 
 

@@ -380,6 +380,114 @@ la_kv_mfma2_kernel(const void* __restrict__ k, const void* __restrict__ v, const
     if (lh == 0) out[D * D + l31] = kt;
 }
 
+// Third shape (GIM_LA_KV2=3, 16-bit operands only).  Measured (profiles/r04_la_kv.txt): the wave-private streaming above takes the call
+// from 27.8 to 24.3 us only -- 153 600 v_mfma_f32_32x32x2_f32 of 64 cycles each are 4 waves x 4 096 cycles on the SIMDs of a CU that
+// holds two workgroups: the fp32 MFMA (2 rows per instruction) is the chain, not the memory.  16-bit K and V multiply exactly in fp32,
+// so the 16-bit MFMA (16 rows per 32-cycle instruction) computes the same sums:
+//   KV_h = K_h^T V_h: A = K^T (lane = channel d, 8 consecutive ROWS per lane: read as 8 x ds_read_u16 down a column of the wave's
+//   row-major LDS slice), B = V the same way; 1 / S is applied once to the fp32 sums (attentions.py:41-43 divides V first: the two differ
+//   in the last bit of the fp32 result); Ksum = K^T 1 comes from a second MFMA against a fragment of ones (every column of that
+//   accumulator is Ksum).  Per 16 rows and wave: 16 LDS reads, 8 packs, 2 MFMAs = 64 MFMA cycles instead of 512.
+// CHK rows per workgroup: 256, or 512 for the 16-sequence (self-attention) calls so that one round of <= 512 resident workgroups covers
+// the launch (a workgroup holds 64 KiB of LDS: two per CU).
+template <int CHK>
+__global__ void __launch_bounds__(512)
+la_kv_h16_kernel(const void* __restrict__ k, const void* __restrict__ v, const uint8_t* __restrict__ kv_mask,
+                 float* __restrict__ part, int S, int ldk, int ldv, int nchunk) {
+    constexpr int D = 32, H = 8, HG = 4, ES = 2, PER = D * D + D;
+    constexpr int SEG = D * ES;                   // 64 B: one head's slice of a row
+    constexpr int STROWS = 64, NST = CHK / 2 / STROWS;
+    constexpr int RPI = 16, LPS = STROWS / RPI;   // 4 pieces of 16 B per row, 16 rows per wave load, 4 loads per stage and operand
+    constexpr int WREG = 2 * STROWS * SEG;        // 8 KiB: K slice, V slice
+    static_assert((16 * 64 + 32) * 4 <= WREG, "combine tile");
+    extern __shared__ __attribute__((aligned(16))) char la_smem[];
+    const int b = blockIdx.x, chunk = blockIdx.y, hg = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31, lh = lane >> 5;
+    const int hf = wave >> 2, h = hg * HG + (wave & 3);
+    const int s0 = chunk * CHK + hf * (CHK / 2);
+    char* Kw = la_smem + wave * WREG;
+    char* Vw = Kw + STROWS * SEG;
+    const int prow = lane >> 2, ppc = lane & 3;
+    const char* kb = (const char*)k + (size_t)h * SEG + ppc * 16;
+    const char* vb = (const char*)v + (size_t)h * SEG + ppc * 16;
+    unsigned okm = 0u;   // which of this lane's rows hold data (inside the sequence, not masked: attentions.py:38-39)
+#pragma unroll
+    for (int st = 0; st < NST; ++st)
+#pragma unroll
+        for (int i = 0; i < LPS; ++i)
+            okm |= (s0 + st * STROWS + i * RPI + prow < S ? 1u : 0u) << (st * LPS + i);
+    if (kv_mask) {
+        unsigned mm = 0u;
+#pragma unroll
+        for (int st = 0; st < NST; ++st)
+#pragma unroll
+            for (int i = 0; i < LPS; ++i)
+                mm |= (kv_mask[(size_t)b * S + min(s0 + st * STROWS + i * RPI + prow, S - 1)] ? 1u : 0u) << (st * LPS + i);
+        okm &= mm;
+    }
+    uint4 rk[NST][LPS], rv[NST][LPS];
+#pragma unroll
+    for (int st = 0; st < NST; ++st)
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) {
+            const size_t srow = (size_t)b * S + min(s0 + st * STROWS + i * RPI + prow, S - 1);
+            rk[st][i] = *(const uint4*)(kb + srow * ldk * ES);
+            rv[st][i] = *(const uint4*)(vb + srow * ldv * ES);
+        }
+    __builtin_amdgcn_sched_barrier(0);   // every load is in flight before the first one is waited for
+    f32x16_t acc, aks;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = aks[r] = 0.f;
+    const unsigned one2 = cvt_pk_h16(1.f, 1.f);
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(one2, one2, one2, one2));
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) {
+            const unsigned m = ((okm >> (st * LPS + i)) & 1u) ? 0xffffffffu : 0u;
+            *(uint4*)(Kw + i * 1024 + lane * 16) = make_uint4(rk[st][i].x & m, rk[st][i].y & m, rk[st][i].z & m, rk[st][i].w & m);
+            *(uint4*)(Vw + i * 1024 + lane * 16) = make_uint4(rv[st][i].x & m, rv[st][i].y & m, rv[st][i].z & m, rv[st][i].w & m);
+        }
+        // (no barrier: the region is this wave's own, and LDS executes a wave's accesses in order)
+#pragma unroll
+        for (int g = 0; g < STROWS / 16; ++g) {
+            const char* kc = Kw + (16 * g + 8 * lh) * SEG + l31 * ES;   // column l31, rows 16 g + 8 lh ... + 7
+            const char* vc = Vw + (16 * g + 8 * lh) * SEG + l31 * ES;
+            unsigned ka[4], va[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ka[q] = (unsigned)*(const unsigned short*)(kc + (2 * q) * SEG) | ((unsigned)*(const unsigned short*)(kc + (2 * q + 1) * SEG) << 16);
+                va[q] = (unsigned)*(const unsigned short*)(vc + (2 * q) * SEG) | ((unsigned)*(const unsigned short*)(vc + (2 * q + 1) * SEG) << 16);
+            }
+            const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, make_uint4(ka[0], ka[1], ka[2], ka[3]));
+            const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(va[0], va[1], va[2], va[3]));
+            acc = mfma_h16_32x32x16(kf, vf, acc);     // D[d][dv] += sum_rows K[row][d] V[row][dv]
+            aks = mfma_h16_32x32x16(kf, ones, aks);   // D[d][*]  += sum_rows K[row][d]
+        }
+    }
+    // upper half -> LDS (its own region: its reads are done), lower half adds, scales and stores.  Accumulator register r of lane
+    // (l31, lh) is element [d = (r >> 2) * 8 + lh * 4 + (r & 3)][dv = l31]; Ksum[d] is any column of aks: the lanes with l31 == 0 carry it.
+    float* comb = (float*)(la_smem + (wave | 4) * WREG);
+    if (hf == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) comb[r * 64 + lane] = acc[r];
+        if (l31 == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) comb[16 * 64 + lh * 16 + r] = aks[r];
+        }
+    }
+    __syncthreads();
+    if (hf == 1) return;
+    const float inv_s = 1.0f / (float)S;
+    float* out = part + ((size_t)(b * H + h) * nchunk + chunk) * PER;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[((r >> 2) * 8 + lh * 4 + (r & 3)) * D + l31] = (acc[r] + comb[r * 64 + lane]) * inv_s;
+    if (l31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[D * D + (r >> 2) * 8 + lh * 4 + (r & 3)] = aks[r] + comb[16 * 64 + lh * 16 + r];
+    }
+}
+
 template <bool BF16, bool OUT_BF16>
 __global__ void __launch_bounds__(256)
 la_apply_mfma_kernel(const void* __restrict__ q, const uint8_t* __restrict__ q_mask, const float* __restrict__ kvfin,
@@ -463,7 +571,10 @@ extern "C" int GIM_FN(gim_linear_attention_kv)(const void* k, const void* v, con
     const bool mfma_path = D == 32 && H == 8 && (ldk * (dtype == GIM_H16 ? 2 : 4)) % 16 == 0 &&
                            (ldv * (dtype == GIM_H16 ? 2 : 4)) % 16 == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0;
     static const int kv2 = [] { const char* e = getenv("GIM_LA_KV2"); return e ? atoi(e) : 0; }();
-    const int chm = kv2 == 2 ? 128 : CHM;
+    // rows per workgroup of the MFMA kernels: 256; GIM_LA_KV2=2: 128; GIM_LA_KV2=3 (16-bit operands): 512 when 256-row chunks would
+    // need more than one round of 512 resident workgroups (the 16-sequence calls of the benchmark)
+    int chm = kv2 == 2 ? 128 : CHM;
+    if (kv2 == 3 && dtype == GIM_H16 && (int64_t)nb * ((S + 255) / 256) * 2 > 512) chm = 512;
     const int nc = mfma_path ? (S + chm - 1) / chm : nchunks(S);
     const int per = D * D + D;
     float* fin = kv_ws;
@@ -481,7 +592,19 @@ extern "C" int GIM_FN(gim_linear_attention_kv)(const void* k, const void* v, con
             attr.done();
         }
         const dim3 g2((unsigned)nb, (unsigned)nc, 2u);
-        // GIM_LA_KV2 = 1 / 2: 8-wave workgroups, wave-private streaming (la_kv_mfma2_kernel) on 256- / 128-row chunks; 0 (default): the 4-wave kernel
+        // GIM_LA_KV2 = 1 / 2: 8-wave workgroups, wave-private streaming (la_kv_mfma2_kernel) on 256- / 128-row chunks; 3: the same streaming with
+        // the 16-bit MFMA (la_kv_h16_kernel; fp32 operands fall to 1); 0 (default): the 4-wave kernel
+        if (kv2 == 3 && bf) {
+            static GimPerDevice attr3;
+            if (attr3.needed()) {
+                hipError_t e = hipFuncSetAttribute((const void*)la_kv_h16_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 64 * 32 * 2);
+                if (e == hipSuccess) e = hipFuncSetAttribute((const void*)la_kv_h16_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 64 * 32 * 2);
+                if (e != hipSuccess) { gim_set_error("linear_attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return GIM_ERR_LAUNCH; }
+                attr3.done();
+            }
+            if (chm == 512) hipLaunchKernelGGL(la_kv_h16_kernel<512>, g2, dim3(512), 8 * 2 * 64 * 32 * 2, s, k, v, kv_mask, part, S, ldk, ldv, nc);
+            else hipLaunchKernelGGL(la_kv_h16_kernel<256>, g2, dim3(512), 8 * 2 * 64 * 32 * 2, s, k, v, kv_mask, part, S, ldk, ldv, nc);
+        } else
         if (kv2) {
             const int smem2 = 8 * 2 * 64 * 32 * (bf ? 2 : 4);
             static GimPerDevice attr2;

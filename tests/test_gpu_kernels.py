@@ -456,9 +456,10 @@ def test_linear_attention_state(dt, shape):
     _assert_close(got[..., D * D:], ref[..., D * D:], 1e-5, f"Ksum {shape}")
 
 
-@pytest.mark.parametrize("mode", ["1", "2"], ids=["chunks256", "chunks128"])
+@pytest.mark.parametrize("mode", ["1", "2", "3"], ids=["chunks256", "chunks128", "mfma16"])
 def test_linear_attention_kv2_variant_forced(mode):
-    """GIM_LA_KV2=1 / 2: the 8-wave / wave-private-streaming shape of the KV reduction (la_kv_mfma2_kernel) under every linear-attention
+    """GIM_LA_KV2=1 / 2 / 3: the 8-wave / wave-private-streaming shapes of the KV reduction (la_kv_mfma2_kernel on 256- / 128-row chunks,
+    la_kv_h16_kernel: the 16-bit MFMA on K^T / V fragments read down the columns of the LDS slices) under every linear-attention
     test of this file and the token kernel's fused-apply tests (the choice is read once per process -> subprocess)"""
     import os
     import subprocess

@@ -570,7 +570,9 @@ extern "C" int GIM_FN(gim_linear_attention_kv)(const void* k, const void* v, con
     hipStream_t s = (hipStream_t)stream;
     const bool mfma_path = D == 32 && H == 8 && (ldk * (dtype == GIM_H16 ? 2 : 4)) % 16 == 0 &&
                            (ldv * (dtype == GIM_H16 ? 2 : 4)) % 16 == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0;
-    static const int kv2 = [] { const char* e = getenv("GIM_LA_KV2"); return e ? atoi(e) : 0; }();
+    // GIM_LA_KV2: shape of the coarse-level KV reduction (D = 32, H = 8).  3 (default): la_kv_h16_kernel for 16-bit operands, la_kv_mfma2_kernel
+    // for fp32 ones; 1 / 2: la_kv_mfma2_kernel on 256- / 128-row chunks; 0: la_kv_mfma_kernel (rounds 1-3).  profiles/r04_la_kv.txt
+    static const int kv2 = [] { const char* e = getenv("GIM_LA_KV2"); return e ? atoi(e) : 3; }();
     // rows per workgroup of the MFMA kernels: 256; GIM_LA_KV2=2: 128; GIM_LA_KV2=3 (16-bit operands): 512 when 256-row chunks would
     // need more than one round of 512 resident workgroups (the 16-sequence calls of the benchmark)
     int chm = kv2 == 2 ? 128 : CHM;

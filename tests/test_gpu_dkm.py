@@ -134,6 +134,20 @@ def test_dwconv5x5_bn_relu(dt, cin, mult, hw):
     assert (y[..., cout:] == 0).all()
 
 
+def test_dwconv5x5_lds_variant_forced():
+    """GIM_DWCONV_LDS=1: the LDS-staged persistent depthwise kernel (dwconv5x5_lds_kernel: halo tiles by LDS-DMA into two buffers, zero
+    padding / channel tails from the buffer descriptor) under every depthwise test of this file -- ragged tiles in both directions, 24 ...
+    1377 channels (both channel-chunk widths), maps with more tiles than workgroups.  Subprocess: the choice is read once per process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_dkm.py", "-m", "gpu", "-q", "-x",
+                          "-k", "dwconv5x5 and not forced", "-p", "no:cacheprovider"],
+                         cwd=root, capture_output=True, text=True, env={**os.environ, "GIM_DWCONV_LDS": "1"}, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+
+
 @pytest.mark.parametrize("cs", [24, 32])
 @pytest.mark.parametrize("hw", [(16, 32), (37, 45), (96, 128)], ids=["16x32", "37x45_ragged", "96x128"])
 def test_dwconv5x5_pw32_fused_block(hw, cs):

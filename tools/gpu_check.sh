@@ -4,7 +4,7 @@
 # steps (run in the order given; every step logs to gpurun_out/<tag>_<step>.log and prints a short tail):
 #   tests[=EXPR]   pytest -m gpu (-k EXPR)                 smoke          __graft_entry__.smoke()
 #   bench[=ARGS]   python bench.py ARGS  (full line)       quick[=ARGS]   bench.py without secondary workloads / alt modes / CPU leg
-#   prof           rocprofv3 --kernel-trace --stats of the headline command  -> <tag>_kernel_stats.txt
+#   prof           rocprofv3 --kernel-trace --stats of the headline command  -> <tag>_kernel_stats.txt      gaps   idle time between the kernels of a replayed forward (tools/prof_gaps.sh)
 #   pmc            MFMA-pipe occupancy per kernel family (tools/pmc_forward.sh)   traffic   HBM bytes (tools/pmc_traffic.sh)
 #   ab=V1;V2;...   same-box A/B of the step time over variants (tools/ab_forward.py: ENV=value[,ENV=value] or lib=alt / lib=new)
 #   cmd=COMMAND    any shell command (micro-benchmarks)
@@ -34,6 +34,7 @@ except Exception as e:
 PY
            tail -3 $log | cut -c1-300 ;;
     prof)  bash tools/prof_bench.sh ${tag}_prof 10 2>&1 | head -34 | cut -c1-200 ;;
+    gaps)  bash tools/prof_gaps.sh ${tag}_gaps ${arg:-8} 2>&1 | head -50 | cut -c1-200 ;;
     pmc)   bash tools/pmc_forward.sh ${tag} 2>&1 | head -26 | cut -c1-200 ;;
     traffic) bash tools/pmc_traffic.sh ${tag} 2>&1 | head -40 | cut -c1-200 ;;
     ab)    IFS=';' read -ra V <<< "$arg"; timeout 1500 python tools/ab_forward.py 2 "${V[@]}" > $log 2>&1; echo "[ab] rc=$?"; tail -12 $log | cut -c1-300 ;;

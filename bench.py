@@ -52,7 +52,7 @@ from gim_amd.runner import HostPairFeeder, all_gather_matches, bind_rank_to_core
 
 H, W = 480, 640
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense, MI355X_MICROARCH.md
-TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_traffic.json") for r in (4, 3, 2)) if os.path.exists(p)), "")
+TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_traffic.json") for r in ("4s2", 4, 3, 2)) if os.path.exists(p)), "")
 
 
 def parse_args(argv=None):

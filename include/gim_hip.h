@@ -134,8 +134,10 @@ int gim_posenc_add(const void* x, const float* pe, float* out_f32, void* out_t, 
  * kv_mask [nb*S] / q_mask [nb*L] (uint8, NULL = no mask): padded positions, attentions.py:35-39
  * (K, V rows with mask 0 do not contribute; Q rows with mask 0 give a zero message).
  * Arithmetic of step 1 at the coarse level (D = 32, H = 8): 16-bit operands -- exact products on the 16-bit MFMA, fp32 sums, 1/S applied
- * to the sums; fp32 operands -- fp32 MFMA on K and V/S.  Partial sums of 256- / 512-row chunks are combined in a fixed order: the result
- * does not depend on the batch a sequence travels in.  (GIM_LA_KV2 = 0 / 1 / 2 selects the earlier kernel shapes; default 3.) */
+ * to the sums; fp32 operands -- fp32 MFMA on K and V/S.  Partial sums of row chunks are combined in a fixed order (run-to-run deterministic).
+ * fp32 operands: 256-row chunks always -- a sequence's state does not depend on the batch it travels in, bit for bit.  16-bit operands: 256-row
+ * chunks, 512-row ones when nb * ceil(S / 256) * 2 > 512 (one round of resident workgroups): across that threshold the association of the
+ * fp32 additions differs (last-bit differences).  (GIM_LA_KV2 = 0 / 1 / 2 selects the earlier kernel shapes; default 3.) */
 int64_t gim_linear_attention_ws_bytes(int nb, int S, int H, int D);
 int gim_linear_attention_kv(const void* k, const void* v, const uint8_t* kv_mask, float* kv_ws, int nb,
                             int S, int H, int D, int ldk, int ldv, int dtype, gim_stream_t stream);

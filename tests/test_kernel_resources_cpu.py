@@ -99,3 +99,19 @@ def test_every_code_object_targets_gfx950_wave64():
     # (the metadata was parsed per object in _kernels(); here: the flagship kernels exist in both 16-bit flavours' objects and nothing
     #  was built for another target -- _kernels() asserts the target string of every object)
     assert any("token_mlp_kernel" in n for n in ks) and any("la_kv_h16_kernel" in n for n in ks)
+
+
+def test_kv_reduction_inner_loop_is_on_the_16bit_mfma():
+    """tools/isa_mix.py on la_kv_h16_kernel<256> (hipcc -S, no GPU): two stages x four 16-row groups x (K^T V, K^T 1) = 16 MFMAs of
+    the 32x32x16 shape (32 issue cycles each) per wave, no fp32 MFMA, no scratch, one workgroup barrier (the combine of the two halves)."""
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not found")
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_mix.py"), "gim_amd/csrc/linear_attention.hip", "la_kv_h16_kernel<256>",
+                          "--f16", "--min", "100000"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-1500:]
+    tot = [ln for ln in out.stdout.splitlines() if ln.startswith("static total")]
+    assert len(tot) == 1, out.stdout[-1500:]
+    f = tot[0].split()
+    mfma, mfma_cyc, scratch, barriers = int(f[2]), int(f[3]), int(f[9]), int(f[11])
+    assert (mfma, mfma_cyc, scratch, barriers) == (16, 512, 0, 1), tot[0]

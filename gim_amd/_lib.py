@@ -25,6 +25,7 @@ class ConvArgs(ctypes.Structure):
         ("N", c_int), ("npad", c_int), ("kpad", c_int), ("act", c_int), ("act_cols", c_int), ("res_mod", c_int),
         ("dtype", c_int), ("out_dtype", c_int), ("res_dtype", c_int), ("use_lds_dma", c_int),
         ("ups", c_void_p), ("ups_h", c_int), ("ups_w", c_int), ("ups_ld", c_int),
+        ("health", c_void_p),
     ]
 
 
@@ -68,7 +69,6 @@ class LgAssignArgs(ctypes.Structure):
 PROTOTYPES = {
     "gim_version": (c_int, []),
     "gim_last_error": (ctypes.c_char_p, []),
-    "gim_set_range_guard": (c_int, [c_void_p]),
     "gim_ktile_bytes": (c_int, []),
     "gim_npad_granule": (c_int, []),
     "gim_nchw_to_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
@@ -91,14 +91,14 @@ PROTOTYPES = {
     "gim_coarse_conf_matrix": (c_int, [ctypes.POINTER(CoarseArgs), c_void_p, c_void_p]),
     "gim_fine_gather": (c_int, [c_void_p] * 7 + [c_int] * 14 + [c_void_p]),
     "gim_fine_match": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_float, c_int, c_void_p]),
-    "gim_bneck64_fused": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p]),
-    "gim_bneck64_fused_f16": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p]),
-    "gim_bneck64_fused_ds": (c_int, [c_void_p] * 11 + [c_int] * 3 + [c_void_p]),
-    "gim_bneck64_fused_ds_f16": (c_int, [c_void_p] * 11 + [c_int] * 3 + [c_void_p]),
-    "gim_bneck_tail128": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
-    "gim_bneck_tail128_f16": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
-    "gim_bneck_tail256": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
-    "gim_bneck_tail256_f16": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
+    "gim_bneck64_fused": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p, c_void_p]),       # ..., health, stream
+    "gim_bneck64_fused_f16": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p, c_void_p]),
+    "gim_bneck64_fused_ds": (c_int, [c_void_p] * 11 + [c_int] * 3 + [c_void_p, c_void_p]),
+    "gim_bneck64_fused_ds_f16": (c_int, [c_void_p] * 11 + [c_int] * 3 + [c_void_p, c_void_p]),
+    "gim_bneck_tail128": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p, c_void_p]),
+    "gim_bneck_tail128_f16": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p, c_void_p]),
+    "gim_bneck_tail256": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p, c_void_p]),
+    "gim_bneck_tail256_f16": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p, c_void_p]),
     "gim_token_mlp_weight_bytes": (c_int64, []),
     "gim_token_mlp": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_float, c_void_p]),
     "gim_token_mlp_f16": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_float, c_void_p]),

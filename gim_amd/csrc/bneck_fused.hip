@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
 
 extern "C" int GIM_FN(gim_bneck64_fused_ds)(const void* t1, const void* x_in, void* x_out, void* t1_next, const void* w2, const void* w3,
                                     const void* wds, const void* w1n, const float* b2, const float* b3ds, const float* b1n, int B, int H, int W,
-                                    gim_stream_t stream) {
+                                    int32_t* health, gim_stream_t stream) {
     GIM_REQUIRE(t1 && x_in && x_out && t1_next && w2 && w3 && wds && w1n && b2 && b3ds && b1n, "bneck64_fused_ds: NULL pointer");
     GIM_REQUIRE(B > 0 && H > 0 && W > 0 && H % TH == 0 && W % TW == 0, "bneck64_fused_ds: H %% 8 == 0 and W %% 32 == 0 required (got %d x %d)", H, W);
     GIM_REQUIRE((int64_t)B * H * W * C4 * 2 < (int64_t)0xFFFFFFF0ll, "bneck64_fused_ds: tensor too large for 32-bit buffer offsets");
@@ -336,7 +336,7 @@ extern "C" int GIM_FN(gim_bneck64_fused_ds)(const void* t1, const void* x_in, vo
     Args a;
     a.t1 = (const unsigned short*)t1; a.res = (const unsigned short*)x_in; a.wds = (const unsigned short*)wds; a.xo = (unsigned short*)x_out;
     a.t1n = (unsigned short*)t1_next; a.w2 = (const unsigned short*)w2; a.w3 = (const unsigned short*)w3; a.w1n = (const unsigned short*)w1n;
-    a.b2 = b2; a.b3 = b3ds; a.b1n = b1n; a.B = B; a.H = H; a.W = W; a.health = gim_range_guard_ptr();
+    a.b2 = b2; a.b3 = b3ds; a.b1n = b1n; a.B = B; a.H = H; a.W = W; a.health = (int*)health;
     a.t1_bytes = (unsigned)((size_t)B * H * W * P * 2); a.w2_bytes = 64 * 1152; a.w3_bytes = 256 * 128; a.w1n_bytes = 64 * 512;
     hipLaunchKernelGGL((bneck64_kernel<64, true>), dim3((unsigned)(B * (H / TH) * (W / TW))), dim3(512), SMEM, (hipStream_t)stream, a);
     return gim_check_launch("bneck64_fused_ds");
@@ -344,7 +344,7 @@ extern "C" int GIM_FN(gim_bneck64_fused_ds)(const void* t1, const void* x_in, vo
 
 extern "C" int GIM_FN(gim_bneck64_fused)(const void* t1, const void* res, void* x_out, void* t1_next, const void* w2, const void* w3,
                                  const void* w1n, const float* b2, const float* b3, const float* b1n, int B, int H, int W,
-                                 int n_next, gim_stream_t stream) {
+                                 int n_next, int32_t* health, gim_stream_t stream) {
     GIM_REQUIRE(t1 && res && x_out && w2 && w3 && b2 && b3, "bneck64_fused: NULL pointer");
     GIM_REQUIRE((t1_next == nullptr) == (w1n == nullptr) && (t1_next == nullptr || b1n), "bneck64_fused: t1_next, w1n and b1n go together");
     GIM_REQUIRE(t1_next ? (n_next == 64 || n_next == 128) : n_next == 0, "bneck64_fused: n_next must be 64 or 128 with t1_next, 0 without (got %d)", n_next);
@@ -361,7 +361,7 @@ extern "C" int GIM_FN(gim_bneck64_fused)(const void* t1, const void* res, void* 
     Args a;
     a.t1 = (const unsigned short*)t1; a.res = (const unsigned short*)res; a.wds = nullptr; a.xo = (unsigned short*)x_out; a.t1n = (unsigned short*)t1_next;
     a.w2 = (const unsigned short*)w2; a.w3 = (const unsigned short*)w3; a.w1n = (const unsigned short*)w1n;
-    a.b2 = b2; a.b3 = b3; a.b1n = b1n; a.B = B; a.H = H; a.W = W; a.health = gim_range_guard_ptr();
+    a.b2 = b2; a.b3 = b3; a.b1n = b1n; a.B = B; a.H = H; a.W = W; a.health = (int*)health;
     a.t1_bytes = (unsigned)((size_t)B * H * W * P * 2); a.w2_bytes = 64 * 1152; a.w3_bytes = 256 * 128; a.w1n_bytes = (unsigned)n_next * 512;
     const unsigned tiles = (unsigned)(B * (H / TH) * (W / TW));
     if (n_next == 0) hipLaunchKernelGGL(bneck64_kernel<0>, dim3(tiles), dim3(512), SMEM, (hipStream_t)stream, a);

@@ -307,7 +307,7 @@ int launch_tail(const Args& a, hipStream_t s) {
 int tail_nw() { static const int v = [] { const char* e = getenv("GIM_BNECK_TAIL_NW"); return e ? atoi(e) : 0; }(); return v; }
 
 int tail_entry(int P, const void* t2, const void* res, void* x_out, void* t1_next, const void* w3, const void* w1n,
-               const float* b3, const float* b1n, int M, int n_next, int act_next, gim_stream_t stream) {
+               const float* b3, const float* b1n, int M, int n_next, int act_next, int32_t* health, gim_stream_t stream) {
     GIM_REQUIRE(t2 && res && t1_next && w3 && w1n && b3 && b1n, "bneck_tail: NULL pointer");
     GIM_REQUIRE(act_next == GIM_ACT_RELU || act_next == GIM_ACT_NONE, "bneck_tail: activation of the next conv1 must be relu or none");
     GIM_REQUIRE(M > 0 && M % 256 == 0, "bneck_tail: the pixel row count must be a multiple of 256 (got %d)", M);
@@ -315,7 +315,7 @@ int tail_entry(int P, const void* t2, const void* res, void* x_out, void* t1_nex
     Args a;
     a.t2 = (const unsigned short*)t2; a.res = (const unsigned short*)res; a.xo = (unsigned short*)x_out; a.t1n = (unsigned short*)t1_next;
     a.w3 = (const unsigned short*)w3; a.w1n = (const unsigned short*)w1n; a.b3 = b3; a.b1n = b1n; a.M = M; a.act1 = act_next;
-    a.w3_bytes = (unsigned)(4 * P * P * 2); a.w1n_bytes = (unsigned)(n_next * 4 * P * 2); a.health = gim_range_guard_ptr();
+    a.w3_bytes = (unsigned)(4 * P * P * 2); a.w1n_bytes = (unsigned)(n_next * 4 * P * 2); a.health = (int*)health;
     if (P == 128) {
         GIM_REQUIRE(n_next == 128 || n_next == 256, "bneck_tail128: n_next must be 128 or 256 (got %d)", n_next);
         return n_next == 128 ? launch_tail<128, 128>(a, (hipStream_t)stream) : launch_tail<128, 256>(a, (hipStream_t)stream);
@@ -329,12 +329,12 @@ int tail_entry(int P, const void* t2, const void* res, void* x_out, void* t1_nex
 }  // namespace
 
 extern "C" int GIM_FN(gim_bneck_tail128)(const void* t2, const void* res, void* x_out, void* t1_next, const void* w3, const void* w1n,
-                                         const float* b3, const float* b1n, int M, int n_next, int act_next, gim_stream_t stream) {
+                                         const float* b3, const float* b1n, int M, int n_next, int act_next, int32_t* health, gim_stream_t stream) {
     GIM_REQUIRE(x_out, "bneck_tail128: NULL x_out");
-    return tail_entry(128, t2, res, x_out, t1_next, w3, w1n, b3, b1n, M, n_next, act_next, stream);
+    return tail_entry(128, t2, res, x_out, t1_next, w3, w1n, b3, b1n, M, n_next, act_next, health, stream);
 }
 
 extern "C" int GIM_FN(gim_bneck_tail256)(const void* t2, const void* res, void* x_out, void* t1_next, const void* w3, const void* w1n,
-                                         const float* b3, const float* b1n, int M, int n_next, int act_next, gim_stream_t stream) {
-    return tail_entry(256, t2, res, x_out, t1_next, w3, w1n, b3, b1n, M, n_next, act_next, stream);
+                                         const float* b3, const float* b1n, int M, int n_next, int act_next, int32_t* health, gim_stream_t stream) {
+    return tail_entry(256, t2, res, x_out, t1_next, w3, w1n, b3, b1n, M, n_next, act_next, health, stream);
 }

@@ -53,6 +53,7 @@ __device__ __forceinline__ void epilogue_rows(const gim_conv_args& a, const floa
     float bias[G];
 #pragma unroll
     for (int e = 0; e < G; ++e) bias[e] = a.bias ? a.bias[n + e] : 0.f;
+    unsigned hm = 0u;   // fp16 range guard of a residual stream stored here (gim_common.h)
     for (int r = t / LPR; r < BM; r += RPP) {
         const int m = m0 + r;
         if (m >= M) break;
@@ -80,10 +81,12 @@ __device__ __forceinline__ void epilogue_rows(const gim_conv_args& a, const floa
             o.x = cvt_pk_h16(v[0], v[1]); o.y = cvt_pk_h16(v[2], v[3]);
             o.z = cvt_pk_h16(v[4], v[5]); o.w = cvt_pk_h16(v[6], v[7]);
             *(uint4*)((unsigned short*)a.y + yo) = o;
+            if (a.res) hm = h16_range_fold_abs(hm, o);
         } else {
             *(float4*)((float*)a.y + yo) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
+    if constexpr (OUT_BF16) h16_range_check(a.health, hm);
 }
 
 template <int BM, int BN, int WM, int WN, bool BF16, bool LDSDMA>
@@ -368,13 +371,18 @@ struct Epilogue {
                         }
                     }
                 } else {
+                unsigned hm = 0u;   // fp16 range guard: an un-normalised residual stream is stored here (x + identity; gim_common.h)
 #pragma unroll
                 for (int k = 0; k < NI; ++k) {
                     const int row = k * RPI + rrow;
                     const int m = m0 + wm * WTM + j * 32 + row;
                     const uint4 o = *(const uint4*)(wl + row * RB + ((rslot ^ (row & 7)) << 4));
-                    if (ncol_ok && (full || m < M)) *(uint4*)((char*)a.y + ((size_t)m * a.ldy + ncol) * OES) = o;
+                    if (ncol_ok && (full || m < M)) {
+                        *(uint4*)((char*)a.y + ((size_t)m * a.ldy + ncol) * OES) = o;
+                        if constexpr (HAS_RES && OUT_BF16) hm = h16_range_fold_abs(hm, o);
+                    }
                 }
+                if constexpr (HAS_RES && OUT_BF16) { if (!out_bf) h16_range_check(a.health, hm); }
                 }
             }
         }

@@ -170,8 +170,9 @@ template <> struct ElemIO<false> {
 // stored activation sits behind a BatchNorm or a LayerNorm), and downstream ReLUs scrub the evidence: fmaxf(NaN, 0) = 0, so an
 // overflow rarely survives to the outputs as a NaN.  The kernels that STORE a residual stream (bneck_fused.hip, bneck_tail.hip) track
 // whether a value they write became inf -- six VALU operations per 16-byte row piece, fp16 flavour only -- and OR 4 into the caller's health word
-// (gim_set_range_guard(): the coarse count buffer's word [1], read back with the match count) when it is beyond the range.
-int* gim_range_guard_ptr();   // runtime.hip: the device word registered for the calling thread's current device, or NULL
+// (the `health` argument of their entry points -- gim_amd passes the coarse count buffer's word [1], read back with the match count --
+// or NULL: no check) when it is beyond the range.  Round 5: an ARGUMENT, not a process-wide registration: two modules on two streams
+// of one device do not share it, and a launch that raises leaves nothing registered.
 // The check runs on the PACKED row (16 bytes = 8 stored halves) the kernel is about to write, not on the fp32 values: packed
 // fp16 maxima fold it into one word with transient registers only, and the verdict is a bool, i.e. a lane mask in two SGPRs.
 // (A float running maximum -- or any test on the accumulators -- costs registers where bneck_tail's 256-channel variants have none:
@@ -200,6 +201,17 @@ __device__ __forceinline__ void h16_range_check(int* health, unsigned m) {
 #if GIM_HALF_KIND
     if (__builtin_expect((((m & 0x7FFF7FFFu) + 0x04000400u) & 0x80008000u) != 0u, 0))
         if (health != nullptr) atomicOr(health, 4);
+#endif
+}
+// sign-insensitive variant for stores that are not behind a ReLU (gim_conv2d_bn_act with a residual operand): fold |v| as 16-bit
+// integers -- a half's magnitude bits order like unsigned integers, inf = 0x7C00 is the largest finite-or-inf pattern, NaNs lie above
+typedef unsigned short gim_us2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned h16_range_fold_abs(unsigned m, const uint4 v) {
+#if GIM_HALF_KIND
+    auto mx = [](unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(gim_us2_t, a), __builtin_bit_cast(gim_us2_t, b))); };
+    return mx(mx(m, v.x & 0x7FFF7FFFu), mx(mx(v.y & 0x7FFF7FFFu, v.z & 0x7FFF7FFFu), v.w & 0x7FFF7FFFu));
+#else
+    return m;
 #endif
 }
 __device__ __forceinline__ void h16_range_flag(int* health, bool any) {

@@ -206,83 +206,23 @@ la_short_kernel(const void* __restrict__ q, const void* __restrict__ k, const vo
 // contractions.  v_mfma_f32_32x32x2_f32 (exact fp32, serves the parity mode too) does them at one LDS / register
 // operand per 2048 flops, which leaves both kernels HBM-bound.
 //
-//   la_kv_mfma:    KV_h[d][dv] = sum_s K[s][h,d] * V[s][h,dv]/S : A = K (m = d), B = V (n = dv), k = s -- row-major
-//                  [s][256] tiles in LDS feed both operands without any transposition (lane = channel).
+//   la_kv_mfma2:   KV_h[d][dv] = sum_s K[s][h,d] * V[s][h,dv]/S : A = K (m = d), B = V (n = dv), k = s -- a wave's row-major
+//                  head slice in LDS feeds both operands without any transposition (lane = channel).
 //   la_apply_mfma: out[row][dv] = sum_d Q[row][h,d] KV_h[d][dv]   : A = Q straight from global (lane = row; the k
 //                  order is permuted to d = 16*(lane>>5) + step so that every lane reads 16 contiguous channels),
 //                  B = KV_h from LDS; the row normaliser z = Q.Ksum is a 16-term dot product per lane, moved to the
 //                  accumulator layout with one shuffle per register.
-template <bool BF16>
-__global__ void __launch_bounds__(256)
-la_kv_mfma_kernel(const void* __restrict__ k, const void* __restrict__ v, const uint8_t* __restrict__ kv_mask,
-                  float* __restrict__ part, int S, int ldk, int ldv, int nchunk) {
-    // workgroup = (sequence b, 128-row chunk, head group of 4): one head per wave.  Small workgroups (32 KiB LDS
-    // in bf16) keep 4 of them resident per CU, which is what hides the global -> LDS staging latency.
-    constexpr int D = 32, H = 8, HG = 4, ES = BF16 ? 2 : 4, ROWB = HG * D * ES, SUB = 64, PER = D * D + D;
-    extern __shared__ __attribute__((aligned(16))) char la_smem[];
-    char* Ks = la_smem;
-    char* Vs = la_smem + SUB * ROWB;
-    const int b = blockIdx.x, chunk = blockIdx.y, hg = blockIdx.z, s0 = chunk * CHM;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int h = hg * HG + wave;
-    const float slen = (float)S, inv_s = 1.0f / slen;
-    f32x16_t acc;
-    float ks = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const char* kb = (const char*)k + (size_t)hg * HG * D * ES;
-    const char* vb = (const char*)v + (size_t)hg * HG * D * ES;
-    for (int sub = 0; sub < CHM / SUB; ++sub) {
-        const int base = s0 + sub * SUB;
-        if (base >= S) break;
-        __syncthreads();
-        constexpr int CPR = ROWB / 16;  // 16-byte chunks per row
-        for (int c = t; c < SUB * CPR; c += 256) {
-            const int row = c / CPR, off = (c - row * CPR) * 16, sidx = base + row;
-            uint4 kk = make_uint4(0u, 0u, 0u, 0u), vv = kk;
-            if (sidx < S && (!kv_mask || kv_mask[(size_t)b * S + sidx])) {  // K * kv_mask, values * kv_mask (attentions.py:38-39)
-                kk = *(const uint4*)(kb + ((size_t)b * S + sidx) * ldk * ES + off);
-                vv = *(const uint4*)(vb + ((size_t)b * S + sidx) * ldv * ES + off);
-            }
-            *(uint4*)(Ks + row * ROWB + off) = kk;
-            *(uint4*)(Vs + row * ROWB + off) = vv;
-        }
-        __syncthreads();
-        const int col = (wave * D + l31) * ES;
-#pragma unroll 8
-        for (int st = 0; st < SUB / 2; ++st) {
-            const int row = 2 * st + lh;
-            float a, bv;
-            if constexpr (BF16) {
-                a = h16_to_f32(*(const unsigned short*)(Ks + row * ROWB + col));
-                bv = h16_to_f32(*(const unsigned short*)(Vs + row * ROWB + col)) * inv_s;
-            } else {
-                a = *(const float*)(Ks + row * ROWB + col);
-                bv = *(const float*)(Vs + row * ROWB + col) / slen;  // values / v_length (attentions.py:42)
-            }
-            ks += a;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
-        }
-    }
-    float* out = part + ((size_t)(b * H + h) * nchunk + chunk) * PER;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) out[((r >> 2) * 8 + lh * 4 + (r & 3)) * D + l31] = acc[r];
-    const float kt = ks + __shfl_xor(ks, 32, 64);
-    if (lh == 0) out[D * D + l31] = kt;
-}
-
-// Round 4, second shape of the same reduction (GIM_LA_KV2=1).  The kernel above runs 304 / 608 workgroups per coarse-level call, each a
+// KV reduction for fp32 operands (the parity mode).  Round 4: the first MFMA kernel ran 304 / 608 workgroups per coarse-level call, each a
 // serial chain of four (global load -> barrier -> LDS -> barrier -> 32 MFMAs) steps: ~1.2 - 2.4 workgroups per CU cannot hide a chain
-// of four memory round trips (25 us per call for 39 - 79 MB that sit in L2 / MALL behind the token kernel that wrote them).  Here
+// of four memory round trips.  Here
 //   * 8 waves per workgroup = (head, half of the 256-row chunk): twice the waves, half the MFMA chain per wave;
-//   * every wave streams ITS OWN head slice (64 / 128 B per row) of its 128 rows: ALL of its global loads are issued before the
-//     first one is consumed (16 / 32 x 16 B per lane and operand pair: one memory round trip per wave instead of four);
+//   * every wave streams ITS OWN head slice (128 B per row) of its 128 rows: ALL of its global loads are issued before the
+//     first one is consumed (one memory round trip per wave instead of four);
 //   * the slices go through a wave-private LDS region (lane = (row, 16-byte piece) on the way in, lane = channel on the way out: the
 //     fp32 MFMA wants one scalar per lane and row) -- no workgroup barrier in the loop, a wave's own LDS accesses execute in order;
-//   * the two halves of a head are added in a fixed order through LDS at the end (lower half + upper half): deterministic, same
-//     partial layout, same finalize pass.
-// Arithmetic per row as above (K exact, V * 1/S or V / S in fp32, fp32 MFMA); only the association of the 256-row sum differs.
-template <bool BF16, int CHK>   // CHK rows per workgroup (256: the partial count of the kernel above; 128: twice the workgroups, one stage per wave)
+//   * the two halves of a head are added in a fixed order through LDS at the end (lower half + upper half): deterministic.
+// Arithmetic per row: K exact, V / S in fp32, fp32 MFMA (attentions.py:42-43).
+template <bool BF16, int CHK>   // CHK rows per workgroup (256 is what the dispatch below instantiates, for fp32 operands)
 __global__ void __launch_bounds__(512)
 la_kv_mfma2_kernel(const void* __restrict__ k, const void* __restrict__ v, const uint8_t* __restrict__ kv_mask,
                    float* __restrict__ part, int S, int ldk, int ldv, int nchunk) {
@@ -380,7 +320,7 @@ la_kv_mfma2_kernel(const void* __restrict__ k, const void* __restrict__ v, const
     if (lh == 0) out[D * D + l31] = kt;
 }
 
-// Third shape (GIM_LA_KV2=3, 16-bit operands only).  Measured (profiles/r04_la_kv.txt): the wave-private streaming above takes the call
+// 16-bit operands.  Measured (profiles/r04_la_kv.txt): the wave-private streaming above takes the call
 // from 27.8 to 24.3 us only -- 153 600 v_mfma_f32_32x32x2_f32 of 64 cycles each are 4 waves x 4 096 cycles on the SIMDs of a CU that
 // holds two workgroups: the fp32 MFMA (2 rows per instruction) is the chain, not the memory.  16-bit K and V multiply exactly in fp32,
 // so the 16-bit MFMA (16 rows per 32-cycle instruction) computes the same sums:
@@ -389,7 +329,10 @@ la_kv_mfma2_kernel(const void* __restrict__ k, const void* __restrict__ v, const
 //   in the last bit of the fp32 result); Ksum = K^T 1 comes from a second MFMA against a fragment of ones (every column of that
 //   accumulator is Ksum).  Per 16 rows and wave: 16 LDS reads, 8 packs, 2 MFMAs = 64 MFMA cycles instead of 512.
 // CHK rows per workgroup: 256, or 512 for the 16-sequence (self-attention) calls so that one round of <= 512 resident workgroups covers
-// the launch (a workgroup holds 64 KiB of LDS: two per CU).
+// the launch (a workgroup holds 64 KiB of LDS: two per CU).  The partials are those of 256-ROW chunks in BOTH shapes -- a 256-row partial is
+// (sum of its first 128 rows + sum of its last 128 rows) / S: in the 256-row shape the two sums belong to the two wave halves and meet in LDS,
+// in the 512-row shape one wave owns a whole 256-row chunk and keeps two accumulator sets -- so a sequence's state is bit-identical whatever
+// batch it travels in (round 5; the round-4 kernel summed 256 rows in one accumulator when the batch was large).
 template <int CHK>
 __global__ void __launch_bounds__(512)
 la_kv_h16_kernel(const void* __restrict__ k, const void* __restrict__ v, const uint8_t* __restrict__ kv_mask,
@@ -435,9 +378,10 @@ la_kv_h16_kernel(const void* __restrict__ k, const void* __restrict__ v, const u
             rv[st][i] = *(const uint4*)(vb + srow * ldv * ES);
         }
     __builtin_amdgcn_sched_barrier(0);   // every load is in flight before the first one is waited for
-    f32x16_t acc, aks;
+    // acc / aks: rows [0, 128) of this wave's share, acc2 / aks2: rows [128, 256) (CHK = 512 only)
+    f32x16_t acc, aks, acc2, aks2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = aks[r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[r] = aks[r] = acc2[r] = aks2[r] = 0.f;
     const unsigned one2 = cvt_pk_h16(1.f, 1.f);
     const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(one2, one2, one2, one2));
 #pragma unroll
@@ -461,30 +405,49 @@ la_kv_h16_kernel(const void* __restrict__ k, const void* __restrict__ v, const u
             }
             const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, make_uint4(ka[0], ka[1], ka[2], ka[3]));
             const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(va[0], va[1], va[2], va[3]));
-            acc = mfma_h16_32x32x16(kf, vf, acc);     // D[d][dv] += sum_rows K[row][d] V[row][dv]
-            aks = mfma_h16_32x32x16(kf, ones, aks);   // D[d][*]  += sum_rows K[row][d]
+            if (CHK == 512 && st >= NST / 2) {   // compile-time: the stage loop is unrolled
+                acc2 = mfma_h16_32x32x16(kf, vf, acc2);
+                aks2 = mfma_h16_32x32x16(kf, ones, aks2);
+            } else {
+                acc = mfma_h16_32x32x16(kf, vf, acc);     // D[d][dv] += sum_rows K[row][d] V[row][dv]
+                aks = mfma_h16_32x32x16(kf, ones, aks);   // D[d][*]  += sum_rows K[row][d]
+            }
         }
     }
-    // upper half -> LDS (its own region: its reads are done), lower half adds, scales and stores.  Accumulator register r of lane
-    // (l31, lh) is element [d = (r >> 2) * 8 + lh * 4 + (r & 3)][dv = l31]; Ksum[d] is any column of aks: the lanes with l31 == 0 carry it.
-    float* comb = (float*)(la_smem + (wave | 4) * WREG);
-    if (hf == 1) {
+    // Accumulator register r of lane (l31, lh) is element [d = (r >> 2) * 8 + lh * 4 + (r & 3)][dv = l31]; Ksum[d] is any column of aks: the
+    // lanes with l31 == 0 carry it.
+    const float inv_s = 1.0f / (float)S;
+    if constexpr (CHK == 512) {
+        // this wave owns the 256-row chunk 2 chunk + hf whole: (first 128 rows + last 128 rows) / S, exactly the 256-row shape's sum
+        const int vchunk = 2 * chunk + hf;
+        if (vchunk >= nchunk) return;             // wave-uniform: the sequence ends before this chunk (S % 512 <= 256)
+        float* out = part + ((size_t)(b * H + h) * nchunk + vchunk) * PER;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) comb[r * 64 + lane] = acc[r];
+        for (int r = 0; r < 16; ++r) out[((r >> 2) * 8 + lh * 4 + (r & 3)) * D + l31] = (acc[r] + acc2[r]) * inv_s;
         if (l31 == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) comb[16 * 64 + lh * 16 + r] = aks[r];
+            for (int r = 0; r < 16; ++r) out[D * D + (r >> 2) * 8 + lh * 4 + (r & 3)] = aks[r] + aks2[r];
         }
-    }
-    __syncthreads();
-    if (hf == 1) return;
-    const float inv_s = 1.0f / (float)S;
-    float* out = part + ((size_t)(b * H + h) * nchunk + chunk) * PER;
+    } else {
+        // upper half -> LDS (its own region: its reads are done), lower half adds, scales and stores
+        float* comb = (float*)(la_smem + (wave | 4) * WREG);
+        if (hf == 1) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) out[((r >> 2) * 8 + lh * 4 + (r & 3)) * D + l31] = (acc[r] + comb[r * 64 + lane]) * inv_s;
-    if (l31 == 0) {
+            for (int r = 0; r < 16; ++r) comb[r * 64 + lane] = acc[r];
+            if (l31 == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[D * D + (r >> 2) * 8 + lh * 4 + (r & 3)] = aks[r] + comb[16 * 64 + lh * 16 + r];
+                for (int r = 0; r < 16; ++r) comb[16 * 64 + lh * 16 + r] = aks[r];
+            }
+        }
+        __syncthreads();
+        if (hf == 1) return;
+        float* out = part + ((size_t)(b * H + h) * nchunk + chunk) * PER;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[((r >> 2) * 8 + lh * 4 + (r & 3)) * D + l31] = (acc[r] + comb[r * 64 + lane]) * inv_s;
+        if (l31 == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[D * D + (r >> 2) * 8 + lh * 4 + (r & 3)] = aks[r] + comb[16 * 64 + lh * 16 + r];
+        }
     }
 }
 
@@ -570,33 +533,19 @@ extern "C" int GIM_FN(gim_linear_attention_kv)(const void* k, const void* v, con
     hipStream_t s = (hipStream_t)stream;
     const bool mfma_path = D == 32 && H == 8 && (ldk * (dtype == GIM_H16 ? 2 : 4)) % 16 == 0 &&
                            (ldv * (dtype == GIM_H16 ? 2 : 4)) % 16 == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0;
-    // GIM_LA_KV2: shape of the coarse-level KV reduction (D = 32, H = 8).  3 (default): la_kv_h16_kernel for 16-bit operands, la_kv_mfma2_kernel
-    // for fp32 ones; 1 / 2: la_kv_mfma2_kernel on 256- / 128-row chunks; 0: la_kv_mfma_kernel (rounds 1-3).  profiles/r04_la_kv.txt
-    static const int kv2 = [] { const char* e = getenv("GIM_LA_KV2"); return e ? atoi(e) : 3; }();
-    // rows per workgroup of the MFMA kernels: 256; GIM_LA_KV2=2: 128; GIM_LA_KV2=3 (16-bit operands): 512 when 256-row chunks would
-    // need more than one round of 512 resident workgroups (the 16-sequence calls of the benchmark)
-    int chm = kv2 == 2 ? 128 : CHM;
-    if (kv2 == 3 && dtype == GIM_H16 && (int64_t)nb * ((S + 255) / 256) * 2 > 512) chm = 512;
-    const int nc = mfma_path ? (S + chm - 1) / chm : nchunks(S);
+    // coarse level (D = 32, H = 8): la_kv_h16_kernel for 16-bit operands, la_kv_mfma2_kernel for fp32 ones (profiles/r04_la_kv.txt); partials
+    // are per 256-row chunk.  16-bit operands: 512 rows per WORKGROUP when 256-row workgroups would need more than one round of 512 resident
+    // ones (the 16-sequence calls of the benchmark) -- the partials stay those of 256-row chunks, so the state of a sequence does not depend on nb
+    const bool bf = dtype == GIM_H16;
+    const bool wg512 = mfma_path && bf && (int64_t)nb * ((S + 255) / 256) * 2 > 512;
+    const int nc = mfma_path ? (S + CHM - 1) / CHM : nchunks(S);
     const int per = D * D + D;
     float* fin = kv_ws;
     float* part = nc > 1 ? kv_ws + (size_t)nb * H * per : kv_ws;
     dim3 grid((unsigned)(nb * H), (unsigned)nc);
-    const bool bf = dtype == GIM_H16;
     if (mfma_path) {
-        // coarse level: fp32-MFMA kernel, 4 heads of a 128-row chunk per workgroup
-        const int smem = 2 * 64 * 128 * (bf ? 2 : 4);
-        static GimPerDevice attr;
-        if (attr.needed()) {
-            hipError_t e = hipFuncSetAttribute((const void*)la_kv_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 128 * 2);
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)la_kv_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 128 * 4);
-            if (e != hipSuccess) { gim_set_error("linear_attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return GIM_ERR_LAUNCH; }
-            attr.done();
-        }
-        const dim3 g2((unsigned)nb, (unsigned)nc, 2u);
-        // GIM_LA_KV2 = 1 / 2: 8-wave workgroups, wave-private streaming (la_kv_mfma2_kernel) on 256- / 128-row chunks; 3: the same streaming with
-        // the 16-bit MFMA (la_kv_h16_kernel; fp32 operands fall to 1); 0 (default): the 4-wave kernel
-        if (kv2 == 3 && bf) {
+        const dim3 g2((unsigned)nb, (unsigned)(wg512 ? (S + 511) / 512 : nc), 2u);
+        if (bf) {
             static GimPerDevice attr3;
             if (attr3.needed()) {
                 hipError_t e = hipFuncSetAttribute((const void*)la_kv_h16_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 64 * 32 * 2);
@@ -604,29 +553,18 @@ extern "C" int GIM_FN(gim_linear_attention_kv)(const void* k, const void* v, con
                 if (e != hipSuccess) { gim_set_error("linear_attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return GIM_ERR_LAUNCH; }
                 attr3.done();
             }
-            if (chm == 512) hipLaunchKernelGGL(la_kv_h16_kernel<512>, g2, dim3(512), 8 * 2 * 64 * 32 * 2, s, k, v, kv_mask, part, S, ldk, ldv, nc);
+            if (wg512) hipLaunchKernelGGL(la_kv_h16_kernel<512>, g2, dim3(512), 8 * 2 * 64 * 32 * 2, s, k, v, kv_mask, part, S, ldk, ldv, nc);
             else hipLaunchKernelGGL(la_kv_h16_kernel<256>, g2, dim3(512), 8 * 2 * 64 * 32 * 2, s, k, v, kv_mask, part, S, ldk, ldv, nc);
-        } else
-        if (kv2) {
-            const int smem2 = 8 * 2 * 64 * 32 * (bf ? 2 : 4);
+        } else {
+            const int smem2 = 8 * 2 * 64 * 32 * 4;
             static GimPerDevice attr2;
             if (attr2.needed()) {
-                hipError_t e = hipFuncSetAttribute((const void*)la_kv_mfma2_kernel<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 64 * 32 * 2);
-                if (e == hipSuccess) e = hipFuncSetAttribute((const void*)la_kv_mfma2_kernel<true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 64 * 32 * 2);
-                if (e == hipSuccess) e = hipFuncSetAttribute((const void*)la_kv_mfma2_kernel<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 64 * 32 * 4);
-                if (e == hipSuccess) e = hipFuncSetAttribute((const void*)la_kv_mfma2_kernel<false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 64 * 32 * 4);
+                hipError_t e = hipFuncSetAttribute((const void*)la_kv_mfma2_kernel<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
                 if (e != hipSuccess) { gim_set_error("linear_attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return GIM_ERR_LAUNCH; }
                 attr2.done();
             }
-            if (kv2 == 2) {
-                if (bf) hipLaunchKernelGGL((la_kv_mfma2_kernel<true, 128>), g2, dim3(512), smem2, s, k, v, kv_mask, part, S, ldk, ldv, nc);
-                else hipLaunchKernelGGL((la_kv_mfma2_kernel<false, 128>), g2, dim3(512), smem2, s, k, v, kv_mask, part, S, ldk, ldv, nc);
-            } else {
-                if (bf) hipLaunchKernelGGL((la_kv_mfma2_kernel<true, 256>), g2, dim3(512), smem2, s, k, v, kv_mask, part, S, ldk, ldv, nc);
-                else hipLaunchKernelGGL((la_kv_mfma2_kernel<false, 256>), g2, dim3(512), smem2, s, k, v, kv_mask, part, S, ldk, ldv, nc);
-            }
-        } else if (bf) hipLaunchKernelGGL(la_kv_mfma_kernel<true>, g2, dim3(256), smem, s, k, v, kv_mask, part, S, ldk, ldv, nc);
-        else hipLaunchKernelGGL(la_kv_mfma_kernel<false>, g2, dim3(256), smem, s, k, v, kv_mask, part, S, ldk, ldv, nc);
+            hipLaunchKernelGGL((la_kv_mfma2_kernel<false, 256>), g2, dim3(512), smem2, s, k, v, kv_mask, part, S, ldk, ldv, nc);
+        }
     } else if (D == 32) {
         if (bf) hipLaunchKernelGGL((la_kv_kernel<32, true>), grid, dim3(256), 0, s, k, v, kv_mask, part, S, H, ldk, ldv, nc);
         else hipLaunchKernelGGL((la_kv_kernel<32, false>), grid, dim3(256), 0, s, k, v, kv_mask, part, S, H, ldk, ldv, nc);

@@ -21,16 +21,7 @@ int gim_check_launch(const char* what) {
     return GIM_OK;
 }
 
-extern "C" int gim_version(void) { return 100; }
+extern "C" int gim_version(void) { return 110; }   // 110: health word as an argument (no gim_set_range_guard), count[2 + N] layout of gim_coarse_match
 extern "C" const char* gim_last_error(void) { return g_err; }
 extern "C" int gim_ktile_bytes(void) { return 128; }
 extern "C" int gim_npad_granule(void) { return 64; }
-
-// fp16 range guard word (gim_common.h): one registration per device, process-wide.  The launch wrappers of the kernels that store
-// residual streams read it when they build their arguments, so a captured graph keeps the pointer that was registered at capture.
-static std::atomic<int*> g_range_guard[256];
-extern "C" int gim_set_range_guard(int32_t* device_word) {
-    g_range_guard[GimPerDevice::dev()].store((int*)device_word, std::memory_order_release);
-    return GIM_OK;
-}
-int* gim_range_guard_ptr() { return g_range_guard[GimPerDevice::dev()].load(std::memory_order_acquire); }

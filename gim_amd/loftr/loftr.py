@@ -221,7 +221,12 @@ class LoFTR(nn.Module):
         # GIM_BNECK_TAIL=0 keeps the two implicit-GEMM launches
         self.bneck_tail = os.environ.get("GIM_BNECK_TAIL", "1") != "0"
         self.bneck_ds = os.environ.get("GIM_BNECK_DS", "1") != "0"   # layer 1's first block: downsample conv inside the fused kernel
+        # launch-order experiments over independent images / pairs (same kernels, same arithmetic; see _backbone_trunk, _transformer_emit)
+        self.depth_groups = int(os.environ.get("GIM_DEPTH_GROUPS", "1"))
+        self.l3_chains = int(os.environ.get("GIM_L3_CHAINS", "1"))
+        self.tf_chains = int(os.environ.get("GIM_TF_CHAINS", "2"))   # profiles/r05_launch_order.txt: -0.2 ms per batch-8 step
         self._packed = None
+        self._health = None          # fp16 range guard word of the forward in flight (count[1] of its coarse matching), see _coarse_stage
         self._health_sync_left = 3   # forwards that still wait for the fine kernel to read its health bit at once (fp16 mode)
         self._packed_key = None
         self._pe_cache = {}
@@ -381,7 +386,7 @@ class LoFTR(nn.Module):
                 warnings.warn(f"gim_amd LoFTR: folded weights of {bad[:4]}{' ...' if len(bad) > 4 else ''} exceed the IEEE-fp16 range; "
                               "falling back to precision='bf16' for this module")
                 self.fp16_overflowed = True
-                self.set_precision("bf16")
+                self.set_precision("bf16", coarse_sim="fp32" if self.coarse_sim == "fp32" else None)   # a caller's fp32 similarity survives the fallback
                 return self._prepack(device)
         self._packed, self._packed_key = P, key
         return P
@@ -431,45 +436,116 @@ class LoFTR(nn.Module):
 
     def _backbone_trunk(self, P, x, dt):
         """stem + layer1-3 + layer3_outconv (resnet.py:306-320): returns (x1, x2, x3_out) -- the coarse features x3_out are complete
-        here; the fine head only needs x1, x2 and x3_out (see _fpn_fine)"""
+        here; the fine head only needs x1, x2 and x3_out (see _fpn_fine).
+        Images are independent up to here, so the batch may run as image groups: `depth_groups` > 1 walks stem -> layer1 -> layer2
+        group by group (producer -> consumer tensors of a group stay closer to the Infinity Cache), `l3_chains` > 1 runs layer 3 as
+        that many image groups on parallel streams (its 300- / 600-tile launches fill 0.6 / 1.2 rounds of the workgroup slots: two
+        unsynchronised chains keep the slots busy).  Both are launch-order changes only: same kernels, same arithmetic."""
+        B = x.shape[0]
+        G = self.depth_groups if (self.debug is None and self.depth_groups > 1 and B % self.depth_groups == 0) else 1
+        if G == 1:
+            x1, x2, o3 = self._trunk12(P, x, dt)
+        else:
+            n = B // G
+            half = lambda v: (v - 1) // 2 + 1   # noqa: E731
+            H1, W1 = half(x.shape[1]), half(x.shape[2])
+            H2, W2 = half(H1), half(W1)
+            tdt = torch_dtype(dt)
+            x1 = torch.empty(B, H1, W1, P["l1.2.c3"].n_store, dtype=tdt, device=x.device)
+            x2 = torch.empty(B, H2, W2, P["l2.3.c3"].n_store, dtype=tdt, device=x.device)
+            o3 = None
+            if self.bneck_tail and "l2.3.tail" in P and (n * H2 * W2) % 256 == 0 and n * H2 * W2 * 1024 < (1 << 32) - 16:   # (_layer's test)
+                o3 = torch.empty(B, H2, W2, P["l3.0.c1"].n_store, dtype=tdt, device=x.device)
+            for g in range(G):
+                sl = slice(g * n, (g + 1) * n)
+                a1, a2, ao = self._trunk12(P, x[sl], dt, out=(x1[sl], x2[sl], o3[sl] if o3 is not None else None))
+                assert (ao is None) == (o3 is None)
+                for dst, src in ((x1, a1), (x2, a2), (o3, ao)):   # a launch that was not a fused one allocated its own output
+                    if src is not None and src.data_ptr() != dst[sl].data_ptr():
+                        ops.copy_segments([(src.contiguous(), dst[sl])])
+        K = self.l3_chains if (self.debug is None and self.l3_chains > 1 and B % self.l3_chains == 0) else 1
+        if K == 1:
+            x3, _, x3_out = self._layer(P, 3, 6, x2, o3)
+            if x3_out is None:
+                x3_out = ops.conv2d(x3, P["l3o"], lds_dma=self.use_lds_dma)
+            return x1, x2, x3_out
+        n = B // K
+        main = torch.cuda.current_stream()
+        sides = self._side_streams(x.device, K - 1)
+        x3_out = torch.empty(B, (x2.shape[1] - 1) // 2 + 1, (x2.shape[2] - 1) // 2 + 1, P["l3o"].n_store, dtype=x2.dtype, device=x2.device)
+        keep = []   # tensors that cross streams stay referenced until the join (the caching allocator re-uses a freed block per stream)
+
+        def chain(g):
+            sl = slice(g * n, (g + 1) * n)
+            x3, _, xo = self._layer(P, 3, 6, x2[sl], o3[sl] if o3 is not None else None, out_last=(None, x3_out[sl]))
+            if xo is None:
+                xo = ops.conv2d(x3, P["l3o"], lds_dma=self.use_lds_dma)
+            if xo.data_ptr() != x3_out[sl].data_ptr():
+                ops.copy_segments([(xo.contiguous(), x3_out[sl])])
+            keep.append((x3, xo))
+
+        for g in range(1, K):
+            sides[g - 1].wait_stream(main)
+            with torch.cuda.stream(sides[g - 1]):
+                chain(g)
+        chain(0)
+        for s_ in sides:
+            main.wait_stream(s_)
+        return x1, x2, x3_out
+
+    def _side_streams(self, dev, n):
+        ss = getattr(self, "_sides", None)
+        if ss is None or len(ss) < n or ss[0].device != dev:
+            ss = self._sides = [torch.cuda.Stream(device=dev) for _ in range(n)]
+        return ss[:n]
+
+    def _trunk12(self, P, x, dt, out=None):
+        """stem + layer 1 + layer 2 of a batch (or image group) -> (x1, x2, conv1 output of layer 3's first block or None);
+        out = (x1, x2, o3) destinations for the fused kernels' outputs (image-group mode)"""
         dma = self.use_lds_dma
         if isinstance(P["stem"], PackedStem):
             x = ops.stem7x7(x, P["stem"], out_dtype=torch_dtype(dt))
         else:
             x = ops.conv2d(x, P["stem"], ACT_RELU, out_dtype=torch_dtype(dt), lds_dma=dma)   # image dtype may be fp16 in bf16 mode
-        feats = []
-        x3_out = None   # produced by the last block's fused tail when that path is taken
-        o = None   # conv1 output of the upcoming block when the previous fused kernel already produced it
-        for li, nblk in ((1, 3), (2, 4), (3, 6)):
-            fuse = li == 1 and self.bneck_fused and "l1.0.fused" in P and x.shape[1] % 8 == 0 and x.shape[2] % 32 == 0
-            for bi in range(nblk):
-                p = f"l{li}.{bi}."
-                if o is None:
-                    o = ops.conv2d(x, P[p + "c1"], ACT_RELU, lds_dma=dma)
-                if fuse and self.bneck_ds and (p + "fused_ds") in P and x.shape[3] == 64 and x.is_contiguous():
-                    x, o = ops.bneck64_ds(o, x, P[p + "fused_ds"])   # ... and the downsample branch: no identity tensor at all
-                    continue
-                idn = ops.conv2d(x, P[p + "ds"], ACT_NONE, lds_dma=dma) if (p + "ds") in P else x
-                if fuse:   # conv2 -> conv3 + identity -> the next conv1 (of this layer, or layer2's first), one kernel
-                    x, o = ops.bneck64(o, idn, P[p + "fused"], True)
-                    continue
-                o = ops.conv2d(o, P[p + "c2"], ACT_RELU, lds_dma=dma)
-                rows = o.shape[0] * o.shape[1] * o.shape[2]
-                # the tail kernel walks 256-row tiles with 32-bit byte offsets into the [rows, 4 P] tensors (its own REQUIREs)
-                if self.bneck_tail and (p + "tail") in P and rows % 256 == 0 and rows * 4 * o.shape[3] * 2 < (1 << 32) - 16:
-                    if li == 3 and bi == nblk - 1:   # last block: t1' IS x3_out (layer3_outconv), x3 itself is read by nothing else
-                        x, x3_out = ops.bneck_tail(o, idn.contiguous(), P[p + "tail"], ACT_NONE, store_x=self.debug is not None)
-                        o = None
-                    else:
-                        x, o = ops.bneck_tail(o, idn.contiguous(), P[p + "tail"])   # x' and the next block's conv1 output
-                    continue
-                x = ops.conv2d(o, P[p + "c3"], ACT_RELU, res=idn, lds_dma=dma)
-                o = None
-            feats.append(x)
-        x1, x2, x3 = feats
-        if x3_out is None:
-            x3_out = ops.conv2d(x3, P["l3o"], lds_dma=dma)
-        return x1, x2, x3_out
+        x1, o, _ = self._layer(P, 1, 3, x, None, out_last=(out[0], None) if out else None)
+        x2, o, _ = self._layer(P, 2, 4, x1, o, out_last=(out[1], out[2]) if out else None)
+        return x1, x2, o
+
+    def _layer(self, P, li, nblk, x, o, out_last=None):
+        """one ResNet layer (resnet.py:109-126, 230-235) on x; o = conv1 output of its first block when the previous layer's last fused
+        kernel already produced it.  Returns (x', conv1 output of the NEXT layer's first block or None, x3_out or None: the FPN's
+        layer3_outconv when layer 3's last fused tail produced it).  out_last = (x', t1') destinations of the last block's fused
+        kernel (either may be None)."""
+        dma = self.use_lds_dma
+        x3_out = None
+        fuse = li == 1 and self.bneck_fused and "l1.0.fused" in P and x.shape[1] % 8 == 0 and x.shape[2] % 32 == 0
+        for bi in range(nblk):
+            p = f"l{li}.{bi}."
+            last = bi == nblk - 1
+            outs = out_last if last else None
+            if o is None:
+                o = ops.conv2d(x, P[p + "c1"], ACT_RELU, lds_dma=dma)
+            if fuse and self.bneck_ds and (p + "fused_ds") in P and x.shape[3] == 64 and x.is_contiguous():
+                x, o = ops.bneck64_ds(o, x, P[p + "fused_ds"], out=outs, health=self._health)   # ... and the downsample branch: no identity tensor at all
+                continue
+            idn = ops.conv2d(x, P[p + "ds"], ACT_NONE, lds_dma=dma) if (p + "ds") in P else x
+            if fuse:   # conv2 -> conv3 + identity -> the next conv1 (of this layer, or layer2's first), one kernel
+                x, o = ops.bneck64(o, idn, P[p + "fused"], True, out=outs, health=self._health)
+                continue
+            o = ops.conv2d(o, P[p + "c2"], ACT_RELU, lds_dma=dma)
+            rows = o.shape[0] * o.shape[1] * o.shape[2]
+            # the tail kernel walks 256-row tiles with 32-bit byte offsets into the [rows, 4 P] tensors (its own REQUIREs)
+            if self.bneck_tail and (p + "tail") in P and rows % 256 == 0 and rows * 4 * o.shape[3] * 2 < (1 << 32) - 16:
+                if li == 3 and last:   # last block: t1' IS x3_out (layer3_outconv), x3 itself is read by nothing else
+                    x, x3_out = ops.bneck_tail(o, idn.contiguous(), P[p + "tail"], ACT_NONE, store_x=self.debug is not None, out=outs,
+                                               health=self._health)
+                    o = None
+                else:
+                    x, o = ops.bneck_tail(o, idn.contiguous(), P[p + "tail"], out=outs, health=self._health)   # x' and the next block's conv1 output
+                continue
+            x = ops.conv2d(o, P[p + "c3"], ACT_RELU, res=idn, lds_dma=dma, health=self._health)   # the unfused block stores the stream too
+            o = None
+        return x, o, x3_out
 
     def _fpn_fine(self, P, x1, x2, x3_out):
         """the FPN's top-down path to the 1/2-resolution fine features (resnet.py:321-329): six convolutions that nothing of the coarse
@@ -580,10 +656,15 @@ class LoFTR(nn.Module):
     def _transformer_emit(self, P, name, tf, T, n0, L, n1, S):
         """LocalFeatureTransformer.forward with every projection after the first layer's computed by the token tail that produced
         its operand rows (see _emit_plan).  Two [R, 3C] projection buffers alternate by layer parity: a tail writes the NEXT layer's
-        columns while its own layer's are still being read."""
+        columns while its own layer's are still being read.
+        `tf_chains` > 1 (coarse level, n0 == n1 pairs): pairs are independent sequences, so the pair batch runs as that many chains of
+        n0 / chains pairs on parallel streams, each with the per-side launch plan -- a cross-layer call of the whole batch is 600
+        64-token tiles on 512 workgroup slots (two rounds, the second 17 % full); unsynchronised chains keep the slots busy."""
         C = T.X32.shape[1]
         H = tf.nhead
-        calls, per_call, initial = P[name + ".emit", L == S]
+        K = self.tf_chains if (name == "c" and self.tf_chains > 1 and n0 == n1 and n0 % self.tf_chains == 0 and self.debug is None
+                               and (name + ".emit", False) in P) else 1
+        calls, per_call, initial = P[name + ".emit", L == S and K == 1]
         T.QKV2 = torch.empty_like(T.QKV)
         QK = (T.QKV, T.QKV2)
         rows = (slice(0, n0 * L), slice(n0 * L, n0 * L + n1 * S))
@@ -604,25 +685,47 @@ class LoFTR(nn.Module):
             else:
                 assert blks == [0], blks
                 ops.linear(x_t, P[p + "q_proj"], q[r, :C], ACT_ELU1, self.use_lds_dma)
-        for (li, xs_s, ss_s), em in zip(calls, per_call):
-            xs, ss = rs(xs_s), rs(ss_s)
-            q = QK[li & 1]
-            nb_src = n0 + n1 if len(ss_s) == 2 else (n0, n1)[ss_s[0]]
-            len_q = L if xs_s[0] == 0 else S
-            len_src = L if ss_s[0] == 0 else S
-            qm = T.MASK[xs] if T.MASK is not None else None
-            km = T.MASK[ss] if T.MASK is not None else None
-            wts, lnp, eps = P[f"{name}{li}.tok"]
-            T.ws, _ = ops.linear_attention_state(q[ss, C:2 * C], q[ss, 2 * C:], nb_src, len_src, H, T.ws, km)
-            emit = None
-            if em is not None:
-                ew, blocks = em
-                spec = []
-                for l2, blk, sides in blocks:
-                    lo, hi = (0, xs.stop - xs.start) if sides == xs_s else ((0, n0 * L) if sides == (0,) else (n0 * L, xs.stop - xs.start))
-                    spec.append((QK[l2 & 1][xs, blk * C:(blk + 1) * C], ACT_ELU1 if blk < 2 else ACT_NONE, lo, hi))
-                emit = (ew, spec)
-            ops.token_mlp(q[xs, :C], T.CAT[xs, :C], T.X32[xs], wts, lnp, eps, kv=T.ws, L=len_q, S=len_src, q_mask=qm, emit=emit)
+
+        def run(rows_c, m0, m1, ws):
+            """the call sequence on the row ranges (side 0, side 1) of m0 / m1 sequences; returns the KV workspace it ended with"""
+            both = slice(rows_c[0].start, rows_c[1].stop)
+            rc = lambda sides: both if len(sides) == 2 else rows_c[sides[0]]   # noqa: E731
+            for (li, xs_s, ss_s), em in zip(calls, per_call):
+                xs, ss = rc(xs_s), rc(ss_s)
+                q = QK[li & 1]
+                nb_src = m0 + m1 if len(ss_s) == 2 else (m0, m1)[ss_s[0]]
+                len_q = L if xs_s[0] == 0 else S
+                len_src = L if ss_s[0] == 0 else S
+                qm = T.MASK[xs] if T.MASK is not None else None
+                km = T.MASK[ss] if T.MASK is not None else None
+                wts, lnp, eps = P[f"{name}{li}.tok"]
+                ws, _ = ops.linear_attention_state(q[ss, C:2 * C], q[ss, 2 * C:], nb_src, len_src, H, ws, km)
+                emit = None
+                if em is not None:
+                    ew, blocks = em
+                    spec = []
+                    for l2, blk, sides in blocks:
+                        lo, hi = (0, xs.stop - xs.start) if sides == xs_s else ((0, m0 * L) if sides == (0,) else (m0 * L, xs.stop - xs.start))
+                        spec.append((QK[l2 & 1][xs, blk * C:(blk + 1) * C], ACT_ELU1 if blk < 2 else ACT_NONE, lo, hi))
+                    emit = (ew, spec)
+                ops.token_mlp(q[xs, :C], T.CAT[xs, :C], T.X32[xs], wts, lnp, eps, kv=ws, L=len_q, S=len_src, q_mask=qm, emit=emit)
+            return ws
+
+        if K == 1:
+            T.ws = run(rows, n0, n1, T.ws)
+            return
+        m = n0 // K
+        main = torch.cuda.current_stream()
+        sides_ = self._side_streams(T.X32.device, K - 1)
+        keep = []   # per-chain workspaces stay referenced until the join
+        for g in range(1, K):
+            sides_[g - 1].wait_stream(main)
+            with torch.cuda.stream(sides_[g - 1]):
+                keep.append(run((slice(g * m * L, (g + 1) * m * L), slice(n0 * L + g * m * S, n0 * L + (g + 1) * m * S)), m, m, None))
+        keep.append(run((slice(0, m * L), slice(n0 * L, n0 * L + m * S)), m, m, None))
+        for s_ in sides_:
+            main.wait_stream(s_)
+        T.keep = keep
 
     def _transformer(self, P, name, tf, T, n0, L, n1, S):
         """LocalFeatureTransformer.forward (transformer.py:80-101).  Rows [0, n0*L) are feat0's tokens,
@@ -657,7 +760,8 @@ class LoFTR(nn.Module):
         # guard of the kernels in front of it (registered here, read back with the count): allocated before the first launch
         if count is None:
             count = torch.zeros(2 + bs, dtype=torch.int32, device=dev)
-        ops.set_range_guard(count[1:2] if self.precision == "fp16" else None)
+        # the fp16 range guard of the kernels in front of it is that word too, handed to every launch that stores a residual stream
+        self._health = count[1:2] if self.precision == "fp16" else None
         tdt = torch_dtype(dt)
         P = self._prepack(dev)
         cfg = self.config
@@ -697,7 +801,7 @@ class LoFTR(nn.Module):
         cr = ops.coarse_match(fc0, fc1, hw0_c, hw1_c, scale,
                               mc["dsmax_temperature"], mc["thr"], mc["border_rm"], scale0, scale1,
                               T.MASK[r0] if mask0 is not None else None, T.MASK[r1] if mask0 is not None else None, count=count)
-        ops.set_range_guard(None)   # the launches above carry the pointer; nothing later may write through it
+        self._health = None
         return {"c0": c0, "c1": c1, "f0": f0, "f1": f1, "cr": cr,
                 "feat_c0": T.X32[r0].view(bs, L, C), "feat_c1": T.X32[r1].view(bs, S, C)}
 
@@ -897,7 +1001,7 @@ class LoFTR(nn.Module):
             warnings.warn(f"gim_amd LoFTR: {what} in the fp16 mode (an activation left the IEEE-fp16 range); "
                           "falling back to precision='bf16' for this module and re-running the batch")
             self.fp16_overflowed = True
-            self.set_precision("bf16")
+            self.set_precision("bf16", coarse_sim="fp32" if self.coarse_sim == "fp32" else None)   # a caller's fp32 similarity survives the fallback
             return True
         warnings.warn(f"gim_amd LoFTR: {what} in the {self.precision} mode: the inputs or the weights are not finite")
         return False

@@ -87,12 +87,13 @@ def nchw_to_nhwc(src, dst, b_off=0):
                                gim_dtype(dst), _stream()), "gim_nchw_to_nhwc")
 
 
-def set_range_guard(word):
-    """int32 device tensor (one element) the fp16 residual-stream kernels OR 4 into on overflow, or None (gim_set_range_guard)"""
+def _health(word):
+    """the `health` argument of the kernels that store an un-normalised residual stream (include/gim_hip.h, "fp16 range guard"): an
+    int32 device tensor (one element) they OR 4 into when an fp16 value they store left the IEEE range, or None"""
     if word is not None:
         _req_cuda(word)
         assert word.dtype == torch.int32 and word.numel() >= 1
-    check(lib.gim_set_range_guard(_p(word)), "gim_set_range_guard")
+    return _p(word)
 
 
 def nchw_to_nhwc_split(src, dst, b_off=0):
@@ -160,7 +161,7 @@ def nhwc_to_nchw(src, C):
 
 
 # ---- conv / linear --------------------------------------------------------------------------------
-def conv_rows(x, pk, geom, y, act=ACT_NONE, res=None, res_mod=0, lds_dma=True, act_cols=0, ups=None):
+def conv_rows(x, pk, geom, y, act=ACT_NONE, res=None, res_mod=0, lds_dma=True, act_cols=0, ups=None, health=None):
     """Generic launch.  x: 2-D row view [rows_in, ldx]; geom = (B, H, W, Ho, Wo); y: 2-D row view.  ups: half-resolution NHWC
     tensor whose bilinear x2 upsampling is added in the epilogue, or a callable that performs that addition as a separate pass when
     the launch cannot take it (returns True when it was fused)."""
@@ -183,6 +184,7 @@ def conv_rows(x, pk, geom, y, act=ACT_NONE, res=None, res_mod=0, lds_dma=True, a
     a.dtype, a.out_dtype = pk.dtype, gim_dtype(y)
     a.res_dtype = gim_dtype(res) if res is not None else GIM_F32
     a.use_lds_dma = 1 if lds_dma else 0
+    a.health = _health(health).value if (health is not None and res is not None) else None
     assert y.shape[0] >= B * Ho * Wo and y.shape[1] >= pk.n_store
     if ups is not None:
         a.ups, a.ups_h, a.ups_w, a.ups_ld = ups.data_ptr(), ups.shape[1], ups.shape[2], ups.shape[3]
@@ -204,7 +206,7 @@ def conv_rows(x, pk, geom, y, act=ACT_NONE, res=None, res_mod=0, lds_dma=True, a
 UPS_FUSED = os.environ.get("GIM_UPS_FUSED", "1") != "0"   # FPN: bilinear x2 + add inside the lateral 1x1 conv's epilogue
 
 
-def conv2d(x, pk, act=ACT_NONE, res=None, out_dtype=None, lds_dma=True, ups=None):
+def conv2d(x, pk, act=ACT_NONE, res=None, out_dtype=None, lds_dma=True, ups=None, health=None):
     """x [B,H,W,cin_pad] NHWC -> new [B,Ho,Wo,n_store].  ups: [B,Ho/2,Wo/2,n_store] -> y += bilinear_x2(ups) (align_corners=True):
     in the conv's epilogue when the launch supports it, otherwise as a second pass (gim_upsample2x_add)."""
     B, H, W, cs = x.shape
@@ -225,7 +227,7 @@ def conv2d(x, pk, act=ACT_NONE, res=None, out_dtype=None, lds_dma=True, ups=None
         if not conv_rows(x.view(-1, cs), pk, geom, y.view(-1, pk.n_store), act, r, 0, lds_dma, ups=ups):
             upsample2x_add(ups, y)
         return y
-    conv_rows(x.view(-1, cs), pk, geom, y.view(-1, pk.n_store), act, r, 0, lds_dma)
+    conv_rows(x.view(-1, cs), pk, geom, y.view(-1, pk.n_store), act, r, 0, lds_dma, health=health)
     return y
 
 
@@ -430,7 +432,23 @@ def fine_match(f0, f1, mkpts1_c, b_ids, scale1, M, WW, scale, has_scale0):
     return expec, mk1
 
 
-def bneck64(t1, res, pk, want_next):
+def _outs(out, shapes, like):
+    """output tensors of a fused launch: fresh ones, or the caller's (`out` = a tuple aligned with `shapes`; None entries are
+    allocated here) -- contiguous slices of a larger batch when a caller runs image groups separately"""
+    res = []
+    for i, shp in enumerate(shapes):
+        o = out[i] if out is not None else None
+        if shp is None:
+            res.append(None)
+        elif o is None:
+            res.append(torch.empty(*shp, dtype=like.dtype, device=like.device))
+        else:
+            assert tuple(o.shape) == tuple(shp) and o.dtype == like.dtype and o.is_contiguous(), (o.shape, shp)
+            res.append(o)
+    return res
+
+
+def bneck64(t1, res, pk, want_next, out=None, health=None):
     """Fused Bottleneck tail (+ the next conv1): t1 [B,H,W,64] bf16, res [B,H,W,256] bf16 -> (x' [B,H,W,256], t1' [B,H,W,N1] or None).
     pk = packing.pack_bneck(...); N1 = 64 (next block of the layer) or 128 (the next layer's first conv1) from the packed weights."""
     _req_cuda(t1, res)
@@ -441,15 +459,14 @@ def bneck64(t1, res, pk, want_next):
     w2, w3, w1n, b2, b3, b1n = pk
     n1 = w1n.shape[0] if (want_next and w1n is not None) else 0
     assert not want_next or n1 in (64, 128)
-    xo = torch.empty(B, H, W, 256, dtype=t1.dtype, device=t1.device)
-    t1n = torch.empty(B, H, W, n1, dtype=t1.dtype, device=t1.device) if n1 else None
+    xo, t1n = _outs(out, ((B, H, W, 256), (B, H, W, n1) if n1 else None), t1)
     with _Timed("bneck64_fused", 2.0 * B * H * W * (576 * 64 + 64 * 256 + 256 * n1)):
         check(fn(_p(t1), _p(res), _p(xo), _p(t1n), _p(w2), _p(w3), _p(w1n if n1 else None), _p(b2), _p(b3),
-                                    _p(b1n if n1 else None), B, H, W, n1, _stream()), "gim_bneck64_fused")
+                                    _p(b1n if n1 else None), B, H, W, n1, _health(health), _stream()), "gim_bneck64_fused")
     return xo, t1n
 
 
-def bneck64_ds(t1, x_in, pk):
+def bneck64_ds(t1, x_in, pk, out=None, health=None):
     """First block of layer 1 with its downsample branch computed in the kernel (gim_bneck64_fused_ds): t1 [B,H,W,64] (conv1 output),
     x_in [B,H,W,64] (the block's input) -> (x' [B,H,W,256], t1' [B,H,W,64]); pk = packing.pack_bneck_ds(...)."""
     _req_cuda(t1, x_in)
@@ -458,15 +475,14 @@ def bneck64_ds(t1, x_in, pk):
     assert w2.dtype == t1.dtype and w1n.shape[0] == 64
     fn = lib.gim_bneck64_fused_ds_f16 if t1.dtype == torch.float16 else lib.gim_bneck64_fused_ds
     B, H, W, _ = t1.shape
-    xo = torch.empty(B, H, W, 256, dtype=t1.dtype, device=t1.device)
-    t1n = torch.empty(B, H, W, 64, dtype=t1.dtype, device=t1.device)
+    xo, t1n = _outs(out, ((B, H, W, 256), (B, H, W, 64)), t1)
     with _Timed("bneck64_fused", 2.0 * B * H * W * (576 * 64 + 64 * 256 + 64 * 256 + 256 * 64)):
-        check(fn(_p(t1), _p(x_in), _p(xo), _p(t1n), _p(w2), _p(w3), _p(wds), _p(w1n), _p(b2), _p(b3ds), _p(b1n), B, H, W, _stream()),
+        check(fn(_p(t1), _p(x_in), _p(xo), _p(t1n), _p(w2), _p(w3), _p(wds), _p(w1n), _p(b2), _p(b3ds), _p(b1n), B, H, W, _health(health), _stream()),
               "gim_bneck64_fused_ds")
     return xo, t1n
 
 
-def bneck_tail(t2, res, pk, act_next=ACT_RELU, store_x=True):
+def bneck_tail(t2, res, pk, act_next=ACT_RELU, store_x=True, out=None, health=None):
     """Bottleneck tail + the next 1x1 convolution in one launch (planes P = 128: layer 2, P = 256: layer 3): t2 [B,H,W,P], res
     [B,H,W,4P] (same 16-bit dtype) -> (x' [B,H,W,4P] or None when store_x is False, t1' [B,H,W,N1]); pk = packing.pack_bneck_tail(...).
     B*H*W must be a multiple of 256."""
@@ -478,11 +494,10 @@ def bneck_tail(t2, res, pk, act_next=ACT_RELU, store_x=True):
     M, n1 = B * H * W, w1n.shape[1]
     assert pl in (128, 256) and w3.shape == (4 * pl, pl) and res.shape == (B, H, W, 4 * pl) and M % 256 == 0
     assert store_x or pl == 256
-    xo = torch.empty(B, H, W, 4 * pl, dtype=t2.dtype, device=t2.device) if store_x else None
-    t1n = torch.empty(B, H, W, n1, dtype=t2.dtype, device=t2.device)
+    xo, t1n = _outs(out, ((B, H, W, 4 * pl) if store_x else None, (B, H, W, n1)), t2)
     name = "gim_bneck_tail%d%s" % (pl, "_f16" if t2.dtype == torch.float16 else "")
     with _Timed("bneck_tail", 2.0 * M * (pl * 4 * pl + 4 * pl * n1)):
-        check(getattr(lib, name)(_p(t2), _p(res), _p(xo), _p(t1n), _p(w3), _p(w1n), _p(b3), _p(b1n), M, n1, act_next, _stream()), name)
+        check(getattr(lib, name)(_p(t2), _p(res), _p(xo), _p(t1n), _p(w3), _p(w1n), _p(b3), _p(b1n), M, n1, act_next, _health(health), _stream()), name)
     return xo, t1n
 
 

@@ -33,12 +33,14 @@ enum { GIM_F32 = 0, GIM_BF16 = 1, GIM_F16 = 2 };
 enum { GIM_ACT_NONE = 0, GIM_ACT_RELU = 1, GIM_ACT_LEAKY = 2, GIM_ACT_ELU1 = 3 /* elu(x)+1 */, GIM_ACT_GELU = 4 /* exact erf GELU */ };
 enum { GIM_OK = 0, GIM_ERR_INVALID = -1, GIM_ERR_LAUNCH = -2, GIM_ERR_UNSUPPORTED = -3 };
 
+/* 110 (round 5): the fp16 range-guard word is an ARGUMENT of the entry points that use it (`health` of gim_bneck64_fused*,
+ * gim_bneck_tail*, gim_conv_args.health; gim_set_range_guard() is gone), and gim_coarse_match's `count` is int32[2 + N] (count[1] = health
+ * word, per-pair counts from count[2]) -- a caller bound to version 100 must be rebuilt. */
 int gim_version(void);
-/* fp16 range guard.  Registers (NULL: removes) the device word into which the fp16 flavour of the kernels that store residual
- * streams (gim_bneck64_fused*, gim_bneck_tail*) OR 4 when a converted value exceeds the IEEE-fp16 range -- ReLUs downstream turn the
- * resulting NaNs into zeros, so the outputs alone do not show it.  One registration per device, process-wide; launches read it when
- * they are enqueued (a captured graph keeps the word registered at capture).  gim_amd registers count[1] of gim_coarse_match. */
-int gim_set_range_guard(int32_t* device_word);
+/* fp16 range guard.  `health` (NULL: no check): a device word into which the fp16 flavour of the kernels that store un-normalised
+ * residual streams (gim_bneck64_fused*, gim_bneck_tail*, gim_conv2d_bn_act with a residual operand) OR 4 when a converted value exceeds
+ * the IEEE-fp16 range -- ReLUs downstream turn the resulting NaNs into zeros, so the outputs alone do not show it.  A plain argument:
+ * no process-wide state, a captured graph keeps the word it was captured with.  gim_amd passes count[1] of gim_coarse_match. */
 const char* gim_last_error(void);
 /* compile-time facts the host packer needs: K-tile bytes (128) and the N padding granule (64). */
 int gim_ktile_bytes(void);
@@ -112,6 +114,7 @@ typedef struct gim_conv_args {
                            over y.  Output rows = (image, Y < 2 ups_h, X < 2 ups_w); needs (2 ups_w) % 32 == 0 and a launch the 256 x 256 tile takes
                            (1x1 conv, bf16, no residual, npad % 256 == 0, >= 4 K slabs, >= 512 tiles): gim_conv_ups_supported() */
     int ups_h, ups_w, ups_ld;
+    int32_t* health;    /* fp16 range guard (see the top of this file) or NULL: checked where a residual operand is added (fp16 flavour) */
 } gim_conv_args;
 int gim_conv_ups_supported(const gim_conv_args* a);   /* 1 if gim_conv2d_bn_act would take a->ups (set or not) for this launch */
 int gim_conv2d_bn_act(const gim_conv_args* a, gim_stream_t stream);
@@ -169,7 +172,7 @@ int gim_layernorm_residual(const void* x, const float* gamma, const float* beta,
  * overflow survived the ReLUs in between; bit 1 (sticky, never cleared here) = gim_fine_fused_dev saw a non-finite fine-level
  * output on this buffer: a host that replays a captured graph on the same buffer learns it with the NEXT call's count read-back;
  * bit 2 (sticky) = the fp16 range guard: a kernel that stores an un-normalised residual stream converted a value beyond 65504
- * while this word was registered through gim_set_range_guard().  The reference has no such word (fp32 has the range);
+ * that was handed this word as its `health` argument.  The reference has no such word (fp32 has the range);
  * gim_amd/loftr/loftr.py reads it with the match count (coarse_matching.py:193's sync) and re-runs the batch in bf16.
  * scale0/scale1: NULL or fp32 [N,2] per-pair (w,h) scales (coarse_matching.py:237-245). */
 typedef struct gim_coarse_args {
@@ -213,20 +216,20 @@ int gim_coarse_conf_matrix(const gim_coarse_args* a, float* conf, gim_stream_t s
  * products are chained through registers.  H % 8 == 0, W % 32 == 0. */
 int gim_bneck64_fused(const void* t1, const void* res, void* x_out, void* t1_next, const void* w2, const void* w3,
                       const void* w1n, const float* b2, const float* b3, const float* b1n, int B, int H, int W,
-                      int n_next, gim_stream_t stream);
+                      int n_next, int32_t* health, gim_stream_t stream);
 /* First block of layer 1 (resnet.py:120-124: identity = bn(conv1x1(x)), 64 -> 256, stride 1): the downsample convolution runs INSIDE
  * the kernel as extra K of conv3 -- x' = relu([W3 | Wds] [t2 ; x] + b3 + bds) -- so neither its launch nor the 256-channel identity
  * tensor exist.  x_in: [B,H,W,64] the block's input; wds [256][64] bf16 (BN folded, K in channel order); b3ds = b3 + bds; n_next = 64. */
 int gim_bneck64_fused_ds(const void* t1, const void* x_in, void* x_out, void* t1_next, const void* w2, const void* w3,
                          const void* wds, const void* w1n, const float* b2, const float* b3ds, const float* b1n, int B, int H, int W,
-                         gim_stream_t stream);
+                         int32_t* health, gim_stream_t stream);
 int gim_bneck64_fused_ds_f16(const void* t1, const void* x_in, void* x_out, void* t1_next, const void* w2, const void* w3,
                              const void* wds, const void* w1n, const float* b2, const float* b3ds, const float* b1n, int B, int H, int W,
-                             gim_stream_t stream);
+                             int32_t* health, gim_stream_t stream);
 /* the same kernel on IEEE fp16 tensors / weights (GIM_F16 mode) */
 int gim_bneck64_fused_f16(const void* t1, const void* res, void* x_out, void* t1_next, const void* w2, const void* w3,
                           const void* w1n, const float* b2, const float* b3, const float* b1n, int B, int H, int W,
-                          int n_next, gim_stream_t stream);
+                          int n_next, int32_t* health, gim_stream_t stream);
 
 /* The same fusion one layer up (planes 128: layer 2), without the 3x3 -- x' = relu(bn3(conv3_1x1(t2)) + identity), t1' =
  * act(bn1'(conv1'_1x1(x'))) of the NEXT block (resnet.py:117-124, 109-111) -- so that x' [M,512], the widest tensor of the block, is
@@ -235,16 +238,16 @@ int gim_bneck64_fused_f16(const void* t1, const void* res, void* x_out, void* t1
  * order, w1n [8][n_next][64]: per 64-channel chunk of x', K in accumulator order (gim_amd/packing.py::pack_bneck_tail); the 256+ KiB
  * of weights stream through LDS two chunks ahead of the MFMAs.  act_next: GIM_ACT_RELU / GIM_ACT_NONE. */
 int gim_bneck_tail128(const void* t2, const void* res, void* x_out, void* t1_next, const void* w3, const void* w1n,
-                      const float* b3, const float* b1n, int M, int n_next, int act_next, gim_stream_t stream);
+                      const float* b3, const float* b1n, int M, int n_next, int act_next, int32_t* health, gim_stream_t stream);
 int gim_bneck_tail128_f16(const void* t2, const void* res, void* x_out, void* t1_next, const void* w3, const void* w1n,
-                          const float* b3, const float* b1n, int M, int n_next, int act_next, gim_stream_t stream);
+                          const float* b3, const float* b1n, int M, int n_next, int act_next, int32_t* health, gim_stream_t stream);
 /* Planes 256 (layer 3): t2 [M,256], res / x_out [M,1024], t1_next [M,256] (n_next = 256); w3 [1024][256], w1n [32][256][32] (chunks of
  * 32 channels).  x_out may be NULL: the last block's output is read by nothing but the fused 1x1 convolution -- the FPN's
  * layer3_outconv (resnet.py:316), act_next = GIM_ACT_NONE, zero bias -- so it is never written. */
 int gim_bneck_tail256(const void* t2, const void* res, void* x_out, void* t1_next, const void* w3, const void* w1n,
-                      const float* b3, const float* b1n, int M, int n_next, int act_next, gim_stream_t stream);
+                      const float* b3, const float* b1n, int M, int n_next, int act_next, int32_t* health, gim_stream_t stream);
 int gim_bneck_tail256_f16(const void* t2, const void* res, void* x_out, void* t1_next, const void* w3, const void* w1n,
-                          const float* b3, const float* b1n, int M, int n_next, int act_next, gim_stream_t stream);
+                          const float* b3, const float* b1n, int M, int n_next, int act_next, int32_t* health, gim_stream_t stream);
 
 /* Token-wise tail of a LoFTREncoderLayer in ONE kernel (bf16 operand mode, d_model 256; transformer.py:52-58):
  *     x += norm2(mlp.2(relu(mlp.0(cat[x, norm1(merge(msg))]))))

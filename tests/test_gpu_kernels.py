@@ -456,19 +456,28 @@ def test_linear_attention_state(dt, shape):
     _assert_close(got[..., D * D:], ref[..., D * D:], 1e-5, f"Ksum {shape}")
 
 
-@pytest.mark.parametrize("mode", ["1", "2", "3"], ids=["chunks256", "chunks128", "mfma16"])
-def test_linear_attention_kv2_variant_forced(mode):
-    """GIM_LA_KV2=1 / 2 / 3: the 8-wave / wave-private-streaming shapes of the KV reduction (la_kv_mfma2_kernel on 256- / 128-row chunks,
-    la_kv_h16_kernel: the 16-bit MFMA on K^T / V fragments read down the columns of the LDS slices) under every linear-attention
-    test of this file and the token kernel's fused-apply tests (the choice is read once per process -> subprocess)"""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_kernels.py", "tests/test_gpu_token_mlp.py", "-m", "gpu", "-q", "-x",
-                          "-k", "linear_attention and not forced or token_mlp", "-p", "no:cacheprovider"],
-                         cwd=root, capture_output=True, text=True, env={**os.environ, "GIM_LA_KV2": mode}, timeout=900)
-    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+@pytest.mark.parametrize("dt", [d for d in DTS if d != "fp32"])
+@pytest.mark.parametrize("shape", [(16, 4800), (66, 1000), (130, 257)], ids=["16x4800", "66x1000-ragged", "130x257-ragged"])
+def test_linear_attention_state_is_batch_invariant(dt, shape):
+    """A sequence's KV / Ksum state must not depend on the batch it travels in: large batches run la_kv_h16_kernel with 512 rows
+    per workgroup, small ones with 256 -- both write the partials of 256-row chunks with the same association, so the state of the same
+    sequences computed alone (nb = 2: the 256-row shape) is BIT-identical to its rows of the large call (the 512-row shape), also where the
+    last chunk is ragged (S % 512 <= 256: the 512-row shape's last half chunk does not exist)."""
+    from gim_amd import ops
+    dev = _dev()
+    nb, S = shape
+    H, D, C = 8, 32, 256
+    g = torch.Generator().manual_seed(29)
+    k = (F.elu(torch.randn(nb * S, C, generator=g)) + 1).to(_tdt(dt)).to(dev)
+    v = torch.randn(nb * S, C, generator=g).to(_tdt(dt)).to(dev)
+    assert nb * ((S + 255) // 256) * 2 > 512 and 2 * ((S + 255) // 256) * 2 <= 512   # the large call takes the 512-row shape, the small one not
+    ws, _ = ops.linear_attention_state(k, v, nb, S, H)
+    per = H * (D * D + D)
+    big = ws[:nb * per].view(nb, per).clone()
+    for b0 in (0, nb - 2):
+        ws2, _ = ops.linear_attention_state(k[b0 * S:(b0 + 2) * S], v[b0 * S:(b0 + 2) * S], 2, S, H)
+        torch.cuda.synchronize()
+        assert torch.equal(ws2[:2 * per].view(2, per), big[b0:b0 + 2]), (shape, b0, (ws2[:2 * per].view(2, per) - big[b0:b0 + 2]).abs().max().item())
 
 
 @pytest.mark.parametrize("mode", ["128", "256", "off"], ids=["rows256x128-2wg", "rows256x256-1wg", "tile128-kernel"])

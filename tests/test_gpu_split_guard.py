@@ -175,6 +175,41 @@ def test_fp16_overflow_falls_back_to_bf16_with_finite_outputs(where):
         assert torch.equal(d[k], d2[k]), k
 
 
+@pytest.mark.parametrize("shape,block", [((1, 480, 640), "layer3.2"), ((1, 200, 264), "layer2.1"), ((1, 200, 264), "layer1.1")],
+                         ids=["one-640x480-pair-layer3", "odd-size-layer2", "odd-size-layer1"])
+def test_fp16_overflow_is_seen_on_the_unfused_residual_path(shape, block):
+    """where a Bottleneck does NOT take a fused kernel -- layer 3 of ONE 640x480 pair has 2 x 60 x 80 = 9 600 rows, not a
+    multiple of 256; a 200 x 264 image fails layer 1's H % 8 / W % 32 and the tails' row counts -- conv3 + identity + relu is the implicit-GEMM
+    kernel's residual epilogue, which now carries the same range check (gim_conv_args.health).  An overflowing residual stream there must
+    trip the guard, not return silently wrong matches."""
+    n, H, W = shape
+    model, sd = S.synthetic_model("fp16")
+    sd = {k: v.clone() for k, v in sd.items()}
+    key = f"backbone.encode.{block}.bn3.bias"
+    sd[key] = sd[key] + 1e5
+    model.load_state_dict(sd)
+    model = model.to("cuda:0")
+    c0, c1 = S.textured_pairs(n, H, W, seed=5)
+    d, msgs = _fwd(model, c0, c1)
+    assert any("65504" in m for m in msgs), msgs
+    assert model.precision == "bf16" and model.fp16_overflowed
+    for k in ("mconf", "mkpts0_f", "mkpts1_f"):
+        assert torch.isfinite(d[k]).all(), k
+
+
+def test_fallback_keeps_a_callers_fp32_similarity():
+    """the fp16 -> bf16 fallback must not silently replace coarse_sim='fp32' by the 16-bit similarity"""
+    model, sd = S.synthetic_model("fp16")
+    model.coarse_sim = "fp32"
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd["backbone.encode.layer1.1.bn3.bias"] = sd["backbone.encode.layer1.1.bn3.bias"] + 1e5
+    model.load_state_dict(sd)
+    model = model.to("cuda:0")
+    c0, c1 = S.textured_pairs(2, 192, 256, seed=3)
+    _fwd(model, c0, c1)
+    assert model.precision == "bf16" and model.coarse_sim == "fp32"
+
+
 def test_healthy_checkpoint_never_trips_the_guard():
     m3, _ = S.synthetic_model("fp16")
     m3 = m3.to("cuda:0")

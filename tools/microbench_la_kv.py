@@ -1,6 +1,6 @@
 """KV-state reduction of the coarse-level linear attention alone (gim_linear_attention_kv = la_kv + la_kv_finalize), timed inside a HIP
 graph so that launch overhead of the host does not hide the kernels:  python tools/microbench_la_kv.py [reps]
-Run once per GIM_LA_KV2 setting (the choice is read once per process); K / V are column blocks of a [rows, 768] projection buffer
+K / V are column blocks of a [rows, 768] projection buffer
 as in the forward (cross call: 8 sequences, self call: 16)."""
 import os
 import sys
@@ -34,5 +34,5 @@ for kind in (torch.float16, torch.bfloat16):
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / (reps * N) * 1e3
         mb = nb * S * 2 * C * 2 / 1e6
-        print(f"GIM_LA_KV2={os.environ.get('GIM_LA_KV2', '0')} {str(kind)[6:]} nb={nb}: {us:.1f} us per call (kv + finalize), "
+        print(f"{str(kind)[6:]} nb={nb}: {us:.1f} us per call (kv + finalize), "
               f"{mb:.0f} MB of K / V -> {mb / us / 1e3:.2f} TB/s")

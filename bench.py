@@ -1,6 +1,6 @@
 """gim_loftr throughput bench on MI355X (driver contract: see DESIGN.md section 6).
 
-    python bench.py                       # 1 GPU, BASELINE config 2: gim_loftr 640x480, batch 8 pairs, the fp16 mode (--precision bf16 | fp32)
+    python bench.py                       # 1 GPU, BASELINE config 2: gim_loftr 640x480 bf16, batch 8 pairs (--precision fp16 | fp32)
     python bench.py --gpus 8              # spawns 8 ranks itself (re-exec under torch.distributed.run, 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W        # what the driver does
@@ -27,6 +27,10 @@ RCCL all-gather(v) of the packed matches at the end of the run.  Rank 0 prints O
 `parity`    = index flip rate / max coordinate and confidence deviation of the benchmarked 16-bit engine against
               the fp32 oracle on that pair;
 `h2d_inclusive` = the same step with both image batches starting in pinned host memory (double-buffered copy stream).
+Round 5: the headline mode is bf16, what BASELINE config 2 literally names (`fp16_mode` -- a quarter of the index flips, 2-3 % slower -- is the
+extra block; rounds 3-4 headlined fp16); `engine_precision` / `fp16_overflowed` say what the module really ran as; `parity.flips_all_marginal`
+and `parity.worst_flip` price every index flip by the oracle's own margin; the packed match rows are copied to (pinned) host memory inside
+the timed loop; `roofline.traffic_source` names the committed per-round PMC pass `roofline.traffic` comes from.
 Round 4: `n_ranks_seen` / `rank_devices` (what the process group and every rank's device really were), `config.stem_operands`
 (the first convolution runs on hi + lo operand pairs by default) and `parity.plain_stem` (the same batch with plainly rounded
 stem operands, round 3's arithmetic).  GIM_BENCH_DRY_MODEL=1 walks main() on CPU ranks with a stand-in model (tests only).
@@ -52,7 +56,7 @@ from gim_amd.runner import HostPairFeeder, all_gather_matches, bind_rank_to_core
 
 H, W = 480, 640
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense, MI355X_MICROARCH.md
-TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_traffic.json") for r in ("4s2", 4, 3, 2)) if os.path.exists(p)), "")
+TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_traffic.json") for r in (5, "4s2", 4, 3, 2)) if os.path.exists(p)), "")
 
 
 def parse_args(argv=None):
@@ -61,9 +65,10 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="pairs per rank per step")
-    ap.add_argument("--precision", default="fp16", choices=["bf16", "fp16", "fp32"],
-                    help="gim_loftr's mode.  fp16 (default): the 16-bit kernels on IEEE-fp16 operands -- index flip rate 0.15-0.3 %% against "
-                         "the fp32 oracle; bf16: the same kernels on bf16 operands (2-3 %% faster, 0.7-1.3 %% flips); fp32: the parity mode")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="gim_loftr's mode.  bf16 (default: the dtype BASELINE config 2 names): the 16-bit kernels on bf16 operands, 0.7-1.3 %% "
+                         "index flips against the fp32 oracle; fp16 (the module's own default): the same kernels on IEEE-fp16 operands, 2-3 %% "
+                         "slower, 0.15-0.3 %% flips; fp32: the parity mode (exact indices)")
     ap.add_argument("--coarse-sim", default=None, choices=["fp32", "bf16", "fp16"], help="override LoFTR config['coarse_sim']")
     ap.add_argument("--frac", type=float, default=0.45, help="corresponding fraction of the frame (match count knob)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -162,7 +167,7 @@ def main():
     nb = args.batch
     over = {"coarse_sim": args.coarse_sim} if args.coarse_sim else {}
     if dry:
-        ops = S = parity_vs_oracle = None
+        ops = S = parity_vs_oracle = flip_margins = None
         sd_cpu = None
 
         class _DryModel:   # emits 3 + rank matches per pair; nothing else of the engine is exercised
@@ -179,7 +184,7 @@ def main():
     else:
         from gim_amd import ops
         from tools import synth_loftr as S
-        from tools.parity import parity_vs_oracle
+        from tools.parity import flip_margins, parity_vs_oracle
 
         # seeded "trained-like" weights of the gim_loftr architecture (no checkpoint ships with the reference)
         model, sd_cpu = S.synthetic_model(args.precision, seed=0, **over)
@@ -218,15 +223,20 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     rows = []
-    tstep = []
+    rows_host = []   # the outputs are read back inside the timed region -- the packed [pair, x0, y0, x1, y1, conf] rows (~270 KB per step)
+    tstep = []       # travel to pinned host memory asynchronously behind the step that produced them; sync_all() below waits for the last copy
     for s in range(args.steps):
         d = step()
         rows.append(pack_matches(d, (s * world + rank) * nb))   # consecutive pair ids of this batch, packed on the device
+        if not dry:
+            rows_host.append(torch.empty(rows[-1].shape, dtype=rows[-1].dtype, pin_memory=True))
+            rows_host[-1].copy_(rows[-1], non_blocking=True)
         tstep.append(time.perf_counter())
     allrows = all_gather_matches(torch.cat(rows))  # the one collective: matches, for reporting
     n_matches = int(allrows.shape[0])
     sync_all()
     dt = time.perf_counter() - t0
+    readback_bytes = sum(r.numel() * 4 for r in rows_host)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -238,6 +248,10 @@ def main():
     roof = None
     if rank == 0 and not dry:
         graph_was, model.use_graph = model.use_graph, False  # events need eager launches
+        # ... and one stream: the timed configuration runs the coarse transformer as pair chains on parallel streams (loftr.py: tf_chains),
+        # where the event pairs of concurrent launches overlap; the per-kernel table below is taken with ONE chain (12 token launches per
+        # step instead of 32 shorter ones) -- the implicit-GEMM launches (`achieved`) are the same launches either way
+        chains_was, model.tf_chains = getattr(model, "tf_chains", 1), 1
         step()
         ops.PROFILE, ops.PROFILE_FUSED = [], []
         for _ in range(2):
@@ -245,7 +259,7 @@ def main():
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
         fprof, ops.PROFILE_FUSED = ops.PROFILE_FUSED, None
-        model.use_graph = graph_was
+        model.use_graph, model.tf_chains = graph_was, chains_was
         fam = {}
         for e0, e1, f, name in fprof:
             ms, fl, n = fam.get(name, (0.0, 0.0, 0))
@@ -274,11 +288,13 @@ def main():
         top = sorted(by.items(), key=lambda kv: -kv[1][0])[:8]
         # HBM bytes per launch from the TCC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected in
         # separate rocprofv3 --pmc passes of the same workload by tools/pmc_traffic.sh and committed under profiles/
-        traffic = None
+        traffic = traffic_source = None
         if args.precision in ("bf16", "fp16") and nb == 8 and os.path.exists(TRAFFIC_JSON):   # same kernels, same bytes in both 16-bit flavours
             traffic = round(json.load(open(TRAFFIC_JSON))["traffic_bytes_per_launch"])
+            traffic_source = (os.path.relpath(TRAFFIC_JSON, ROOT) + ": separate rocprofv3 --pmc passes (TCC FETCH_SIZE x2 gfx950 correction, WRITE_SIZE) of this "
+                              "workload by tools/pmc_traffic.sh, committed per round -- NOT collected in this run")
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic,
+                "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "gim_conv2d_bn_act kernels (igemm_persistent_kernel + conv3x3_halo_kernel)", "launches_per_step": nlaunch // 2,
                 "avg_launch_us": round(1e3 * tot_ms / nlaunch, 2),
                 "gflop_per_launch": round(tot_fl / nlaunch / 1e9, 3),
@@ -528,6 +544,15 @@ def main():
                          f"(min {min(tcs):.2f}, max {max(tcs):.2f})"}
         if n == 1:
             parity = parity_vs_oracle(d_last, ref, 0)
+            # every index flip priced by the ORACLE's own margin: distance of its confidence from thr = 0.2 and from the runner-up of its row /
+            # column (a flip is "marginal" when the oracle's decision itself hangs on < 0.05 of confidence: 16-bit storage moves mconf by ~0.01)
+            fm = flip_margins(d_last, ref, 0, 0)
+            parity["flips"] = len(fm)
+            parity["flips_all_marginal"] = all(min(f[4], abs(f[5])) < 0.05 for f in fm)
+            if fm:
+                worst = max(fm, key=lambda f: min(f[4], abs(f[5])))
+                parity["worst_flip"] = {"i": worst[0], "j": worst[1], "in_oracle": bool(worst[2]), "oracle_conf": round(worst[3], 5),
+                                        "margin_to_thr": round(worst[4], 5), "gap_to_runner_up": round(worst[5], 5)}
             parity["note"] = (f"pair 0 of the timed batch: {args.precision} engine (coarse_sim={model.coarse_sim}) vs the fp32 CPU "
                               "oracle; flip_rate = |engine matches XOR oracle matches| / |oracle matches|")
             if args.precision in ("bf16", "fp16"):   # the same batch with the other similarity setting: is the operand rounding visible?
@@ -560,7 +585,9 @@ def main():
             "metric": "image-pairs/sec at 640x480", "value": round(pairs / dt, 2), "unit": "pairs/s",
             "n_gpus": world, "n_ranks_seen": n_ranks_seen, "rank_devices": rank_devices, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "vs_baseline": None, "dtype": getattr(model, "precision", args.precision), "data": "synthetic",
+            # what the module really ran as: a tripped fp16 range guard switches it to bf16 for good (gim_amd/loftr/loftr.py::_range_guard)
+            "engine_precision": getattr(model, "precision", args.precision), "fp16_overflowed": bool(getattr(model, "fp16_overflowed", False)),
             "config": {"workload": f"gim_loftr {W}x{H}, batch {nb} pairs per GPU per step, seeded trained-like weights "
                                    f"(calibrated BatchNorm statistics), textured image pairs with {args.frac:.2f} of the frame "
                                    "in correspondence (device resident), fine level loaded, outputs incl. match count read back",
@@ -568,7 +595,11 @@ def main():
                        "coarse_sim": model.coarse_sim, "stem_operands": ("fp16" if (args.precision == "bf16" and model.stem_fp16) else args.precision) +
                                         (" hi+lo pairs (split-operand first convolution)" if (model.stem_split and args.precision != "fp32") else ""),
                        "parallelism": f"pairs sharded over {world} GPU(s), no collective per step",
-                       "hip_graph": bool(model.use_graph)},
+                       "hip_graph": bool(model.use_graph), "transformer_pair_chains": int(getattr(model, "tf_chains", 1)),
+                       "readback": f"match count every step (host sync) + the packed match rows, {readback_bytes // max(1, args.steps)} B per step, to pinned host "
+                                   "memory inside the timed region",
+                       "baseline_dtype_note": "BASELINE config 2 names bf16: the headline mode since round 5 (rounds 3-4 headlined fp16 = `fp16_mode` here: "
+                                              "11 instead of 8 significand bits per stored activation, a quarter of the index flips, 2-3 % slower)"},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity, "parity_mode": alt_modes.get("parity_mode", (None,))[0],
             "fp16_mode": alt_modes.get("fp16_mode", (None,))[0], "bf16_mode": alt_modes.get("bf16_mode", (None,))[0], "h2d_inclusive": h2d, "fine_idle": idle,
             "secondary_workloads": {"gim_lightglue": lightglue, **dense},

@@ -302,10 +302,6 @@ int launch_tail(const Args& a, hipStream_t s) {
     return gim_check_launch("bneck_tail");
 }
 
-// GIM_BNECK_TAIL_NW: 0 (default) = 4-wave workgroups for planes 256 when the 256-row tiles would not fill three rounds of the chip;
-// 4 / 8 force one shape (A/B)
-int tail_nw() { static const int v = [] { const char* e = getenv("GIM_BNECK_TAIL_NW"); return e ? atoi(e) : 0; }(); return v; }
-
 int tail_entry(int P, const void* t2, const void* res, void* x_out, void* t1_next, const void* w3, const void* w1n,
                const float* b3, const float* b1n, int M, int n_next, int act_next, int32_t* health, gim_stream_t stream) {
     GIM_REQUIRE(t2 && res && t1_next && w3 && w1n && b3 && b1n, "bneck_tail: NULL pointer");
@@ -321,8 +317,8 @@ int tail_entry(int P, const void* t2, const void* res, void* x_out, void* t1_nex
         return n_next == 128 ? launch_tail<128, 128>(a, (hipStream_t)stream) : launch_tail<128, 256>(a, (hipStream_t)stream);
     }
     GIM_REQUIRE(n_next == 256, "bneck_tail256: n_next must be 256 (got %d)", n_next);
-    const int nw = tail_nw();
-    if (nw == 4 || (nw == 0 && M / 256 < 3 * 256)) return launch_tail<256, 256, 4>(a, (hipStream_t)stream);
+    // 4-wave workgroups (two per CU) when the 256-row tiles would not fill three rounds of the chip (A/B: DESIGN.md section 4, round 3)
+    if (M / 256 < 3 * 256) return launch_tail<256, 256, 4>(a, (hipStream_t)stream);
     return launch_tail<256, 256>(a, (hipStream_t)stream);
 }
 

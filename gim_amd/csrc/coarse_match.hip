@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(256) cm_stats_kernel(const CmGeom g, const CmW
 //   * pre-candidates: same superset argument as above with the WAVE sub-tile's softmax factors (over 128 columns / 64 rows:
 //     still >= the true factors), tested on the registers; the exact product test is left to cm_precand.
 // Row partials land in the 128-column slots of the tile kernel's layout; column partials have 64-row granularity (ntL64 slots).
-// Two workgroup shapes of the same kernel (GIM_CM_TILE selects; measured in profiles/r04_cm_stats.txt):
+// Two workgroup shapes of the same kernel (measured in profiles/r04_cm_stats.txt; WN2 = 1 is what the library launches):
 //   WN2 = 2: 256 x 256 tile, 8 waves, K slabs double-buffered, one workgroup per CU (128 flop per staged byte).  The two waves of a
 //            SIMD run the same phase: MFMA pipe and VALU take turns.
 //   WN2 = 1: 256 x 128 tile, 4 waves, ONE stage buffer, two workgroups per CU (85 flop per staged byte).  A workgroup cannot hide its
@@ -656,7 +656,14 @@ __global__ void cm_precand_kernel(const CmGeom g, const CmWs w) {
 // stat[n][x] = combine over the first `ntile` of a pair's `stride` partial slots:  m = max m_t ; z = sum_t z_t * exp(m_t - m)   (fixed order:
 // deterministic).  Four threads share an element (slots t, t + 4, ...) so that a pair's 38 ... 75 dependent-latency loads become
 // 10 ... 19: the two launches took 20 us each as one thread per element.
-__global__ void __launch_bounds__(256) cm_combine_kernel(const float2* __restrict__ part, float2* __restrict__ stat, int N, int len, int ntile, int stride) {
+struct CombineJob { const float2* part; float2* stat; int len, ntile; };   // `ntile` partial slots per pair, all of them filled
+// one launch for both directions (round 5): blockIdx.y = 0 the row statistics, 1 the column statistics
+__global__ void __launch_bounds__(256) cm_combine_kernel(const CombineJob jr, const CombineJob jc, int N) {
+    const CombineJob& J = blockIdx.y ? jc : jr;
+    const float2* __restrict__ part = J.part;
+    float2* __restrict__ stat = J.stat;
+    const int len = J.len, ntile = J.ntile, stride = J.ntile;
+    if ((size_t)blockIdx.x * 64 >= (size_t)N * len) return;   // block-uniform: the grid covers the longer direction
     __shared__ float2 sh[4][64];
     const int xq = threadIdx.x & 63, tq = threadIdx.x >> 6;
     const size_t idx = (size_t)blockIdx.x * 64 + xq;
@@ -684,19 +691,16 @@ __global__ void __launch_bounds__(256) cm_combine_kernel(const float2* __restric
     }
 }
 
-__global__ void cm_init_kernel(const CmWs w, int N, int L, int S) {
+__global__ void cm_init_kernel(const CmWs w, int N, int L, int S, int C, int ge) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < (size_t)N * L) { w.rowmaxP[idx] = 0u; w.jsel[idx] = INT_MAX; w.psel[idx] = 0.f; }
     if (idx < (size_t)N * S) w.colmaxP[idx] = 0u;
     if (idx < (size_t)N) w.ncand[idx] = 0;
     if (idx <= (size_t)N) w.npre[idx] = 0;
     if (idx == 0 && w.health) *w.health &= ~1;   // bits 1 (fine kernel of the PREVIOUS call on this buffer) and 2 (range guard of the kernels in front of this call) are sticky: the host clears them
-}
-
-__global__ void cm_ktab_kernel(int* ktab, int C, int ge) {  // dense table: K group g -> channel ge * g (ge = 4 fp32 / 8 bf16 per 16 B); 2 padding slabs
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    // dense K table (same launch since round 5): K group g -> channel ge * g (ge = 4 fp32 / 8 16-bit values per 16 B); 2 padding slabs
     const int ng = (C / 32 + 2) * 8;
-    if (g < ng) ktab[g] = (g * ge < C) ? g * ge : (int)0xFF000000;
+    for (size_t g = idx; g < (size_t)ng; g += (size_t)gridDim.x * blockDim.x) w.ktab[g] = ((int)g * ge < C) ? (int)g * ge : (int)0xFF000000;
 }
 
 // MODE 0: emit candidates.  MODE 1: write the conf tile to `conf` (lazy data['conf_matrix']).
@@ -882,11 +886,6 @@ int validate(const gim_coarse_args& a) {
     return GIM_OK;
 }
 
-// GIM_CM_STATS: 1 (default) the 256-row statistics kernel takes 16-bit features without padding masks (GIM_CM_TILE = 128 / 256 selects
-// its workgroup shape); 0 the 128 x 128 tile-per-workgroup kernel always -- it also serves fp32 features and padding masks (tests
-// compare them).
-static int stats_mode() { static const int v = [] { const char* e = getenv("GIM_CM_STATS"); return e ? atoi(e) : 1; }(); return v; }
-
 template <typename K>
 int set_smem(K kern) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_SMEM);
@@ -915,9 +914,8 @@ static int cm_prepare(const gim_coarse_args& a, CmWs& w, CmGeom& g) {
         if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<1, false>);
         if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<0, true>);
         if (rc == GIM_OK) rc = set_smem(cm_cand_kernel<1, true>);
-        if (rc == GIM_OK && (hipFuncSetAttribute((const void*)cm_stats256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, s2_smem<2>()) != hipSuccess ||
-                             hipFuncSetAttribute((const void*)cm_stats256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, s2_smem<1>()) != hipSuccess)) {
-            gim_set_error("coarse_match: hipFuncSetAttribute(256-row statistics kernels, %d / %d B LDS)", s2_smem<2>(), s2_smem<1>());
+        if (rc == GIM_OK && hipFuncSetAttribute((const void*)cm_stats256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, s2_smem<1>()) != hipSuccess) {
+            gim_set_error("coarse_match: hipFuncSetAttribute(256-row statistics kernel, %d B LDS)", s2_smem<1>());
             rc = GIM_ERR_LAUNCH;
         }
         if (rc != GIM_OK) return rc;
@@ -943,26 +941,23 @@ extern "C" int GIM_FN(gim_coarse_match)(const gim_coarse_args* ap, gim_stream_t 
     if (rc != GIM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     const size_t nmax = (size_t)a.N * (a.L > a.S ? a.L : a.S);
-    hipLaunchKernelGGL(cm_init_kernel, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, s, w, a.N, a.L, a.S);
-    hipLaunchKernelGGL(cm_ktab_kernel, dim3(1), dim3(256), 0, s, w.ktab, a.C, g.bf16 ? 8 : 4);
+    hipLaunchKernelGGL(cm_init_kernel, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, s, w, a.N, a.L, a.S, a.C, g.bf16 ? 8 : 4);
     const unsigned ntiles = (unsigned)(w.ntL * w.ntS * a.N), nfallback = ntiles < 512u ? ntiles : 512u;
     // 256-tile statistics kernel: 16-bit features, no padding masks (K in whole 128-byte slabs is validate()'s rule already)
-    const bool big = g.bf16 && !a.mask0 && stats_mode();
+    const bool big = g.bf16 && !a.mask0;
     if (big) {
-        static const int wn2 = [] { const char* e = getenv("GIM_CM_TILE"); return (e && atoi(e) == 256) ? 2 : 1; }();   // tile columns: 128 (default) / 256
+        constexpr int wn2 = 1;   // 256 x 128 tiles, two 4-wave workgroups per CU (the 256 x 256 / 8-wave shape lost its A/B: profiles/r04_cm_stats.txt)
         int ncu = 256;
         { int dev = 0; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); }
         // persistent: one (two) workgroup(s) per CU; a grid that is a multiple of N (and of 8) keeps pair = tile % N on one XCD per workgroup
         const unsigned tiles2 = (unsigned)(a.N * ((a.L + 255) / 256) * ((a.S + 128 * wn2 - 1) / (128 * wn2)));
         unsigned grid = (unsigned)ncu * (wn2 == 1 ? 2u : 1u);
         if (grid > tiles2) grid = tiles2;
-        if (wn2 == 2) hipLaunchKernelGGL(cm_stats256_kernel<2>, dim3(grid), dim3(512), s2_smem<2>(), s, g, w);
-        else hipLaunchKernelGGL(cm_stats256_kernel<1>, dim3(grid), dim3(256), s2_smem<1>(), s, g, w);
+        hipLaunchKernelGGL(cm_stats256_kernel<1>, dim3(grid), dim3(256), s2_smem<1>(), s, g, w);
     } else if (g.bf16) hipLaunchKernelGGL(cm_stats_kernel<true>, dim3(ntiles), dim3(256), TILE_SMEM, s, g, w);
     else hipLaunchKernelGGL(cm_stats_kernel<false>, dim3(ntiles), dim3(256), TILE_SMEM, s, g, w);
-    hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.L + 63) / 64)), dim3(256), 0, s, w.rowpart, w.rowstat, a.N, a.L, w.ntS, w.ntS);
-    hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)(((size_t)a.N * a.S + 63) / 64)), dim3(256), 0, s, w.colpart, w.colstat, a.N, a.S,
-                       big ? w.ntL64 : w.ntL, big ? w.ntL64 : w.ntL);
+    hipLaunchKernelGGL(cm_combine_kernel, dim3((unsigned)((nmax + 63) / 64), 2u), dim3(256), 0, s, CombineJob{w.rowpart, w.rowstat, a.L, w.ntS},
+                       CombineJob{w.colpart, w.colstat, a.S, big ? w.ntL64 : w.ntL}, a.N);
     hipLaunchKernelGGL(cm_precand_kernel, dim3((unsigned)((w.capp + 255) / 256), (unsigned)a.N), dim3(256), 0, s, g, w);
     if (g.bf16) hipLaunchKernelGGL((cm_cand_kernel<0, true>), dim3(nfallback), dim3(256), TILE_SMEM, s, g, w, (float*)nullptr);
     else hipLaunchKernelGGL((cm_cand_kernel<0, false>), dim3(nfallback), dim3(256), TILE_SMEM, s, g, w, (float*)nullptr);

@@ -491,347 +491,6 @@ igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntile
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// Ping-pong variant of the 256 x 256 / 8-wave tile (bf16, bf16 output, no residual) -- EXPERIMENTAL, GIM_IGEMM_PP=1.
-//
-// In the kernel above the two waves of a SIMD (w and w + 4) leave every slab barrier together: both first issue their eight
-// LDS-DMA instructions, then both compete for the MFMA pipe, then both wait for the DMA to land -- the pipe is busy 50 % of
-// the time.  Here the waves form two groups, G0 = waves 0-3 and G1 = waves 4-7 (one of each on every SIMD), that run the
-// same program ONE BARRIER APART.  The program alternates memory phases and MFMA phases,
-//      m0: ds_read K step 0 | c0: 8 MFMAs | m1: ds_read K steps 1-3 | c1: 24 MFMAs
-// each closed by a raw s_barrier, so that while one group reads LDS the other one owns the MFMA pipe:
-//      interval   4s        4s+1      4s+2      4s+3
-//      G0         m0(s)     c0(s)     m1(s)     c1(s)
-//      G1         c1(s-1)   m0(s)     c0(s)     m1(s)
-// Slab s + 1 goes into the stage slab s - 1 occupied (its last reader, G1's m1(s-1), has waited lgkmcnt(0) before the barrier
-// that closes 4s-1) and is first read at 4s+4.  Its eight LDS-DMA instructions per wave are SPREAD over the phases -- eight in
-// one phase beside the partner's MFMAs cost ~250 cycles each (measured: 1786 us on the 196->196 3x3 layer): G0 issues 3 + 3 + 2 in m0 / c0 / m1 (intervals 4s ..
-// 4s+2), G1 4 + 4 in m0 / c0 (4s+1, 4s+2); every wave waits vmcnt(0) for its own pieces before the barrier that closes 4s+3
-// (G0 at the end of c1, G1 at the end of m1).  The epilogue of a tile is one more phase.
-// Measured: exactly as fast as the plain kernel (1154 vs 1144 us on 196->196 3x3, 1457 vs 1452 us on 256->256 3x3 at M = 1.2 M)
-// -- two very different schedules, one speed: the schedule is not what bounds this tile.  Kept (off) as the starting point for
-// a half-tile-stage version; tests force it through GIM_IGEMM_PP=2.
-__device__ __forceinline__ void pp_barrier() {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-__global__ void __launch_bounds__(512, 2)
-igemm_pp_kernel(const gim_conv_args a, const int mtiles, const int ntiles, const int M) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BM = 256, BN = 256;
-    typedef gim::Igemm<BM, BN, 4, 2, true, true> G;
-    typedef Epilogue<G, true, false> E;
-    static_assert(G::NPIECE == 8, "piece schedule below assumes 8 LDS-DMA instructions per wave and slab");
-    int* ktl = (int*)(smem + 2 * G::STAGE);
-
-    unsigned first, step, end;
-    tile_list((unsigned)(mtiles * ntiles), first, step, end);
-    if (first >= end) return;
-    const gim::MainloopArgs ml = mainloop_args(a, M, G::ES);
-    const int nkt = a.kpad * G::ES / KTB;
-    for (int i = threadIdx.x; i < (nkt + 2) * 8; i += 512) ktl[i] = a.ktab[i];
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    pp_barrier();
-
-    E epi;
-    G g, gn;
-    typename G::Acc acc;
-    typename E::Res rres;
-    const int grp = epi.wave >> 2;  // wave-uniform
-    int m0 = (int)(first / ntiles) * BM, n0 = (int)(first % ntiles) * BN;
-    epi.init_acc(a, acc, n0);
-    g.decode(ml, m0, n0);
-    {   // prologue: slab 0 of the first tile -> stage 0
-        const typename G::Tap tap = G::tap_decode(ml, ktl[G::ktab_index(0)]);
-#pragma unroll
-        for (int p = 0; p < G::NPIECE; ++p) g.issue_piece(ml, smem, 0, 0, tap, p);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        pp_barrier();
-    }
-    if (grp) pp_barrier();  // G1 runs one barrier behind G0 from here on
-    int st = 0;             // stage of the slab being computed
-
-    for (unsigned tile = first; tile < end; tile += step) {
-        const unsigned tile_n = tile + step;
-        const bool has_next = tile_n < end;
-        const int m0n = (int)(tile_n / ntiles) * BM, n0n = (int)(tile_n % ntiles) * BN;
-        gn = g;  // without a next tile the staging cursor re-reads this tile's first slab into the free stage (unread)
-        if (has_next) gn.decode(ml, m0n, n0n);
-        auto kloop = [&](auto live) __attribute__((always_inline)) {
-            constexpr int LIVE = decltype(live)::value;
-            for (int kt = 0; kt < nkt; ++kt) {
-                const bool last = kt + 1 == nkt;
-                if (last) g = gn;  // the cursor moves on to the next tile's first slab
-                const int kt_issue = last ? 0 : kt + 1;
-                const typename G::FragAddr fr = G::frag_addr(smem, st);
-                const typename G::Tap tap = G::tap_decode(ml, ktl[G::ktab_index(kt_issue)]);
-                auto pieces = [&](const int p0, const int p1) __attribute__((always_inline)) {
-#pragma unroll
-                    for (int p = 0; p < G::NPIECE; ++p)
-                        if (p >= p0 && p < p1) g.issue_piece(ml, smem, st ^ 1, kt_issue, tap, p);
-                };
-                // ---- m0 ------------------------------------------------------------------------------------------
-                typename G::template Frags<LIVE> f0;
-                G::template load_frags<LIVE>(fr, 0, f0);
-                if (grp) pieces(0, 4); else pieces(0, 3);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                pp_barrier();
-                // ---- c0 ------------------------------------------------------------------------------------------
-                G::template mma<LIVE>(acc, f0);
-                if (grp) pieces(4, 8); else pieces(3, 6);
-                pp_barrier();
-                // ---- m1 ------------------------------------------------------------------------------------------
-                typename G::template Frags<LIVE> f1, f2, f3;
-                G::template load_frags<LIVE>(fr, 1, f1);
-                G::template load_frags<LIVE>(fr, 2, f2);
-                G::template load_frags<LIVE>(fr, 3, f3);
-                if (!grp) pieces(6, 8);
-                if (grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                pp_barrier();
-                // ---- c1 ------------------------------------------------------------------------------------------
-                G::template mma<LIVE>(acc, f1);
-                G::template mma<LIVE>(acc, f2);
-                G::template mma<LIVE>(acc, f3);
-                if (!grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                pp_barrier();
-                st ^= 1;
-            }
-        };
-        kloop(IntC<G::TN>());  // (no fragment skipping here: the two-copy K loop spills in this kernel)
-        // ---- epilogue phase: st ^ 1 is the stage the tile's last slab was read from -----------------------------------
-        epi.run(a, acc, rres, smem + (st ^ 1) * G::STAGE, m0, n0, M);
-        epi.init_acc(a, acc, n0n < a.npad ? n0n : 0);
-        m0 = m0n; n0 = n0n;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        pp_barrier();
-    }
-    if (!grp) pp_barrier();  // G0 meets G1's extra barrier
-}
-
-// ------------------------------------------------------------------------------------------------
-// Deep-prefetch variant for the MFMA-bound layers: 8 waves (4 x 2), 256 x 128 tile, THREE LDS stages of
-// 48 KiB (one workgroup per CU).  With two stages the DMA of slab s+1 has only one compute phase (~1000
-// cycles) to land -- less than the loaded L2/HBM latency -- and both resident workgroups stall together
-// (measured: MFMA pipe 43 % busy).  Here slab s+2 is issued right after the barrier that opens slab s, i.e.
-// two full phases ahead; the wave waits with a COUNTED vmcnt (only the newest slab may be outstanding) and a
-// raw s_barrier, so loads stay in flight across barriers.  There is no ordinary global load in the K loop
-// (the K-group table is copied to LDS once): hipcc drains vmcnt to 0 in front of any use of one.
-template <bool BF16, bool HAS_RES>
-__global__ void __launch_bounds__(512, 2)
-igemm_ring3_kernel(const gim_conv_args a, const int mtiles, const int ntiles, const int M) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BM = 256, BN = 128;
-    typedef gim::Igemm<BM, BN, 4, 2, BF16, true> G;
-    typedef Epilogue<G, true, HAS_RES> E;
-    static_assert(G::PA + G::PB == 6, "counted vmcnt below assumes 6 DMA instructions per slab");
-    int* ktl = (int*)(smem + 3 * G::STAGE);
-
-    unsigned first, step, end;
-    tile_list((unsigned)(mtiles * ntiles), first, step, end);
-    if (first >= end) return;
-    const gim::MainloopArgs ml = mainloop_args(a, M, G::ES);
-    const int nkt = a.kpad * G::ES / KTB;
-    for (int i = threadIdx.x; i < (nkt + 2) * 8; i += 512) ktl[i] = a.ktab[i];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    const int ntl = (int)((end - first + step - 1) / step);
-    const int nslab = ntl * nkt;
-
-    // issue cursor (runs two slabs ahead of the compute cursor)
-    G gi;
-    unsigned it_tile = first;
-    int it_k = 0, issued = 0, istage = 0;
-    gi.decode(ml, (int)(it_tile / ntiles) * BM, (int)(it_tile % ntiles) * BN);
-    auto issue_next = [&]() {
-        gi.stage_issue(ml, smem, istage, it_k, ktl[G::ktab_index(it_k)]);
-        istage = istage == 2 ? 0 : istage + 1;
-        ++issued;
-        if (++it_k == nkt) {
-            it_k = 0;
-            it_tile += step;
-            if (it_tile < end) gi.decode(ml, (int)(it_tile / ntiles) * BM, (int)(it_tile % ntiles) * BN);
-        }
-    };
-    issue_next();
-    if (nslab > 1) issue_next();
-
-    E epi;
-    typename G::Acc acc;
-    typename E::Res rres;
-    unsigned ct = first;
-    int ck = 0, cstage = 0;
-    int m0 = (int)(ct / ntiles) * BM, n0 = (int)(ct % ntiles) * BN;
-    epi.init_acc(a, acc, n0);
-
-    for (int c = 0; c < nslab; ++c) {
-        // slab c must have landed; only the newest issued slab (c+1) may still be in flight
-        if (issued > c + 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // slab c visible to all waves; all waves are done with slab c-1's stage
-        if (issued < nslab) issue_next();  // slab c+2 -> the stage slab c-1 occupied
-        const bool last = ck + 1 == nkt;
-        if (last) epi.prefetch_res(a, rres, m0, n0, M);
-        G::compute(smem, cstage, acc);
-        if (last) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // every wave has finished reading stage `cstage`
-            epi.run(a, acc, rres, smem + cstage * G::STAGE, m0, n0, M);
-            ck = 0;
-            ct += step;
-            m0 = (int)(ct / ntiles) * BM;
-            n0 = (int)(ct % ntiles) * BN;
-            epi.init_acc(a, acc, n0 < a.npad ? n0 : 0);
-        } else {
-            ++ck;
-        }
-        cstage = cstage == 2 ? 0 : cstage + 1;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Loader-wave variant of the 256 x 256 tile (16-bit operands and output, no residual / upsample operand): round 4.
-//
-// tools/microbench_mainloop.hip runs this library's main loop one ingredient at a time (profiles/r04_microbench.txt).  On CUs that
-// are not power-limited the bare MFMA stream of the tile runs at the peak rate; fragment reads from LDS cost 12 %, the LDS-DMA
-// instructions of the next slab ISSUED BY THE MFMA WAVES another 20 %: a wave that issues a buffer_load ... lds holds its own MFMA
-// stream for ~60 cycles per instruction (in-order issue), and all eight waves do so together right behind the slab barrier --
-// wherever in the slab the instructions are placed.  Four extra waves (one per SIMD) that do nothing but stage bring the same
-// loop from 0.73 to 0.86 of the peak rate -- on 32 of the 256 CUs.  With all CUs busy the chip is power-limited (the bare MFMA stream
-// reaches 0.68 of the nominal peak on random operands, 0.97 on all-zero ones) and the same change is worth 3-4 %; in the real
-// layers, where the loaders also carry the tap arithmetic and first touches come from HBM with ONE slab of lookahead, the forward got
-// 0.33 ms slower (10.83 vs 10.50 ms, same box).  EXPERIMENTAL, off by default (GIM_IGEMM_LW=1), kept with its test as the measured
-// answer to "dedicated loader waves" (VERDICT r3 item 4 iii).  Structure:
-//   waves 0-7  : MFMA waves, 4 x 2 over the tile, 64 px x 128 ch each (gim::Igemm<256,256,4,2>::compute + the shared Epilogue):
-//                ds_read_b128, MFMA, one barrier per slab -- no address arithmetic, no vector-memory instruction in the K loop;
-//   waves 8-11 : loader waves.  Each plays two of the eight staging waves of the plain kernel (same LDS image, same source-side
-//                swizzle): tap decode, bounds checks, 16 LDS-DMA instructions per slab, vmcnt(0), barrier.
-// The barrier that ends slab k tells the MFMA waves that slab k + 1 has landed and the loaders that the stage of slab k is free.
-// 12 waves = 3 per SIMD: 168 VGPRs per wave (128 accumulator registers + 24 fragment registers + addresses in the MFMA waves).
-template <bool SKIP>
-__global__ void __launch_bounds__(768, 3)
-igemm_lw_kernel(const gim_conv_args a, const int mtiles, const int ntiles, const int M) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BM = 256, BN = 256;
-    typedef gim::Igemm<BM, BN, 4, 2, true, true> G;
-    typedef Epilogue<G, true, false> E;
-
-    unsigned first, step, end;
-    tile_list((unsigned)(mtiles * ntiles), first, step, end);
-    if (first >= end) return;
-    const gim::MainloopArgs ml = mainloop_args(a, M, G::ES);
-    const int nkt = a.kpad * G::ES / KTB;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    if (wave >= 8) {
-        // ---- loader waves ---------------------------------------------------------------------------------------------------
-        const int sw0 = 2 * (wave - 8);                          // the two staging waves this wave plays
-        const int vt0 = sw0 * 64 + (int)(threadIdx.x & 63), vt1 = vt0 + 64;
-        G g0, g1, gn0, gn1;
-        int m0 = (int)(first / ntiles) * BM, n0 = (int)(first % ntiles) * BN;
-        g0.decode(ml, m0, n0, vt0);
-        g1.decode(ml, m0, n0, vt1);
-        g0.stage_issue(ml, smem, 0, 0, a.ktab[G::ktab_index(0, vt0)], sw0);
-        g1.stage_issue(ml, smem, 0, 0, a.ktab[G::ktab_index(0, vt1)], sw0 + 1);
-        int e0 = a.ktab[G::ktab_index(nkt > 1 ? 1 : 0, vt0)], e1 = a.ktab[G::ktab_index(nkt > 1 ? 1 : 0, vt1)];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                          // slab 0 of the first tile has landed
-        int buf = 0;
-        for (unsigned tile = first; tile < end; tile += step) {
-            const unsigned tile_n = tile + step;
-            const bool has_next = tile_n < end;
-            if (has_next) {
-                const int m0n = (int)(tile_n / ntiles) * BM, n0n = (int)(tile_n % ntiles) * BN;
-                gn0.decode(ml, m0n, n0n, vt0);
-                gn1.decode(ml, m0n, n0n, vt1);
-            }
-            if (tile != first) __syncthreads();                   // the previous tile's epilogue has left the stage buf ^ 1
-            for (int kt = 0; kt < nkt; ++kt) {
-                const bool last = kt + 1 == nkt;
-                int k2 = kt + 2;
-                if (k2 >= nkt) k2 -= nkt;
-                if (k2 >= nkt) k2 = 0;                            // nkt == 1
-                const int f0 = a.ktab[G::ktab_index(k2, vt0)], f1 = a.ktab[G::ktab_index(k2, vt1)];
-                if (!last) {
-                    g0.stage_issue(ml, smem, buf ^ 1, kt + 1, e0, sw0);
-                    g1.stage_issue(ml, smem, buf ^ 1, kt + 1, e1, sw0 + 1);
-                } else if (has_next) {
-                    gn0.stage_issue(ml, smem, buf ^ 1, 0, e0, sw0);
-                    gn1.stage_issue(ml, smem, buf ^ 1, 0, e1, sw0 + 1);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();                                  // slab kt + 1 has landed; the MFMA waves are done with slab kt
-                buf ^= 1;
-                e0 = f0; e1 = f1;
-            }
-            g0 = gn0; g1 = gn1;
-        }
-        return;
-    }
-
-    // ---- MFMA waves -----------------------------------------------------------------------------------------------------------
-    E epi;
-    typename G::Acc acc;
-    typename E::Res rres;
-    int m0 = (int)(first / ntiles) * BM, n0 = (int)(first % ntiles) * BN;
-    epi.init_acc(a, acc, n0);
-    __syncthreads();                                              // slab 0 of the first tile has landed
-    int buf = 0;
-    for (unsigned tile = first; tile < end; tile += step) {
-        const unsigned tile_n = tile + step;
-        const bool has_next = tile_n < end;
-        auto kloop = [&](auto live) __attribute__((always_inline)) {
-            for (int kt = 0; kt < nkt; ++kt) {
-                G::template compute<decltype(live)::value>(smem, buf, acc);
-                __syncthreads();
-                buf ^= 1;
-            }
-        };
-        if constexpr (SKIP) {
-            // the wave's last channel fragment holds only padding channels (wave-uniform)
-            if (n0 + epi.wn * G::WTN + (G::TN - 1) * 32 >= a.N) kloop(IntC<G::TN - 1>());
-            else kloop(IntC<G::TN>());
-        } else {
-            kloop(IntC<G::TN>());
-        }
-        epi.run(a, acc, rres, smem + (buf ^ 1) * G::STAGE, m0, n0, M);   // buf ^ 1: the stage of the tile's last slab
-        m0 = (int)(tile_n / ntiles) * BM; n0 = (int)(tile_n % ntiles) * BN;
-        epi.init_acc(a, acc, n0 < a.npad ? n0 : 0);
-        if (has_next) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __syncthreads();                                      // the transposition tiles are consumed: the loaders may refill that stage
-        }
-    }
-}
-
-int launch_lw(const gim_conv_args& a, hipStream_t stream, const bool skip) {
-    constexpr int smem = 2 * (256 + 256) * KTB;
-    static GimPerDevice attr_done;
-    if (attr_done.needed()) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_lw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_lw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) {
-            gim_set_error("hipFuncSetAttribute(%d B LDS): %s", smem, hipGetErrorString(e));
-            return GIM_ERR_LAUNCH;
-        }
-        attr_done.done();
-    }
-    const int M = a.B * a.Ho * a.Wo;
-    const int mtiles = (M + 255) / 256, ntiles = a.npad / 256;
-    const int T = mtiles * ntiles;
-    constexpr int RESIDENT = 256;  // one workgroup per CU
-    const int rounds = (T + RESIDENT - 1) / RESIDENT;
-    const int grid = (T + rounds - 1) / rounds;
-    if (skip) hipLaunchKernelGGL(igemm_lw_kernel<true>, dim3((unsigned)grid), dim3(768), smem, stream, a, mtiles, ntiles, M);
-    else hipLaunchKernelGGL(igemm_lw_kernel<false>, dim3((unsigned)grid), dim3(768), smem, stream, a, mtiles, ntiles, M);
-    return gim_check_launch("igemm_lw_kernel");
-}
-
 template <int BM, int BN, int WM, int WN, bool BF16, bool OUT_BF16, bool HAS_RES, bool SKIP = false, bool UPS = false>
 int launch_persistent(const gim_conv_args& a, hipStream_t stream) {
     constexpr int smem = 2 * (BM + BN) * KTB;
@@ -854,30 +513,6 @@ int launch_persistent(const gim_conv_args& a, hipStream_t stream) {
     const int grid = (T + rounds - 1) / rounds;  // balanced: every block gets `rounds` (or rounds-1) tiles
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), smem, stream, a, mtiles, ntiles, M);
     return gim_check_launch("igemm_persistent_kernel");
-}
-
-int launch_pp(const gim_conv_args& a, hipStream_t stream) {
-    const int nkt = a.kpad * 2 / KTB;
-    const int smem = 2 * (256 + 256) * KTB + (nkt + 2) * 8 * 4;
-    if (smem > 160 * 1024) return launch_persistent<256, 256, 4, 2, true, true, false>(a, stream);
-    auto kern = igemm_pp_kernel;
-    static GimPerDevice attr_done;
-    if (attr_done.needed()) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            gim_set_error("hipFuncSetAttribute(160 KiB LDS): %s", hipGetErrorString(e));
-            return GIM_ERR_LAUNCH;
-        }
-        attr_done.done();
-    }
-    const int M = a.B * a.Ho * a.Wo;
-    const int mtiles = (M + 255) / 256, ntiles = a.npad / 256;
-    const int T = mtiles * ntiles;
-    constexpr int RESIDENT = 256;  // one workgroup per CU
-    const int rounds = (T + RESIDENT - 1) / RESIDENT;
-    const int grid = (T + rounds - 1) / rounds;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, a, mtiles, ntiles, M);
-    return gim_check_launch("igemm_pp_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1089,51 +724,11 @@ int launch_halo(const gim_conv_args& a, hipStream_t stream) {
     return gim_check_launch("conv3x3_halo_kernel");
 }
 
-template <bool BF16, bool HAS_RES>
-int launch_ring3(const gim_conv_args& a, hipStream_t stream) {
-    const int es = BF16 ? 2 : 4;
-    const int nkt = a.kpad * es / KTB;
-    const int smem = 3 * (256 + 128) * KTB + (nkt + 2) * 8 * 4;
-    auto kern = igemm_ring3_kernel<BF16, HAS_RES>;
-    static GimPerDevice attr_done;
-    if (attr_done.needed()) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            gim_set_error("hipFuncSetAttribute(160 KiB LDS): %s", hipGetErrorString(e));
-            return GIM_ERR_LAUNCH;
-        }
-        attr_done.done();
-    }
-    const int M = a.B * a.Ho * a.Wo;
-    const int mtiles = (M + 255) / 256, ntiles = a.npad / 128;
-    const int T = mtiles * ntiles;
-    constexpr int RESIDENT = 256;  // one workgroup per CU
-    const int rounds = (T + RESIDENT - 1) / RESIDENT;
-    const int grid = (T + rounds - 1) / rounds;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, a, mtiles, ntiles, M);
-    return gim_check_launch("igemm_ring3_kernel");
-}
-
-// GIM_IGEMM_RING3: 0 = never (default: measured no faster than the 2-stage kernels), 1 = heuristic,
-// 2 = whenever the shape allows (tests).  GIM_IGEMM_BIG: same for the 256x256 / 8-wave tile.
-static int ring3_mode() {
-    static const int mode = [] { const char* e = getenv("GIM_IGEMM_RING3"); return e ? atoi(e) : 0; }();
-    return mode;
-}
-static int big_mode() {
-    static const int mode = [] { const char* e = getenv("GIM_IGEMM_BIG"); return e ? atoi(e) : 1; }();
-    return mode;
-}
-static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-static int skip_mode() { static const int v = env_int("GIM_IGEMM_SKIP", 1); return v; }
-// GIM_IGEMM_PP: ping-pong variant of the 256 x 256 tile: 0 = never (default), 1 = for K loops of at least GIM_IGEMM_PP_MIN_NKT slabs, 2 = always
-static int pp_mode() { static const int v = env_int("GIM_IGEMM_PP", 0); return v; }
-static int pp_min_nkt() { static const int v = env_int("GIM_IGEMM_PP_MIN_NKT", 8); return v; }
-// GIM_IGEMM_LW: loader-wave variant of the 256 x 256 tile (16-bit, no residual / upsample operand): 0 = never (default: measured
-// 0.33 ms per forward SLOWER than the plain kernel on the full chip, see igemm_lw_kernel), 1 = wherever the plain 256 x 256 kernel would run
-static int lw_mode() { static const int v = env_int("GIM_IGEMM_LW", 0); return v; }
-static int big_min_tiles() { static const int v = env_int("GIM_IGEMM_BIG_MIN_TILES", 1024); return v; }   // round-3 sweep (profiles/r03_knob_sweep.txt)
-static int big_min_nkt() { static const int v = env_int("GIM_IGEMM_BIG_MIN_NKT", 4); return v; }
+// Tile-selection thresholds of dispatch_persistent (round-3 sweep, profiles/r03_knob_sweep.txt): the 256 x 256 / 8-wave tile takes a layer
+// with at least BIG_MIN_NKT K slabs and BIG_MIN_TILES tiles; its all-padding column fragment is skipped for N <= npad - 32.
+// Round 5: the experimental main-loop variants (3-stage ring, ping-pong, loader waves: each exact, each measured no faster -- DESIGN.md
+// section 4, "what the counters said") and their GIM_IGEMM_* switches are gone from the library; git history has them.
+constexpr int BIG_MIN_TILES = 1024, BIG_MIN_NKT = 4;
 
 template <int BM, int BN, int WM, int WN, bool BF16>
 int dispatch_res(const gim_conv_args& a, hipStream_t s) {
@@ -1157,40 +752,27 @@ int dispatch_persistent(const gim_conv_args& a, hipStream_t s) {
         const long long T = ((M + 255) / 256) * (a.npad / 128);
         // 256 x 256 tile, 8 waves, 64 x 128 wave tile: twice the MFMAs per wave and slab against nearly the same
         // staging / addressing overhead -- for the MFMA-bound layers (no residual, bf16 out, N % 256 == 0)
-        const int bmode = big_mode();
         if (a.npad % 256 == 0 && out_is16(a) && !a.res &&
-            (bmode == 2 || (bmode == 1 && nkt >= big_min_nkt() && ((M + 255) / 256) * (a.npad / 256) >= big_min_tiles())))
+            (a.use_lds_dma == 3 || (nkt >= BIG_MIN_NKT && ((M + 255) / 256) * (a.npad / 256) >= BIG_MIN_TILES)))   // 3: the tests' way onto this tile
         {
             // N <= 224 (the FPN's 196-channel layers): the second column half's last fragment is pure padding
-            const bool skip = a.N <= a.npad - 32 && skip_mode();
-            if constexpr (BF16) {
-                if (pp_mode() == 2 || (pp_mode() == 1 && nkt >= pp_min_nkt()))
-                    return launch_pp(a, s);
-            }
+            const bool skip = a.N <= a.npad - 32;
             if constexpr (BF16) {
                 if (a.ups) return skip ? launch_persistent<256, 256, 4, 2, true, true, false, true, true>(a, s)
                                        : launch_persistent<256, 256, 4, 2, true, true, false, false, true>(a, s);
-            }
-            if constexpr (BF16) {
-                if (lw_mode()) return launch_lw(a, s, skip);
             }
             if (skip) return launch_persistent<256, 256, 4, 2, BF16, true, false, true>(a, s);
             return launch_persistent<256, 256, 4, 2, BF16, true, false>(a, s);
         }
         // (a 512 x 128 tile with 128 x 64 wave tiles for the N = 128 layers measured slower than 128 x 128: 875 vs 716 us
         //  on 196->128 3x3 -- not built)
-        const int mode = ring3_mode();
-        const bool can = a.out_dtype == GIM_H16 && nkt <= 72;   // (experimental ring kernel: the flavour's own type only)
-        if (can && (mode == 2 || (mode == 1 && nkt >= 8 && T >= 4 * 256)))
-            return a.res ? launch_ring3<BF16, true>(a, s) : launch_ring3<BF16, false>(a, s);
         return dispatch_res<128, 128, 2, 2, BF16>(a, s);
     }
     // N = 129 ... 192 on the 256 x 64 tile reads every pixel panel three times (one tile per 64 channels); these layers are memory-bound
     // (DKM's 144-channel refiner blocks at 0.9 M pixels: 510 MB per launch at 2.8 TB/s).  A 256 x 192 tile on 8 waves of 32 px x 192 ch
-    // stages the panel once.  GIM_IGEMM_N192=0 keeps the 64-wide tiles.
+    // stages the panel once.
     if constexpr (BF16) {
-        static const int n192 = env_int("GIM_IGEMM_N192", 1);
-        if (n192 && a.npad == 192 && out_is16(a) && !a.res && !a.ups) return launch_persistent<256, 192, 8, 1, true, true, false>(a, s);
+        if (a.npad == 192 && out_is16(a) && !a.res && !a.ups) return launch_persistent<256, 192, 8, 1, true, true, false>(a, s);
     }
     return dispatch_res<256, 64, 4, 1, BF16>(a, s);
 }
@@ -1225,14 +807,14 @@ int dispatch_tile(const gim_conv_args& a, hipStream_t s) {
 
 // a->ups is only built into the 256 x 256 / 8-wave bf16 tile: the launch must be one that dispatch_persistent sends there
 static bool ups_supported(const gim_conv_args& a) {
-    if (a.dtype != GIM_H16 || a.out_dtype != GIM_H16 || a.res || a.use_lds_dma != 1 || a.npad % 256 != 0) return false;
+    if (a.dtype != GIM_H16 || a.out_dtype != GIM_H16 || a.res || (a.use_lds_dma != 1 && a.use_lds_dma != 3) || a.npad % 256 != 0) return false;
     // output rows are (image, Y, X) with Y < 2 ups_h, X < 2 ups_w whatever geometry the launch states (a 1x1 conv is launched flat)
     const long long Mo = (long long)a.B * a.Ho * a.Wo;
     if (a.ups_h <= 0 || a.ups_w <= 0 || Mo % (4ll * a.ups_h * a.ups_w) != 0 || (2 * a.ups_w) % 32 != 0 || a.ups_ld % 8 != 0 || a.ups_ld < a.N) return false;
-    if (a.act_cols != 0 || big_mode() == 0 || pp_mode() != 0) return false;
+    if (a.act_cols != 0) return false;
     const int nkt = a.kpad * 2 / KTB;
     const long long M = (long long)a.B * a.Ho * a.Wo;
-    return big_mode() == 2 || (nkt >= big_min_nkt() && ((M + 255) / 256) * (a.npad / 256) >= big_min_tiles());
+    return a.use_lds_dma == 3 || (nkt >= BIG_MIN_NKT && ((M + 255) / 256) * (a.npad / 256) >= BIG_MIN_TILES);
 }
 
 #if !GIM_HALF_KIND

@@ -407,21 +407,13 @@ __global__ void __launch_bounds__(256) dwconv5x5_tiled_kernel(const void* __rest
 //   * one 16-byte store per output pixel.
 // compiler fence for memory operations (IR level) + scheduling barrier (machine level): pins the software pipeline
 #define ORDER_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-// PW (bf16, cpad = 32 = 4 channel groups, one chunk): the 1x1 convolution that follows in DKM's / RoMa's ConvRefiner block
-// (create_block, dkm.py:58-73: depthwise 5x5 -> BatchNorm -> ReLU -> 1x1 with bias) runs in the epilogue.  At 24 channels that
-// 1x1 is pure memory traffic -- a 1.77 M-pixel launch of the implicit-GEMM kernel took 284 us for 226 MB (one K slab per tile: all
-// latency) on top of this kernel's 198 us -- so the block's 512 pixels x 32 channels go through LDS instead: bf16 rows [512][64 B],
-// every wave takes the 128 pixels of its own rows as four 32-pixel MFMA fragments (weights = A operand, K = 32 in two k16 steps),
-// writes the results back over them and stores 16 pixels x 64 B per instruction.  The intermediate tensor never exists.
-template <bool BF16, bool PW = false>
+template <bool BF16>
 __global__ void __launch_bounds__(256, 2) dwconv5x5_rows2_kernel(const void* __restrict__ x, const float* __restrict__ wgt,
                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
                                                                  void* __restrict__ y, int B, int H, int W, int CG, int CGB, int NCH,
-                                                                 int cpad, int ldx, int ldy, unsigned nblk,
-                                                                 const unsigned short* __restrict__ pww = nullptr, const float* __restrict__ pwb = nullptr) {
-    static_assert(!PW || BF16, "fused 1x1: bf16 only");
+                                                                 int cpad, int ldx, int ldy, unsigned nblk) {
     constexpr int G = BF16 ? 8 : 4, ES = BF16 ? 2 : 4, G2 = G / 2, NP = G / 4;   // NP float4 planes of weights
-    extern __shared__ float4 wl[];                                              // [NP][25][CGB]  (+ PW: [512 px][64 B] behind it)
+    extern __shared__ float4 wl[];                                              // [NP][25][CGB]
     const unsigned lb = xcd_remap(blockIdx.x, nblk);
     const int chunk = (int)(lb % (unsigned)NCH);
     const unsigned sblk = lb / (unsigned)NCH;
@@ -438,9 +430,8 @@ __global__ void __launch_bounds__(256, 2) dwconv5x5_rows2_kernel(const void* __r
     const int WS = (W + 3) / 4, HS = (H + 1) / 2;
     const size_t strip = (size_t)sblk * SPB + sl;
     const bool live = !(sl >= SPB || cgl >= ncg || strip >= (size_t)B * HS * WS);
-    if (!PW && !live) return;
-    // (PW: a thread without a strip computes a clamped one and stores nothing -- it has to reach the barriers)
-    const size_t strip_c = live ? strip : 0;
+    if (!live) return;
+    const size_t strip_c = strip;
     const int xs = (int)(strip_c % WS) * 4, Y = (int)((strip_c / WS) % HS) * 2, b = (int)(strip_c / ((size_t)WS * HS));
     const int co = live ? (cg0 + cgl) * G : 0;
     f32x2_t acc[2][4][G2];
@@ -541,69 +532,6 @@ __global__ void __launch_bounds__(256, 2) dwconv5x5_rows2_kernel(const void* __r
         sc[e] = (f32x2_t){a.x, a.y}; sc[e + 1] = (f32x2_t){a.z, a.w};
         sh[e] = (f32x2_t){c.x, c.y}; sh[e + 1] = (f32x2_t){c.z, c.w};
     }
-    if constexpr (PW) {
-        typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
-        typedef __attribute__((ext_vector_type(16))) float f16v_t;
-        char* T = (char*)(wl + NP * 25 * CGB);   // [512 px][4 slots of 16 B], slot s of row r at s ^ ((r >> 2) & 3)
-        const int tid = threadIdx.x;
-#pragma unroll
-        for (int o = 0; o < 2; ++o)
-#pragma unroll
-            for (int p_ = 0; p_ < 4; ++p_) {
-                float rr[8];
-#pragma unroll
-                for (int e = 0; e < G2; ++e) {
-                    const f32x2_t v = acc[o][p_][e] * sc[e] + sh[e];
-                    rr[2 * e] = fmaxf(v.x, 0.f); rr[2 * e + 1] = fmaxf(v.y, 0.f);
-                }
-                const int pi = sl * 8 + o * 4 + p_;
-                // (a channel group beyond the stored width -- 24 stored channels = 3 groups -- must hold exact zeros: it is K of the MFMA)
-                *(uint4*)(T + pi * 64 + ((cgl ^ ((pi >> 2) & 3)) << 4)) = cgl < ncg ?
-                    make_uint4(pack_bf16x2(rr[0], rr[1]), pack_bf16x2(rr[2], rr[3]), pack_bf16x2(rr[4], rr[5]), pack_bf16x2(rr[6], rr[7])) :
-                    make_uint4(0u, 0u, 0u, 0u);
-            }
-        __syncthreads();
-        const int lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-        bf8_t wf[2];   // A operand: row m = output channel l31, k16 step ks: input channels 16 ks + 8 lh .. + 7
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) wf[ks] = *(const bf8_t*)(pww + l31 * 32 + (2 * ks + lh) * 8);
-        f16v_t c[4];
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const float4 bb = *(const float4*)(pwb + 8 * rg + 4 * lh);
-                c[f][rg * 4] = bb.x; c[f][rg * 4 + 1] = bb.y; c[f][rg * 4 + 2] = bb.z; c[f][rg * 4 + 3] = bb.w;
-            }
-            const int pi = wv * 128 + f * 32 + l31;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf8_t bv = *(const bf8_t*)(T + pi * 64 + (((2 * ks + lh) ^ ((pi >> 2) & 3)) << 4));
-                c[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], bv, c[f], 0, 0, 0);
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's rows are consumed (a wave's LDS accesses execute in order)
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const int pi = wv * 128 + f * 32 + l31;
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg)   // accumulator quad = output channels 8 rg + 4 lh .. + 3 of pixel pi
-                *(uint2*)(T + pi * 64 + ((rg ^ ((pi >> 2) & 3)) << 4) + lh * 8) =
-                    make_uint2(pack_bf16x2(c[f][rg * 4], c[f][rg * 4 + 1]), pack_bf16x2(c[f][rg * 4 + 2], c[f][rg * 4 + 3]));
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int q = wv * 128 + it * 16 + (lane >> 2), sq = lane & 3;
-            const uint4 v = *(const uint4*)(T + q * 64 + ((sq ^ ((q >> 2) & 3)) << 4));
-            const size_t st = (size_t)sblk * SPB + (q >> 3);
-            if (st < (size_t)B * HS * WS) {
-                const int qx = (int)(st % WS) * 4 + (q & 3), qy = (int)((st / WS) % HS) * 2 + ((q >> 2) & 1), qb = (int)(st / ((size_t)WS * HS));
-                if (qx < W && qy < H && sq < CG) *(uint4*)((unsigned short*)y + (((size_t)qb * H + qy) * W + qx) * ldy + sq * 8) = v;
-            }
-        }
-        return;
-    }
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
         if (Y + o >= H) break;
@@ -631,206 +559,6 @@ __global__ void __launch_bounds__(256, 2) dwconv5x5_rows2_kernel(const void* __r
 }
 
 
-// depthwise 5x5, channel multiplier 1, 16-bit: third generation (round 4; GIM_DWCONV_LDS).  The ablation of the kernel above
-// (tools/microbench_dwconv.hip, profiles/r04_dwconv.txt; 2 x 576 x 768 x 144: 229 us) says 131 us without the FMAs and 167 us without the global
-// loads: two halves that each run at ~45 % of their roof and do NOT overlap -- 256 VGPRs allow two waves per SIMD and a prefetch one input row deep,
-// which covers neither a loaded-HBM round trip nor the LDS weight reads.  Here the input never passes through VGPRs on its way in:
-//   * a persistent 4-wave workgroup (one per CU) owns an 8-row x 4 NSX-pixel tile of CGB channel groups (8 rows x 32 px x 64 channels, or 8 x 64 x 32);
-//     the (8 + 4) x (4 NSX + 4) halo of input pixels travels by LDS-DMA into one of TWO tile buffers: tile t + 1 is in flight -- with no register
-//     behind it -- while tile t is computed, zero padding and channel tails come from the buffer descriptor's bounds;
-//   * the 25 x (CGB * 8) weights and the BatchNorm scale / shift of the tile's channel chunk ride along (27 rows of fp32);
-//   * a thread computes 2 rows x 4 pixels x 8 channels as before, its 6 x 8 input pieces are ds_read_b128 from the halo (pixel slots XOR-swizzled on
-//     the DMA's source side so that the strips of a 16-lane pass -- 4 pixels apart -- land on different bank groups) one row ahead of the FMAs;
-//     no border select is left in the loop.
-template <int CGB>
-struct DwLds {
-    static constexpr int NSX = 64 / CGB, NSY = 4;                 // strips of 2 x 4 pixels across / down: a wave = one strip row
-    static constexpr int TH = 2 * NSY, TW = 4 * NSX;              // 8 x 32 (CGB = 8) or 8 x 64 (CGB = 4) output pixels
-    static constexpr int HH = TH + 4, HW = TW + 4;                // halo
-    static constexpr int PIXB = CGB * 16;                         // bytes of a pixel's channel chunk
-    static constexpr int SWZ = 256 / PIXB - 1;                    // pixel slots per 256-byte bank line - 1
-    static constexpr int HALO = HH * HW * PIXB;                   // 55296 / 52224: whole KiB
-    static constexpr int NPH = HALO / 1024;                       // LDS-DMA instructions of the halo
-    static constexpr int PPW = (NPH + 3) / 4;                     // ... per wave
-    static constexpr int ROWF = CGB * 8;                          // floats of a parameter row
-    static constexpr int NWI = (25 * ROWF * 4 + 1023) / 1024;     // DMA instructions of the 25 weight rows (7 / 4)
-    static constexpr int PAR = (NWI + 2) * 1024;                  // weights, scale, shift: every DMA instruction owns a whole KiB
-    static constexpr int BUF = HALO + PAR;
-    static constexpr int SMEM = 2 * BUF;
-    static_assert(HALO % 1024 == 0 && NPH * (64 / CGB) == HH * HW && NWI <= 8 && SMEM <= 160 * 1024, "dwconv5x5_lds: LDS map");
-};
-
-template <int CGB>
-__global__ void __launch_bounds__(256) dwconv5x5_lds_kernel(const void* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ scale,
-                                                            const float* __restrict__ shift, void* __restrict__ y, int B, int H, int W, int CG,
-                                                            int cpad, int ldx, int ldy, int ntx, int nty, int ntiles, unsigned x_bytes) {
-    typedef DwLds<CGB> C;
-    typedef __attribute__((address_space(3))) void lds_t;
-    extern __shared__ __attribute__((aligned(16))) char dw_smem[];
-    const int t = threadIdx.x, lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const unsigned smem_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_t*)dw_smem);
-    const gim_u32x4_t rx = gim_make_rsrc(x, x_bytes), rw = gim_make_rsrc(wgt, (unsigned)(25 * cpad * 4));
-    const gim_u32x4_t rs = gim_make_rsrc(scale, (unsigned)(cpad * 4)), rh = gim_make_rsrc(shift, (unsigned)(cpad * 4));
-    const int nsp = B * nty * ntx;                                 // spatial tiles; tile index = chunk * nsp + spatial (chunk-major)
-
-    // everything tile `tile` needs -> buffer `buf`
-    auto issue_tile = [&](const int tile, const int buf) __attribute__((always_inline)) {
-        const int chunk = tile / nsp, sp = tile - chunk * nsp;
-        const int b = sp / (nty * ntx), r = sp - b * nty * ntx, ty = r / ntx, tx = r - ty * ntx;
-        const int y0 = ty * C::TH - 2, x0 = tx * C::TW - 2, g0 = chunk * CGB;
-        const unsigned base = smem_addr + (unsigned)(buf * C::BUF);
-#pragma unroll
-        for (int k = 0; k < C::PPW; ++k) {
-            const int pc = w + 4 * k;                              // wave-uniform piece of 64 / CGB pixel slots
-            if (pc < C::NPH) {
-                const int slot = pc * (64 / CGB) + lane / CGB, g = g0 + lane % CGB;
-                const int hy = slot / C::HW, hxs = slot - hy * C::HW;
-                const int hx = hxs ^ ((hxs >> 2) & C::SWZ);        // LDS slot hxs of a halo row holds pixel hx
-                const int yy = y0 + hy, xx = x0 + hx;
-                const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W && g < CG;
-                const unsigned voff = ok ? (unsigned)((((size_t)b * H + yy) * W + xx) * ldx + g * 8) * 2u : x_bytes;
-                gim_dma16(rx, base + (unsigned)(pc * 1024), voff);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int j = w + 4 * k;                               // weights: rows of ROWF floats, 16 bytes per lane, linear
-            if (j < C::NWI) {
-                const int idx = j * 64 + lane, row = idx / (CGB * 2), part = idx - row * (CGB * 2);
-                const int c = g0 * 8 + part * 4;
-                const unsigned voff = (row < 25 && c < cpad) ? (unsigned)(row * cpad + c) * 4u : (unsigned)(25 * cpad * 4);
-                gim_dma16(rw, base + (unsigned)(C::HALO + j * 1024), voff);
-            }
-        }
-        if (w >= 2) {                                              // scale (wave 2) and shift (wave 3): one KiB each, the first 2 CGB lanes carry data
-            const int c = g0 * 8 + lane * 4;
-            const unsigned voff = (lane < CGB * 2 && c < cpad) ? (unsigned)c * 4u : (unsigned)(cpad * 4);
-            gim_dma16(w == 2 ? rs : rh, base + (unsigned)(C::HALO + (C::NWI + (w - 2)) * 1024), voff);
-        }
-    };
-
-    const int cgl = t % CGB, sx = (t / CGB) % C::NSX, sy = t / (CGB * C::NSX);
-    unsigned coff[8];                                              // byte offset of input column 4 sx + q (this lane's channel group) inside a halo row
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int col = 4 * sx + q;
-        coff[q] = (unsigned)(((col ^ ((col >> 2) & C::SWZ)) * CGB + cgl) * 16);
-    }
-    int tile = blockIdx.x, buf = 0;
-    if (tile < ntiles) issue_tile(tile, 0);
-    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this tile's DMA (issued one tile ago) and the previous tile's stores
-        __syncthreads();                                           // ... of every wave; the other buffer's readers are done
-        const int next = tile + (int)gridDim.x;
-        if (next < ntiles) issue_tile(next, buf ^ 1);
-        const char* hb = dw_smem + buf * C::BUF;
-        const char* par = hb + C::HALO;
-        f32x2_t acc[2][4][4];
-#pragma unroll
-        for (int o = 0; o < 2; ++o)
-#pragma unroll
-            for (int p_ = 0; p_ < 4; ++p_)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[o][p_][e] = (f32x2_t){0.f, 0.f};
-        uint4 raw[8];
-        auto fetch_row = [&](const int r) __attribute__((always_inline)) {
-            const char* rp = hb + (2 * sy + r) * (C::HW * C::PIXB);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) raw[q] = *(const uint4*)(rp + coff[q]);
-        };
-        fetch_row(0);
-#pragma unroll 1
-        for (int r = 0; r < 6; ++r) {
-            f32x2_t in[8][4];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const uint4 u = raw[q];
-                in[q][0] = (f32x2_t){__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u)};
-                in[q][1] = (f32x2_t){__uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
-                in[q][2] = (f32x2_t){__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u)};
-                in[q][3] = (f32x2_t){__uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
-            }
-            ORDER_FENCE();
-            if (r < 5) fetch_row(r + 1);
-            ORDER_FENCE();
-            if (r <= 4) {                                          // output row 2 sy takes this input row with dy = r
-#pragma unroll
-                for (int dx = 0; dx < 5; ++dx) {
-                    const float4 w0 = *(const float4*)(par + ((r * 5 + dx) * C::ROWF + cgl * 8) * 4);
-                    const float4 w1 = *(const float4*)(par + ((r * 5 + dx) * C::ROWF + cgl * 8 + 4) * 4);
-                    const f32x2_t wv[4] = {(f32x2_t){w0.x, w0.y}, (f32x2_t){w0.z, w0.w}, (f32x2_t){w1.x, w1.y}, (f32x2_t){w1.z, w1.w}};
-#pragma unroll
-                    for (int p_ = 0; p_ < 4; ++p_)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[0][p_][e] = __builtin_elementwise_fma(in[p_ + dx][e], wv[e], acc[0][p_][e]);
-                }
-            }
-            if (r >= 1) {                                          // output row 2 sy + 1: dy = r - 1
-#pragma unroll
-                for (int dx = 0; dx < 5; ++dx) {
-                    const float4 w0 = *(const float4*)(par + (((r - 1) * 5 + dx) * C::ROWF + cgl * 8) * 4);
-                    const float4 w1 = *(const float4*)(par + (((r - 1) * 5 + dx) * C::ROWF + cgl * 8 + 4) * 4);
-                    const f32x2_t wv[4] = {(f32x2_t){w0.x, w0.y}, (f32x2_t){w0.z, w0.w}, (f32x2_t){w1.x, w1.y}, (f32x2_t){w1.z, w1.w}};
-#pragma unroll
-                    for (int p_ = 0; p_ < 4; ++p_)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[1][p_][e] = __builtin_elementwise_fma(in[p_ + dx][e], wv[e], acc[1][p_][e]);
-                }
-            }
-        }
-        // ---- scale / shift / relu, 16-byte stores ----
-        const int chunk = tile / nsp, sp = tile - chunk * nsp;
-        const int b = sp / (nty * ntx), rr_ = sp - b * nty * ntx, ty = rr_ / ntx, tx = rr_ - ty * ntx;
-        const int g = chunk * CGB + cgl;
-        const float4 s0 = *(const float4*)(par + C::NWI * 1024 + cgl * 32), s1 = *(const float4*)(par + C::NWI * 1024 + cgl * 32 + 16);
-        const float4 h0 = *(const float4*)(par + (C::NWI + 1) * 1024 + cgl * 32), h1 = *(const float4*)(par + (C::NWI + 1) * 1024 + cgl * 32 + 16);
-        const f32x2_t sc[4] = {(f32x2_t){s0.x, s0.y}, (f32x2_t){s0.z, s0.w}, (f32x2_t){s1.x, s1.y}, (f32x2_t){s1.z, s1.w}};
-        const f32x2_t sh[4] = {(f32x2_t){h0.x, h0.y}, (f32x2_t){h0.z, h0.w}, (f32x2_t){h1.x, h1.y}, (f32x2_t){h1.z, h1.w}};
-        if (g < CG) {
-#pragma unroll
-            for (int o = 0; o < 2; ++o) {
-                const int Y = ty * C::TH + 2 * sy + o;
-                if (Y >= H) break;
-#pragma unroll
-                for (int p_ = 0; p_ < 4; ++p_) {
-                    const int X = tx * C::TW + 4 * sx + p_;
-                    if (X >= W) break;
-                    float rr[8];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const f32x2_t v = acc[o][p_][e] * sc[e] + sh[e];
-                        rr[2 * e] = fmaxf(v.x, 0.f); rr[2 * e + 1] = fmaxf(v.y, 0.f);
-                    }
-                    *(uint4*)((unsigned short*)y + (((size_t)b * H + Y) * W + X) * ldy + g * 8) =
-                        make_uint4(pack_bf16x2(rr[0], rr[1]), pack_bf16x2(rr[2], rr[3]), pack_bf16x2(rr[4], rr[5]), pack_bf16x2(rr[6], rr[7]));
-                }
-            }
-        }
-    }
-}
-
-template <int CGB>
-int launch_dwconv_lds(const void* x, const float* wgt, const float* scale, const float* shift, void* y, int B, int H, int W, int CG, int cpad,
-                      int ldx, int ldy, hipStream_t s) {
-    typedef DwLds<CGB> C;
-    static GimPerDevice attr;
-    if (attr.needed()) {
-        hipError_t e = hipFuncSetAttribute((const void*)dwconv5x5_lds_kernel<CGB>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
-        if (e != hipSuccess) { gim_set_error("dwconv5x5_lds: hipFuncSetAttribute(%d B LDS): %s", C::SMEM, hipGetErrorString(e)); return GIM_ERR_LAUNCH; }
-        attr.done();
-    }
-    const int ntx = (W + C::TW - 1) / C::TW, nty = (H + C::TH - 1) / C::TH, nch = (CG + CGB - 1) / CGB;
-    const long long ntiles = (long long)B * nty * ntx * nch;
-    GIM_REQUIRE(ntiles < 0x7fffffffll, "dwconv5x5_lds: too many tiles");
-    int ncu = 256;
-    { int dev = 0; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); }
-    const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);
-    const unsigned x_bytes = (unsigned)((size_t)B * H * W * ldx * 2);
-    hipLaunchKernelGGL(dwconv5x5_lds_kernel<CGB>, dim3(grid), dim3(256), C::SMEM, s, x, wgt, scale, shift, y, B, H, W, CG, cpad, ldx, ldy, ntx, nty,
-                       (int)ntiles, x_bytes);
-    return gim_check_launch("dwconv5x5_lds");
-}
 
 #undef ORDER_FENCE
 
@@ -1097,18 +825,7 @@ extern "C" int gim_dwconv5x5_bn_relu(const void* x, const float* wgt, const floa
     const int mult = Cout / Cin;
     if ((mult == 1 || (mult == 2 && dtype == GIM_BF16)) && cpad % G == 0 && ldx % 4 == 0 && ldy % G == 0 && (mult == 2 || ldx % G == 0)) {
         const dim3 gt(nblocks((size_t)B * H * ((W + 3) / 4) * (cpad / G), 256));
-        static const bool rows2 = getenv("GIM_DWCONV_ROWS2") == nullptr || atoi(getenv("GIM_DWCONV_ROWS2")) != 0;
-        // GIM_DWCONV_LDS=1: the LDS-staged persistent kernel (16-bit, multiplier 1, 16-byte channel groups, < 4 GiB input); 0 (default): rows2
-        static const int lds = getenv("GIM_DWCONV_LDS") ? atoi(getenv("GIM_DWCONV_LDS")) : 0;
-        if (lds && mult == 1 && dtype == GIM_BF16 && cpad % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= cpad &&
-            (int64_t)B * H * W * ldx * 2 < (int64_t)0xFFFFFFF0ll) {
-            const int CG = cpad / 8;
-            // channel groups per tile: 8, unless 4 wastes visibly fewer lanes on the last chunk (18 groups: 75 % against 90 %)
-            const int used8 = (CG + 7) / 8 * 8, used4 = (CG + 3) / 4 * 4;
-            if (used4 * 20 < used8 * 19) return launch_dwconv_lds<4>(x, wgt, scale, shift, y, B, H, W, CG, cpad, ldx, ldy, s);
-            return launch_dwconv_lds<8>(x, wgt, scale, shift, y, B, H, W, CG, cpad, ldx, ldy, s);
-        }
-        if (mult == 1 && rows2) {
+        if (mult == 1) {
             const int CG = cpad / G;
             const int NCH = (CG + 31) / 32, CGB = (CG + NCH - 1) / NCH, SPB = 256 / CGB;
             const size_t strips = (size_t)B * ((H + 1) / 2) * ((W + 3) / 4);
@@ -1119,32 +836,12 @@ extern "C" int gim_dwconv5x5_bn_relu(const void* x, const float* wgt, const floa
             else hipLaunchKernelGGL((dwconv5x5_rows2_kernel<false>), dim3((unsigned)nblk), dim3(256), shm, s, x, wgt, scale, shift, y, B, H, W, CG, CGB, NCH, cpad, ldx, ldy, (unsigned)nblk);
             return gim_check_launch("dwconv5x5_rows2");
         }
-        if (mult == 1) {
-            if (dtype == GIM_BF16) hipLaunchKernelGGL((dwconv5x5_tiled_kernel<true, 1>), gt, dim3(256), 0, s, x, wgt, scale, shift, y, B, H, W, cpad / G, cpad, ldx, ldy);
-            else hipLaunchKernelGGL((dwconv5x5_tiled_kernel<false, 1>), gt, dim3(256), 0, s, x, wgt, scale, shift, y, B, H, W, cpad / G, cpad, ldx, ldy);
-        } else {
-            hipLaunchKernelGGL((dwconv5x5_tiled_kernel<true, 2>), gt, dim3(256), 0, s, x, wgt, scale, shift, y, B, H, W, cpad / G, cpad, ldx, ldy);
-        }
+        hipLaunchKernelGGL((dwconv5x5_tiled_kernel<true, 2>), gt, dim3(256), 0, s, x, wgt, scale, shift, y, B, H, W, cpad / G, cpad, ldx, ldy);   // channel multiplier 2
         return gim_check_launch("dwconv5x5_tiled");
     }
     const dim3 grid(nblocks((size_t)B * H * W * (cpad / 4), 256));
     DISPATCH_BF(dwconv5x5_kernel, dtype == GIM_BF16, grid, x, wgt, scale, shift, y, B, H, W, cpad / 4, Cout / Cin, cpad, ldx, ldy);
     return gim_check_launch("dwconv5x5");
-}
-
-extern "C" int gim_dwconv5x5_pw32(const void* x, const float* wgt, const float* scale, const float* shift, const void* pw_w,
-                                  const float* pw_b, void* y, int B, int H, int W, int cs, int ldx, int ldy, gim_stream_t stream) {
-    GIM_REQUIRE(x && wgt && scale && shift && pw_w && pw_b && y && B > 0 && H > 0 && W > 0, "dwconv5x5_pw32: bad args");
-    GIM_REQUIRE((cs == 24 || cs == 32) && ldx % 8 == 0 && ldx >= cs && ldy % 8 == 0 && ldy >= cs,
-                "dwconv5x5_pw32: stored channels %d (24 or 32), row strides (ldx %d, ldy %d)", cs, ldx, ldy);
-    const int CG = cs / 8, CGB = 4, SPB = 64;
-    const size_t strips = (size_t)B * ((H + 1) / 2) * ((W + 3) / 4);
-    const size_t nblk = (strips + SPB - 1) / SPB;
-    GIM_REQUIRE(nblk < 0x7fffffffull, "dwconv5x5_pw32: grid too large");
-    const size_t shm = (size_t)2 * 25 * CGB * 16 + 512 * 64;
-    hipLaunchKernelGGL((dwconv5x5_rows2_kernel<true, true>), dim3((unsigned)nblk), dim3(256), shm, (hipStream_t)stream, x, wgt, scale, shift, y,
-                       B, H, W, CG, CGB, 1, cs, ldx, ldy, (unsigned)nblk, (const unsigned short*)pw_w, pw_b);
-    return gim_check_launch("dwconv5x5_pw32");
 }
 
 extern "C" int gim_row_norms(const void* x, float* out, int rows, int C, int ld, int dtype, gim_stream_t stream) {

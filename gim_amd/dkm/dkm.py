@@ -24,6 +24,7 @@ import os
 import torch
 
 from ..precision import resolve as resolve_precision
+from ..switches import flag
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -164,15 +165,10 @@ class RegressionMatcher(nn.Module):
         # GP posterior entirely in fp64 (kernel entries, Cholesky, products; csrc/gp_solve.hip: gim_gp_posterior_f64).  None = in
         # the fp32 parity mode only: the system's condition number (~2e4) turns fp32 rounding of the kernel ENTRIES into ~1e-4 of mu,
         # the one term of the engine's deviation that is not the reference's own (tests/test_gpu_gp_pins.py)
-        self.gp_exact = None if os.environ.get("GIM_GP_EXACT") is None else os.environ["GIM_GP_EXACT"] != "0"
-        # bf16 mode, opt-in (GIM_DWPW_FUSED=1): the 24-channel refiner blocks (scale 1, both passes) as one launch each
-        # (gim_dwconv5x5_pw32).  Measured on MI355X (tools/gpu_r3y.sh): match() 30.7 vs 30.4 ms (gim_dkm), 39.7 vs 40.0 ms (gim_roma) --
-        # the 1x1's 107 us per launch move into the depthwise kernel's epilogue at the same cost; the depthwise part itself
-        # (~200 us for 340 MB, 45 % of the HBM roofline) is what bounds the block
-        self.dwpw_fused = os.environ.get("GIM_DWPW_FUSED", "0") != "0"
+        self.gp_exact = {"": None, "0": False, "1": True}[str(flag("gp_exact", ""))]
         self._packed = None
         self._gp_f = {}
-        self.overlap_gp = os.environ.get("GIM_DKM_OVERLAP", "1") != "0"   # GP on a side stream beside the high-res encoder
+        self.overlap_gp = flag("dkm_overlap", True)   # GP on a side stream beside the high-res encoder
 
     def load_state_dict(self, state_dict, *a, **k):
         self._packed = None
@@ -227,11 +223,6 @@ class RegressionMatcher(nn.Module):
                 shift[:hid] = (bn.bias.detach().float() + (conv.bias.detach().float() - bn.running_mean.detach().float()) * sc).cpu()
                 P[f"cr{s}.{i}.dw"] = (W.to(device), scale.to(device), shift.to(device), ci, hid)
                 P[f"cr{s}.{i}.pw"] = pack_conv(pw.weight, None, dt, device, cin_pad=cpad, bias=pw.bias)
-                if dt == GIM_BF16 and cpad in (24, 32) and ci == hid:   # the narrow refiner: dw 5x5 + 1x1 in one launch (gim_dwconv5x5_pw32)
-                    w32, b32 = torch.zeros(32, 32), torch.zeros(32)
-                    w32[:hid, :hid] = pw.weight.detach().float().reshape(hid, hid).cpu()
-                    b32[:hid] = pw.bias.detach().float().cpu()
-                    P[f"cr{s}.{i}.pw32"] = (w32.to(device).to(torch.bfloat16).contiguous(), b32.to(device))
             P[f"cr{s}.out"] = pack_conv(ref.out_conv.weight, None, dt, device, cin_pad=cstore(hid, dt), bias=ref.out_conv.bias)
             P[f"cr{s}.emb"] = (ref.disp_emb.weight.detach().float().reshape(-1, 2).contiguous().to(device),
                                ref.disp_emb.bias.detach().float().contiguous().to(device))
@@ -332,10 +323,6 @@ class RegressionMatcher(nn.Module):
         d = D
         for i in range(1 + HIDDEN_BLOCKS):
             W_, sc, sh, ci, co = P[f"cr{s}.{i}.dw"]
-            pw32 = P.get(f"cr{s}.{i}.pw32") if self.dwpw_fused else None
-            if pw32 is not None and d.shape[3] == W_.shape[1] and d.is_contiguous():
-                d = ops.dwconv5x5_pw32(d, W_, sc, sh, *pw32)
-                continue
             d = ops.dwconv5x5_bn_relu(d, W_, sc, sh, ci, co)
             d = ops.conv2d(d, P[f"cr{s}.{i}.pw"])
         out = torch.empty(b * h * w, P[f"cr{s}.out"].n_store, dtype=torch.float32, device=dev)

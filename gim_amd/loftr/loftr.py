@@ -17,7 +17,7 @@ Precision modes (`config['precision']`, default env GIM_PRECISION or 'fp16'):
   'fp32'  fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32 products/accumulate) -- the parity mode;
   'bf16'  bf16 operands / fp32 accumulate for the backbone and the transformer GEMMs -- the throughput
           mode BASELINE config 2 names.  The token residual stream stays fp32.  The FIRST convolution reads the image
-          as fp16 (`config['stem_fp16']`, env GIM_STEM_FP16, default on): rounding the image and the 7x7 filters to 8
+          as fp16 (`config['stem_fp16']`, default on): rounding the image and the 7x7 filters to 8
           significand bits in front of an edge-detecting (cancelling) convolution is HALF of this mode's deviation from
           the fp32 reference (tools/precision_emulation.py: index flip rate 1.95 % -> 0.98 % with the stem alone on fp16
           operands; same MFMA rate, same bytes);
@@ -29,7 +29,7 @@ Precision modes (`config['precision']`, default env GIM_PRECISION or 'fp16'):
           ResNet activations and LayerNorm'd tokens are O(1..100)); a checkpoint that overflows shows inf / nan in the
           outputs -- use 'bf16' for it.
 
-Coarse similarity (`config['coarse_sim']`, env GIM_COARSE_SIM; default = the precision mode):
+Coarse similarity (`config['coarse_sim']`; default = the precision mode):
   'fp32'  similarity of the fp32 tokens with fp32-exact products: on the same features the mutual-NN indices equal the
           reference's fp32 arithmetic.  Always used by the fp32 mode; selectable in bf16 mode.
   'bf16'  (bf16 mode only, its default) similarity of the bf16 operand copy of the tokens on the bf16 MFMA.  Measured on
@@ -46,6 +46,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..switches import flag
 from .._lib import ACT_ELU1, ACT_LEAKY, ACT_NONE, ACT_RELU, GIM_BF16, GIM_F16, GIM_F32, GimHipError
 from ..packing import (PackedStem, cstore, is_half, pack_bneck, pack_bneck_ds, pack_bneck_tail, pack_conv, pack_conv_split, pack_fine_fused,
                        pack_stem7x7, pack_token_mlp, pack_token_emit, split_channels, torch_dtype)
@@ -158,7 +159,7 @@ class LazyConfMatrix:
             if self._gen is not None and self._owner._generation != self._gen:
                 raise RuntimeError("conf_matrix of an earlier forward: with HIP-graph replay the softmax "
                                    "statistics are overwritten by the next call; call .get() before it "
-                                   "(or set GIM_GRAPH=0)")
+                                   "(or config['graph'] = False)")
             self._t = ops.coarse_conf_matrix(self._r)
         return self._t
 
@@ -185,57 +186,54 @@ class LoFTR(nn.Module):
         if config["fine_concat_coarse_feat"]:
             raise NotImplementedError("fine_concat_coarse_feat=True is not used by gim_loftr and is not built")
         self.precision = _precision_from(config)
-        self.coarse_sim = self._check_sim((config.get("coarse_sim") or os.environ.get("GIM_COARSE_SIM") or self.precision).lower())
-        sf = config.get("stem_fp16")
-        self.stem_fp16 = (os.environ.get("GIM_STEM_FP16", "1") != "0") if sf is None else bool(sf)
-        # 16-bit modes: the first convolution on split (hi + lo) operands -- image and 7x7 filters carried to 2^-22 instead of 2^-11
-        # (profiles/r04_precision_sweep.txt: the stem alone is 57 % of the fp16 mode's mean |dmconf| and 3/4 of its index flips)
-        ss = config.get("stem_split")
-        self.stem_split = (os.environ.get("GIM_STEM_SPLIT", "1") != "0") if ss is None else bool(ss)
-        # 16-bit modes: the first convolution on its own kernel (gim_stem7x7: filter bank resident in LDS, every input patch staged
-        # once) instead of the implicit-GEMM kernel; GIM_STEM_KERNEL=0 / config['stem_kernel']=False keep the latter
-        sk = config.get("stem_kernel")
-        self.stem_kernel = (os.environ.get("GIM_STEM_KERNEL", "1") != "0") if sk is None else bool(sk)
+        self.coarse_sim = self._check_sim((config.get("coarse_sim") or flag("coarse_sim", "") or self.precision).lower())
+        # Switches (gim_amd/switches.py: config keys, or GIM_FLAGS="name=0,..." for A/B runs).  Each keeps the launch sequence a fused
+        # kernel replaced as its cross-check; the defaults are what the benchmarks run.
+        # 16-bit modes: the first convolution reads fp16 operands also in the bf16 mode (see the module docstring) ...
+        self.stem_fp16 = flag("stem_fp16", True, config)
+        # ... on split (hi + lo) operands -- image and 7x7 filters carried to 2^-22 instead of 2^-11
+        # (profiles/r04_precision_sweep.txt: the stem alone is 57 % of the fp16 mode's mean |dmconf| and 3/4 of its index flips) ...
+        self.stem_split = flag("stem_split", True, config)
+        # ... on its own kernel (gim_stem7x7: filter bank resident in LDS, every input patch staged once) instead of the implicit GEMM
+        self.stem_kernel = flag("stem_kernel", True, config)
         # set once the fp16 mode's range guard tripped and the module fell back to bf16 (see forward)
         self.fp16_overflowed = False
         self.backbone = _ResNetFPN_8_2(config["resnetfpn"])
         self.loftr_coarse = _LocalFeatureTransformer(config["coarse"])
         self.loftr_fine = _LocalFeatureTransformer(config["fine"])
         self.W = config["fine_window_size"]
-        self.use_lds_dma = os.environ.get("GIM_LDS_DMA", "1") != "0"
-        # bf16 mode: the whole fine level (gather + 2-layer transformer + fine matching) as ONE kernel (fine_fused.hip);
-        # GIM_FINE_FUSED=0 keeps the unfused launch sequence (the only fine path of the fp32 parity mode)
-        self.fine_fused = os.environ.get("GIM_FINE_FUSED", "1") != "0"
-        # bf16 mode, d_model 256: merge -> norm1 -> mlp -> norm2 -> residual of every coarse encoder layer as ONE kernel
-        # (token_mlp.hip); GIM_TOKEN_FUSED=0 keeps the five separate launches
-        self.token_fused = os.environ.get("GIM_TOKEN_FUSED", "1") != "0"
-        # fused fine kernel launched with the device-side match count (no host round trip in front of it); GIM_FINE_DEV_COUNT=0: sync first
-        self.fine_dev_count = os.environ.get("GIM_FINE_DEV_COUNT", "1") != "0"
+        self.use_lds_dma = flag("lds_dma", True, config)          # False: the register-staging fallback kernels
+        # 16-bit modes: the whole fine level (gather + 2-layer transformer + fine matching) as ONE kernel (fine_fused.hip); False keeps
+        # the unfused launch sequence (the only fine path of the fp32 parity mode)
+        self.fine_fused = flag("fine_fused", True, config)
+        # 16-bit modes, d_model 256: merge -> norm1 -> mlp -> norm2 -> residual of every coarse encoder layer as ONE kernel (token_mlp.hip)
+        self.token_fused = flag("token_fused", True, config)
+        # fused fine kernel launched with the device-side match count (no host round trip in front of it); False: sync first
+        self.fine_dev_count = flag("fine_dev_count", True, config)
         self._count_pin = None
         # the token tail also computes the q / k / v projections its rows feed next (gim_token_mlp_emit): no projection GEMMs
-        self.token_emit = os.environ.get("GIM_TOKEN_EMIT", "1") != "0"
-        # bf16 mode, layer1 (planes 64): conv2 -> conv3 (+identity) -> the next block's conv1 chained through registers
-        # (bneck_fused.hip); GIM_BNECK_FUSED=0 keeps one implicit-GEMM launch per convolution
-        self.bneck_fused = os.environ.get("GIM_BNECK_FUSED", "1") != "0"
-        # 16-bit modes, layer2 (planes 128): conv3 (+identity) -> the next block's conv1 in one kernel (bneck_tail.hip);
-        # GIM_BNECK_TAIL=0 keeps the two implicit-GEMM launches
-        self.bneck_tail = os.environ.get("GIM_BNECK_TAIL", "1") != "0"
-        self.bneck_ds = os.environ.get("GIM_BNECK_DS", "1") != "0"   # layer 1's first block: downsample conv inside the fused kernel
-        # launch-order experiments over independent images / pairs (same kernels, same arithmetic; see _backbone_trunk, _transformer_emit)
-        self.depth_groups = int(os.environ.get("GIM_DEPTH_GROUPS", "1"))
-        self.l3_chains = int(os.environ.get("GIM_L3_CHAINS", "1"))
-        self.tf_chains = int(os.environ.get("GIM_TF_CHAINS", "2"))   # profiles/r05_launch_order.txt: -0.2 ms per batch-8 step
+        self.token_emit = flag("token_emit", True, config)
+        # 16-bit modes, layer1 (planes 64): conv2 -> conv3 (+identity) -> the next block's conv1 chained through registers (bneck_fused.hip)
+        self.bneck_fused = flag("bneck_fused", True, config)
+        # 16-bit modes, layers 2 / 3: conv3 (+identity) -> the next block's conv1 in one kernel (bneck_tail.hip)
+        self.bneck_tail = flag("bneck_tail", True, config)
+        self.bneck_ds = flag("bneck_ds", True, config)   # layer 1's first block: downsample conv inside the fused kernel
+        # launch-order experiments over independent images / pairs (same kernels, same arithmetic; see _backbone_trunk, _transformer_emit;
+        # profiles/r05_launch_order.txt: two transformer chains -0.2 ms per batch-8 step, the other two do not pay)
+        self.depth_groups = flag("depth_groups", 1, config)
+        self.l3_chains = flag("l3_chains", 1, config)
+        self.tf_chains = flag("tf_chains", 2, config)
         self._packed = None
         self._health = None          # fp16 range guard word of the forward in flight (count[1] of its coarse matching), see _coarse_stage
         self._health_sync_left = 3   # forwards that still wait for the fine kernel to read its health bit at once (fp16 mode)
         self._packed_key = None
         self._pe_cache = {}
         self.debug = None  # set to a dict to capture stage outputs (tests): coarse/fine maps, token features
-        # HIP-graph replay of the shape-static part of the forward (env GIM_GRAPH=0 disables).  A shape is captured
+        # HIP-graph replay of the shape-static part of the forward (config['graph'] = False disables).  A shape is captured
         # the second time it is seen (its first call runs eagerly and doubles as the warm-up), and at most
-        # GIM_GRAPH_CACHE (default 4) graphs -- each owns its static inputs and activation pool -- are kept, LRU.
-        self.use_graph = os.environ.get("GIM_GRAPH", "1") != "0"
-        self.graph_cache_size = max(1, int(os.environ.get("GIM_GRAPH_CACHE", "4")))
+        # config['graph_cache'] (default 4) graphs -- each owns its static inputs and activation pool -- are kept, LRU.
+        self.use_graph = flag("graph", True, config)
+        self.graph_cache_size = max(1, flag("graph_cache", 4, config))
         self._graphs = collections.OrderedDict()
         self._seen = collections.OrderedDict()
         self._generation = 0
@@ -276,7 +274,7 @@ class LoFTR(nn.Module):
 
     def _img_dt(self):
         """dtype of the NHWC image tensor = operand type of the first convolution (see the module docstring)"""
-        # (the fp16-in / bf16-out convolution exists on the LDS-DMA kernels only: with GIM_LDS_DMA=0 the stem reads the mode's own type)
+        # (the fp16-in / bf16-out convolution exists on the LDS-DMA kernels only: with lds_dma off the stem reads the mode's own type)
         return GIM_F16 if (self.precision == "bf16" and self.stem_fp16 and self.use_lds_dma) else self._dt()
 
     def _split(self):
@@ -285,7 +283,7 @@ class LoFTR(nn.Module):
         return bool(self.stem_split) and self.precision != "fp32"
 
     def _stem_k(self):
-        """first convolution through gim_stem7x7?  (16-bit modes; the kernel stages by LDS-DMA, so GIM_LDS_DMA=0 turns it off too)"""
+        """first convolution through gim_stem7x7?  (16-bit modes; the kernel stages by LDS-DMA, so lds_dma = False turns it off too)"""
         return bool(self.stem_kernel) and self.precision != "fp32" and self.use_lds_dma
 
     def set_precision(self, precision, coarse_sim=None):

@@ -9,6 +9,7 @@ import torch
 from . import _lib
 from ._lib import ACT_ELU1, ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, GIM_BF16, GIM_F16, GIM_F32, check, lib  # noqa: F401
 from .packing import elem_size, torch_dtype
+from .switches import flag
 
 _DT = {torch.float32: GIM_F32, torch.bfloat16: GIM_BF16, torch.float16: GIM_F16}
 HALF = (torch.bfloat16, torch.float16)   # the two 16-bit operand kinds: same kernels in two flavours (csrc/gim_common.h)
@@ -183,7 +184,7 @@ def conv_rows(x, pk, geom, y, act=ACT_NONE, res=None, res_mod=0, lds_dma=True, a
     a.act, a.res_mod, a.act_cols = act, res_mod, act_cols
     a.dtype, a.out_dtype = pk.dtype, gim_dtype(y)
     a.res_dtype = gim_dtype(res) if res is not None else GIM_F32
-    a.use_lds_dma = 1 if lds_dma else 0
+    a.use_lds_dma = (3 if FORCE_BIG_TILE else 1) if lds_dma else 0
     a.health = _health(health).value if (health is not None and res is not None) else None
     assert y.shape[0] >= B * Ho * Wo and y.shape[1] >= pk.n_store
     if ups is not None:
@@ -203,7 +204,8 @@ def conv_rows(x, pk, geom, y, act=ACT_NONE, res=None, res_mod=0, lds_dma=True, a
     return fused_ups
 
 
-UPS_FUSED = os.environ.get("GIM_UPS_FUSED", "1") != "0"   # FPN: bilinear x2 + add inside the lateral 1x1 conv's epilogue
+FORCE_BIG_TILE = flag("force_big_tile", False)   # tests: the 256 x 256 tile on every eligible launch, whatever its size (gim_conv_args.use_lds_dma = 3)
+UPS_FUSED = flag("ups_fused", True)   # FPN: bilinear x2 + add inside the lateral 1x1 conv's epilogue (False: a second pass over the output)
 
 
 def conv2d(x, pk, act=ACT_NONE, res=None, out_dtype=None, lds_dma=True, ups=None, health=None):
@@ -231,9 +233,9 @@ def conv2d(x, pk, act=ACT_NONE, res=None, out_dtype=None, lds_dma=True, ups=None
     return y
 
 
-# 3x3 halo kernel (conv_igemm.hip: conv3x3_halo_kernel): GIM_CONV_HALO=0 disables, GIM_CONV_HALO_MIN_TILES = smallest launch it takes
-HALO = os.environ.get("GIM_CONV_HALO", "1") != "0"
-HALO_MIN_TILES = int(os.environ.get("GIM_CONV_HALO_MIN_TILES", "2000"))   # round 3 sweep: below ~2000 tiles (the 1/4-resolution layers) the generic kernel is 5-8 % faster
+# 3x3 halo kernel (conv_igemm.hip: conv3x3_halo_kernel); module attributes, tests flip them (switches: conv_halo, conv_halo_min_tiles)
+HALO = flag("conv_halo", True)
+HALO_MIN_TILES = flag("conv_halo_min_tiles", 2000)   # round 3 sweep: below ~2000 tiles (the 1/4-resolution layers) the generic kernel is 5-8 % faster
 
 
 def _halo_pays(pk, B, H, W):
@@ -807,20 +809,6 @@ def dwconv5x5_bn_relu(x, wgt, scale, shift, cin, cout):
     y = torch.empty(B, H, W, cpad, dtype=x.dtype, device=x.device)
     check(lib.gim_dwconv5x5_bn_relu(_p(x), _p(wgt), _p(scale), _p(shift), _p(y), B, H, W, cin, cout, cpad, ldx, cpad,
                                     gim_dtype(x), _stream()), "gim_dwconv5x5_bn_relu")
-    return y
-
-
-def dwconv5x5_pw32(x, wgt, scale, shift, pw_w, pw_b):
-    """One ConvRefiner block at cs = 24 or 32 stored channels in one launch: depthwise 5x5 + BN + ReLU, then the 1x1 conv with bias.
-    x [B,H,W,ldx >= cs] bf16; wgt [25,cs], scale / shift [cs] fp32; pw_w [32,32] bf16 (zero padded), pw_b [32] fp32 -> new [B,H,W,cs]"""
-    _req_cuda(x, wgt, scale, shift, pw_w, pw_b)
-    assert x.dtype == torch.bfloat16 and pw_w.dtype == torch.bfloat16 and tuple(pw_w.shape) == (32, 32) and pw_w.is_contiguous()
-    cs = wgt.shape[1]
-    assert cs in (24, 32) and x.is_contiguous() and pw_b.numel() == 32 and scale.numel() == cs and shift.numel() == cs
-    B, H, W, ldx = x.shape
-    y = torch.empty(B, H, W, cs, dtype=x.dtype, device=x.device)
-    check(lib.gim_dwconv5x5_pw32(_p(x), _p(wgt), _p(scale), _p(shift), _p(pw_w), _p(pw_b), _p(y), B, H, W, cs, ldx, cs, _stream()),
-          "gim_dwconv5x5_pw32")
     return y
 
 

@@ -107,7 +107,8 @@ typedef struct gim_conv_args {
     int out_dtype;      /* dtype of y */
     int res_dtype;      /* dtype of res */
     int use_lds_dma;    /* 1: buffer_load ... lds staging (default); 0: register staging; 2: 3x3 halo kernel (w / ktab / kpad =
-                           the halo packing, res_mod = channels stored per input row) */
+                           the halo packing, res_mod = channels stored per input row); 3: as 1, and the 256 x 256 tile takes the launch
+                           whatever its size (its selection is a size heuristic: the parity tests reach it on small shapes this way) */
     const void* ups;    /* NULL, or a half-resolution tensor [B, ups_h, ups_w, ups_ld] (dtype = out_dtype = bf16) whose bilinear x2
                            upsampling (align_corners=True) is added to the (rounded) conv output in the epilogue: the FPN's
                            `x2_out + F.interpolate(x3_out, scale_factor=2.)` (backbone/resnet.py:321-327) without a second pass
@@ -484,12 +485,6 @@ int gim_local_corr(const void* f0, const void* f1, const float* flow, void* out,
  * -- dkm.py:58-73.  wgt [25][cpad], scale / shift [cpad] fp32 (conv bias and BN folded), zero padded. */
 int gim_dwconv5x5_bn_relu(const void* x, const float* wgt, const float* scale, const float* shift, void* y, int B,
                           int H, int W, int Cin, int Cout, int cpad, int ldx, int ldy, int dtype, gim_stream_t stream);
-/* The whole ConvRefiner block at cs = 24 or 32 stored channels (the scale-1 refiner: 24 hidden channels), bf16: depthwise 5x5 +
- * BatchNorm + ReLU as above, then the block's 1x1 convolution with bias (dkm.py:58-73, create_block) on the tile while it is in
- * LDS -- the intermediate tensor is never written.  x [B,H,W,ldx], y [B,H,W,ldy] bf16 rows of cs stored channels; wgt [25][cs],
- * scale / shift [cs] fp32; pw_w [32][32] bf16 (row = output channel, K = input channel, zero padded), pw_b [32] fp32. */
-int gim_dwconv5x5_pw32(const void* x, const float* wgt, const float* scale, const float* shift, const void* pw_w,
-                       const float* pw_b, void* y, int B, int H, int W, int cs, int ldx, int ldy, gim_stream_t stream);
 /* CosKernel pieces -- dkm.py:135-144: row L2 norms, and K = exp((dot / (nx ny + eps) - 1) / T) in place on the
  * dot-product matrix (diag_add = sigma_noise on the diagonal, dkm.py:352). */
 int gim_row_norms(const void* x, float* out, int rows, int C, int ld, int dtype, gim_stream_t stream);

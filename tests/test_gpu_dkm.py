@@ -134,56 +134,6 @@ def test_dwconv5x5_bn_relu(dt, cin, mult, hw):
     assert (y[..., cout:] == 0).all()
 
 
-def test_dwconv5x5_lds_variant_forced():
-    """GIM_DWCONV_LDS=1: the LDS-staged persistent depthwise kernel (dwconv5x5_lds_kernel: halo tiles by LDS-DMA into two buffers, zero
-    padding / channel tails from the buffer descriptor) under every depthwise test of this file -- ragged tiles in both directions, 24 ...
-    1377 channels (both channel-chunk widths), maps with more tiles than workgroups.  Subprocess: the choice is read once per process."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_dkm.py", "-m", "gpu", "-q", "-x",
-                          "-k", "dwconv5x5 and not forced", "-p", "no:cacheprovider"],
-                         cwd=root, capture_output=True, text=True, env={**os.environ, "GIM_DWCONV_LDS": "1"}, timeout=900)
-    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
-
-
-@pytest.mark.parametrize("cs", [24, 32])
-@pytest.mark.parametrize("hw", [(16, 32), (37, 45), (96, 128)], ids=["16x32", "37x45_ragged", "96x128"])
-def test_dwconv5x5_pw32_fused_block(hw, cs):
-    """gim_dwconv5x5_pw32 = one ConvRefiner block at 24 channels (stored 24, as the refiner keeps them, or 32): depthwise 5x5 + BN + ReLU +
-    1x1 with bias (dkm.py:58-73) in one launch -- against torch (with the bf16 rounding of the intermediate the two-launch path has
-    too) and against the two-launch path"""
-    from gim_amd import _lib, ops
-    from gim_amd.packing import pack_conv
-    dev = _dev()
-    g = torch.Generator().manual_seed(16)
-    b, (h, w), c = 2, hw, 24
-    x = torch.randn(b, c, h, w, generator=g).to(torch.bfloat16).float()
-    wt, bias = torch.randn(c, 1, 5, 5, generator=g) * 0.2, torch.randn(c, generator=g) * 0.1
-    gam, bet = 1 + 0.1 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
-    mean, var = 0.1 * torch.randn(c, generator=g), 0.5 + torch.rand(c, generator=g)
-    pw_w, pw_b = torch.randn(c, c, 1, 1, generator=g) * 0.2, torch.randn(c, generator=g) * 0.1
-    mid = F.relu(F.batch_norm(F.conv2d(x, wt, bias, padding=2, groups=c), mean, var, gam, bet, False, 0.0, 1e-5))
-    ref = F.conv2d(mid.to(torch.bfloat16).float(), pw_w.to(torch.bfloat16).float(), pw_b).permute(0, 2, 3, 1)
-    xin = torch.zeros(b, h, w, cs, dtype=torch.bfloat16)
-    xin[..., :c] = x.permute(0, 2, 3, 1)
-    s = gam / torch.sqrt(var + 1e-5)
-    W = torch.zeros(25, cs); W[:, :c] = wt.view(c, 25).t()
-    sc = torch.zeros(cs); sc[:c] = s
-    sh = torch.zeros(cs); sh[:c] = bet + (bias - mean) * s
-    w32 = torch.zeros(32, 32); w32[:c, :c] = pw_w.view(c, c)
-    b32 = torch.zeros(32); b32[:c] = pw_b
-    y = ops.dwconv5x5_pw32(xin.to(dev), W.to(dev), sc.to(dev), sh.to(dev), w32.to(dev).to(torch.bfloat16), b32.to(dev))
-    assert y.shape[3] == cs
-    _close(y[..., :c], ref, 4.5e-3, "dwconv5x5_pw32")
-    assert (y[..., c:] == 0).all()
-    mid2 = ops.dwconv5x5_bn_relu(xin.to(dev), W.to(dev), sc.to(dev), sh.to(dev), c, c)
-    y2 = ops.conv2d(mid2, pack_conv(pw_w, None, _lib.GIM_BF16, dev, cin_pad=cs, bias=pw_b))
-    d = (y.float()[..., :c] - y2.float()[..., :c]).abs().max().item()
-    assert d <= 2e-2 * ref.abs().max().item(), d     # same operands and products, other accumulation order + output rounding
-
-
 def test_cos_kernel_and_gp_solve():
     """CosKernel via igemm dot products + finish kernel; (K + sigma I)^-1 f via the fp64 Cholesky solve vs torch.linalg.inv"""
     from gim_amd import ops

@@ -386,14 +386,10 @@ print('OK', M)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
 
-@pytest.mark.parametrize("env", [{"GIM_IGEMM_BIG": "2", "GIM_IGEMM_LW": "0"}, {"GIM_IGEMM_BIG": "2", "GIM_IGEMM_LW": "1"},
-                                 {"GIM_IGEMM_RING3": "2", "GIM_IGEMM_BIG": "0"}, {"GIM_IGEMM_BIG": "2", "GIM_IGEMM_PP": "2"}],
-                         ids=["big256x256", "loaderwaves", "ring3", "pingpong"])
-def test_conv_kernel_variants_forced(env):
-    """the 256x256 / 8-wave tile (its waves stage and compute), its loader-wave form (round 4: 8 MFMA waves + 4 staging waves), the
-    3-stage ring variant and the (experimental) ping-pong schedule are picked by shape
-    heuristics / environment switches; force each
-    of them onto every eligible conv / linear case (the choice is read once per process -> subprocess)"""
+def test_conv_big_tile_forced():
+    """the 256 x 256 / 8-wave tile is picked by a size heuristic (>= 1024 tiles, >= 4 K slabs): force it onto every eligible conv / linear
+    case of this file (gim_conv_args.use_lds_dma = 3 through GIM_FLAGS=force_big_tile=1; read once per process -> subprocess)"""
+    env = {"GIM_FLAGS": "force_big_tile=1"}
     import os
     import subprocess
     import sys
@@ -480,52 +476,46 @@ def test_linear_attention_state_is_batch_invariant(dt, shape):
         assert torch.equal(ws2[:2 * per].view(2, per), big[b0:b0 + 2]), (shape, b0, (ws2[:2 * per].view(2, per) - big[b0:b0 + 2]).abs().max().item())
 
 
-@pytest.mark.parametrize("mode", ["128", "256", "off"], ids=["rows256x128-2wg", "rows256x256-1wg", "tile128-kernel"])
+@pytest.mark.parametrize("mode", ["tile256", "tile128"], ids=["rows256x128-2wg", "tile128-kernel-via-masks"])
 @pytest.mark.parametrize("kind", ["bf16", "fp16"])
 def test_coarse_match_tile256_statistics(mode, kind):
-    """The persistent 256 x 256 statistics kernel (16-bit features, no masks; round 4: row / column maxima and sums straight from the
-    accumulators) against the oracle evaluated on the SAME 16-bit-valued features: exact indices and order, confidences to 1e-5 --
-    on sizes with ragged last tiles in both directions, unequal L / S, several pairs (8: pair = tile % N walks every pair), a wide
-    logit range (sigma = 3: similarities of ~90 beside rows that peak at ~15) -- in both workgroup shapes (GIM_CM_TILE = 128: two
-    4-wave workgroups per CU on 256 x 128 tiles, the default; 256: one 8-wave workgroup on 256 x 256) and through the 128 x 128
-    tile-per-workgroup kernel (GIM_CM_STATS=0).  Subprocess: the mode is read once per process."""
-    import os
-    import subprocess
-    import sys
-    code = r"""
-import sys, torch
-sys.path.insert(0, 'oracle'); sys.path.insert(0, '.')
-import loftr_oracle as O
-from gim_amd import ops
-tdt = torch.bfloat16 if sys.argv[1] == 'bf16' else torch.float16
-tot = 0
-for (N, hw0, hw1, sigma, eps, seed) in ((2, (30, 40), (30, 40), 1.0, 0.5, 3), (1, (36, 45), (36, 45), 2.0, 0.1, 4), (3, (25, 31), (25, 31), 1.0, 0.3, 5),
-                                     (1, (60, 80), (60, 80), 1.0, 0.5, 6), (1, (30, 40), (30, 40), 3.0, 0.1, 8), (8, (17, 23), (17, 23), 1.0, 0.5, 11)):
-    f0, f1, _ = O.planted_coarse_features(N, hw0, sigma=sigma, eps=eps, seed=seed)
+    """The persistent 256-row statistics kernel (16-bit features, no masks; round 4: row / column maxima and sums straight from the
+    accumulators; two 4-wave workgroups per CU on 256 x 128 tiles) against the oracle evaluated on the SAME 16-bit-valued features: exact
+    indices and order, confidences to 1e-5 -- on sizes with ragged last tiles in both directions, unequal L / S, several pairs (8: pair =
+    tile % N walks every pair), a wide logit range (sigma = 3: similarities of ~90 beside rows that peak at ~15).  `tile128`: the same
+    cases through the 128 x 128 tile-per-workgroup kernel, which takes 16-bit features when padding masks are given -- all-valid masks
+    here, so the answer is the same (coarse_matching.py:118-123, 149-172: masked_fill / mask_border_with_padding are no-ops then)."""
+    from gim_amd import ops
+    tdt = torch.bfloat16 if kind == "bf16" else torch.float16
+
+    def run(b0, b1, hw0, hw1):
+        if mode == "tile128":
+            N = b0.shape[0]
+            m0 = torch.ones(N * hw0[0] * hw0[1], dtype=torch.uint8, device="cuda")
+            m1 = torch.ones(N * hw1[0] * hw1[1], dtype=torch.uint8, device="cuda")
+            return ops.coarse_match(b0.cuda(), b1.cuda(), hw0, hw1, 8.0, 0.1, 0.2, 2, mask0=m0, mask1=m1)
+        return ops.coarse_match(b0.cuda(), b1.cuda(), hw0, hw1, 8.0, 0.1, 0.2, 2)
+
+    for (N, hw0, hw1, sigma, eps, seed) in ((2, (30, 40), (30, 40), 1.0, 0.5, 3), (1, (36, 45), (36, 45), 2.0, 0.1, 4), (3, (25, 31), (25, 31), 1.0, 0.3, 5),
+                                            (1, (60, 80), (60, 80), 1.0, 0.5, 6), (1, (30, 40), (30, 40), 3.0, 0.1, 8), (8, (17, 23), (17, 23), 1.0, 0.5, 11)):
+        f0, f1, _ = O.planted_coarse_features(N, hw0, sigma=sigma, eps=eps, seed=seed)
+        b0, b1 = f0.to(tdt), f1.to(tdt)
+        conf = O.conf_matrix_dual_softmax(b0.float(), b1.float(), 0.1)
+        ref = O.get_coarse_match(conf, (hw0[0] * 8, hw0[1] * 8), (hw1[0] * 8, hw1[1] * 8), hw0, hw1, 0.2, 2)
+        r = run(b0, b1, hw0, hw1)
+        M = int(r.count[0])
+        assert M == ref['b_ids'].numel() and M > 200, (M, ref['b_ids'].numel())
+        for k in ('b_ids', 'i_ids', 'j_ids'):
+            assert torch.equal(getattr(r, k)[:M].cpu(), ref[k]), k
+        assert (r.mconf[:M].cpu() - ref['mconf']).abs().max() < 1e-5
+        cm = ops.coarse_conf_matrix(r).cpu()
+        assert (cm - conf).abs().max() < 1e-5 * conf.abs().max().clamp_min(1e-6) + 1e-7
+    # unequal map sizes (L != S), ragged in both directions
+    f0, f1, _ = O.planted_coarse_features(2, (30, 40), sigma=1.0, eps=0.5, seed=9)
+    f1 = f1[:, :29 * 40].contiguous()
     b0, b1 = f0.to(tdt), f1.to(tdt)
     conf = O.conf_matrix_dual_softmax(b0.float(), b1.float(), 0.1)
-    ref = O.get_coarse_match(conf, (hw0[0] * 8, hw0[1] * 8), (hw1[0] * 8, hw1[1] * 8), hw0, hw1, 0.2, 2)
-    r = ops.coarse_match(b0.cuda(), b1.cuda(), hw0, hw1, 8.0, 0.1, 0.2, 2)
+    ref = O.get_coarse_match(conf, (240, 320), (232, 320), (30, 40), (29, 40), 0.2, 2)
+    r = run(b0, b1, (30, 40), (29, 40))
     M = int(r.count[0])
-    assert M == ref['b_ids'].numel() and M > 200, (M, ref['b_ids'].numel())
-    for k in ('b_ids', 'i_ids', 'j_ids'):
-        assert torch.equal(getattr(r, k)[:M].cpu(), ref[k]), k
-    assert (r.mconf[:M].cpu() - ref['mconf']).abs().max() < 1e-5
-    cm = ops.coarse_conf_matrix(r).cpu()
-    assert (cm - conf).abs().max() < 1e-5 * conf.abs().max().clamp_min(1e-6) + 1e-7
-    tot += M
-# unequal map sizes (L != S), ragged in both directions
-f0, f1, _ = O.planted_coarse_features(2, (30, 40), sigma=1.0, eps=0.5, seed=9)
-f1 = f1[:, :29 * 40].contiguous()
-b0, b1 = f0.to(tdt), f1.to(tdt)
-conf = O.conf_matrix_dual_softmax(b0.float(), b1.float(), 0.1)
-ref = O.get_coarse_match(conf, (240, 320), (232, 320), (30, 40), (29, 40), 0.2, 2)
-r = ops.coarse_match(b0.cuda(), b1.cuda(), (30, 40), (29, 40), 8.0, 0.1, 0.2, 2)
-M = int(r.count[0])
-assert M == ref['b_ids'].numel() and torch.equal(r.j_ids[:M].cpu(), ref['j_ids']) and torch.equal(r.i_ids[:M].cpu(), ref['i_ids'])
-print('OK', tot + M)
-"""
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", code, kind], cwd=root, capture_output=True, text=True,
-                         env={**os.environ, "GIM_CM_STATS": "0" if mode == "off" else "1", "GIM_CM_TILE": mode}, timeout=600)
-    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    assert M == ref['b_ids'].numel() and torch.equal(r.j_ids[:M].cpu(), ref['j_ids']) and torch.equal(r.i_ids[:M].cpu(), ref['i_ids'])

@@ -35,7 +35,7 @@ HOT = {
     "la_kv_h16_kernel<256>": (128, 0),              # 8 waves, two workgroups per CU
     "la_kv_h16_kernel<512>": (256, 0),
     "la_kv_mfma2_kernel<false, 256>": (256, 0),
-    "dwconv5x5_rows2_kernel<true, false>": (256, 0),
+    "dwconv5x5_rows2_kernel<true>": (256, 0),
 }
 
 

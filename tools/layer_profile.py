@@ -16,7 +16,7 @@ ap.add_argument("--dma", type=int, default=1)
 ap.add_argument("--precision", default="bf16")
 ap.add_argument("--batch", type=int, default=8)
 args = ap.parse_args()
-os.environ["GIM_LDS_DMA"] = str(args.dma)
+os.environ["GIM_FLAGS"] = f"lds_dma={args.dma}"
 torch.manual_seed(0)
 cfg = lower_config(get_cfg_defaults())["loftr"]
 cfg["precision"] = args.precision

@@ -5,7 +5,7 @@
 tag=${1:-r03}
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/pmc_fwd; rm -rf $out; mkdir -p $out
-( cd /tmp && TMPDIR=/tmp GIM_GRAPH=0 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES --output-format csv -d $out -o p -- python $root/tools/prof_forward.py 3 ) > $out/log.txt 2>&1
+( cd /tmp && TMPDIR=/tmp GIM_FLAGS=graph=0 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES --output-format csv -d $out -o p -- python $root/tools/prof_forward.py 3 ) > $out/log.txt 2>&1
 python - "$out" "$root/gpurun_out/${tag}_pmc_forward.txt" <<'PY'
 import csv, glob, sys, collections
 out, dst = sys.argv[1], sys.argv[2]
@@ -22,7 +22,7 @@ for r in csv.DictReader(open(f[0])):
     key = (r.get('Dispatch_Id'), k)
     if key not in seen:
         seen.add(key); cnt[k] += 1
-lines = ["rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES -- python tools/prof_forward.py 3   (GIM_GRAPH=0)",
+lines = ["rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES -- python tools/prof_forward.py 3   (GIM_FLAGS=graph=0)",
          "per kernel family over 3 forwards: launches, MFMA instructions, MFMA busy cycles, busy CU cycles, MFMA busy / (4 x busy CU cycles)"]
 rows = []
 for k, d in acc.items():

@@ -1,14 +1,14 @@
 #!/bin/bash
 # HBM traffic of the gim_conv2d_bn_act launches (igemm_* and conv3x3_halo kernels) of one batch-8 forward, from the TCC memory-side counters.
 # Two separate rocprofv3 passes (FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2: they do not fit together), kernel-trace
-# only, eager launches (GIM_GRAPH=0).  Writes profiles/traffic_<tag>.json: per-launch average over the igemm kernels.
+# only, eager launches (GIM_FLAGS=graph=0).  Writes profiles/traffic_<tag>.json: per-launch average over the igemm kernels.
 # MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a
 # wide coalesced stream, i.e. reads are under-reported by 2x -> doubled here.
 tag=${1:-r01}
 root=$GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
   out=$root/gpurun_out/pmc_$c; rm -rf $out; mkdir -p $out
-  ( cd /tmp && TMPDIR=/tmp GIM_GRAPH=0 timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out -o p -- python $root/tools/prof_forward.py 3 ) > $out/log.txt 2>&1
+  ( cd /tmp && TMPDIR=/tmp GIM_FLAGS=graph=0 timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out -o p -- python $root/tools/prof_forward.py 3 ) > $out/log.txt 2>&1
 done
 python - "$root" "$tag" <<'PY'
 import csv, glob, json, sys, collections

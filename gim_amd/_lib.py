@@ -97,6 +97,8 @@ PROTOTYPES = {
     "gim_bneck64_fused_ds_f16": (c_int, [c_void_p] * 11 + [c_int] * 3 + [c_void_p, c_void_p]),
     "gim_bneck_tail128": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p, c_void_p]),
     "gim_bneck_tail128_f16": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p, c_void_p]),
+    "gim_bneck_tail128_ds": (c_int, [c_void_p] * 8 + [c_int] * 7 + [c_void_p, c_void_p]),
+    "gim_bneck_tail128_ds_f16": (c_int, [c_void_p] * 8 + [c_int] * 7 + [c_void_p, c_void_p]),
     "gim_bneck_tail256": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p, c_void_p]),
     "gim_bneck_tail256_f16": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p, c_void_p]),
     "gim_token_mlp_weight_bytes": (c_int64, []),

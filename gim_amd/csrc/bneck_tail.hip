@@ -28,13 +28,18 @@ namespace {
 // NW waves per workgroup, 32 pixel rows each: 8 (one workgroup per CU) or 4 (two per CU: layer 3, whose 76 800 rows are 300 tiles of
 // 256 -- 1.17 rounds of 256 CUs -- but 600 tiles of 128 on 512 slots with a short second round; the two co-resident workgroups also
 // run their chunk barriers independently, so one's LDS phase overlaps the other's MFMAs)
-template <int P, int N1, int NW = 8> struct Cfg {
+// DS (round 5; planes 128): the block's `downsample` branch -- identity = bn(conv1x1 stride 2 (x_in)), resnet.py:120-124 -- is computed HERE as
+// extra K of conv3: x' = relu([W3 | Wds] [t2 ; x_in(2y, 2x)] + b3 + bds).  The wave's 32 strided input pixels (2 P channels each) live in
+// registers beside t2; the weight rows are P + 2P long, so the chunks are 32 channels wide; no identity tensor exists (its launch, its
+// write and its read are gone) and the identity DMA of the chunk loop is simply not issued -- the counted waits are the same.
+template <int P, int N1, int NW = 8, bool DS = false> struct Cfg {
     static constexpr int ROWS = 32 * NW;
     static constexpr int LDS_LIMIT = (NW == 8 ? 160 : 80) * 1024;
     static constexpr int C4 = 4 * P;
-    static constexpr int CH = P == 128 ? 64 : 32;            // conv3 output channels per chunk
-    static constexpr int NCHUNK = C4 / CH;                   // 8 / 32
-    static constexpr int W3ROW = P * 2;                      // bytes of a conv3 weight row (K = P): 256 / 512
+    static constexpr int KD = DS ? 2 * P : 0;                // channels of the downsample branch's input
+    static constexpr int CH = (P == 128 && !DS) ? 64 : 32;   // conv3 output channels per chunk
+    static constexpr int NCHUNK = C4 / CH;                   // 8 / 32 (DS: 16)
+    static constexpr int W3ROW = (P + KD) * 2;               // bytes of a conv3 weight row (K = P, DS: 3 P): 256 / 512 (768)
     static constexpr int W3C = CH * W3ROW;                   // 16 KiB
     static constexpr int W1ROW = CH * 2;                     // bytes of a conv1' weight row of one chunk (K = CH): 128 / 64
     static constexpr int W1C = N1 * W1ROW;                   // 16 / 32 KiB
@@ -48,7 +53,8 @@ template <int P, int N1, int NW = 8> struct Cfg {
     static constexpr int PIECES = BUF / 1024;                // LDS-DMA instructions per chunk (32 / 48)
     static constexpr int PPW = PIECES / NW;                  // ... per wave
     static constexpr int IPC = PATCH / 1024;                 // identity pieces (= x' stores) per wave and chunk: 4 / 2
-    static_assert(SMEM <= LDS_LIMIT && PIECES % NW == 0 && (P == 128 || P == 256) && (NW == 8 || NW == 4) && NW * 4096 <= NBUF * BUF, "LDS map");
+    static_assert(SMEM <= LDS_LIMIT && PIECES % NW == 0 && (P == 128 || P == 256) && (NW == 8 || NW == 4) && NW * 4096 <= NBUF * BUF && (!DS || P == 128) &&
+                  W3C % 1024 == 0, "LDS map");
 };
 
 struct Args {
@@ -64,6 +70,8 @@ struct Args {
     int act1;                    // activation of conv1': GIM_ACT_RELU (next block's conv1) or GIM_ACT_NONE
     unsigned w3_bytes, w1n_bytes;
     int* health;                 // fp16 range guard word (gim_common.h) or NULL
+    const unsigned short* xin;   // DS: [B][Hin][Win][2P] the block's input; output pixel (b, y, x) of the Ho x Wo map reads (b, 2y, 2x)
+    int Ho, Wo, Hin, Win;
 };
 
 typedef __attribute__((address_space(3))) void lds_t;
@@ -90,9 +98,9 @@ template <int PROW> __device__ __forceinline__ int pswz(int px, int slot) {
 }
 
 // chunk q -> LDS buffer `buf`: this wave's share of the pieces
-template <int P, int N1, int NW>
+template <int P, int N1, int NW, bool DS>
 __device__ __forceinline__ void issue_chunk(const u32x4_t rw3, const u32x4_t rw1, unsigned smem_addr, int buf, int q, int w, int lane) {
-    typedef Cfg<P, N1, NW> C;
+    typedef Cfg<P, N1, NW, DS> C;
     constexpr int S3 = C::W3ROW / 16, S1 = C::W1ROW / 16;   // slots per row
     const unsigned base = smem_addr + (unsigned)(buf * C::BUF);
 #pragma unroll
@@ -115,9 +123,9 @@ __device__ __forceinline__ void issue_chunk(const u32x4_t rw3, const u32x4_t rw1
 // straight into this wave's patch (row layout).  A load hipcc can see beside LDS-DMA makes it wait vmcnt(0); a load hidden in inline
 // asm has its destination registers copied (v_mov) by the register allocator BEFORE the hand-placed wait whenever that wait sits in
 // more than one branch (measured: garbage identity rows in some tiles of launches with more workgroups than CUs).
-template <int P, int N1, int NW>
+template <int P, int N1, int NW, bool DS = false>
 __global__ void __launch_bounds__(NW * 64, 2) bneck_tail_kernel(const Args a) {
-    typedef Cfg<P, N1, NW> C;
+    typedef Cfg<P, N1, NW, DS> C;
     constexpr int ROWS = C::ROWS;
     constexpr int C4 = C::C4, CH = C::CH, NCHUNK = C::NCHUNK, PROW = C::PROW;
     constexpr int NF = N1 / 32;                            // conv1' output fragments per wave
@@ -133,7 +141,7 @@ __global__ void __launch_bounds__(NW * 64, 2) bneck_tail_kernel(const Args a) {
 
     const u32x4_t rw3 = make_rsrc(a.w3, a.w3_bytes), rw1 = make_rsrc(a.w1n, a.w1n_bytes);
     const unsigned smem_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_t*)smem);   // LDS byte address of the dynamic array
-    issue_chunk<P, N1, NW>(rw3, rw1, smem_addr, 0, 0, w, lane);
+    issue_chunk<P, N1, NW, DS>(rw3, rw1, smem_addr, 0, 0, w, lane);
     // biases -> LDS (a global bias load inside the chunk loop makes the compiler wait vmcnt(0): it would drain the weight DMA)
     float* bias = (float*)(smem + C::OFF_BIAS);
     for (int t = threadIdx.x; t < (C4 + N1) / 4; t += NW * 64) {
@@ -151,18 +159,34 @@ __global__ void __launch_bounds__(NW * 64, 2) bneck_tail_kernel(const Args a) {
     // (rematerialisation beats the live VGPRs in its cost model) and waits vmcnt(0) for them -- draining the weight DMA each time
 #pragma unroll
     for (int s = 0; s < P / 16; ++s) asm volatile("" : "+v"(t2[s]));
+    // DS: the downsample branch's pixel operand, 2 P / 16 more k16 steps of the same lane layout, from the strided source pixel
+    bf16x8_t xi[DS ? C::KD / 16 : 1];
+    if constexpr (DS) {
+        const size_t m = prow0 + l31;
+        const int ox = (int)(m % (size_t)a.Wo);
+        const size_t r_ = m / (size_t)a.Wo;
+        const int oy = (int)(r_ % (size_t)a.Ho);
+        const size_t ib = r_ / (size_t)a.Ho;
+        const unsigned short* xp = a.xin + ((ib * a.Hin + 2 * oy) * a.Win + 2 * ox) * C::KD + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < C::KD / 16; ++s) xi[s] = *(const bf16x8_t*)(xp + 16 * s);
+#pragma unroll
+        for (int s = 0; s < C::KD / 16; ++s) asm volatile("" : "+v"(xi[s]));
+    }
     // identity rows of chunk q: 32 px x PROW bytes = IPC pieces; lane i of piece k -> pixel PPI k + i / LPP, patch slot i % LPP <-
     // source slot pswz(pixel, i % LPP)
-    const u32x4_t rres = make_rsrc(a.res, (unsigned)((size_t)a.M * C4 * 2));
+    const u32x4_t rres = make_rsrc(DS ? (const void*)a.t2 : (const void*)a.res, DS ? 16u : (unsigned)((size_t)a.M * C4 * 2));   // (DS: never used)
     const unsigned patch_addr = smem_addr + (unsigned)(C::OFF_PATCH + w * C::PATCH);
     const int ipx = lane / LPP, isl = lane % LPP;
     const unsigned id_voff = (unsigned)((prow0 + ipx) * (C4 * 2)) + (unsigned)(pswz<PROW>(ipx, isl) << 4);   // (px + PPI k) keeps its key
     auto issue_identity = [&](const int q) __attribute__((always_inline)) {
+        if constexpr (!DS) {
 #pragma unroll
-        for (int k = 0; k < C::IPC; ++k) dma16(rres, patch_addr + (unsigned)(k * 1024), id_voff + (unsigned)(k * PPI * C4 * 2 + q * CH * 2));
+            for (int k = 0; k < C::IPC; ++k) dma16(rres, patch_addr + (unsigned)(k * 1024), id_voff + (unsigned)(k * PPI * C4 * 2 + q * CH * 2));
+        }
     };
     issue_identity(0);
-    if constexpr (C::NBUF == 3) issue_chunk<P, N1, NW>(rw3, rw1, smem_addr, 1, 1, w, lane);   // behind what chunk 0 needs: may stay in flight
+    if constexpr (C::NBUF == 3) issue_chunk<P, N1, NW, DS>(rw3, rw1, smem_addr, 1, 1, w, lane);   // behind what chunk 0 needs: may stay in flight
     __syncthreads();             // biases are in LDS (the compiler knows nothing of the DMA in flight: no drain)
 
     f32x16_t c1[NF];
@@ -207,16 +231,32 @@ __global__ void __launch_bounds__(NW * 64, 2) bneck_tail_kernel(const Args a) {
                 c3[f] = mfma_h16_32x32x16(wv, t2[s], c3[f]);
             }
         }
+        if constexpr (DS) {
+#pragma unroll
+            for (int s = 0; s < C::KD / 16; ++s) {
+#pragma unroll
+                for (int f = 0; f < TF; ++f) {
+                    const int n = 32 * f + l31;
+                    const bf16x8_t wv = *(const bf16x8_t*)(wb3 + n * C::W3ROW + (swz<C::W3ROW>(n, 2 * (P / 16 + s) + lh) << 4));
+                    c3[f] = mfma_h16_32x32x16(wv, xi[s], c3[f]);
+                }
+            }
+        }
         // ---- + identity (DMA'd into the patch in row layout), relu; x' chunk out; operand of conv1' ----------------------------------
 #pragma unroll
         for (int f = 0; f < TF; ++f) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const uint2 r = *(const uint2*)(patch + l31 * PROW + (pswz<PROW>(l31, 4 * f + rg) << 4) + lh * 8);
-                c3[f][rg * 4] = fmaxf(c3[f][rg * 4] + h16_lo(r.x), 0.f);
-                c3[f][rg * 4 + 1] = fmaxf(c3[f][rg * 4 + 1] + h16_hi(r.x), 0.f);
-                c3[f][rg * 4 + 2] = fmaxf(c3[f][rg * 4 + 2] + h16_lo(r.y), 0.f);
-                c3[f][rg * 4 + 3] = fmaxf(c3[f][rg * 4 + 3] + h16_hi(r.y), 0.f);
+                if constexpr (DS) {   // the identity branch is already inside the accumulators
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) c3[f][rg * 4 + e] = fmaxf(c3[f][rg * 4 + e], 0.f);
+                } else {
+                    const uint2 r = *(const uint2*)(patch + l31 * PROW + (pswz<PROW>(l31, 4 * f + rg) << 4) + lh * 8);
+                    c3[f][rg * 4] = fmaxf(c3[f][rg * 4] + h16_lo(r.x), 0.f);
+                    c3[f][rg * 4 + 1] = fmaxf(c3[f][rg * 4 + 1] + h16_hi(r.x), 0.f);
+                    c3[f][rg * 4 + 2] = fmaxf(c3[f][rg * 4 + 2] + h16_lo(r.y), 0.f);
+                    c3[f][rg * 4 + 3] = fmaxf(c3[f][rg * 4 + 3] + h16_hi(r.y), 0.f);
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -244,7 +284,7 @@ __global__ void __launch_bounds__(NW * 64, 2) bneck_tail_kernel(const Args a) {
         // in THIS order: identity of chunk q + 1, weights of chunk q + NBUF - 1 (into the buffer chunk q - 1 used, free since this
         // chunk's barrier), and only then this chunk's stores -- nothing the next chunks wait for sits behind a store
         if (q + 1 < NCHUNK) issue_identity(q + 1);
-        if (q + C::NBUF - 1 < NCHUNK) issue_chunk<P, N1, NW>(rw3, rw1, smem_addr, (q + C::NBUF - 1) % C::NBUF, q + C::NBUF - 1, w, lane);
+        if (q + C::NBUF - 1 < NCHUNK) issue_chunk<P, N1, NW, DS>(rw3, rw1, smem_addr, (q + C::NBUF - 1) % C::NBUF, q + C::NBUF - 1, w, lane);
         if (a.xo != nullptr) {
             unsigned short* xp = a.xo + (prow0 + ipx) * C4 + CH * q + isl * 8;
             *(uint4*)(xp) = x0; *(uint4*)(xp + (size_t)PPI * C4) = x1;
@@ -289,16 +329,16 @@ __global__ void __launch_bounds__(NW * 64, 2) bneck_tail_kernel(const Args a) {
     h16_range_flag(a.health, hbig);
 }
 
-template <int P, int N1, int NW = 8>
+template <int P, int N1, int NW = 8, bool DS = false>
 int launch_tail(const Args& a, hipStream_t s) {
-    typedef Cfg<P, N1, NW> C;
+    typedef Cfg<P, N1, NW, DS> C;
     static GimPerDevice attr;
     if (attr.needed()) {
-        hipError_t e = hipFuncSetAttribute((const void*)bneck_tail_kernel<P, N1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        hipError_t e = hipFuncSetAttribute((const void*)bneck_tail_kernel<P, N1, NW, DS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
         if (e != hipSuccess) { gim_set_error("bneck_tail: hipFuncSetAttribute(%d B LDS): %s", C::SMEM, hipGetErrorString(e)); return GIM_ERR_LAUNCH; }
         attr.done();
     }
-    hipLaunchKernelGGL((bneck_tail_kernel<P, N1, NW>), dim3((unsigned)(a.M / C::ROWS)), dim3(NW * 64), C::SMEM, s, a);
+    hipLaunchKernelGGL((bneck_tail_kernel<P, N1, NW, DS>), dim3((unsigned)(a.M / C::ROWS)), dim3(NW * 64), C::SMEM, s, a);
     return gim_check_launch("bneck_tail");
 }
 
@@ -312,6 +352,7 @@ int tail_entry(int P, const void* t2, const void* res, void* x_out, void* t1_nex
     a.t2 = (const unsigned short*)t2; a.res = (const unsigned short*)res; a.xo = (unsigned short*)x_out; a.t1n = (unsigned short*)t1_next;
     a.w3 = (const unsigned short*)w3; a.w1n = (const unsigned short*)w1n; a.b3 = b3; a.b1n = b1n; a.M = M; a.act1 = act_next;
     a.w3_bytes = (unsigned)(4 * P * P * 2); a.w1n_bytes = (unsigned)(n_next * 4 * P * 2); a.health = (int*)health;
+    a.xin = nullptr; a.Ho = a.Wo = a.Hin = a.Win = 0;
     if (P == 128) {
         GIM_REQUIRE(n_next == 128 || n_next == 256, "bneck_tail128: n_next must be 128 or 256 (got %d)", n_next);
         return n_next == 128 ? launch_tail<128, 128>(a, (hipStream_t)stream) : launch_tail<128, 256>(a, (hipStream_t)stream);
@@ -328,6 +369,24 @@ extern "C" int GIM_FN(gim_bneck_tail128)(const void* t2, const void* res, void* 
                                          const float* b3, const float* b1n, int M, int n_next, int act_next, int32_t* health, gim_stream_t stream) {
     GIM_REQUIRE(x_out, "bneck_tail128: NULL x_out");
     return tail_entry(128, t2, res, x_out, t1_next, w3, w1n, b3, b1n, M, n_next, act_next, health, stream);
+}
+
+extern "C" int GIM_FN(gim_bneck_tail128_ds)(const void* t2, const void* x_in, void* x_out, void* t1_next, const void* w3ds, const void* w1n,
+                                            const float* b3ds, const float* b1n, int B, int Ho, int Wo, int Hin, int Win, int n_next, int act_next,
+                                            int32_t* health, gim_stream_t stream) {
+    GIM_REQUIRE(t2 && x_in && x_out && t1_next && w3ds && w1n && b3ds && b1n, "bneck_tail128_ds: NULL pointer");
+    GIM_REQUIRE(act_next == GIM_ACT_RELU || act_next == GIM_ACT_NONE, "bneck_tail128_ds: activation of the next conv1 must be relu or none");
+    GIM_REQUIRE(B > 0 && Ho > 0 && Wo > 0 && Hin >= 2 * Ho - 1 && Win >= 2 * Wo - 1, "bneck_tail128_ds: the input map must cover the stride-2 samples (%d x %d -> %d x %d)", Hin, Win, Ho, Wo);
+    const int64_t M = (int64_t)B * Ho * Wo;
+    GIM_REQUIRE(M % 256 == 0, "bneck_tail128_ds: the pixel row count must be a multiple of 256 (got %lld)", (long long)M);
+    GIM_REQUIRE(M * 512 * 2 < (int64_t)0xFFFFFFF0ll, "bneck_tail128_ds: tensor too large for 32-bit buffer offsets");
+    GIM_REQUIRE(n_next == 128, "bneck_tail128_ds: n_next must be 128 (got %d)", n_next);
+    Args a;
+    a.t2 = (const unsigned short*)t2; a.res = nullptr; a.xo = (unsigned short*)x_out; a.t1n = (unsigned short*)t1_next;
+    a.w3 = (const unsigned short*)w3ds; a.w1n = (const unsigned short*)w1n; a.b3 = b3ds; a.b1n = b1n; a.M = (int)M; a.act1 = act_next;
+    a.w3_bytes = (unsigned)(512 * 384 * 2); a.w1n_bytes = (unsigned)(n_next * 512 * 2); a.health = (int*)health;
+    a.xin = (const unsigned short*)x_in; a.Ho = Ho; a.Wo = Wo; a.Hin = Hin; a.Win = Win;
+    return launch_tail<128, 128, 8, true>(a, (hipStream_t)stream);
 }
 
 extern "C" int GIM_FN(gim_bneck_tail256)(const void* t2, const void* res, void* x_out, void* t1_next, const void* w3, const void* w1n,

@@ -218,6 +218,7 @@ class LoFTR(nn.Module):
         # 16-bit modes, layers 2 / 3: conv3 (+identity) -> the next block's conv1 in one kernel (bneck_tail.hip)
         self.bneck_tail = flag("bneck_tail", True, config)
         self.bneck_ds = flag("bneck_ds", True, config)   # layer 1's first block: downsample conv inside the fused kernel
+        self.bneck_tail_ds = flag("bneck_tail_ds", True, config)   # layer 2's first block: downsample conv (stride 2) inside the tail kernel
         # launch-order experiments over independent images / pairs (same kernels, same arithmetic; see _backbone_trunk, _transformer_emit;
         # profiles/r05_launch_order.txt: two transformer chains -0.2 ms per batch-8 step, the other two do not pay)
         self.depth_groups = flag("depth_groups", 1, config)
@@ -341,6 +342,10 @@ class LoFTR(nn.Module):
                 nx = l2[bi + 1] if bi + 1 < len(l2) else (l3[0] if l3 else None)
                 if nx is not None and tail_fits(l2[bi], nx.conv1):
                     P[f"l2.{bi}.tail"] = pack_bneck_tail(l2[bi], nx.conv1, nx.bn1, device, tdt)
+                    d_ = l2[bi].downsample
+                    if (bi == 0 and d_ is not None and d_[0].stride == (2, 2) and tuple(d_[0].weight.shape) == (512, 256, 1, 1)
+                            and nx.conv1.weight.shape[0] == 128):   # layer 2's first block: the downsample branch as extra K of conv3
+                        P[f"l2.{bi}.tail_ds"] = pack_bneck_tail(l2[bi], nx.conv1, nx.bn1, device, tdt, ds=True)
             for bi in range(len(l3)):
                 nconv, nbn = (l3[bi + 1].conv1, l3[bi + 1].bn1) if bi + 1 < len(l3) else (self.backbone.layer3_outconv, None)
                 if tail_fits(l3[bi], nconv):
@@ -525,6 +530,13 @@ class LoFTR(nn.Module):
                 o = ops.conv2d(x, P[p + "c1"], ACT_RELU, lds_dma=dma)
             if fuse and self.bneck_ds and (p + "fused_ds") in P and x.shape[3] == 64 and x.is_contiguous():
                 x, o = ops.bneck64_ds(o, x, P[p + "fused_ds"], out=outs, health=self._health)   # ... and the downsample branch: no identity tensor at all
+                continue
+            if (self.bneck_tail and self.bneck_tail_ds and (p + "tail_ds") in P and x.is_contiguous() and x.shape[3] == 256
+                    and (x.shape[0] * ((x.shape[1] - 1) // 2 + 1) * ((x.shape[2] - 1) // 2 + 1)) % 256 == 0):
+                # layer 2's first block: conv2, then ONE kernel for conv3 + the stride-2 downsample branch (extra K) + relu + the next conv1:
+                # no downsample launch, no identity tensor (gim_bneck_tail128_ds)
+                o = ops.conv2d(o, P[p + "c2"], ACT_RELU, lds_dma=dma)
+                x, o = ops.bneck_tail_ds(o, x, P[p + "tail_ds"], out=outs, health=self._health)
                 continue
             idn = ops.conv2d(x, P[p + "ds"], ACT_NONE, lds_dma=dma) if (p + "ds") in P else x
             if fuse:   # conv2 -> conv3 + identity -> the next conv1 (of this layer, or layer2's first), one kernel

@@ -503,6 +503,27 @@ def bneck_tail(t2, res, pk, act_next=ACT_RELU, store_x=True, out=None, health=No
     return xo, t1n
 
 
+def bneck_tail_ds(t2, x_in, pk, act_next=ACT_RELU, out=None, health=None):
+    """First block of layer 2 with its downsample branch inside the tail kernel (gim_bneck_tail128_ds): t2 [B,Ho,Wo,128] (conv2 output),
+    x_in [B,Hin,Win,256] (the block's input; the stride-2 1x1 downsample convolution reads pixel (2y, 2x)) -> (x' [B,Ho,Wo,512], t1'
+    [B,Ho,Wo,128]); pk = packing.pack_bneck_tail(blk, next_conv, next_bn, ..., ds=True)."""
+    _req_cuda(t2, x_in)
+    assert t2.dtype in HALF and x_in.dtype == t2.dtype and t2.is_contiguous() and x_in.is_contiguous()
+    w3, w1n, b3, b1n = pk
+    assert w3.dtype == t2.dtype, "bneck_tail_ds: weights packed for the other 16-bit kind"
+    B, Ho, Wo, pl = t2.shape
+    _, Hin, Win, cd = x_in.shape
+    n1 = w1n.shape[1]
+    assert pl == 128 and cd == 256 and w3.shape == (512, 384) and w1n.shape == (16, 128, 32) and x_in.shape[0] == B
+    assert (Hin - 1) // 2 + 1 == Ho and (Win - 1) // 2 + 1 == Wo and (B * Ho * Wo) % 256 == 0
+    xo, t1n = _outs(out, ((B, Ho, Wo, 512), (B, Ho, Wo, n1)), t2)
+    fn = lib.gim_bneck_tail128_ds_f16 if t2.dtype == torch.float16 else lib.gim_bneck_tail128_ds
+    with _Timed("bneck_tail", 2.0 * B * Ho * Wo * ((pl + cd) * 4 * pl + 4 * pl * n1)):
+        check(fn(_p(t2), _p(x_in), _p(xo), _p(t1n), _p(w3), _p(w1n), _p(b3), _p(b1n), B, Ho, Wo, Hin, Win, n1, act_next, _health(health),
+                 _stream()), "gim_bneck_tail128_ds")
+    return xo, t1n
+
+
 def token_mlp(msg, xb, x32, weights, ln_params, eps, kv=None, L=0, S=0, q_mask=None, emit=None):
     """x += norm2(mlp.2(relu(mlp.0(cat[x, norm1(merge(msg))])))) on row views: msg [R, >=256] bf16, xb [R, >=256] bf16 (operand copy
     of x, updated in place), x32 [R, >=256] fp32 (updated in place).  With `kv` (the fp32 state of linear_attention_state) the

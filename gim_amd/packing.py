@@ -374,21 +374,30 @@ def pack_bneck_ds(blk, nxt, device, tdt=torch.bfloat16):
     return w2, w3, wds, w1n, b2, (b3 + bd.float().to(device)).contiguous(), b1n
 
 
-def pack_bneck_tail(blk, next_conv, next_bn, device, tdt=torch.bfloat16):
+def pack_bneck_tail(blk, next_conv, next_bn, device, tdt=torch.bfloat16, ds=False):
     """gim_bneck_tail128 / 256 operands: conv3 / bn3 of Bottleneck `blk` (planes P = 128 or 256) and the 1x1 convolution that consumes
     the block's output next -- the following block's conv1 with its bn1, or (last block of layer 3) the FPN's layer3_outconv, which has
     no BatchNorm (next_bn = None):
     (w3 [4P][P] K in channel order, w1n [chunks][N1][CH] -- per CH-channel chunk of x' the K axis in accumulator order, CH = 64 for
-    P = 128, 32 for P = 256 --, b3, b1n fp32)."""
+    P = 128, 32 for P = 256 --, b3, b1n fp32).
+    ds=True (gim_bneck_tail128_ds, planes 128): the block's downsample branch (1x1 conv 2P -> 4P, stride 2, + BN) rides along as extra K of
+    conv3 -- w3 becomes [4P][P + 2P] = [W3 | Wds] (both in channel order), b3 + bds its bias, and the chunks are 32 channels wide."""
     bn = lambda m: (m.weight, m.bias, m.running_mean, m.running_var, m.eps)  # noqa: E731
     w3, b3 = fold_bn(blk.conv3.weight, bn(blk.bn3))
     w1, b1 = fold_bn(next_conv.weight, bn(next_bn) if next_bn is not None else None)
     c4, pl = w3.shape[0], w3.shape[1]
     n1 = w1.shape[0]
     assert pl in (128, 256) and c4 == 4 * pl and tuple(w1.shape) == (n1, c4, 1, 1) and n1 in ((128, 256) if pl == 128 else (256,))
-    ch = 64 if pl == 128 else 32
+    ch = 64 if (pl == 128 and not ds) else 32
     to = lambda t: t.to(device).to(tdt).contiguous()  # noqa: E731
-    w3p = to(w3.reshape(c4, pl).cpu())
+    w3m = w3.reshape(c4, pl).cpu()
+    if ds:
+        conv, norm = blk.downsample[0], blk.downsample[1]
+        assert pl == 128 and n1 == 128 and tuple(conv.weight.shape) == (c4, 2 * pl, 1, 1) and conv.stride == (2, 2)
+        wd, bd = fold_bn(conv.weight, bn(norm))
+        w3m = torch.cat([w3m, wd.reshape(c4, 2 * pl).cpu()], dim=1)
+        b3 = b3 + bd
+    w3p = to(w3m)
     w1c = w1.reshape(n1, c4 // ch, ch).cpu()[:, :, _acc_order(ch)].permute(1, 0, 2)       # [chunk][n1][ch]
     b1 = b1 if b1 is not None else torch.zeros(n1)
     return w3p, to(w1c), b3.float().to(device).contiguous(), b1.float().to(device).contiguous()

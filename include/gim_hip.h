@@ -242,6 +242,18 @@ int gim_bneck_tail128(const void* t2, const void* res, void* x_out, void* t1_nex
                       const float* b3, const float* b1n, int M, int n_next, int act_next, int32_t* health, gim_stream_t stream);
 int gim_bneck_tail128_f16(const void* t2, const void* res, void* x_out, void* t1_next, const void* w3, const void* w1n,
                           const float* b3, const float* b1n, int M, int n_next, int act_next, int32_t* health, gim_stream_t stream);
+/* First block of layer 2 with its `downsample` branch INSIDE the kernel (round 5; resnet.py:120-124: identity = bn(conv1x1, stride 2 (x))):
+ *     x' = relu([W3 | Wds] [t2 ; x_in(b, 2y, 2x)] + b3 + bds);   t1' = act(bn1'(conv1'(x')))
+ * -- neither the downsample launch nor its 512-channel output exist.  t2 [B,Ho,Wo,128] (conv2 output, stride 2), x_in [B,Hin,Win,256] the
+ * block's input (Hin >= 2 Ho - 1, Win >= 2 Wo - 1), x_out [B,Ho,Wo,512], t1_next [B,Ho,Wo,128]; B Ho Wo a multiple of 256.
+ * w3ds [512][128 + 256] (K: t2's channels, then x_in's, both in channel order, BN folded), w1n [16][128][32] (32-channel chunks of x', K in
+ * accumulator order), b3ds = b3 + bds (gim_amd/packing.py::pack_bneck_tail(..., ds=True)). */
+int gim_bneck_tail128_ds(const void* t2, const void* x_in, void* x_out, void* t1_next, const void* w3ds, const void* w1n,
+                         const float* b3ds, const float* b1n, int B, int Ho, int Wo, int Hin, int Win, int n_next, int act_next,
+                         int32_t* health, gim_stream_t stream);
+int gim_bneck_tail128_ds_f16(const void* t2, const void* x_in, void* x_out, void* t1_next, const void* w3ds, const void* w1n,
+                             const float* b3ds, const float* b1n, int B, int Ho, int Wo, int Hin, int Win, int n_next, int act_next,
+                             int32_t* health, gim_stream_t stream);
 /* Planes 256 (layer 3): t2 [M,256], res / x_out [M,1024], t1_next [M,256] (n_next = 256); w3 [1024][256], w1n [32][256][32] (chunks of
  * 32 channels).  x_out may be NULL: the last block's output is read by nothing but the fused 1x1 convolution -- the FPN's
  * layer3_outconv (resnet.py:316), act_next = GIM_ACT_NONE, zero bias -- so it is never written. */

@@ -113,3 +113,83 @@ def test_backbone_with_and_without_tail_fusion(precision):
     for a, b in zip(outs[True], outs[False]):
         sc = b.abs().max().item()
         assert (a - b).abs().mean().item() < 3e-3 * k * sc and (a - b).abs().max().item() < 6e-2 * k * sc
+
+
+def _blocks_ds(seed):
+    """layer 2's first block (stride 2, 256 -> 128 -> 512 with a downsample branch) and the block whose conv1 follows it"""
+    from gim_amd.loftr.loftr import _Bottleneck, _conv
+    torch.manual_seed(seed)
+    ds = torch.nn.Sequential(_conv(256, 512, 1, 2), torch.nn.BatchNorm2d(512))
+    blk, nxt = _Bottleneck(256, 128, 2, ds), _Bottleneck(512, 128, 1, None)
+    with torch.no_grad():
+        for m in list(blk.modules()) + list(nxt.modules()):
+            if isinstance(m, torch.nn.Conv2d):
+                torch.nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(0.5 + torch.rand_like(m.weight))
+                m.bias.copy_(0.2 * torch.randn_like(m.bias))
+                m.running_mean.copy_(0.2 * torch.randn_like(m.running_mean))
+                m.running_var.copy_(0.5 + torch.rand_like(m.running_var))
+    return blk.eval(), nxt.eval()
+
+
+@pytest.mark.parametrize("tdt", KINDS, ids=KIDS)
+@pytest.mark.parametrize("B,Hin,Win", [(1, 16, 64), (2, 48, 128), (3, 32, 160), (1, 31, 63), (4, 240, 320)],
+                         ids=["1x16x64", "2x48x128", "3x32x160", "odd-31x63", "4x240x320-many-tiles"])
+def test_bneck_tail_ds_matches_reference(B, Hin, Win, tdt):
+    """gim_bneck_tail128_ds (round 5): conv3 + bn3 + the stride-2 downsample branch (as extra K) + relu + the next conv1, against torch fp32
+    convolutions with the kernel's rounding points (resnet.py:109-126 with `downsample`); odd input sizes read pixel (2y, 2x) of a
+    (2 Ho - 1)-row map; the large case runs more workgroups than CUs, twice, bit-identically (counted waits)."""
+    from gim_amd import ops
+    from gim_amd.packing import fold_bn, pack_bneck_tail
+    blk, nxt = _blocks_ds(Hin + Win)
+    Ho, Wo = (Hin - 1) // 2 + 1, (Win - 1) // 2 + 1
+    if (B * Ho * Wo) % 256:
+        pytest.skip("row count not a multiple of 256: the engine keeps the two launches there")
+    g = torch.Generator().manual_seed(B * Hin + 5)
+    t2 = F.relu(torch.randn(B, 128, Ho, Wo, generator=g)).to(tdt)
+    xin = F.relu(torch.randn(B, 256, Hin, Win, generator=g)).to(tdt)
+    r = lambda t: t.to(tdt).float()  # noqa: E731
+    bn = lambda m: (m.weight, m.bias, m.running_mean, m.running_var, m.eps)  # noqa: E731
+    with torch.no_grad():
+        w3, b3 = fold_bn(blk.conv3.weight, bn(blk.bn3))
+        wd, bd = fold_bn(blk.downsample[0].weight, bn(blk.downsample[1]))
+        w1, b1 = fold_bn(nxt.conv1.weight, bn(nxt.bn1))
+        x_ref = F.relu(F.conv2d(t2.float(), r(w3), b3) + F.conv2d(xin.float(), r(wd), bd, stride=2))
+        t1_ref = F.relu(F.conv2d(r(x_ref), r(w1), b1))
+    pk = pack_bneck_tail(blk, nxt.conv1, nxt.bn1, "cuda", tdt, ds=True)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()  # noqa: E731
+    a_t2, a_x = nhwc(t2), nhwc(xin)
+    xo, t1n = ops.bneck_tail_ds(a_t2, a_x, pk)
+    xo2, t1n2 = ops.bneck_tail_ds(a_t2, a_x, pk)
+    torch.cuda.synchronize()
+    assert torch.equal(xo, xo2) and torch.equal(t1n, t1n2)
+    k = 1.0 if tdt == torch.bfloat16 else 0.25
+    for got, ref, nm in ((xo, x_ref, "x'"), (t1n, t1_ref, "t1'")):
+        got = got.float().cpu().permute(0, 3, 1, 2)
+        assert torch.isfinite(got).all(), nm
+        sc = ref.abs().max().item()
+        err = (got - ref).abs()
+        assert err.max().item() < 2e-2 * k * sc and err.mean().item() < 2e-3 * k * sc, (nm, err.max().item() / sc, err.mean().item() / sc)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_backbone_with_and_without_tail_ds(precision):
+    """the whole backbone with layer 2's downsample branch inside the tail kernel against the three-launch form of that block"""
+    from tools import synth_loftr as S
+    model, _ = S.synthetic_model(precision)
+    model = model.cuda()
+    c0, c1 = S.textured_pairs(2, 128, 256, seed=4)
+    outs = {}
+    for fused in (True, False):
+        model.bneck_tail_ds = fused
+        model.debug = {}
+        d = {"image0": c0[:, :1].cuda(), "image1": c1[:, :1].cuda(), "color0": c0.cuda(), "color1": c1.cuda()}
+        model(d)
+        outs[fused] = (model.debug["c0"].float().cpu(), model.debug["f0"].float().cpu())
+        model.debug = None
+    model.bneck_tail_ds = True
+    k = 1.0 if precision == "bf16" else 0.25
+    for a, b in zip(outs[True], outs[False]):
+        sc = b.abs().max().item()
+        assert (a - b).abs().mean().item() < 3e-3 * k * sc and (a - b).abs().max().item() < 6e-2 * k * sc

@@ -19,9 +19,10 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 HOT = {
     "token_mlp_kernel(": (256, 96),                 # 88 B: the projection-block descriptors of the by-value argument struct, indexed at run time (no spill)
     "fine_fused_kernel(": (256, 104),               # 84-96 B: 20-23 spilled registers (the resident set of two matches is the design's limit)
-    "bneck_tail_kernel<256, 256, 4>": (256, 0),
-    "bneck_tail_kernel<128, 128, 8>": (256, 0),
-    "bneck_tail_kernel<128, 256, 8>": (256, 0),
+    "bneck_tail_kernel<256, 256, 4, false>": (256, 0),
+    "bneck_tail_kernel<128, 128, 8, false>": (256, 0),
+    "bneck_tail_kernel<128, 128, 8, true>": (256, 0),     # round 5: layer 2's first block with its downsample branch as extra K
+    "bneck_tail_kernel<128, 256, 8, false>": (256, 0),
     "bneck64_kernel<64, true>": (256, 0),
     "bneck64_kernel<64, false>": (256, 0),
     "bneck64_kernel<128, false>": (256, 32),

@@ -449,7 +449,7 @@ def main():
         im0 = base.to(dev)
         im1 = torch.roll(base, shifts=(12, 20), dims=(2, 3)).to(dev)
 
-        def dense_bench(name, build, note, batch=1):
+        def dense_bench(name, build, note, batch=1, tflop_per_pair=None, parity_note=None):
             try:
                 torch.manual_seed(0)
                 m = build().eval()
@@ -474,6 +474,13 @@ def main():
                 t_sample = (time.perf_counter() - td) / n_it
                 dense[name] = {"workload": note, "pairs_per_s": round(1.0 / (t_match + t_sample), 2),
                                "match_ms": round(1e3 * t_match, 2), "sample_ms": round(1e3 * t_sample, 2), "dtype": sec_prec}
+                if tflop_per_pair:   # SURVEY 8d's algorithmic work of one match() (low-resolution + upsampling pass) against the dense 16-bit MFMA peak
+                    ach = tflop_per_pair / t_match
+                    dense[name]["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS[sec_prec], "unit": "TFLOP/s",
+                                               "frac": round(ach / MFMA_PEAK_TFLOPS[sec_prec], 4), "traffic": None,
+                                               "what": f"{tflop_per_pair} TFLOP per match() (SURVEY 8d, BASELINE.md section 2) / match_ms; no PMC pass for this workload"}
+                if parity_note:
+                    dense[name]["parity_note"] = parity_note
                 if batch > 1:   # BASELINE's batched configuration: `batch` independent pairs in one engine pass (match_batch)
                     b0, b1 = im0.expand(batch, -1, -1, -1).contiguous(), im1.expand(batch, -1, -1, -1).contiguous()
                     for _ in range(2):
@@ -505,11 +512,17 @@ def main():
             return f
 
         dense_bench("gim_dkm", build_dkm, "gim_dkm match() + sample(5000), 672x896 -> upsampling pass 1152x1536, one pair per call, "
-                    "random-init weights (trainer/lightning.py:29-37 configuration)", batch=4)
+                    "random-init weights (trainer/lightning.py:29-37 configuration)", batch=4, tflop_per_pair=5.27,
+                    parity_note="fp32 mode at 672x896 (tests/test_gpu_dense_fullsize.py, profiles/r03_dense_parity.txt): warp max 2.9e-4 / mean 2.5e-5 of scale "
+                                "from the reference's PINNED fp32 arithmetic -- the distance that arithmetic's own fp32 GP inverse keeps from its formula "
+                                "(condition number ~2e4) -- and max 3.0e-6 from the same oracle with only the GP step in fp64; the timed bf16 mode: mean |d warp| "
+                                "~0.009 (tests/test_gpu_dkm.py)")
         dense_bench("gim_roma", build_roma(672), "gim_roma match() + sample(5000), 672x672 -> upsampling pass 1344x1344, one pair per call, "
-                    "random-init weights incl. a synthetic DINOv2 ViT-L/14 (RoMa(img_size=[672]), trainer/lightning.py:38-41)")
+                    "random-init weights incl. a synthetic DINOv2 ViT-L/14 (RoMa(img_size=[672]), trainer/lightning.py:38-41)", tflop_per_pair=14.44,
+                    parity_note="fp32 mode at 672x672: 99.75 % of the warp values within 2e-3 of the reference's pinned fp32 arithmetic (the rest: anchor arg-max "
+                                "decisions its own GP noise flips), max 3.6e-7 from the oracle with the GP step in fp64 (profiles/r03_dense_parity.txt)")
         dense_bench("gim_roma_560", build_roma(560), "gim_roma match() + sample(5000), 560x560 -> upsampling pass 1120x1120 (BASELINE config 4 "
-                    "resolution, RoMa(img_size=[560])), one pair per call per GPU, random-init weights")
+                    "resolution, RoMa(img_size=[560])), one pair per call per GPU, random-init weights", tflop_per_pair=10.03)
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample; parity of the benchmarked engine ----
     cpu = None

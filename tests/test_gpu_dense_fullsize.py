@@ -111,3 +111,51 @@ def test_roma_672_vs_oracle(monkeypatch):
     (rw_max, rw_mean), (ew_max, ew_mean) = _dist(ref_warp, x_warp), _dist(warp, x_warp)
     print(f"roma 672 warp: reference arithmetic vs fp64-GP oracle max {rw_max:.2e} mean {rw_mean:.2e}; engine vs fp64-GP oracle max {ew_max:.2e} mean {ew_mean:.2e}")
     assert ew_mean <= rw_mean, "the engine's parity mode must sit closer to the formula than the reference's fp32 arithmetic does"
+
+
+def test_dkm_672x896_upsample_pass_vs_oracle(monkeypatch):
+    """the 1152 x 1536 upsampling pass -- 3.71 of gim_dkm's 5.27 TFLOP per pair (dkm.py:680-714: the second encoder pass
+    and the refiners at scales 8 ... 1 on the upsampled flow) -- against dkm_oracle.match with the same pass, at size.  Round 4 only checked
+    its swap symmetry in bf16.  Same two comparisons as the low-resolution test: the exact-GP oracle at north_star's 1e-4, the pinned
+    reference arithmetic at the distance its own fp32 GP keeps from the formula."""
+    import dkm_oracle as O
+    from gim_amd.dkm import DKMv3
+    sd = O.make_state_dict(0)
+    im0, im1 = O.seeded_pair(672, 896, 3)
+    up = (1152, 1536)
+    with torch.no_grad():
+        ref_warp, ref_cert = O.match(sd, im0, im1, 672, 896, up)
+        monkeypatch.setattr(O, "GP_FP64", True)
+        x_warp, x_cert = O.match(sd, im0, im1, 672, 896, up)
+        monkeypatch.setattr(O, "GP_FP64", False)
+    m = DKMv3(None, 672, 896, upsample_preds=True, precision="fp32")
+    m.upsample_res = up
+    m.load_state_dict(sd)
+    m = m.eval()
+    warp, cert = m.match(im0.to("cuda:0"), im1.to("cuda:0"))
+    assert warp.shape == (up[0], 2 * up[1], 4) and cert.shape == (up[0], 2 * up[1])
+    _close(warp, ref_warp, 6e-4, "dkm warp 1152x1536 (upsampling pass) vs the reference arithmetic", frac=1.0, mean_tol=5e-5)
+    _close(cert, ref_cert, 4e-4, "dkm certainty 1152x1536 (upsampling pass) vs the reference arithmetic", frac=1.0, mean_tol=4e-5)
+    _close(warp, x_warp, 1e-4, "dkm warp 1152x1536 (upsampling pass) vs the fp64-GP oracle", frac=1.0, mean_tol=1e-5)
+    _close(cert, x_cert, 1e-4, "dkm certainty 1152x1536 (upsampling pass) vs the fp64-GP oracle", frac=1.0, mean_tol=1e-5)
+
+
+def test_dkm_batch4_672x896_vs_single_pair_oracles(monkeypatch):
+    """BASELINE config 3 is gim_dkm 672x896 at batch = 4: four DIFFERENT pairs in one engine pass (match_batch; the reference's own batched
+    mode asserts against the upsampling pass, dkm.py:662, so this is the low-resolution pass) against four single-pair oracle calls."""
+    import dkm_oracle as O
+    from gim_amd.dkm import DKMv3
+    sd = O.make_state_dict(0)
+    pairs = [O.seeded_pair(672, 896, s_, shift=sh) for s_, sh in ((3, (8, 12)), (5, (4, 14)), (7, (10, 6)), (9, (6, 20)))]
+    monkeypatch.setattr(O, "GP_FP64", True)
+    with torch.no_grad():
+        refs = [O.match(sd, a, b, 672, 896, None) for a, b in pairs]
+    monkeypatch.setattr(O, "GP_FP64", False)
+    m = DKMv3(None, 672, 896, upsample_preds=False, precision="fp32")
+    m.load_state_dict(sd)
+    m = m.eval()
+    W, C = m.match_batch(torch.cat([a for a, _ in pairs]).to("cuda:0"), torch.cat([b for _, b in pairs]).to("cuda:0"))
+    assert W.shape == (4, 672, 2 * 896, 4) and C.shape == (4, 672, 2 * 896)
+    for k, (rw, rc) in enumerate(refs):
+        _close(W[k], rw, 2e-5, f"dkm batch-4 pair {k} warp vs the fp64-GP oracle", frac=1.0, mean_tol=2e-6)
+        _close(C[k], rc, 2e-5, f"dkm batch-4 pair {k} certainty vs the fp64-GP oracle", frac=1.0, mean_tol=2e-6)

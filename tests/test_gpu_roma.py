@@ -196,12 +196,12 @@ def test_stage_goldens_fp32(golden_dir):
     m.match(im0.to(dev), im1.to(dev))
     P, dt, _ = m._packed
     pyr = m._encode(P, dt, m._images(dt, im0.to(dev), im1.to(dev), H, W))
-    _close(pyr[16].permute(0, 3, 1, 2), torch.as_tensor(g["dino16"]), 2e-4, "dino16")
-    _close(pyr[8].permute(0, 3, 1, 2)[:, ::8], torch.as_tensor(g["vgg8_sub"]), 1e-4, "vgg8")
-    _close(pyr[1].permute(0, 3, 1, 2)[:, ::16, ::4, ::4], torch.as_tensor(g["vgg1_sub"]), 1e-4, "vgg1")
+    _close(pyr[16].permute(0, 3, 1, 2), torch.as_tensor(g["dino16"]), 5e-6, "dino16")   # bounds: 2-3 x measured on MI355X (profiles/r04_secondary_measured.txt)
+    _close(pyr[8].permute(0, 3, 1, 2)[:, ::8], torch.as_tensor(g["vgg8_sub"]), 1e-5, "vgg8")
+    _close(pyr[1].permute(0, 3, 1, 2)[:, ::16, ::4, ::4], torch.as_tensor(g["vgg1_sub"]), 3e-6, "vgg1")
     gm_flow, gm_cert = m._debug["low"]["gm"]
-    _close(gm_cert.permute(0, 3, 1, 2), torch.as_tensor(g["gm_certainty"]), 1e-3, "gm_certainty")
-    _close(gm_flow, torch.as_tensor(g["gm_flow"]), 1e-3, "gm_flow")
+    _close(gm_cert.permute(0, 3, 1, 2), torch.as_tensor(g["gm_certainty"]), 1e-4, "gm_certainty")
+    _close(gm_flow, torch.as_tensor(g["gm_flow"]), 1e-6, "gm_flow")
 
 
 def test_match_golden_fp32(golden_dir):
@@ -212,12 +212,12 @@ def test_match_golden_fp32(golden_dir):
     m = _model("fp32", H, W, up)
     warp, cert = m.match(im0.to(dev), im1.to(dev))
     low = m._debug["low"]
-    _close(low[16][0].permute(0, 3, 1, 2), torch.as_tensor(g["flow16"]), 2e-3, "flow16")
-    _close(low[16][1].permute(0, 3, 1, 2), torch.as_tensor(g["cert16"]), 2e-3, "cert16")
-    _close(low[1][0].permute(0, 3, 1, 2), torch.as_tensor(g["flow1"]), 2e-3, "flow1")
+    _close(low[16][0].permute(0, 3, 1, 2), torch.as_tensor(g["flow16"]), 1e-4, "flow16")   # measured 3.0e-5 / 4.5e-5 / 2.1e-5 / 1.5e-5 / 4.0e-6 (round 4 asserted 2e-3 / 5e-3)
+    _close(low[16][1].permute(0, 3, 1, 2), torch.as_tensor(g["cert16"]), 1e-4, "cert16")
+    _close(low[1][0].permute(0, 3, 1, 2), torch.as_tensor(g["flow1"]), 6e-5, "flow1")
     assert warp.shape == (up[0], 2 * up[1], 4) and cert.shape == (up[0], 2 * up[1])
-    _close(warp[::2, ::2], torch.as_tensor(g["warp"]), 2e-3, "warp")
-    _close(cert[::2, ::2], torch.as_tensor(g["certainty"]), 5e-3, "certainty")
+    _close(warp[::2, ::2], torch.as_tensor(g["warp"]), 5e-5, "warp")
+    _close(cert[::2, ::2], torch.as_tensor(g["certainty"]), 2e-5, "certainty")
 
 
 def test_match_bf16_batch_and_sample(golden_dir):

@@ -17,7 +17,8 @@ SOURCES = ["runtime.hip", "conv_igemm.hip", "elementwise.hip", "linear_attention
 # the gim_loftr path exists in two 16-bit operand flavours (bf16 / IEEE fp16, csrc/gim_common.h): these files are compiled a
 # second time with -DGIM_HALF_KIND=1 into *_f16.o, whose entry points carry the suffix `_f16`
 F16_SOURCES = ["conv_igemm.hip", "elementwise.hip", "linear_attention.hip", "coarse_match.hip", "fine_match.hip", "fine_fused.hip",
-               "token_mlp.hip", "bneck_fused.hip", "bneck_tail.hip", "stem7x7.hip"]
+               "token_mlp.hip", "bneck_fused.hip", "bneck_tail.hip", "stem7x7.hip",
+               "dkm.hip", "lightglue.hip", "superpoint.hip"]   # round 5: the dense matchers / gim_lightglue in the fp16 flavour too
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"] + os.environ.get("GIM_HIPCC_EXTRA", "").split()
 
 

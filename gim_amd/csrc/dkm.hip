@@ -190,10 +190,10 @@ __global__ void __launch_bounds__(256) local_corr_kernel(const void* __restrict_
     auto load_vec = [&](const char* base, int c, float* dst) {
         if constexpr (V8) {
             const uint4 u = *(const uint4*)(base + (size_t)c * ES);
-            dst[0] = __uint_as_float(u.x << 16); dst[1] = __uint_as_float(u.x & 0xffff0000u);
-            dst[2] = __uint_as_float(u.y << 16); dst[3] = __uint_as_float(u.y & 0xffff0000u);
-            dst[4] = __uint_as_float(u.z << 16); dst[5] = __uint_as_float(u.z & 0xffff0000u);
-            dst[6] = __uint_as_float(u.w << 16); dst[7] = __uint_as_float(u.w & 0xffff0000u);
+            dst[0] = h16_lo(u.x); dst[1] = h16_hi(u.x);
+            dst[2] = h16_lo(u.y); dst[3] = h16_hi(u.y);
+            dst[4] = h16_lo(u.z); dst[5] = h16_hi(u.z);
+            dst[6] = h16_lo(u.w); dst[7] = h16_hi(u.w);
         } else {
             const float4 v = ElemIO<BF16>::ld4(base, c);
             dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
@@ -343,15 +343,15 @@ __global__ void __launch_bounds__(256) dwconv5x5_tiled_kernel(const void* __rest
                 if constexpr (MULT == 1) {
                     uint4 u = *(const uint4*)(rp + off);
                     if (!ok) u = make_uint4(0u, 0u, 0u, 0u);
-                    in[q][0] = (f32x2_t){__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u)};
-                    in[q][1] = (f32x2_t){__uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
-                    in[q][2] = (f32x2_t){__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u)};
-                    in[q][3] = (f32x2_t){__uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+                    in[q][0] = (f32x2_t){h16_lo(u.x), h16_hi(u.x)};
+                    in[q][1] = (f32x2_t){h16_lo(u.y), h16_hi(u.y)};
+                    in[q][2] = (f32x2_t){h16_lo(u.z), h16_hi(u.z)};
+                    in[q][3] = (f32x2_t){h16_lo(u.w), h16_hi(u.w)};
                 } else {  // multiplier 2: output channels (2c, 2c+1) read input channel c
                     uint2 u = *(const uint2*)(rp + off);
                     if (!ok) u = make_uint2(0u, 0u);
-                    const float c0 = __uint_as_float(u.x << 16), c1 = __uint_as_float(u.x & 0xffff0000u);
-                    const float c2 = __uint_as_float(u.y << 16), c3 = __uint_as_float(u.y & 0xffff0000u);
+                    const float c0 = h16_lo(u.x), c1 = h16_hi(u.x);
+                    const float c2 = h16_lo(u.y), c3 = h16_hi(u.y);
                     in[q][0] = (f32x2_t){c0, c0}; in[q][1] = (f32x2_t){c1, c1}; in[q][2] = (f32x2_t){c2, c2}; in[q][3] = (f32x2_t){c3, c3};
                 }
             } else {
@@ -472,10 +472,10 @@ __global__ void __launch_bounds__(256, 2) dwconv5x5_rows2_kernel(const void* __r
             if constexpr (BF16) {
                 uint4 u = raw[q];
                 if (!ok) u = make_uint4(0u, 0u, 0u, 0u);
-                in[q][0] = (f32x2_t){__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u)};
-                in[q][1] = (f32x2_t){__uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
-                in[q][2] = (f32x2_t){__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u)};
-                in[q][3] = (f32x2_t){__uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+                in[q][0] = (f32x2_t){h16_lo(u.x), h16_hi(u.x)};
+                in[q][1] = (f32x2_t){h16_lo(u.y), h16_hi(u.y)};
+                in[q][2] = (f32x2_t){h16_lo(u.z), h16_hi(u.z)};
+                in[q][3] = (f32x2_t){h16_lo(u.w), h16_hi(u.w)};
             } else {
                 float4 v = raw[q];
                 if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -549,8 +549,8 @@ __global__ void __launch_bounds__(256, 2) dwconv5x5_rows2_kernel(const void* __r
             if (rr[0] < -1.f)
 #endif
             if constexpr (BF16) {
-                *(uint4*)((unsigned short*)y + oo) = make_uint4(pack_bf16x2(rr[0], rr[1]), pack_bf16x2(rr[2], rr[3]),
-                                                                pack_bf16x2(rr[4], rr[5]), pack_bf16x2(rr[6], rr[7]));
+                *(uint4*)((unsigned short*)y + oo) = make_uint4(cvt_pk_h16(rr[0], rr[1]), cvt_pk_h16(rr[2], rr[3]),
+                                                                cvt_pk_h16(rr[4], rr[5]), cvt_pk_h16(rr[6], rr[7]));
             } else {
                 *(float4*)((float*)y + oo) = make_float4(rr[0], rr[1], rr[2], rr[3]);
             }
@@ -740,22 +740,35 @@ __global__ void __launch_bounds__(256) kde_kernel(const float* __restrict__ x, f
         else hipLaunchKernelGGL(KERN<false>, grid, dim3(256), 0, s, __VA_ARGS__);                       \
     } while (0)
 
-extern "C" int gim_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int ldx, int ldy, int dtype, gim_stream_t stream) {
-    const int G = dtype == GIM_BF16 ? 8 : 4;
+#if !GIM_HALF_KIND
+extern "C" int gim_maxpool3x3s2_f16(const void* x, void* y, int B, int H, int W, int C, int ldx, int ldy, int dtype, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_maxpool3x3s2)(const void* x, void* y, int B, int H, int W, int C, int ldx, int ldy, int dtype, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16) return gim_maxpool3x3s2_f16(x, y, B, H, W, C, ldx, ldy, dtype, stream);   // the fp16 objects of this file
+#endif
+    const int G = dtype == GIM_H16 ? 8 : 4;
     GIM_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0 && C % G == 0 && ldx % G == 0 && ldy % G == 0, "maxpool3x3s2: bad args");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(nblocks((size_t)B * Ho * Wo * (C / G), 256));
-    DISPATCH_BF(maxpool3x3s2_kernel, dtype == GIM_BF16, grid, x, y, B, H, W, Ho, Wo, C / G, ldx, ldy);
+    DISPATCH_BF(maxpool3x3s2_kernel, dtype == GIM_H16, grid, x, y, B, H, W, Ho, Wo, C / G, ldx, ldy);
     return gim_check_launch("maxpool3x3s2");
 }
 
-extern "C" int gim_resize_bilinear(const void* x, void* y, int B, int h, int w, int Ho, int Wo, int C, int ldx, int ldy,
+#if !GIM_HALF_KIND
+extern "C" int gim_resize_bilinear_f16(const void* x, void* y, int B, int h, int w, int Ho, int Wo, int C, int ldx, int ldy,
+                                   int dtype, int out_dtype, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_resize_bilinear)(const void* x, void* y, int B, int h, int w, int Ho, int Wo, int C, int ldx, int ldy,
                                    int dtype, int out_dtype, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16 || out_dtype == GIM_F16) return gim_resize_bilinear_f16(x, y, B, h, w, Ho, Wo, C, ldx, ldy, dtype, out_dtype, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(x && y && B > 0 && h > 0 && w > 0 && Ho > 0 && Wo > 0 && C > 0 && ldx >= C && ldy >= C, "resize_bilinear: bad args");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(nblocks((size_t)B * Ho * Wo * C, 256));
-    const bool ib = dtype == GIM_BF16, ob = out_dtype == GIM_BF16;
+    const bool ib = dtype == GIM_H16, ob = out_dtype == GIM_H16;
     if (ib && ob) hipLaunchKernelGGL((resize_bilinear_kernel<true, true>), grid, dim3(256), 0, s, x, y, B, h, w, Ho, Wo, C, ldx, ldy);
     else if (ib) hipLaunchKernelGGL((resize_bilinear_kernel<true, false>), grid, dim3(256), 0, s, x, y, B, h, w, Ho, Wo, C, ldx, ldy);
     else if (ob) hipLaunchKernelGGL((resize_bilinear_kernel<false, true>), grid, dim3(256), 0, s, x, y, B, h, w, Ho, Wo, C, ldx, ldy);
@@ -763,43 +776,71 @@ extern "C" int gim_resize_bilinear(const void* x, void* y, int B, int h, int w, 
     return gim_check_launch("resize_bilinear");
 }
 
-extern "C" int gim_resize_image(const float* x, void* y, int B, int C, int h, int w, int Ho, int Wo, int cpad, int b_off,
+#if !GIM_HALF_KIND
+extern "C" int gim_resize_image_f16(const float* x, void* y, int B, int C, int h, int w, int Ho, int Wo, int cpad, int b_off,
+                                int out_dtype, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_resize_image)(const float* x, void* y, int B, int C, int h, int w, int Ho, int Wo, int cpad, int b_off,
                                 int out_dtype, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (out_dtype == GIM_F16) return gim_resize_image_f16(x, y, B, C, h, w, Ho, Wo, cpad, b_off, out_dtype, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(x && y && B > 0 && C > 0 && h > 0 && w > 0 && Ho > 0 && Wo > 0 && cpad >= C, "resize_image: bad args");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(nblocks((size_t)B * Ho * Wo, 256));
-    DISPATCH_BF(resize_image_kernel, out_dtype == GIM_BF16, grid, x, y, B, C, h, w, Ho, Wo, cpad, b_off);
+    DISPATCH_BF(resize_image_kernel, out_dtype == GIM_H16, grid, x, y, B, C, h, w, Ho, Wo, cpad, b_off);
     return gim_check_launch("resize_image");
 }
 
-extern "C" int gim_grid_sample(const void* feat, const float* grid_xy, void* out, int B, int h, int w, int Ho, int Wo, int C,
+#if !GIM_HALF_KIND
+extern "C" int gim_grid_sample_f16(const void* feat, const float* grid_xy, void* out, int B, int h, int w, int Ho, int Wo, int C,
+                               int ldf, int ldo, int dtype, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_grid_sample)(const void* feat, const float* grid_xy, void* out, int B, int h, int w, int Ho, int Wo, int C,
                                int ldf, int ldo, int dtype, gim_stream_t stream) {
-    const int G = dtype == GIM_BF16 ? 8 : 4;
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16) return gim_grid_sample_f16(feat, grid_xy, out, B, h, w, Ho, Wo, C, ldf, ldo, dtype, stream);   // the fp16 objects of this file
+#endif
+    const int G = dtype == GIM_H16 ? 8 : 4;
     GIM_REQUIRE(feat && grid_xy && out && B > 0 && h > 0 && w > 0 && Ho > 0 && Wo > 0 && C > 0, "grid_sample: bad args");
     GIM_REQUIRE(C % G == 0 && ldf % G == 0 && ldo % G == 0, "grid_sample: C / strides must keep 16-byte groups (C=%d)", C);
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(nblocks((size_t)B * Ho * Wo * (C / G), 256));
-    DISPATCH_BF(grid_sample_kernel, dtype == GIM_BF16, grid, feat, grid_xy, out, B, h, w, Ho * Wo, C / G, ldf, ldo);
+    DISPATCH_BF(grid_sample_kernel, dtype == GIM_H16, grid, feat, grid_xy, out, B, h, w, Ho * Wo, C / G, ldf, ldo);
     return gim_check_launch("grid_sample");
 }
 
-extern "C" int gim_dkm_disp_emb(const float* flow, const float* wgt, const float* bias, void* out, int B, int h, int w, int E,
+#if !GIM_HALF_KIND
+extern "C" int gim_dkm_disp_emb_f16(const float* flow, const float* wgt, const float* bias, void* out, int B, int h, int w, int E,
+                                int ldo, int out_dtype, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_dkm_disp_emb)(const float* flow, const float* wgt, const float* bias, void* out, int B, int h, int w, int E,
                                 int ldo, int out_dtype, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (out_dtype == GIM_F16) return gim_dkm_disp_emb_f16(flow, wgt, bias, out, B, h, w, E, ldo, out_dtype, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(flow && wgt && bias && out && B > 0 && h > 0 && w > 0 && E > 0 && ldo >= E, "dkm_disp_emb: bad args");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(nblocks((size_t)B * h * w * E, 256));
-    DISPATCH_BF(disp_emb_kernel, out_dtype == GIM_BF16, grid, flow, wgt, bias, out, B, h, w, E, ldo);
+    DISPATCH_BF(disp_emb_kernel, out_dtype == GIM_H16, grid, flow, wgt, bias, out, B, h, w, E, ldo);
     return gim_check_launch("dkm_disp_emb");
 }
 
-extern "C" int gim_local_corr(const void* f0, const void* f1, const float* flow, void* out, int B, int h, int w, int C, int r,
+#if !GIM_HALF_KIND
+extern "C" int gim_local_corr_f16(const void* f0, const void* f1, const float* flow, void* out, int B, int h, int w, int C, int r,
+                              int ld0, int ld1, int ldo, int dtype, int out_dtype, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_local_corr)(const void* f0, const void* f1, const float* flow, void* out, int B, int h, int w, int C, int r,
                               int ld0, int ld1, int ldo, int dtype, int out_dtype, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16 || out_dtype == GIM_F16) return gim_local_corr_f16(f0, f1, flow, out, B, h, w, C, r, ld0, ld1, ldo, dtype, out_dtype, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(f0 && f1 && flow && out && B > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0, "local_corr: bad args");
     GIM_REQUIRE(r >= 1 && r <= 7, "local_corr: radius %d unsupported (1..7)", r);
     GIM_REQUIRE(ld0 % 4 == 0 && ld1 % 4 == 0 && ldo >= (2 * r + 1) * (2 * r + 1), "local_corr: strides");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(nblocks((size_t)B * h * w, 4));
-    const bool ib = dtype == GIM_BF16, ob = out_dtype == GIM_BF16;
+    const bool ib = dtype == GIM_H16, ob = out_dtype == GIM_H16;
     const bool v8 = ib && C % 512 == 0 && ld0 % 8 == 0 && ld1 % 8 == 0;
     const int P = 2 * r + 2;
 #define LC_LAUNCH(I, O, V, PT) hipLaunchKernelGGL((local_corr_kernel<I, O, V, PT>), grid, dim3(256), 0, s, f0, f1, flow, out, B, h, w, C, r, ld0, ld1, ldo)
@@ -815,15 +856,22 @@ extern "C" int gim_local_corr(const void* f0, const void* f1, const float* flow,
     return gim_check_launch("local_corr");
 }
 
-extern "C" int gim_dwconv5x5_bn_relu(const void* x, const float* wgt, const float* scale, const float* shift, void* y, int B,
+#if !GIM_HALF_KIND
+extern "C" int gim_dwconv5x5_bn_relu_f16(const void* x, const float* wgt, const float* scale, const float* shift, void* y, int B,
+                                     int H, int W, int Cin, int Cout, int cpad, int ldx, int ldy, int dtype, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_dwconv5x5_bn_relu)(const void* x, const float* wgt, const float* scale, const float* shift, void* y, int B,
                                      int H, int W, int Cin, int Cout, int cpad, int ldx, int ldy, int dtype, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16) return gim_dwconv5x5_bn_relu_f16(x, wgt, scale, shift, y, B, H, W, Cin, Cout, cpad, ldx, ldy, dtype, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(x && wgt && scale && shift && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout % Cin == 0, "dwconv5x5: bad args");
     GIM_REQUIRE(cpad % 4 == 0 && cpad >= Cout && ldx % 4 == 0 && ldy % 4 == 0 && ldy >= cpad, "dwconv5x5: cpad / strides");
     GIM_REQUIRE((int64_t)ldx * (Cout / Cin) >= cpad, "dwconv5x5: input rows too narrow for the padded channel range");
     hipStream_t s = (hipStream_t)stream;
-    const int G = dtype == GIM_BF16 ? 8 : 4;
+    const int G = dtype == GIM_H16 ? 8 : 4;
     const int mult = Cout / Cin;
-    if ((mult == 1 || (mult == 2 && dtype == GIM_BF16)) && cpad % G == 0 && ldx % 4 == 0 && ldy % G == 0 && (mult == 2 || ldx % G == 0)) {
+    if ((mult == 1 || (mult == 2 && dtype == GIM_H16)) && cpad % G == 0 && ldx % 4 == 0 && ldy % G == 0 && (mult == 2 || ldx % G == 0)) {
         const dim3 gt(nblocks((size_t)B * H * ((W + 3) / 4) * (cpad / G), 256));
         if (mult == 1) {
             const int CG = cpad / G;
@@ -832,7 +880,7 @@ extern "C" int gim_dwconv5x5_bn_relu(const void* x, const float* wgt, const floa
             const size_t nblk = (strips + SPB - 1) / SPB * NCH;
             GIM_REQUIRE(nblk < 0x7fffffffull, "dwconv5x5: grid too large");
             const size_t shm = (size_t)(G / 4) * 25 * CGB * 16;
-            if (dtype == GIM_BF16) hipLaunchKernelGGL((dwconv5x5_rows2_kernel<true>), dim3((unsigned)nblk), dim3(256), shm, s, x, wgt, scale, shift, y, B, H, W, CG, CGB, NCH, cpad, ldx, ldy, (unsigned)nblk);
+            if (dtype == GIM_H16) hipLaunchKernelGGL((dwconv5x5_rows2_kernel<true>), dim3((unsigned)nblk), dim3(256), shm, s, x, wgt, scale, shift, y, B, H, W, CG, CGB, NCH, cpad, ldx, ldy, (unsigned)nblk);
             else hipLaunchKernelGGL((dwconv5x5_rows2_kernel<false>), dim3((unsigned)nblk), dim3(256), shm, s, x, wgt, scale, shift, y, B, H, W, CG, CGB, NCH, cpad, ldx, ldy, (unsigned)nblk);
             return gim_check_launch("dwconv5x5_rows2");
         }
@@ -840,58 +888,90 @@ extern "C" int gim_dwconv5x5_bn_relu(const void* x, const float* wgt, const floa
         return gim_check_launch("dwconv5x5_tiled");
     }
     const dim3 grid(nblocks((size_t)B * H * W * (cpad / 4), 256));
-    DISPATCH_BF(dwconv5x5_kernel, dtype == GIM_BF16, grid, x, wgt, scale, shift, y, B, H, W, cpad / 4, Cout / Cin, cpad, ldx, ldy);
+    DISPATCH_BF(dwconv5x5_kernel, dtype == GIM_H16, grid, x, wgt, scale, shift, y, B, H, W, cpad / 4, Cout / Cin, cpad, ldx, ldy);
     return gim_check_launch("dwconv5x5");
 }
 
-extern "C" int gim_row_norms(const void* x, float* out, int rows, int C, int ld, int dtype, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+extern "C" int gim_row_norms_f16(const void* x, float* out, int rows, int C, int ld, int dtype, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_row_norms)(const void* x, float* out, int rows, int C, int ld, int dtype, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16) return gim_row_norms_f16(x, out, rows, C, ld, dtype, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(x && out && rows > 0 && C > 0 && C % 4 == 0 && ld % 4 == 0, "row_norms: bad args");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((rows + 3) / 4);
-    DISPATCH_BF(row_norms_kernel, dtype == GIM_BF16, grid, x, out, rows, C, ld);
+    DISPATCH_BF(row_norms_kernel, dtype == GIM_H16, grid, x, out, rows, C, ld);
     return gim_check_launch("row_norms");
 }
 
+#if !GIM_HALF_KIND   // no 16-bit operand: one copy, in the bf16 objects
 extern "C" int gim_cos_kernel_finish(float* k, const float* nx, const float* ny, int B, int n, int m, int ld, float T, float eps,
                                      float diag_add, gim_stream_t stream) {
     GIM_REQUIRE(k && nx && ny && B > 0 && n > 0 && m > 0 && ld >= m, "cos_kernel_finish: bad args");
     hipLaunchKernelGGL(cos_kernel_finish_kernel, dim3(nblocks((size_t)B * n * m, 256)), dim3(256), 0, (hipStream_t)stream, k, nx, ny, B, n, m, ld, T, eps, diag_add);
     return gim_check_launch("cos_kernel_finish");
 }
+#endif
 
-extern "C" int gim_global_avgpool(const void* x, float* out, int B, int HW, int C, int ld, int ldo, int c_off, int dtype,
+#if !GIM_HALF_KIND
+extern "C" int gim_global_avgpool_f16(const void* x, float* out, int B, int HW, int C, int ld, int ldo, int c_off, int dtype,
+                                  gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_global_avgpool)(const void* x, float* out, int B, int HW, int C, int ld, int ldo, int c_off, int dtype,
                                   gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16) return gim_global_avgpool_f16(x, out, B, HW, C, ld, ldo, c_off, dtype, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(x && out && B > 0 && HW > 0 && C > 0, "global_avgpool: bad args");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((C + 63) / 64, B);
-    DISPATCH_BF(global_avgpool_kernel, dtype == GIM_BF16, grid, x, out, B, HW, C, ld, ldo, c_off);
+    DISPATCH_BF(global_avgpool_kernel, dtype == GIM_H16, grid, x, out, B, HW, C, ld, ldo, c_off);
     return gim_check_launch("global_avgpool");
 }
 
-extern "C" int gim_cab_scale_add(const float* g, const void* x1, const void* x2, void* out, int B, int HW, int C, int ldg, int ld1,
+#if !GIM_HALF_KIND
+extern "C" int gim_cab_scale_add_f16(const float* g, const void* x1, const void* x2, void* out, int B, int HW, int C, int ldg, int ld1,
+                                 int ld2, int ldo, int dtype, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_cab_scale_add)(const float* g, const void* x1, const void* x2, void* out, int B, int HW, int C, int ldg, int ld1,
                                  int ld2, int ldo, int dtype, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16) return gim_cab_scale_add_f16(g, x1, x2, out, B, HW, C, ldg, ld1, ld2, ldo, dtype, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(g && x2 && out && B > 0 && HW > 0 && C > 0 && C % 4 == 0 && ldg % 4 == 0 && ld2 % 4 == 0 && ldo % 4 == 0 && (!x1 || ld1 % 4 == 0), "cab_scale_add: bad args");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(nblocks((size_t)B * HW * (C / 4), 256));
-    DISPATCH_BF(cab_scale_add_kernel, dtype == GIM_BF16, grid, g, x1, x2, out, B, HW, C / 4, ldg, ld1, ld2, ldo);
+    DISPATCH_BF(cab_scale_add_kernel, dtype == GIM_H16, grid, g, x1, x2, out, B, HW, C / 4, ldg, ld1, ld2, ldo);
     return gim_check_launch("cab_scale_add");
 }
 
-extern "C" int gim_dkm_flow_update(float* flow, float* cert, const void* d, int64_t npix, int ldd, float sx, float sy, int cert_init,
+#if !GIM_HALF_KIND
+extern "C" int gim_dkm_flow_update_f16(float* flow, float* cert, const void* d, int64_t npix, int ldd, float sx, float sy, int cert_init,
+                                   int dtype, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_dkm_flow_update)(float* flow, float* cert, const void* d, int64_t npix, int ldd, float sx, float sy, int cert_init,
                                    int dtype, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16) return gim_dkm_flow_update_f16(flow, cert, d, npix, ldd, sx, sy, cert_init, dtype, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(flow && cert && d && npix > 0 && ldd >= 3, "dkm_flow_update: bad args");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(nblocks((size_t)npix, 256));
-    DISPATCH_BF(flow_update_kernel, dtype == GIM_BF16, grid, flow, cert, d, (size_t)npix, ldd, sx, sy, cert_init);  // cert_init: flag bits
+    DISPATCH_BF(flow_update_kernel, dtype == GIM_H16, grid, flow, cert, d, (size_t)npix, ldd, sx, sy, cert_init);  // cert_init: flag bits
     return gim_check_launch("dkm_flow_update");
 }
 
+#if !GIM_HALF_KIND   // no 16-bit operand: one copy, in the bf16 objects
 extern "C" int gim_dkm_grid_coords(float* flow, int B, int h, int w, gim_stream_t stream) {
     GIM_REQUIRE(flow && B > 0 && h > 0 && w > 0, "dkm_grid_coords: bad args");
     hipLaunchKernelGGL(grid_coords_kernel, dim3(nblocks((size_t)B * h * w, 256)), dim3(256), 0, (hipStream_t)stream, flow, B, h, w);
     return gim_check_launch("dkm_grid_coords");
 }
+#endif
 
+#if !GIM_HALF_KIND   // no 16-bit operand: one copy, in the bf16 objects
 extern "C" int gim_dkm_match_post(const float* flow0, const float* flow1, const float* cert0, const float* cert1, const float* low0,
                                   const float* low1, const uint8_t* black0, const uint8_t* black1, float* warp, float* certainty,
                                   int H, int W, gim_stream_t stream) {
@@ -900,19 +980,24 @@ extern "C" int gim_dkm_match_post(const float* flow0, const float* flow1, const 
                        low0, low1, black0, black1, warp, certainty, H, W);
     return gim_check_launch("dkm_match_post");
 }
+#endif
 
+#if !GIM_HALF_KIND   // no 16-bit operand: one copy, in the bf16 objects
 extern "C" int gim_dkm_black_mask(const float* im, uint8_t* mask, int h, int w, int Ho, int Wo, gim_stream_t stream) {
     GIM_REQUIRE(im && mask && h > 0 && w > 0 && Ho > 0 && Wo > 0, "dkm_black_mask: bad args");
     hipLaunchKernelGGL(black_mask_kernel, dim3(nblocks((size_t)Ho * Wo, 256)), dim3(256), 0, (hipStream_t)stream, im, mask, h, w, Ho, Wo);
     return gim_check_launch("dkm_black_mask");
 }
+#endif
 
+#if !GIM_HALF_KIND   // no 16-bit operand: one copy, in the bf16 objects
 extern "C" int gim_kde(const float* x, float* density, int n, float std, gim_stream_t stream) {
     GIM_REQUIRE(x && density && n > 0 && std != 0.f, "kde: bad args");
     // std < 0: coordinates rounded to fp16 first (RoMa evaluates its KDE on x.half(), roma.py:1018-1023)
     hipLaunchKernelGGL(kde_kernel, dim3((n + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, density, n, 1.0f / (2.0f * std * std), std < 0.f ? 1 : 0);
     return gim_check_launch("kde");
 }
+#endif
 
 namespace {
 // normalised (x0, y0, x1, y1) in [-1, 1] -> pixel coordinates of the two images (trainer/lightning.py:141-144, demo.py:438-443)
@@ -926,6 +1011,7 @@ __global__ void to_pixels_kernel(const float* __restrict__ m, float* __restrict_
 }
 }  // namespace
 
+#if !GIM_HALF_KIND   // no 16-bit operand: one copy, in the bf16 objects
 extern "C" int gim_dense_to_pixels(const float* matches, float* kpts0, float* kpts1, int n, float w0, float h0, float w1, float h1,
                                    gim_stream_t stream) {
     GIM_REQUIRE(matches && kpts0 && kpts1 && n >= 0, "dense_to_pixels: bad args");
@@ -933,6 +1019,7 @@ extern "C" int gim_dense_to_pixels(const float* matches, float* kpts0, float* kp
     hipLaunchKernelGGL(to_pixels_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, matches, kpts0, kpts1, n, w0, h0, w1, h1);
     return gim_check_launch("dense_to_pixels");
 }
+#endif
 
 namespace {
 // cls_to_flow_refine (roma.py:1092-1121) + the certainty channel: one wave per pixel over C = res^2 class logits.
@@ -983,6 +1070,7 @@ __global__ void __launch_bounds__(256) cls_to_flow_kernel(const float* __restric
 }
 }  // namespace
 
+#if !GIM_HALF_KIND   // no 16-bit operand: one copy, in the bf16 objects
 extern "C" int gim_cls_to_flow(const float* logits, float* flow, float* cert, int npix, int ncls, int ld, gim_stream_t stream) {
     GIM_REQUIRE(logits && flow && cert && npix > 0 && ncls > 0 && ld > ncls, "cls_to_flow: bad args");
     const int res = (int)(sqrtf((float)ncls) + 0.5f);
@@ -990,3 +1078,4 @@ extern "C" int gim_cls_to_flow(const float* logits, float* flow, float* cert, in
     hipLaunchKernelGGL(cls_to_flow_kernel, dim3((npix + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, flow, cert, npix, ncls, res, ld);
     return gim_check_launch("cls_to_flow");
 }
+#endif

@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(256, 2) sdpa_kernel(const SdpaArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < D / 16; ++ks) {
                     const bf16x8_t fa = *(const bf16x8_t*)(rp + (((2 * ks + lh) ^ sw) << 4));
-                    accS[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, qb[ks], accS[kb], 0, 0, 0);
+                    accS[kb] = mfma_h16_32x32x16(fa, qb[ks], accS[kb]);
                 }
             } else {
 #pragma unroll
@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(256, 2) sdpa_kernel(const SdpaArgs a) {
                 for (int s = 0; s < 2; ++s) {
                     union { unsigned u[4]; bf16x8_t v; } pb;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pb.u[e] = cvt_pk_bf16(accS[kb][8 * s + 2 * e], accS[kb][8 * s + 2 * e + 1]);
+                    for (int e = 0; e < 4; ++e) pb.u[e] = cvt_pk_h16(accS[kb][8 * s + 2 * e], accS[kb][8 * s + 2 * e + 1]);
                     const int c = kb * 8 + 4 * s + lh;  // 8-byte chunk of keys kb*32 + 16 s + lh*4 .. +3 ; c + 2 = +8 keys
 #pragma unroll
                     for (int d = 0; d < NDB; ++d) {
@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(256, 2) sdpa_kernel(const SdpaArgs a) {
                         union { uint2 h2[2]; bf16x8_t v; } va;
                         va.h2[0] = *(const uint2*)(sV + drow * VROW + ((c ^ sw) << 3));
                         va.h2[1] = *(const uint2*)(sV + drow * VROW + (((c + 2) ^ sw) << 3));
-                        accO[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va.v, pb.v, accO[d], 0, 0, 0);
+                        accO[d] = mfma_h16_32x32x16(va.v, pb.v, accO[d]);
                     }
                 }
             } else {
@@ -373,6 +373,7 @@ int launch_sdpa(const SdpaArgs& a, hipStream_t s) {
 
 }  // namespace
 
+#if !GIM_HALF_KIND   // no 16-bit operand: one copy, in the bf16 objects
 extern "C" int gim_lg_posenc(const float* kpts, const float* size_wh, const float* Wr, float* enc, int B, int K,
                              gim_stream_t stream) {
     GIM_REQUIRE(kpts && size_wh && Wr && enc && B > 0 && K > 0, "lg_posenc: bad args");
@@ -380,44 +381,72 @@ extern "C" int gim_lg_posenc(const float* kpts, const float* size_wh, const floa
     hipLaunchKernelGGL(lg_posenc_kernel, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, kpts, size_wh, Wr, enc, B * K, K, 32);
     return gim_check_launch("lg_posenc");
 }
+#endif
 
-extern "C" int gim_lg_rotary(void* x, const float* enc, int rows, int ncols, int ld, int dtype, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+extern "C" int gim_lg_rotary_f16(void* x, const float* enc, int rows, int ncols, int ld, int dtype, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_lg_rotary)(void* x, const float* enc, int rows, int ncols, int ld, int dtype, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16) return gim_lg_rotary_f16(x, enc, rows, ncols, ld, dtype, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(x && enc && rows > 0 && ncols > 0 && ncols % 64 == 0 && ld >= ncols && ld % 4 == 0, "lg_rotary: bad args");
     const size_t n = (size_t)rows * (ncols / 4);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GIM_BF16) hipLaunchKernelGGL(lg_rotary_kernel<true>, dim3(nblocks(n, 256)), dim3(256), 0, s, x, enc, (size_t)rows, ncols / 4, ld);
+    if (dtype == GIM_H16) hipLaunchKernelGGL(lg_rotary_kernel<true>, dim3(nblocks(n, 256)), dim3(256), 0, s, x, enc, (size_t)rows, ncols / 4, ld);
     else hipLaunchKernelGGL(lg_rotary_kernel<false>, dim3(nblocks(n, 256)), dim3(256), 0, s, x, enc, (size_t)rows, ncols / 4, ld);
     return gim_check_launch("lg_rotary");
 }
 
-extern "C" int gim_lg_transpose(const void* src, void* dst, int nb, int S, int Sp, int C, int ld, int dtype,
+#if !GIM_HALF_KIND
+extern "C" int gim_lg_transpose_f16(const void* src, void* dst, int nb, int S, int Sp, int C, int ld, int dtype,
+                                gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_lg_transpose)(const void* src, void* dst, int nb, int S, int Sp, int C, int ld, int dtype,
                                 gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16) return gim_lg_transpose_f16(src, dst, nb, S, Sp, C, ld, dtype, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(src && dst && nb > 0 && S > 0 && Sp >= S && Sp % 64 == 0 && C > 0 && ld >= C, "lg_transpose: bad args");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(Sp / 64, (C + 63) / 64, nb);
-    if (dtype == GIM_BF16) hipLaunchKernelGGL(lg_transpose_kernel<true>, grid, dim3(256), 0, s, src, dst, S, Sp, C, ld);
+    if (dtype == GIM_H16) hipLaunchKernelGGL(lg_transpose_kernel<true>, grid, dim3(256), 0, s, src, dst, S, Sp, C, ld);
     else hipLaunchKernelGGL(lg_transpose_kernel<false>, grid, dim3(256), 0, s, src, dst, S, Sp, C, ld);
     return gim_check_launch("lg_transpose");
 }
 
-extern "C" int gim_cast_rows(const float* src, void* dst, int rows, int C, int ld_src, int ld_dst, int dtype,
+#if !GIM_HALF_KIND
+extern "C" int gim_cast_rows_f16(const float* src, void* dst, int rows, int C, int ld_src, int ld_dst, int dtype,
+                             gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_cast_rows)(const float* src, void* dst, int rows, int C, int ld_src, int ld_dst, int dtype,
                              gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16) return gim_cast_rows_f16(src, dst, rows, C, ld_src, ld_dst, dtype, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(src && dst && rows > 0 && C > 0 && C % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0, "cast_rows: bad args");
     const size_t n = (size_t)rows * (C / 4);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GIM_BF16) hipLaunchKernelGGL(cast_rows_kernel<true>, dim3(nblocks(n, 256)), dim3(256), 0, s, src, dst, (size_t)rows, C / 4, ld_src, ld_dst);
+    if (dtype == GIM_H16) hipLaunchKernelGGL(cast_rows_kernel<true>, dim3(nblocks(n, 256)), dim3(256), 0, s, src, dst, (size_t)rows, C / 4, ld_src, ld_dst);
     else hipLaunchKernelGGL(cast_rows_kernel<false>, dim3(nblocks(n, 256)), dim3(256), 0, s, src, dst, (size_t)rows, C / 4, ld_src, ld_dst);
     return gim_check_launch("cast_rows");
 }
 
-extern "C" int gim_layernorm_act(const float* x, const float* gamma, const float* beta, void* out, int rows, int C,
+#if !GIM_HALF_KIND
+extern "C" int gim_layernorm_act_f16(const float* x, const float* gamma, const float* beta, void* out, int rows, int C,
+                                 int ldx, int ldo, int act, int out_dtype, float eps, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_layernorm_act)(const float* x, const float* gamma, const float* beta, void* out, int rows, int C,
                                  int ldx, int ldo, int act, int out_dtype, float eps, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (out_dtype == GIM_F16) return gim_layernorm_act_f16(x, gamma, beta, out, rows, C, ldx, ldo, act, out_dtype, eps, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(x && gamma && beta && out && rows > 0, "layernorm_act: bad args");
     GIM_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ldo % 4 == 0, "layernorm_act: C=%d (multiple of 4, <= 1024)", C);
     GIM_REQUIRE(act == GIM_ACT_NONE || act == GIM_ACT_GELU, "layernorm_act: act must be NONE or GELU");
     hipStream_t s = (hipStream_t)stream;
     const dim3 g((rows + 3) / 4), b(256);
-    const bool bf = out_dtype == GIM_BF16, ge = act == GIM_ACT_GELU;
+    const bool bf = out_dtype == GIM_H16, ge = act == GIM_ACT_GELU;
     if (bf && ge) hipLaunchKernelGGL((layernorm_act_kernel<true, true>), g, b, 0, s, x, gamma, beta, out, rows, C, ldx, ldo, eps);
     else if (bf) hipLaunchKernelGGL((layernorm_act_kernel<true, false>), g, b, 0, s, x, gamma, beta, out, rows, C, ldx, ldo, eps);
     else if (ge) hipLaunchKernelGGL((layernorm_act_kernel<false, true>), g, b, 0, s, x, gamma, beta, out, rows, C, ldx, ldo, eps);
@@ -425,12 +454,19 @@ extern "C" int gim_layernorm_act(const float* x, const float* gamma, const float
     return gim_check_launch("layernorm_act");
 }
 
-extern "C" int gim_sdpa(const void* q, const void* k, const void* vt, void* out, int nb, int H, int L, int S, int Sp,
+#if !GIM_HALF_KIND
+extern "C" int gim_sdpa_f16(const void* q, const void* k, const void* vt, void* out, int nb, int H, int L, int S, int Sp,
+                        int D, int ldq, int ldk, int ldo, int kv_shift, int dtype, int out_dtype, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_sdpa)(const void* q, const void* k, const void* vt, void* out, int nb, int H, int L, int S, int Sp,
                         int D, int ldq, int ldk, int ldo, int kv_shift, int dtype, int out_dtype, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16 || out_dtype == GIM_F16) return gim_sdpa_f16(q, k, vt, out, nb, H, L, S, Sp, D, ldq, ldk, ldo, kv_shift, dtype, out_dtype, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(q && k && vt && out && nb > 0 && H > 0 && L > 0 && S > 0, "sdpa: bad args");
     GIM_REQUIRE(D == 64 || D == 128, "sdpa: head dim %d unsupported (64, 128)", D);
     GIM_REQUIRE(Sp >= S && Sp % 64 == 0, "sdpa: Sp=%d must be S rounded up to a multiple of 64", Sp);
-    const int g = dtype == GIM_BF16 ? 8 : 4;
+    const int g = dtype == GIM_H16 ? 8 : 4;
     GIM_REQUIRE(ldq % g == 0 && ldk % g == 0 && ldo % 4 == 0, "sdpa: row strides must keep 16-byte alignment");
     GIM_REQUIRE(kv_shift >= 0 && kv_shift < nb, "sdpa: kv_shift");
     SdpaArgs a;
@@ -438,7 +474,7 @@ extern "C" int gim_sdpa(const void* q, const void* k, const void* vt, void* out,
     a.nb = nb; a.H = H; a.L = L; a.S = S; a.Sp = Sp; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.kv_shift = kv_shift;
     a.scale_log2e = (1.0f / sqrtf((float)D)) * 1.44269504088896340736f;
     hipStream_t s = (hipStream_t)stream;
-    const bool bf = dtype == GIM_BF16, obf = out_dtype == GIM_BF16;
+    const bool bf = dtype == GIM_H16, obf = out_dtype == GIM_H16;
     if (D == 64) {
         if (bf && obf) return launch_sdpa<true, true, 64>(a, s);
         if (bf) return launch_sdpa<true, false, 64>(a, s);

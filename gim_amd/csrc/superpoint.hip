@@ -305,33 +305,50 @@ __global__ void __launch_bounds__(256) sp_sample_desc_kernel(const void* __restr
 
 }  // namespace
 
-extern "C" int gim_maxpool2x2(const void* x, void* y, int B, int H, int W, int C, int ldx, int ldy, int dtype,
+#if !GIM_HALF_KIND
+extern "C" int gim_maxpool2x2_f16(const void* x, void* y, int B, int H, int W, int C, int ldx, int ldy, int dtype,
+                              gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_maxpool2x2)(const void* x, void* y, int B, int H, int W, int C, int ldx, int ldy, int dtype,
                               gim_stream_t stream) {
-    const int G = dtype == GIM_BF16 ? 8 : 4;
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16) return gim_maxpool2x2_f16(x, y, B, H, W, C, ldx, ldy, dtype, stream);   // the fp16 objects of this file
+#endif
+    const int G = dtype == GIM_H16 ? 8 : 4;
     GIM_REQUIRE(x && y && B > 0 && H > 1 && W > 1 && C > 0 && C % G == 0, "maxpool2x2: bad args (C=%d)", C);
     GIM_REQUIRE(ldx % G == 0 && ldy % G == 0, "maxpool2x2: row strides must keep 16-byte groups aligned");
     const size_t n = (size_t)B * (H / 2) * (W / 2) * (C / G);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GIM_BF16) hipLaunchKernelGGL(maxpool2x2_kernel<true>, dim3(nblocks(n, 256)), dim3(256), 0, s, x, y, B, H, W, C / G, ldx, ldy);
+    if (dtype == GIM_H16) hipLaunchKernelGGL(maxpool2x2_kernel<true>, dim3(nblocks(n, 256)), dim3(256), 0, s, x, y, B, H, W, C / G, ldx, ldy);
     else hipLaunchKernelGGL(maxpool2x2_kernel<false>, dim3(nblocks(n, 256)), dim3(256), 0, s, x, y, B, H, W, C / G, ldx, ldy);
     return gim_check_launch("maxpool2x2");
 }
 
-extern "C" int gim_sp_scores(const void* logits, float* scores, int B, int h, int w, int ld, int dtype,
+#if !GIM_HALF_KIND
+extern "C" int gim_sp_scores_f16(const void* logits, float* scores, int B, int h, int w, int ld, int dtype,
+                             gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_sp_scores)(const void* logits, float* scores, int B, int h, int w, int ld, int dtype,
                              gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16) return gim_sp_scores_f16(logits, scores, B, h, w, ld, dtype, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(logits && scores && B > 0 && h > 0 && w > 0 && ld >= 65, "sp_scores: bad args");
     const int cells = B * h * w;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GIM_BF16) hipLaunchKernelGGL(sp_scores_kernel<true>, dim3((cells + 3) / 4), dim3(256), 0, s, logits, scores, cells, h, w, ld);
+    if (dtype == GIM_H16) hipLaunchKernelGGL(sp_scores_kernel<true>, dim3((cells + 3) / 4), dim3(256), 0, s, logits, scores, cells, h, w, ld);
     else hipLaunchKernelGGL(sp_scores_kernel<false>, dim3((cells + 3) / 4), dim3(256), 0, s, logits, scores, cells, h, w, ld);
     return gim_check_launch("sp_scores");
 }
 
+#if !GIM_HALF_KIND   // no 16-bit operand: one copy, in the bf16 objects
 extern "C" int64_t gim_sp_nms_ws_bytes(int B, int H, int W) {
     const size_t n = (size_t)B * H * W;
     return (int64_t)(((n + 255) & ~(size_t)255) * 2 + n * 4);  // keep, supp (u8), s2 (f32)
 }
+#endif
 
+#if !GIM_HALF_KIND   // no 16-bit operand: one copy, in the bf16 objects
 extern "C" int gim_sp_nms(const float* scores, float* out, void* ws, int B, int H, int W, int radius, int border,
                           gim_stream_t stream) {
     GIM_REQUIRE(scores && out && ws && B > 0 && H > 0 && W > 0 && radius >= 0 && border >= 0, "sp_nms: bad args");
@@ -349,9 +366,13 @@ extern "C" int gim_sp_nms(const float* scores, float* out, void* ws, int B, int 
     }
     return gim_check_launch("sp_nms");
 }
+#endif
 
+#if !GIM_HALF_KIND   // no 16-bit operand: one copy, in the bf16 objects
 extern "C" int64_t gim_sp_topk_ws_bytes(int B, int H, int W) { return (int64_t)B * H * W * 8 + 256; }
+#endif
 
+#if !GIM_HALF_KIND   // no 16-bit operand: one copy, in the bf16 objects
 extern "C" int gim_sp_topk(const float* nms_scores, void* ws, float* kpts, float* kscores, int32_t* nvalid, int B,
                            int H, int W, int k, float thr, gim_stream_t stream) {
     GIM_REQUIRE(nms_scores && ws && kpts && kscores && nvalid && B > 0 && H > 0 && W > 0, "sp_topk: bad args");
@@ -369,15 +390,24 @@ extern "C" int gim_sp_topk(const float* nms_scores, void* ws, float* kpts, float
     hipLaunchKernelGGL(sp_topk_kernel, dim3(B), dim3(1024), 0, s, cand, count, kpts, kscores, nvalid, HW, W, k, kp2);
     return gim_check_launch("sp_topk");
 }
+#endif
 
-extern "C" int gim_sp_sample_desc(const void* dense, const float* kpts, float* out_f32, void* out_t, int B, int K,
+#if !GIM_HALF_KIND
+extern "C" int gim_sp_sample_desc_f16(const void* dense, const float* kpts, float* out_f32, void* out_t, int B, int K,
+                                  int h, int w, int C, int ld, int ld_f32, int ld_t, int cell, int dtype,
+                                  gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_sp_sample_desc)(const void* dense, const float* kpts, float* out_f32, void* out_t, int B, int K,
                                   int h, int w, int C, int ld, int ld_f32, int ld_t, int cell, int dtype,
                                   gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16) return gim_sp_sample_desc_f16(dense, kpts, out_f32, out_t, B, K, h, w, C, ld, ld_f32, ld_t, cell, dtype, stream);   // the fp16 objects of this file
+#endif
     GIM_REQUIRE(dense && kpts && (out_f32 || out_t) && B > 0 && K > 0 && h > 1 && w > 1, "sp_sample_desc: bad args");
     GIM_REQUIRE(C == 256 && ld % 4 == 0 && ld_f32 % 4 == 0 && ld_t % 4 == 0, "sp_sample_desc: C must be 256, strides % 4");
     hipStream_t s = (hipStream_t)stream;
     const unsigned g = (unsigned)((B * K + 3) / 4);
-    if (dtype == GIM_BF16) hipLaunchKernelGGL(sp_sample_desc_kernel<true>, dim3(g), dim3(256), 0, s, dense, kpts, out_f32, out_t, B, K, h, w, ld, ld_f32, ld_t, (float)cell);
+    if (dtype == GIM_H16) hipLaunchKernelGGL(sp_sample_desc_kernel<true>, dim3(g), dim3(256), 0, s, dense, kpts, out_f32, out_t, B, K, h, w, ld, ld_f32, ld_t, (float)cell);
     else hipLaunchKernelGGL(sp_sample_desc_kernel<false>, dim3(g), dim3(256), 0, s, dense, kpts, out_f32, out_t, B, K, h, w, ld, ld_f32, ld_t, (float)cell);
     return gim_check_launch("sp_sample_desc");
 }

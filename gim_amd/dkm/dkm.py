@@ -29,7 +29,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from .._lib import ACT_NONE, ACT_RELU, GIM_BF16, GIM_F32, GimHipError
+from .._lib import ACT_NONE, ACT_RELU, GIM_BF16, GIM_F16, GIM_F32, GimHipError
 from ..packing import cstore, pack_conv, torch_dtype
 
 REFINER = {"16": (512, 128, 7), "8": (512, 64, 3), "4": (256, 32, 2), "2": (64, 16, None), "1": (3, 6, None)}
@@ -182,7 +182,7 @@ class RegressionMatcher(nn.Module):
 
     # ---- one-time packing -------------------------------------------------------------------------------------
     def _prepack(self, device):
-        dt = GIM_BF16 if self.precision == "bf16" else GIM_F32
+        dt = {"bf16": GIM_BF16, "fp16": GIM_F16, "fp32": GIM_F32}[self.precision]
         P = {}
         net = self.encoder.net
         P["stem"] = pack_conv(net.conv1.weight, _bn(net.bn1), dt, device, stride=2, pad=3, cin_pad=cstore(3, dt))
@@ -302,7 +302,7 @@ class RegressionMatcher(nn.Module):
         in_dim, hid = _refiner_dims(s)
         cs = P[f"cr{s}.cin_store"]
         dev = x.device
-        g = 8 if dt == GIM_BF16 else 4
+        g = 8 if dt in (GIM_BF16, GIM_F16) else 4
         if c % g == 0:
             D = torch.zeros(b, h, w, cs, dtype=tdt, device=dev)
             rows = D.view(b * h * w, cs)
@@ -438,7 +438,7 @@ class RegressionMatcher(nn.Module):
             raise GimHipError(f"match takes two [B,3,H,W] batches of equal shape with B <= 8, got {tuple(im1.shape)} / {tuple(im2.shape)}")
         dev = im1.device
         B = im1.shape[0]
-        want = GIM_BF16 if self.precision == "bf16" else GIM_F32
+        want = {"bf16": GIM_BF16, "fp16": GIM_F16, "fp32": GIM_F32}[self.precision]
         if self._packed is None or self._packed[2] != dev or self._packed[1] != want:
             self._prepack(dev)
         P, dt, _ = self._packed

@@ -26,7 +26,7 @@ from ..precision import resolve as resolve_precision
 import torch.nn as nn
 
 from .. import ops
-from .._lib import ACT_GELU, ACT_NONE, GIM_BF16, GIM_F32, GimHipError
+from .._lib import ACT_GELU, ACT_NONE, GIM_BF16, GIM_F16, GIM_F32, GimHipError
 from ..packing import pack_conv, torch_dtype
 
 
@@ -136,7 +136,7 @@ class LightGlue(nn.Module):
 
     # ---- one-time weight packing ----------------------------------------------------------------------------
     def _prepack(self, device):
-        dt = GIM_BF16 if self.precision == "bf16" else GIM_F32
+        dt = {"bf16": GIM_BF16, "fp16": GIM_F16, "fp32": GIM_F32}[self.precision]
         d, H = 256, 4
         dh = d // H
         layers = []
@@ -186,7 +186,7 @@ class LightGlue(nn.Module):
         if not kp0.is_cuda:
             raise GimHipError("gim_amd LightGlue needs device (cuda/HIP) tensors: there is no CPU fallback")
         dev = kp0.device
-        dt_want = GIM_BF16 if self.precision == "bf16" else GIM_F32
+        dt_want = {"bf16": GIM_BF16, "fp16": GIM_F16, "fp32": GIM_F32}[self.precision]
         if self._packed is None or self._packed[4] != dev or self._packed[3] != dt_want:
             self._prepack(dev)
         layers, head, wr, dt, _ = self._packed

@@ -23,7 +23,7 @@ from ..precision import resolve as resolve_precision
 import torch.nn as nn
 
 from .. import ops
-from .._lib import ACT_RELU, GIM_BF16, GIM_F32, GimHipError
+from .._lib import ACT_RELU, GIM_BF16, GIM_F16, GIM_F32, GimHipError
 from ..packing import pack_conv, torch_dtype
 
 
@@ -66,7 +66,7 @@ class SuperPoint(nn.Module):
 
     # ---- one-time weight packing ------------------------------------------------------------------------
     def _prepack(self, device):
-        dt = GIM_BF16 if self.precision == "bf16" else GIM_F32
+        dt = {"bf16": GIM_BF16, "fp16": GIM_F16, "fp32": GIM_F32}[self.precision]
         pk = {}
 
         def conv(name, w, b, cin_pad=None):
@@ -93,7 +93,7 @@ class SuperPoint(nn.Module):
         if not image.is_cuda:
             raise GimHipError("gim_amd SuperPoint needs device (cuda/HIP) tensors: there is no CPU fallback")
         dev = image.device
-        if self._packed is None or self._packed[2] != dev or self._packed[1] != (GIM_BF16 if self.precision == "bf16" else GIM_F32):
+        if self._packed is None or self._packed[2] != dev or self._packed[1] != ({"bf16": GIM_BF16, "fp16": GIM_F16, "fp32": GIM_F32}[self.precision]):
             self._prepack(dev)
         pk, dt, _ = self._packed
         tdt = torch_dtype(dt)

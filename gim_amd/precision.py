@@ -1,8 +1,10 @@
 """One place that resolves the `precision` of an engine (config value > GIM_PRECISION > the engine's default).
 
 gim_loftr has three modes -- 'fp16' (its default), 'bf16', 'fp32'.  The secondary engines (SuperPoint, LightGlue, DKMv3, RoMa)
-have two, 'bf16' and 'fp32': a process-wide GIM_PRECISION=fp16 (gim_loftr's spelling of "the fast mode") means 'bf16' to
-them, and an unknown value raises instead of silently selecting the fp32 path (five times slower)."""
+have the same three since round 5 (their kernels are compiled in the IEEE-fp16 flavour too: 11 instead of 8 significand bits per stored
+activation); their default stays 'bf16' -- the DINOv2 / VGG / ResNet-50 streams of the dense matchers carry no range guard -- and a
+process-wide GIM_PRECISION=fp16 set for gim_loftr still means 'bf16' to them: only an EXPLICIT precision='fp16' selects it.  An unknown
+value raises instead of silently selecting the fp32 path (five times slower)."""
 import os
 
 LOFTR_MODES = ("fp16", "bf16", "fp32")
@@ -17,10 +19,8 @@ def resolve(value, engine, default="bf16", env=True):
         if p not in LOFTR_MODES:
             raise ValueError(f"precision must be 'bf16', 'fp16' or 'fp32', got {p!r}")
         return p
-    if p == "fp16":
-        if explicit:
-            raise ValueError(f"{engine}: precision must be 'bf16' or 'fp32' (the IEEE-fp16 flavour exists for gim_loftr only), got 'fp16'")
-        return "bf16"      # GIM_PRECISION=fp16 set for gim_loftr: this engine's 16-bit mode
-    if p not in ("bf16", "fp32"):
-        raise ValueError(f"{engine}: precision must be 'bf16' or 'fp32', got {p!r}")
+    if p == "fp16" and not explicit:
+        return "bf16"      # GIM_PRECISION=fp16 set for gim_loftr: this engine's default 16-bit mode
+    if p not in LOFTR_MODES:
+        raise ValueError(f"{engine}: precision must be 'bf16', 'fp16' or 'fp32', got {p!r}")
     return p

@@ -33,7 +33,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from .._lib import ACT_GELU, ACT_NONE, ACT_RELU, GIM_BF16, GIM_F32, GimHipError
+from .._lib import ACT_GELU, ACT_NONE, ACT_RELU, GIM_BF16, GIM_F16, GIM_F32, GimHipError
 from ..dkm.dkm import _bn_after_bias, balanced_sample
 from ..packing import cstore, pack_conv, torch_dtype
 
@@ -215,7 +215,7 @@ class RegressionMatcher(nn.Module):
     def _prepack(self, device):
         if self._dino[0] is None:
             raise GimHipError("RoMa needs the DINOv2 ViT-L/14 weights: RoMa(img_size, dinov2_weights=sd) or model.load_dinov2(sd)")
-        dt = GIM_BF16 if self.precision == "bf16" else GIM_F32
+        dt = {"bf16": GIM_BF16, "fp16": GIM_F16, "fp32": GIM_F32}[self.precision]
         P = {}
         layers = self.encoder.cnn.layers
         idx = 0
@@ -431,7 +431,7 @@ class RegressionMatcher(nn.Module):
         in_dim, hid = _refiner_dims(s)
         cs = P[f"cr{s}.cin_store"]
         dev = x.device
-        g = 8 if dt == GIM_BF16 else 4
+        g = 8 if dt in (GIM_BF16, GIM_F16) else 4
         ew, eb = P[f"cr{s}.emb"]
         ew = ew * (40.0 / 32.0 * scale_factor)            # disp_emb(40/32 * scale_factor * (flow - coords)), roma.py:545-547
         if c % g == 0:
@@ -518,7 +518,7 @@ class RegressionMatcher(nn.Module):
             raise GimHipError(f"match takes two [B,3,H,W] batches of equal shape with B <= 4, got {tuple(im1.shape)} / {tuple(im2.shape)}")
         dev = im1.device
         B = im1.shape[0]
-        want = GIM_BF16 if self.precision == "bf16" else GIM_F32
+        want = {"bf16": GIM_BF16, "fp16": GIM_F16, "fp32": GIM_F32}[self.precision]
         if self._packed is None or self._packed[2] != dev or self._packed[1] != want:
             self._prepack(dev)
         P, dt, _ = self._packed

@@ -134,10 +134,12 @@ def test_dkm_672x896_upsample_pass_vs_oracle(monkeypatch):
     m = m.eval()
     warp, cert = m.match(im0.to("cuda:0"), im1.to("cuda:0"))
     assert warp.shape == (up[0], 2 * up[1], 4) and cert.shape == (up[0], 2 * up[1])
+    # measured on MI355X (round 5): vs the pinned arithmetic warp max 2.7e-4 / mean 2.4e-5, certainty max 8.5e-5 / mean 1.7e-5; vs the
+    # fp64-GP oracle warp max 3.1e-6 / mean 2.6e-7, certainty max 1.1e-6 / mean 2.0e-7 -- the upsampling pass adds nothing to either distance
     _close(warp, ref_warp, 6e-4, "dkm warp 1152x1536 (upsampling pass) vs the reference arithmetic", frac=1.0, mean_tol=5e-5)
-    _close(cert, ref_cert, 4e-4, "dkm certainty 1152x1536 (upsampling pass) vs the reference arithmetic", frac=1.0, mean_tol=4e-5)
-    _close(warp, x_warp, 1e-4, "dkm warp 1152x1536 (upsampling pass) vs the fp64-GP oracle", frac=1.0, mean_tol=1e-5)
-    _close(cert, x_cert, 1e-4, "dkm certainty 1152x1536 (upsampling pass) vs the fp64-GP oracle", frac=1.0, mean_tol=1e-5)
+    _close(cert, ref_cert, 2e-4, "dkm certainty 1152x1536 (upsampling pass) vs the reference arithmetic", frac=1.0, mean_tol=4e-5)
+    _close(warp, x_warp, 1e-5, "dkm warp 1152x1536 (upsampling pass) vs the fp64-GP oracle", frac=1.0, mean_tol=1e-6)
+    _close(cert, x_cert, 1e-5, "dkm certainty 1152x1536 (upsampling pass) vs the fp64-GP oracle", frac=1.0, mean_tol=1e-6)
 
 
 def test_dkm_batch4_672x896_vs_single_pair_oracles(monkeypatch):
@@ -146,7 +148,7 @@ def test_dkm_batch4_672x896_vs_single_pair_oracles(monkeypatch):
     import dkm_oracle as O
     from gim_amd.dkm import DKMv3
     sd = O.make_state_dict(0)
-    pairs = [O.seeded_pair(672, 896, s_, shift=sh) for s_, sh in ((3, (8, 12)), (5, (4, 14)), (7, (10, 6)), (9, (6, 20)))]
+    pairs = [O.seeded_pair(672, 896, s_, shift=sh) for s_, sh in ((3, (8, 12)), (5, (4, 14)), (7, (10, 6)), (9, (6, 16)))]   # (seeded_pair keeps a 16-pixel margin)
     monkeypatch.setattr(O, "GP_FP64", True)
     with torch.no_grad():
         refs = [O.match(sd, a, b, 672, 896, None) for a, b in pairs]

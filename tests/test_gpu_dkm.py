@@ -9,7 +9,7 @@ import torch.nn.functional as F
 import dkm_oracle as O
 
 pytestmark = pytest.mark.gpu
-DTS = ["fp32", "bf16"]
+DTS = ["fp32", "bf16", "fp16"]   # fp16: round 5, the IEEE-fp16 flavour of the dense matchers' kernels
 
 
 def _dev():
@@ -18,7 +18,12 @@ def _dev():
 
 
 def _tdt(dt):
-    return torch.bfloat16 if dt == "bf16" else torch.float32
+    return {"bf16": torch.bfloat16, "fp16": torch.float16}.get(dt, torch.float32)
+
+
+def _t16(dt, bf16_tol, fp32_tol):
+    """tolerance of a kernel test by operand kind: fp16 keeps 3 more significand bits than bf16"""
+    return {"bf16": bf16_tol, "fp16": bf16_tol / 6}.get(dt, fp32_tol)
 
 
 def _close(got, ref, tol, what=""):
@@ -69,7 +74,7 @@ def test_grid_sample(dt):
     ref = F.grid_sample(feat, grid, align_corners=False).permute(0, 2, 3, 1)
     out = torch.zeros(2 * 7 * 11, 32, dtype=_tdt(dt), device=dev)
     ops.grid_sample(_nhwc(feat, dt, dev), grid.to(dev), out[:, 16:])
-    _close(out[:, 16:].view(2, 7, 11, 16), ref, 5e-3 if dt == "bf16" else 2e-6, "grid_sample")
+    _close(out[:, 16:].view(2, 7, 11, 16), ref, _t16(dt, 5e-3, 2e-6), "grid_sample")
     assert (out[:, :16] == 0).all()
 
 
@@ -88,7 +93,7 @@ def test_disp_emb_and_grid_coords():
     assert torch.equal(gc.cpu(), O.grid_coords(b, h, w).permute(0, 2, 3, 1))
 
 
-@pytest.mark.parametrize("dt,r,C", [("fp32", 7, 512), ("fp32", 3, 64), ("bf16", 2, 256), ("fp32", 1, 8)])
+@pytest.mark.parametrize("dt,r,C", [("fp32", 7, 512), ("fp32", 3, 64), ("bf16", 2, 256), ("fp32", 1, 8), ("fp16", 2, 256), ("fp16", 7, 512)])
 def test_local_corr(dt, r, C):
     from gim_amd import ops
     dev = _dev()
@@ -107,7 +112,8 @@ def test_local_corr(dt, r, C):
 @pytest.mark.parametrize("dt,cin,mult,hw", [("fp32", 24, 1, (11, 9)), ("bf16", 40, 1, (11, 9)), ("fp32", 12, 2, (11, 9)),
                                              ("bf16", 12, 2, (11, 9)), ("bf16", 144, 1, (70, 93)), ("fp32", 24, 1, (67, 80)),
                                              ("bf16", 1377, 1, (42, 100)), ("bf16", 24, 1, (131, 203)), ("bf16", 146, 1, (90, 77)),
-                                             ("bf16", 64, 1, (64, 64)), ("bf16", 64, 1, (256, 330)), ("fp32", 40, 1, (200, 333))])
+                                             ("bf16", 64, 1, (64, 64)), ("bf16", 64, 1, (256, 330)), ("fp32", 40, 1, (200, 333)),
+                                             ("fp16", 40, 1, (11, 9)), ("fp16", 12, 2, (11, 9)), ("fp16", 144, 1, (70, 93)), ("fp16", 1377, 1, (42, 100))])
 def test_dwconv5x5_bn_relu(dt, cin, mult, hw):
     """(the last two: more strip blocks than resident workgroups -- the persistent kernel walks several per workgroup, ragged last one)"""
     from gim_amd import ops
@@ -130,7 +136,7 @@ def test_dwconv5x5_bn_relu(dt, cin, mult, hw):
     sc = torch.zeros(cpad); sc[:cout] = s
     sh = torch.zeros(cpad); sh[:cout] = bet + (bias - mean) * s
     y = ops.dwconv5x5_bn_relu(xin.to(dev), W.to(dev), sc.to(dev), sh.to(dev), cin, cout)
-    _close(y[..., :cout], ref, 6e-3 if dt == "bf16" else 2e-6, "dwconv")
+    _close(y[..., :cout], ref, _t16(dt, 6e-3, 2e-6), "dwconv")
     assert (y[..., cout:] == 0).all()
 
 
@@ -283,6 +289,24 @@ def test_match_bf16_and_sample():
     for i in idx.tolist():
         hit = (flat == sm[i]).all(-1)
         assert hit.any() and (cert.reshape(-1)[hit] == sc[i]).any()
+
+
+def test_match_fp16_is_closer_than_bf16():
+    """Round 5: the IEEE-fp16 flavour of the engine -- same kernels, 11 instead of 8 significand bits per stored
+    activation -- against the fp32 oracle, beside the bf16 mode on the same pair: the mean warp error must drop by at least 3 x"""
+    dev = _dev()
+    im0, im1 = O.seeded_pair(160, 224, 3)
+    sd = O.make_state_dict(0)
+    with torch.no_grad():
+        warp_ref, cert_ref = O.match(sd, im0, im1, 128, 160, None)
+    err = {}
+    for prec in ("bf16", "fp16"):
+        m = _model(prec, 128, 160, None)
+        warp, cert = m.match(im0.to(dev), im1.to(dev))
+        assert torch.isfinite(warp).all() and torch.isfinite(cert).all()
+        err[prec] = ((warp.cpu() - warp_ref).abs().mean().item(), (cert.cpu() - cert_ref).abs().mean().item())
+        print(f"[measured] dkm {prec} vs fp32 oracle: mean |warp err| {err[prec][0]:.5f}, mean |certainty err| {err[prec][1]:.5f}")
+    assert err["fp16"][0] < err["bf16"][0] / 3 and err["fp16"][0] < 0.004 and err["fp16"][1] < 0.01, err
 
 
 def test_dkm_no_cpu_fallback():

@@ -358,7 +358,7 @@ def test_lightglue_unequal_counts_and_bf16():
     rs = torch.tensor([[480, 640]])
     data = {"keypoints0": kp0, "keypoints1": kp1, "descriptors0": d0, "descriptors1": d1, "resize0": rs, "resize1": rs}
     ref = O.lightglue_forward(lg_sd, data)
-    for prec, need in (("fp32", 1.0), ("bf16", 0.985)):   # bf16 measured 0.9948 (one of 192 keypoints differs): 2 x the disagreement
+    for prec, need in (("fp32", 1.0), ("bf16", 0.985), ("fp16", 0.99)):   # bf16 measured 0.9948 (one of 192 keypoints differs): 2 x the disagreement; fp16: round 5
         _, lg, _, _ = _models(prec, 128)
         pred = lg({k: v.to(dev) for k, v in data.items()})
         agree = (pred["matches0"].cpu() == ref["matches0"]).float().mean().item()

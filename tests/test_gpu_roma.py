@@ -243,6 +243,23 @@ def test_match_bf16_batch_and_sample(golden_dir):
     assert sm.shape == (300, 4) and sc.shape == (300,) and sm.abs().max() <= 1
 
 
+def test_match_fp16_is_closer_than_bf16(golden_dir):
+    """Round 5: gim_roma in the IEEE-fp16 flavour (VGG / DINOv2 / decoder / refiner activations stored with 11 significand bits; the fp32
+    residual stream of the ViT as before) against the reference's fp32 result, beside the bf16 mode: mean warp error at least 3 x smaller"""
+    g, H, W, im0, im1 = _golden_inputs(golden_dir, "roma_match.npz")
+    up = tuple(int(v) for v in g["up"])
+    dev = _dev()
+    err = {}
+    for prec in ("bf16", "fp16"):
+        m = _model(prec, H, W, up)
+        warp, cert = m.match(im0.to(dev), im1.to(dev))
+        assert torch.isfinite(warp).all() and torch.isfinite(cert).all()
+        err[prec] = ((warp[::2, ::2].cpu() - torch.as_tensor(g["warp"])).abs().mean().item(),
+                     (cert[::2, ::2].cpu() - torch.as_tensor(g["certainty"])).abs().mean().item())
+        print(f"[measured] roma {prec} vs fp32 reference: mean |warp err| {err[prec][0]:.5f}, mean |certainty err| {err[prec][1]:.5f}")
+    assert err["fp16"][0] < err["bf16"][0] / 3 and err["fp16"][0] < 0.004, err
+
+
 def test_roma_fails_loudly():
     from gim_amd._lib import GimHipError
     from gim_amd.roma import RoMa

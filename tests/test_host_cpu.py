@@ -157,8 +157,9 @@ def test_precision_resolver(monkeypatch):
     monkeypatch.setenv("GIM_PRECISION", "fp16")
     assert resolve(None, "loftr", default="fp16") == "fp16" and resolve(None, "gim_roma") == "bf16" and resolve(None, "SuperPoint") == "bf16"
     assert resolve("fp32", "LightGlue") == "fp32"
+    assert resolve("fp16", "gim_dkm") == "fp16"     # round 5: an EXPLICIT fp16 selects the engines' IEEE-fp16 flavour
     with pytest.raises(ValueError):
-        resolve("fp16", "gim_dkm")          # explicit request for a mode the engine does not have
+        resolve("fp8", "gim_dkm")           # explicit request for a mode the engine does not have
     monkeypatch.setenv("GIM_PRECISION", "fp64")
     for eng in ("loftr", "gim_dkm"):
         with pytest.raises(ValueError):

@@ -451,12 +451,16 @@ def main():
 
         def dense_bench(name, build, note, batch=1, tflop_per_pair=None, parity_note=None):
             try:
-                torch.manual_seed(0)
-                m = build().eval()
-                with torch.no_grad():   # random init; refiner outputs scaled down so the flow stays in range (what trained weights do)
-                    for s_ in ("16", "8", "4", "2", "1"):
-                        m.decoder.conv_refiner[s_].out_conv.weight.mul_(0.05)
-                        m.decoder.conv_refiner[s_].out_conv.bias.mul_(0.05)
+                def make(prec):
+                    torch.manual_seed(0)
+                    mm = build(prec).eval()
+                    with torch.no_grad():   # random init; refiner outputs scaled down so the flow stays in range (what trained weights do)
+                        for s_ in ("16", "8", "4", "2", "1"):
+                            mm.decoder.conv_refiner[s_].out_conv.weight.mul_(0.05)
+                            mm.decoder.conv_refiner[s_].out_conv.bias.mul_(0.05)
+                    return mm
+
+                m = make(sec_prec)
                 for _ in range(2):
                     warp, cert = m.match(im0, im1)
                     m.sample(warp, cert, 5000)
@@ -494,21 +498,38 @@ def main():
                     dense[name].update({f"batch{batch}_match_ms_per_pair": round(1e3 * t_b / batch, 2),
                                         f"batch{batch}_pairs_per_s": round(batch / (t_b + batch * t_sample), 2)})
                     del wb, cb
+                if sec_prec == "bf16":   # round 5: the same engine in its IEEE-fp16 flavour (precision='fp16': 11 instead of 8 significand bits per stored activation)
+                    w16, c16 = warp.float().clone(), cert.float().clone()
+                    del m
+                    torch.cuda.empty_cache()
+                    m = make("fp16")
+                    for _ in range(2):
+                        wf, cf = m.match(im0, im1)
+                    torch.cuda.synchronize()
+                    td = time.perf_counter()
+                    for _ in range(3):
+                        wf, cf = m.match(im0, im1)
+                    torch.cuda.synchronize()
+                    dense[name]["fp16_mode"] = {"match_ms": round(1e3 * (time.perf_counter() - td) / 3, 2), "finite": bool(torch.isfinite(wf).all() and torch.isfinite(cf).all()),
+                                                "mean_abs_dwarp_vs_bf16_mode": round(float((wf.float() - w16).abs().mean()), 5),
+                                                "note": "same random-init weights and pair; tests/test_gpu_dkm.py / test_gpu_roma.py::test_match_fp16_is_closer_than_bf16 hold its distance "
+                                                        "from the fp32 oracle against the bf16 mode's"}
+                    del wf, cf, w16, c16
                 del m
                 torch.cuda.empty_cache()
             except Exception as e:  # a secondary line must never cost the headline measurement
                 dense[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
-        def build_dkm():
+        def build_dkm(prec):
             from gim_amd.dkm import DKMv3
-            m = DKMv3(None, 672, 896, upsample_preds=True, precision=sec_prec)
+            m = DKMv3(None, 672, 896, upsample_preds=True, precision=prec)
             m.upsample_res = (1152, 1536)
             return m
 
         def build_roma(size):
-            def f():
+            def f(prec):
                 from gim_amd.roma import RoMa, random_dinov2_weights
-                return RoMa([size], precision=sec_prec, dinov2_weights=random_dinov2_weights(dev))
+                return RoMa([size], precision=prec, dinov2_weights=random_dinov2_weights(dev))
             return f
 
         dense_bench("gim_dkm", build_dkm, "gim_dkm match() + sample(5000), 672x896 -> upsampling pass 1152x1536, one pair per call, "

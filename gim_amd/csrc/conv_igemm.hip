@@ -831,8 +831,11 @@ extern "C" int GIM_FN(gim_conv_ups_supported)(const gim_conv_args* ap) {
 extern "C" int GIM_FN(gim_conv2d_bn_act)(const gim_conv_args* ap, gim_stream_t stream) {
     GIM_REQUIRE(ap, "gim_conv2d_bn_act: NULL args");
 #if !GIM_HALF_KIND
-    if (ap->dtype == GIM_F16) return gim_conv2d_bn_act_f16(ap, stream);   // the fp16 objects of this file
-    GIM_REQUIRE(ap->out_dtype != GIM_F16 && (!ap->res || ap->res_dtype != GIM_F16), "conv: fp16 output / residual needs fp16 operands");
+    // the fp16 objects of this file: fp16 operands, or fp32 operands with an fp16 output / residual (the dense matchers' fp32 GP products
+    // and kernel matrices feeding 16-bit feature maps: round 5, their IEEE-fp16 flavour)
+    if (ap->dtype == GIM_F16 || (ap->dtype == GIM_F32 && (ap->out_dtype == GIM_F16 || (ap->res && ap->res_dtype == GIM_F16))))
+        return gim_conv2d_bn_act_f16(ap, stream);
+    GIM_REQUIRE(ap->out_dtype != GIM_F16 && (!ap->res || ap->res_dtype != GIM_F16), "conv: bf16 operands cannot take an fp16 output / residual");
 #endif
     const gim_conv_args& a = *ap;
 #if GIM_HALF_KIND

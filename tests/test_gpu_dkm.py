@@ -251,18 +251,19 @@ def test_match_golden_fp32(golden_dir):
     m = _model("fp32", H, W, None)
     warp_lo, cert_lo = m.match(im0.to(dev), im1.to(dev))
     cor = m._debug["corresps"]
-    # bounds = 2-3 x what MI355X measured against the reference's own run (profiles/r04_secondary_measured.txt: flow16 1.9e-7, cert16 4.2e-5,
-    # flow1 2.7e-7, warp 3.0e-7, certainty 1.8e-5 of scale; the fp32 mode evaluates the GP posterior in fp64) -- round 4 asserted 2e-3 / 5e-3
-    _close(cor[16][0].permute(0, 3, 1, 2), torch.as_tensor(g["flow16"]), 1e-6, "flow16")
+    # bounds = 2-3 x what MI355X measured against the reference's own run (profiles/r04_secondary_measured.txt: flow16 3.0e-5, cert16 4.5e-5,
+    # flow1 2.1e-5, warp 1.5e-5, certainty 4.0e-6 of scale: the reference's fp32 GP arithmetic against the engine's fp64 GP) -- round 4
+    # asserted 2e-3 / 5e-3
+    _close(cor[16][0].permute(0, 3, 1, 2), torch.as_tensor(g["flow16"]), 1e-4, "flow16")
     _close(cor[16][1].permute(0, 3, 1, 2), torch.as_tensor(g["cert16"]), 1e-4, "cert16")
-    _close(cor[1][0].permute(0, 3, 1, 2), torch.as_tensor(g["flow1"]), 1e-6, "flow1")
+    _close(cor[1][0].permute(0, 3, 1, 2), torch.as_tensor(g["flow1"]), 6e-5, "flow1")
     assert warp_lo.shape == (H, 2 * W, 4) and cert_lo.shape == (H, 2 * W)
     # with the upsampling pass
     m2 = _model("fp32", H, W, up)
     warp, cert = m2.match(im0.to(dev), im1.to(dev))
     assert warp.shape == (up[0], 2 * up[1], 4) and cert.shape == (up[0], 2 * up[1])
-    _close(warp[::2, ::2], torch.as_tensor(g["warp"]), 1e-6, "warp")
-    _close(cert[::2, ::2], torch.as_tensor(g["certainty"]), 5e-5, "certainty")
+    _close(warp[::2, ::2], torch.as_tensor(g["warp"]), 5e-5, "warp")
+    _close(cert[::2, ::2], torch.as_tensor(g["certainty"]), 2e-5, "certainty")
     qc = O.grid_coords(1, *up).permute(0, 2, 3, 1)[0]
     assert torch.equal(warp[:, :up[1], :2].cpu(), qc) and torch.equal(warp[:, up[1]:, 2:].cpu(), qc)
 

@@ -307,7 +307,7 @@ def test_match_fp16_is_closer_than_bf16():
         assert torch.isfinite(warp).all() and torch.isfinite(cert).all()
         err[prec] = ((warp.cpu() - warp_ref).abs().mean().item(), (cert.cpu() - cert_ref).abs().mean().item())
         print(f"[measured] dkm {prec} vs fp32 oracle: mean |warp err| {err[prec][0]:.5f}, mean |certainty err| {err[prec][1]:.5f}")
-    assert err["fp16"][0] < err["bf16"][0] / 3 and err["fp16"][0] < 0.004 and err["fp16"][1] < 0.01, err
+    assert err["fp16"][0] < err["bf16"][0] / 3 and err["fp16"][0] < 3e-4 and err["fp16"][1] < 1.5e-4, err   # measured 9e-5 / 4e-5 (bf16: 7.0e-4 / 3.0e-4)
 
 
 def test_dkm_no_cpu_fallback():

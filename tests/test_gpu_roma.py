@@ -257,7 +257,7 @@ def test_match_fp16_is_closer_than_bf16(golden_dir):
         err[prec] = ((warp[::2, ::2].cpu() - torch.as_tensor(g["warp"])).abs().mean().item(),
                      (cert[::2, ::2].cpu() - torch.as_tensor(g["certainty"])).abs().mean().item())
         print(f"[measured] roma {prec} vs fp32 reference: mean |warp err| {err[prec][0]:.5f}, mean |certainty err| {err[prec][1]:.5f}")
-    assert err["fp16"][0] < err["bf16"][0] / 3 and err["fp16"][0] < 0.004, err
+    assert err["fp16"][0] < err["bf16"][0] / 3 and err["fp16"][0] < 5e-4 and err["fp16"][1] < 4e-4, err   # measured < 5e-6 / 1.3e-4 (bf16: 9.1e-3 / 3.9e-4: its anchor arg-max flips are gone)
 
 
 def test_roma_fails_loudly():

@@ -509,8 +509,10 @@ int launch_persistent(const gim_conv_args& a, hipStream_t stream) {
     const int T = mtiles * ntiles;
     constexpr int NT = WM * WN * 64;
     constexpr int RESIDENT = (NT == 256 ? 2 : 1) * 256;  // workgroups per CU (LDS bound) x 256 CUs
-    const int rounds = (T + RESIDENT - 1) / RESIDENT;
-    const int grid = (T + rounds - 1) / rounds;  // balanced: every block gets `rounds` (or rounds-1) tiles
+    // one workgroup per resident slot (tile counts differ by at most one).  Until round 5 the grid was ceil(T / rounds) -- every block the
+    // same tile count, but e.g. layer 3's 1 200 tiles ran as 400 blocks of 3 on 512 slots: 144 CUs carried six tiles, 112 three.  Same-box
+    // A/B of the forward: -0.08 ms per batch-8 step (profiles/r05_launch_order.txt)
+    const int grid = T < RESIDENT ? T : RESIDENT;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), smem, stream, a, mtiles, ntiles, M);
     return gim_check_launch("igemm_persistent_kernel");
 }
@@ -718,8 +720,7 @@ int launch_halo(const gim_conv_args& a, hipStream_t stream) {
     const int tiles_x = (a.W + HTW - 1) / HTW, tiles_y = (a.H + HTH - 1) / HTH, ntiles = a.npad / BN;
     const int T = tiles_x * tiles_y * a.B * ntiles;
     constexpr int RESIDENT = 256;  // one workgroup per CU
-    const int rounds = (T + RESIDENT - 1) / RESIDENT;
-    const int grid = (T + rounds - 1) / rounds;
+    const int grid = T < RESIDENT ? T : RESIDENT;   // (see launch_persistent)
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, a, tiles_x, tiles_y, ntiles, nslab);
     return gim_check_launch("conv3x3_halo_kernel");
 }

@@ -503,14 +503,14 @@ def main():
                     del m
                     torch.cuda.empty_cache()
                     m = make("fp16")
-                    for _ in range(2):
+                    for _ in range(3):   # (the first calls of a new module build its per-shape tables on the host)
                         wf, cf = m.match(im0, im1)
                     torch.cuda.synchronize()
                     td = time.perf_counter()
-                    for _ in range(3):
+                    for _ in range(n_it):
                         wf, cf = m.match(im0, im1)
                     torch.cuda.synchronize()
-                    dense[name]["fp16_mode"] = {"match_ms": round(1e3 * (time.perf_counter() - td) / 3, 2), "finite": bool(torch.isfinite(wf).all() and torch.isfinite(cf).all()),
+                    dense[name]["fp16_mode"] = {"match_ms": round(1e3 * (time.perf_counter() - td) / n_it, 2), "finite": bool(torch.isfinite(wf).all() and torch.isfinite(cf).all()),
                                                 "mean_abs_dwarp_vs_bf16_mode": round(float((wf.float() - w16).abs().mean()), 5),
                                                 "note": "same random-init weights and pair; tests/test_gpu_dkm.py / test_gpu_roma.py::test_match_fp16_is_closer_than_bf16 hold its distance "
                                                         "from the fp32 oracle against the bf16 mode's"}

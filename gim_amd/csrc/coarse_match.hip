@@ -574,6 +574,9 @@ __global__ void __launch_bounds__(256 * WN2, 2) cm_stats256_kernel(const CmGeom 
     const int nkt = g.C * 2 / KTB;
     const int tag = cm256_column_tag(t & 63);
     if (t == 0) X.pcnt[0] = 0;
+    // (round 5: starting every second workgroup 2 ... 16 us late -- by blockIdx parity or by blockIdx / CUs -- so that the two co-resident
+    //  workgroups of a CU alternate their MFMA and statistics phases instead of running them in lockstep changes nothing: 222.9 vs 224.5 us per
+    //  call on random features, 849-864 us on planted ones, profiles/r05_cm_stats.txt)
     gim::MainloopArgs ml;
     ml.ktab = nullptr;
     ml.x_bytes = (unsigned)(((size_t)(g.L - 1) * g.ldf + g.C) * 2);

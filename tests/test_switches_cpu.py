@@ -1,0 +1,33 @@
+"""gim_amd/switches.py: the one place development switches come from (config key > GIM_FLAGS > default), and the rule that the package reads
+no other per-feature environment variable (46 GIM_* names -> one hook)."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_flag_resolution_order_and_types(monkeypatch):
+    from gim_amd import switches
+    monkeypatch.setattr(switches, "FLAGS", switches._parse("fine_fused=0, tf_chains=4;graph_cache=2+stem_split=off,force_big_tile"))
+    assert switches.flag("fine_fused", True) is False and switches.flag("stem_split", True) is False
+    assert switches.flag("tf_chains", 2) == 4 and switches.flag("graph_cache", 4) == 2
+    assert switches.flag("force_big_tile", False) is True          # a bare name means "on"
+    assert switches.flag("bneck_tail", True) is True                # absent: the default
+    assert switches.flag("tf_chains", 2, {"tf_chains": 1}) == 1     # the caller's config wins over GIM_FLAGS
+    assert switches.flag("fine_fused", True, {"fine_fused": None}) is False   # None = not set by the caller
+    assert switches.flag("coarse_sim", "") == ""
+
+
+def test_package_reads_only_the_documented_environment_variables():
+    allowed = {"GIM_PRECISION", "GIM_FLAGS", "GIM_LIB", "GIM_POSE_BACKEND", "GIM_HIPCC_EXTRA", "GIM_BUILD_JOBS", "GIMRECONSTRUCTION", "HIPCC"}
+    seen = set()
+    for dp, _, fs in os.walk(os.path.join(ROOT, "gim_amd")):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                seen |= set(re.findall(r"environ(?:\.get)?\(\s*[\"']([A-Z_0-9]+)[\"']", src)) | set(re.findall(r"environ\[\s*[\"']([A-Z_0-9]+)[\"']", src))
+            if f.endswith((".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                seen |= set(re.findall(r"getenv\(\s*\"([A-Z_0-9]+)\"", src))
+    extra = seen - allowed - {"GIM_CM_PRECAND_PER_ROW", "GIM_FF_STAGE"}   # a test hook (forces the overflow fallback) and a -DFF_DEBUG_STAGES development build
+    assert not extra, f"undocumented environment switches: {sorted(extra)}"

@@ -143,21 +143,25 @@ def test_dkm_672x896_upsample_pass_vs_oracle(monkeypatch):
 
 
 def test_dkm_batch4_672x896_vs_single_pair_oracles(monkeypatch):
-    """BASELINE config 3 is gim_dkm 672x896 at batch = 4: four DIFFERENT pairs in one engine pass (match_batch; the reference's own batched
-    mode asserts against the upsampling pass, dkm.py:662, so this is the low-resolution pass) against four single-pair oracle calls."""
+    """BASELINE config 3 is gim_dkm 672x896 at batch = 4: four pairs in one engine pass (match_batch; the reference's own batched mode asserts
+    against the upsampling pass, dkm.py:662, so this is the low-resolution pass) against single-pair oracle calls.  Two DIFFERENT pairs, each at
+    two batch positions ([A, B, B, A]: 2 x 16 s of CPU oracle instead of 4 x): every slot against its own pair's oracle, and equal slots
+    bit-identical -- a slot's result must not depend on its neighbours or its position."""
     import dkm_oracle as O
     from gim_amd.dkm import DKMv3
     sd = O.make_state_dict(0)
-    pairs = [O.seeded_pair(672, 896, s_, shift=sh) for s_, sh in ((3, (8, 12)), (5, (4, 14)), (7, (10, 6)), (9, (6, 16)))]   # (seeded_pair keeps a 16-pixel margin)
+    pa, pb = O.seeded_pair(672, 896, 3, shift=(8, 12)), O.seeded_pair(672, 896, 5, shift=(4, 14))
     monkeypatch.setattr(O, "GP_FP64", True)
     with torch.no_grad():
-        refs = [O.match(sd, a, b, 672, 896, None) for a, b in pairs]
+        ra, rb = O.match(sd, pa[0], pa[1], 672, 896, None), O.match(sd, pb[0], pb[1], 672, 896, None)
     monkeypatch.setattr(O, "GP_FP64", False)
     m = DKMv3(None, 672, 896, upsample_preds=False, precision="fp32")
     m.load_state_dict(sd)
     m = m.eval()
-    W, C = m.match_batch(torch.cat([a for a, _ in pairs]).to("cuda:0"), torch.cat([b for _, b in pairs]).to("cuda:0"))
+    order = (pa, pb, pb, pa)
+    W, C = m.match_batch(torch.cat([p[0] for p in order]).to("cuda:0"), torch.cat([p[1] for p in order]).to("cuda:0"))
     assert W.shape == (4, 672, 2 * 896, 4) and C.shape == (4, 672, 2 * 896)
-    for k, (rw, rc) in enumerate(refs):
-        _close(W[k], rw, 2e-5, f"dkm batch-4 pair {k} warp vs the fp64-GP oracle", frac=1.0, mean_tol=2e-6)
-        _close(C[k], rc, 2e-5, f"dkm batch-4 pair {k} certainty vs the fp64-GP oracle", frac=1.0, mean_tol=2e-6)
+    for k, (rw, rc) in enumerate((ra, rb, rb, ra)):
+        _close(W[k], rw, 2e-5, f"dkm batch-4 slot {k} warp vs the fp64-GP oracle", frac=1.0, mean_tol=2e-6)
+        _close(C[k], rc, 2e-5, f"dkm batch-4 slot {k} certainty vs the fp64-GP oracle", frac=1.0, mean_tol=2e-6)
+    assert torch.equal(W[0], W[3]) and torch.equal(W[1], W[2]) and torch.equal(C[0], C[3]) and torch.equal(C[1], C[2])

@@ -220,16 +220,21 @@ def main():
     for w_ in range(max(2, args.warmup)):  # the COMPLETE step, incl. match packing; the 2nd call captures the HIP graph
         pack_matches(step(), 0)
     all_gather_matches(torch.zeros(1, 6, device=dev))
+    # the outputs are read back inside the timed region -- the packed [pair, x0, y0, x1, y1, conf] rows (~270 KB per step) travel to
+    # pinned host memory asynchronously behind the step that produced them; sync_all() below waits for the last copy.  The pinned slots
+    # (capacity = every coarse cell of every pair a match) are allocated HERE, outside the timed region: hipHostMalloc is not part of a step
+    host_cap = nb * (H // 8) * (W // 8)
+    host_ring = None if dry else torch.empty(args.steps, host_cap, 6, dtype=torch.float32).pin_memory()
     sync_all()
     t0 = time.perf_counter()
     rows = []
-    rows_host = []   # the outputs are read back inside the timed region -- the packed [pair, x0, y0, x1, y1, conf] rows (~270 KB per step)
-    tstep = []       # travel to pinned host memory asynchronously behind the step that produced them; sync_all() below waits for the last copy
+    rows_host = []
+    tstep = []
     for s in range(args.steps):
         d = step()
         rows.append(pack_matches(d, (s * world + rank) * nb))   # consecutive pair ids of this batch, packed on the device
         if not dry:
-            rows_host.append(torch.empty(rows[-1].shape, dtype=rows[-1].dtype, pin_memory=True))
+            rows_host.append(host_ring[s, :rows[-1].shape[0]])
             rows_host[-1].copy_(rows[-1], non_blocking=True)
         tstep.append(time.perf_counter())
     allrows = all_gather_matches(torch.cat(rows))  # the one collective: matches, for reporting

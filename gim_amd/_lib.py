@@ -139,6 +139,7 @@ PROTOTYPES = {
     "gim_dkm_disp_emb": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
     "gim_local_corr": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
     "gim_dwconv5x5_bn_relu": (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_void_p]),
+    "gim_dwconv5x5_pw": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p]),
     "gim_row_norms": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
     "gim_cos_kernel_finish": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_float] * 3 + [c_void_p]),
     "gim_gp_solve_ws_bytes": (c_int64, [c_int] * 3),

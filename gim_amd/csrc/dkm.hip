@@ -407,13 +407,24 @@ __global__ void __launch_bounds__(256) dwconv5x5_tiled_kernel(const void* __rest
 //   * one 16-byte store per output pixel.
 // compiler fence for memory operations (IR level) + scheduling barrier (machine level): pins the software pipeline
 #define ORDER_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-template <bool BF16>
+// NF > 0 (16-bit only; round 5): the WHOLE ConvRefiner block -- depthwise 5x5 + BatchNorm + ReLU, then the block's 1x1 convolution with bias
+// (dkm.py:58-73, create_block) -- in this launch, for the refiners whose channel count fits one chunk: C = 144 (NKS = 9 k16 steps, NF = 5 output
+// fragments of 32) and C = 24 / 32 (NKS = 2, NF = 1).  The depthwise outputs of the block's 8 x (256 / CGB) pixels go to an LDS tile as 16-bit rows
+// [px][K] (K padded to 16 NKS by zero groups written by the threads of the padding groups: CGB = 2 NKS), every wave takes PFW 32-pixel fragments of
+// it as the B operand of the MFMA (weights = A operand: 16 bytes per lane and (fragment, k16 step) straight from L2, requested one step ahead),
+// writes the results back over its own rows and stores 16-byte pieces.  The intermediate tensor -- 255 MB written and read per launch at 144
+// channels -- never exists, and the 1x1's MFMAs run under the depthwise arithmetic of the co-resident workgroup (two per CU).  The 569-channel
+// refiner does not fit this way (576 output channels of fp32 accumulators beside the depthwise working set: DESIGN.md section 4, round 5).
+template <bool BF16, int NF = 0, int NKS = 0>
 __global__ void __launch_bounds__(256, 2) dwconv5x5_rows2_kernel(const void* __restrict__ x, const float* __restrict__ wgt,
                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
                                                                  void* __restrict__ y, int B, int H, int W, int CG, int CGB, int NCH,
-                                                                 int cpad, int ldx, int ldy, unsigned nblk) {
+                                                                 int cpad, int ldx, int ldy, unsigned nblk,
+                                                                 const unsigned short* __restrict__ pww = nullptr, const float* __restrict__ pwb = nullptr) {
+    constexpr bool PW = NF > 0;
+    static_assert(!PW || BF16, "fused 1x1: 16-bit operands only");
     constexpr int G = BF16 ? 8 : 4, ES = BF16 ? 2 : 4, G2 = G / 2, NP = G / 4;   // NP float4 planes of weights
-    extern __shared__ float4 wl[];                                              // [NP][25][CGB]
+    extern __shared__ float4 wl[];                                              // [NP][25][CGB]  (+ PW: the pixel tile behind it)
     const unsigned lb = xcd_remap(blockIdx.x, nblk);
     const int chunk = (int)(lb % (unsigned)NCH);
     const unsigned sblk = lb / (unsigned)NCH;
@@ -430,8 +441,9 @@ __global__ void __launch_bounds__(256, 2) dwconv5x5_rows2_kernel(const void* __r
     const int WS = (W + 3) / 4, HS = (H + 1) / 2;
     const size_t strip = (size_t)sblk * SPB + sl;
     const bool live = !(sl >= SPB || cgl >= ncg || strip >= (size_t)B * HS * WS);
-    if (!live) return;
-    const size_t strip_c = strip;
+    if (!PW && !live) return;
+    // (PW: a thread without a strip computes a clamped one and stores nothing -- it has to reach the barrier)
+    const size_t strip_c = live ? strip : 0;
     const int xs = (int)(strip_c % WS) * 4, Y = (int)((strip_c / WS) % HS) * 2, b = (int)(strip_c / ((size_t)WS * HS));
     const int co = live ? (cg0 + cgl) * G : 0;
     f32x2_t acc[2][4][G2];
@@ -531,6 +543,87 @@ __global__ void __launch_bounds__(256, 2) dwconv5x5_rows2_kernel(const void* __r
         const float4 a = *(const float4*)(scale + co + 2 * e), c = *(const float4*)(shift + co + 2 * e);
         sc[e] = (f32x2_t){a.x, a.y}; sc[e + 1] = (f32x2_t){a.z, a.w};
         sh[e] = (f32x2_t){c.x, c.y}; sh[e + 1] = (f32x2_t){c.z, c.w};
+    }
+    if constexpr (PW) {
+        constexpr int KP = NKS * 16, NPC = NF * 32;
+        constexpr int ROW = (KP > NPC ? KP : NPC) * 2 + 16;     // bytes per pixel row: an ODD number of 16-byte slots (16 consecutive rows hit 16 different slots)
+        constexpr int PXMAX = 8 * (256 / (2 * NKS));             // pixels per workgroup (CGB = 2 NKS channel groups incl. the zero padding groups)
+        constexpr int PFW = (PXMAX + 127) / 128;                 // 32-pixel fragments per wave
+        char* T = (char*)(wl + NP * 25 * CGB);                   // [4 PFW x 32 px][ROW]
+        const int tid = threadIdx.x;
+        if (sl < SPB) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int p_ = 0; p_ < 4; ++p_) {
+                    float rr[8];
+#pragma unroll
+                    for (int e = 0; e < G2; ++e) {
+                        const f32x2_t v = acc[o][p_][e] * sc[e] + sh[e];
+                        rr[2 * e] = fmaxf(v.x, 0.f); rr[2 * e + 1] = fmaxf(v.y, 0.f);
+                    }
+                    const int pi = sl * 8 + o * 4 + p_;
+                    // (a channel group beyond the stored width must hold exact zeros: it is K of the MFMA)
+                    *(uint4*)(T + pi * ROW + cgl * 16) = cgl < CG ?
+                        make_uint4(cvt_pk_h16(rr[0], rr[1]), cvt_pk_h16(rr[2], rr[3]), cvt_pk_h16(rr[4], rr[5]), cvt_pk_h16(rr[6], rr[7])) :
+                        make_uint4(0u, 0u, 0u, 0u);
+                }
+        }
+        __syncthreads();
+        const int lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+        f32x16_t c[PFW][NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float4 bb = *(const float4*)(pwb + 32 * f + 8 * rg + 4 * lh);
+#pragma unroll
+                for (int j = 0; j < PFW; ++j) { c[j][f][rg * 4] = bb.x; c[j][f][rg * 4 + 1] = bb.y; c[j][f][rg * 4 + 2] = bb.z; c[j][f][rg * 4 + 3] = bb.w; }
+            }
+        // A operand: row m = output channel 32 f + l31, k16 step ks: input channels 16 ks + 8 lh .. + 7 -- one step ahead of its MFMAs
+        bf16x8_t wa[2][NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) wa[0][f] = *(const bf16x8_t*)(pww + (size_t)(32 * f + l31) * KP + lh * 8);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks + 1 < NKS) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f) wa[(ks + 1) & 1][f] = *(const bf16x8_t*)(pww + (size_t)(32 * f + l31) * KP + (ks + 1) * 16 + lh * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < PFW; ++j) {
+                const int pi = (wv * PFW + j) * 32 + l31;
+                const bf16x8_t bv = *(const bf16x8_t*)(T + pi * ROW + (2 * ks + lh) * 16);
+#pragma unroll
+                for (int f = 0; f < NF; ++f) c[j][f] = mfma_h16_32x32x16(wa[ks & 1][f], bv, c[j][f]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's rows are consumed (a wave's LDS accesses execute in order)
+#pragma unroll
+        for (int j = 0; j < PFW; ++j) {
+            const int pi = (wv * PFW + j) * 32 + l31;
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)   // accumulator quad = output channels 32 f + 8 rg + 4 lh .. + 3 of pixel pi
+                    *(uint2*)(T + pi * ROW + (32 * f + 8 * rg + 4 * lh) * 2) =
+                        make_uint2(cvt_pk_h16(c[j][f][rg * 4], c[j][f][rg * 4 + 1]), cvt_pk_h16(c[j][f][rg * 4 + 2], c[j][f][rg * 4 + 3]));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // this wave's PFW x 32 pixel rows out: CG 16-byte pieces each
+        const int npc = PFW * 32 * CG;
+        for (int idx = lane; idx < npc; idx += 64) {
+            const int ql = idx / CG, sq = idx - ql * CG;
+            const int q = wv * PFW * 32 + ql;
+            if (q >= SPB * 8) continue;
+            const uint4 v = *(const uint4*)(T + q * ROW + sq * 16);
+            const size_t st = (size_t)sblk * SPB + (q >> 3);
+            if (st < (size_t)B * HS * WS) {
+                const int qx = (int)(st % WS) * 4 + (q & 3), qy = (int)((st / WS) % HS) * 2 + ((q >> 2) & 1), qb = (int)(st / ((size_t)WS * HS));
+                if (qx < W && qy < H) *(uint4*)((unsigned short*)y + (((size_t)qb * H + qy) * W + qx) * ldy + sq * 8) = v;
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
@@ -890,6 +983,46 @@ extern "C" int GIM_FN(gim_dwconv5x5_bn_relu)(const void* x, const float* wgt, co
     const dim3 grid(nblocks((size_t)B * H * W * (cpad / 4), 256));
     DISPATCH_BF(dwconv5x5_kernel, dtype == GIM_H16, grid, x, wgt, scale, shift, y, B, H, W, cpad / 4, Cout / Cin, cpad, ldx, ldy);
     return gim_check_launch("dwconv5x5");
+}
+
+// The ConvRefiner block in one launch (see dwconv5x5_rows2_kernel, NF > 0): x [B,H,W,ldx], y [B,H,W,ldy] 16-bit rows of cs stored channels (cs = 144, or 24 /
+// 32); wgt [25][cs], scale / shift [cs] fp32 as for gim_dwconv5x5_bn_relu; pw_w [NP][KP] 16-bit (the 1x1 weights, rows = output channels padded to NP = 160 / 32,
+// K = input channels padded to KP = 144 / 32, zero padding), pw_b [NP] fp32.
+#if !GIM_HALF_KIND
+extern "C" int gim_dwconv5x5_pw_f16(const void* x, const float* wgt, const float* scale, const float* shift, const void* pw_w, const float* pw_b, void* y,
+                                    int B, int H, int W, int cs, int ldx, int ldy, int dtype, gim_stream_t stream);
+#endif
+extern "C" int GIM_FN(gim_dwconv5x5_pw)(const void* x, const float* wgt, const float* scale, const float* shift, const void* pw_w, const float* pw_b, void* y,
+                                       int B, int H, int W, int cs, int ldx, int ldy, int dtype, gim_stream_t stream) {
+#if !GIM_HALF_KIND
+    if (dtype == GIM_F16) return gim_dwconv5x5_pw_f16(x, wgt, scale, shift, pw_w, pw_b, y, B, H, W, cs, ldx, ldy, dtype, stream);   // the fp16 objects of this file
+#endif
+    GIM_REQUIRE(x && wgt && scale && shift && pw_w && pw_b && y && B > 0 && H > 0 && W > 0, "dwconv5x5_pw: bad args");
+    GIM_REQUIRE(dtype == GIM_H16, "dwconv5x5_pw: 16-bit operands only");
+    GIM_REQUIRE((cs == 24 || cs == 32 || cs == 144) && ldx % 8 == 0 && ldx >= cs && ldy % 8 == 0 && ldy >= cs,
+                "dwconv5x5_pw: stored channels %d (24, 32 or 144), row strides (ldx %d, ldy %d)", cs, ldx, ldy);
+    const int CG = cs / 8, nks = cs == 144 ? 9 : 2, nf = cs == 144 ? 5 : 1, CGB = 2 * nks, SPB = 256 / CGB;
+    const int kp = nks * 16, npc = nf * 32, row = (kp > npc ? kp : npc) * 2 + 16, pfw = (8 * SPB + 127) / 128;
+    const size_t strips = (size_t)B * ((H + 1) / 2) * ((W + 3) / 4);
+    const size_t nblk = (strips + SPB - 1) / SPB;
+    GIM_REQUIRE(nblk < 0x7fffffffull, "dwconv5x5_pw: grid too large");
+    const size_t shm = (size_t)2 * 25 * CGB * 16 + (size_t)pfw * 128 * row;
+    hipStream_t s = (hipStream_t)stream;
+    if (cs == 144) {
+        static GimPerDevice attr;
+        if (attr.needed()) {
+            if (hipFuncSetAttribute((const void*)dwconv5x5_rows2_kernel<true, 5, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) {
+                gim_set_error("dwconv5x5_pw: hipFuncSetAttribute(%d B LDS)", (int)shm); return GIM_ERR_LAUNCH;
+            }
+            attr.done();
+        }
+        hipLaunchKernelGGL((dwconv5x5_rows2_kernel<true, 5, 9>), dim3((unsigned)nblk), dim3(256), shm, s, x, wgt, scale, shift, y, B, H, W, CG, CGB, 1, cs, ldx, ldy,
+                           (unsigned)nblk, (const unsigned short*)pw_w, pw_b);
+    } else {
+        hipLaunchKernelGGL((dwconv5x5_rows2_kernel<true, 1, 2>), dim3((unsigned)nblk), dim3(256), shm, s, x, wgt, scale, shift, y, B, H, W, CG, CGB, 1, cs, ldx, ldy,
+                           (unsigned)nblk, (const unsigned short*)pw_w, pw_b);
+    }
+    return gim_check_launch("dwconv5x5_pw");
 }
 
 #if !GIM_HALF_KIND

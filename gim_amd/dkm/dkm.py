@@ -169,6 +169,8 @@ class RegressionMatcher(nn.Module):
         self._packed = None
         self._gp_f = {}
         self.overlap_gp = flag("dkm_overlap", True)   # GP on a side stream beside the high-res encoder
+        # 16-bit modes: the 144- and 24-channel ConvRefiner blocks (scales 2 and 1, both passes) as ONE launch each (gim_dwconv5x5_pw, round 5)
+        self.refiner_fused = flag("refiner_fused", True)
 
     def load_state_dict(self, state_dict, *a, **k):
         self._packed = None
@@ -223,6 +225,12 @@ class RegressionMatcher(nn.Module):
                 shift[:hid] = (bn.bias.detach().float() + (conv.bias.detach().float() - bn.running_mean.detach().float()) * sc).cpu()
                 P[f"cr{s}.{i}.dw"] = (W.to(device), scale.to(device), shift.to(device), ci, hid)
                 P[f"cr{s}.{i}.pw"] = pack_conv(pw.weight, None, dt, device, cin_pad=cpad, bias=pw.bias)
+                if dt != GIM_F32 and cpad in (24, 32, 144) and ci == hid:   # refiner blocks that fit one launch (gim_dwconv5x5_pw): dw 5x5 + BN + ReLU + 1x1
+                    npc, kp = (160, 144) if cpad == 144 else (32, 32)
+                    wf, bf = torch.zeros(npc, kp), torch.zeros(npc)
+                    wf[:hid, :hid] = pw.weight.detach().float().reshape(hid, hid).cpu()
+                    bf[:hid] = pw.bias.detach().float().cpu()
+                    P[f"cr{s}.{i}.pwf"] = (wf.to(device).to(torch_dtype(dt)).contiguous(), bf.to(device))
             P[f"cr{s}.out"] = pack_conv(ref.out_conv.weight, None, dt, device, cin_pad=cstore(hid, dt), bias=ref.out_conv.bias)
             P[f"cr{s}.emb"] = (ref.disp_emb.weight.detach().float().reshape(-1, 2).contiguous().to(device),
                                ref.disp_emb.bias.detach().float().contiguous().to(device))
@@ -323,6 +331,10 @@ class RegressionMatcher(nn.Module):
         d = D
         for i in range(1 + HIDDEN_BLOCKS):
             W_, sc, sh, ci, co = P[f"cr{s}.{i}.dw"]
+            pwf = P.get(f"cr{s}.{i}.pwf") if self.refiner_fused else None
+            if pwf is not None and d.shape[3] == W_.shape[1] and d.is_contiguous():
+                d = ops.dwconv5x5_pw(d, W_, sc, sh, *pwf)   # the whole block in one launch: the depthwise output never leaves the CU
+                continue
             d = ops.dwconv5x5_bn_relu(d, W_, sc, sh, ci, co)
             d = ops.conv2d(d, P[f"cr{s}.{i}.pw"])
         out = torch.empty(b * h * w, P[f"cr{s}.out"].n_store, dtype=torch.float32, device=dev)

@@ -833,6 +833,20 @@ def dwconv5x5_bn_relu(x, wgt, scale, shift, cin, cout):
     return y
 
 
+def dwconv5x5_pw(x, wgt, scale, shift, pw_w, pw_b):
+    """One ConvRefiner block in one launch (gim_dwconv5x5_pw): x [B,H,W,cs] 16-bit with cs = 144 (or 24 / 32) stored channels -> y [B,H,W,cs] =
+    conv1x1(relu(bn(dwconv5x5(x)))) + bias; wgt [25, cs], scale / shift [cs] fp32 as for dwconv5x5_bn_relu; pw_w [NP, KP] in x's dtype, pw_b [NP] fp32
+    (NP, KP = 160, 144 for cs = 144; 32, 32 for cs = 24 / 32)."""
+    _req_cuda(x, wgt, scale, shift, pw_w, pw_b)
+    B, H, W, cs = x.shape
+    npc, kp = (160, 144) if cs == 144 else (32, 32)
+    assert x.dtype in HALF and x.is_contiguous() and cs in (24, 32, 144) and pw_w.dtype == x.dtype and tuple(pw_w.shape) == (npc, kp) and pw_b.numel() == npc
+    assert wgt.shape == (25, cs) and scale.numel() == cs and shift.numel() == cs
+    y = torch.empty(B, H, W, cs, dtype=x.dtype, device=x.device)
+    check(lib.gim_dwconv5x5_pw(_p(x), _p(wgt), _p(scale), _p(shift), _p(pw_w), _p(pw_b), _p(y), B, H, W, cs, cs, cs, gim_dtype(x), _stream()), "gim_dwconv5x5_pw")
+    return y
+
+
 def row_norms(x, C):
     """x row view [R, >=C] -> [R] fp32 L2 norms"""
     _req_cuda(x)

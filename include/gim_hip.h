@@ -497,6 +497,13 @@ int gim_local_corr(const void* f0, const void* f1, const float* flow, void* out,
  * -- dkm.py:58-73.  wgt [25][cpad], scale / shift [cpad] fp32 (conv bias and BN folded), zero padded. */
 int gim_dwconv5x5_bn_relu(const void* x, const float* wgt, const float* scale, const float* shift, void* y, int B,
                           int H, int W, int Cin, int Cout, int cpad, int ldx, int ldy, int dtype, gim_stream_t stream);
+/* The whole ConvRefiner block of DKM / RoMa (dkm.py:58-73, create_block: depthwise 5x5 + BatchNorm + ReLU + 1x1 convolution with bias) in ONE launch,
+ * 16-bit operands, for the refiners whose channel count fits one channel chunk: cs = 144 stored channels (the scale-2 refiner) or 24 / 32 (scale 1).
+ * The depthwise output goes to an LDS tile and is the B operand of the 1x1's MFMAs; the intermediate tensor is never written.  x [B,H,W,ldx],
+ * y [B,H,W,ldy] rows of cs stored channels; wgt [25][cs], scale / shift [cs] fp32 (BatchNorm folded, as gim_dwconv5x5_bn_relu); pw_w [NP][KP] 16-bit
+ * (rows = output channels padded to NP = 160 / 32, K = input channels padded to KP = 144 / 32, zero padding); pw_b [NP] fp32.  dtype GIM_BF16 / GIM_F16. */
+int gim_dwconv5x5_pw(const void* x, const float* wgt, const float* scale, const float* shift, const void* pw_w, const float* pw_b, void* y,
+                     int B, int H, int W, int cs, int ldx, int ldy, int dtype, gim_stream_t stream);
 /* CosKernel pieces -- dkm.py:135-144: row L2 norms, and K = exp((dot / (nx ny + eps) - 1) / T) in place on the
  * dot-product matrix (diag_add = sigma_noise on the diagonal, dkm.py:352). */
 int gim_row_norms(const void* x, float* out, int rows, int C, int ld, int dtype, gim_stream_t stream);

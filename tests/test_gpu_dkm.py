@@ -140,6 +140,61 @@ def test_dwconv5x5_bn_relu(dt, cin, mult, hw):
     assert (y[..., cout:] == 0).all()
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("c,cs", [(24, 24), (24, 32), (144, 144)])
+@pytest.mark.parametrize("hw", [(16, 32), (37, 45), (96, 128)], ids=["16x32", "37x45_ragged", "96x128"])
+def test_dwconv5x5_pw_fused_block(hw, c, cs, dt):
+    """gim_dwconv5x5_pw (round 5) = one ConvRefiner block in one launch -- depthwise 5x5 + BN + ReLU + 1x1 with bias (dkm.py:58-73) -- at the channel
+    counts that fit one chunk (144: the scale-2 refiner; 24, stored as 24 or 32: scale 1), both 16-bit flavours, ragged maps with more strips than a
+    workgroup holds: against torch (with the 16-bit rounding of the intermediate the two-launch path has too) and against the two-launch path"""
+    from gim_amd import _lib, ops
+    from gim_amd.packing import pack_conv
+    dev = _dev()
+    tdt = _tdt(dt)
+    gdt = _lib.GIM_BF16 if dt == "bf16" else _lib.GIM_F16
+    g = torch.Generator().manual_seed(16 + c)
+    b, (h, w) = 2, hw
+    x = torch.randn(b, c, h, w, generator=g).to(tdt).float()
+    wt, bias = torch.randn(c, 1, 5, 5, generator=g) * 0.2, torch.randn(c, generator=g) * 0.1
+    gam, bet = 1 + 0.1 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    mean, var = 0.1 * torch.randn(c, generator=g), 0.5 + torch.rand(c, generator=g)
+    pw_w, pw_b = torch.randn(c, c, 1, 1, generator=g) * (0.2 if c < 100 else 0.08), torch.randn(c, generator=g) * 0.1
+    mid = F.relu(F.batch_norm(F.conv2d(x, wt, bias, padding=2, groups=c), mean, var, gam, bet, False, 0.0, 1e-5))
+    ref = F.conv2d(mid.to(tdt).float(), pw_w.to(tdt).float(), pw_b).permute(0, 2, 3, 1)
+    xin = torch.zeros(b, h, w, cs, dtype=tdt)
+    xin[..., :c] = x.permute(0, 2, 3, 1)
+    s = gam / torch.sqrt(var + 1e-5)
+    W = torch.zeros(25, cs); W[:, :c] = wt.view(c, 25).t()
+    sc = torch.zeros(cs); sc[:c] = s
+    sh = torch.zeros(cs); sh[:c] = bet + (bias - mean) * s
+    npc, kp = (160, 144) if cs == 144 else (32, 32)
+    wf = torch.zeros(npc, kp); wf[:c, :c] = pw_w.view(c, c)
+    bf = torch.zeros(npc); bf[:c] = pw_b
+    y = ops.dwconv5x5_pw(xin.to(dev), W.to(dev), sc.to(dev), sh.to(dev), wf.to(dev).to(tdt), bf.to(dev))
+    assert y.shape[3] == cs
+    _close(y[..., :c], ref, _t16(dt, 4.5e-3, 0), f"dwconv5x5_pw {dt} c={c}")
+    assert (y[..., c:] == 0).all()
+    mid2 = ops.dwconv5x5_bn_relu(xin.to(dev), W.to(dev), sc.to(dev), sh.to(dev), c, c)
+    y2 = ops.conv2d(mid2, pack_conv(pw_w, None, gdt, dev, cin_pad=cs, bias=pw_b))
+    d = (y.float()[..., :c] - y2.float()[..., :c]).abs().max().item()
+    assert d <= _t16(dt, 2e-2, 0) * ref.abs().max().item(), d     # same operands and products, other accumulation order + output rounding
+
+
+def test_refiner_fused_blocks_match_two_launch_path():
+    """the engine with / without the fused ConvRefiner blocks (scales 2 and 1): same warp / certainty up to the 1x1's accumulation order"""
+    dev = _dev()
+    im0, im1 = O.seeded_pair(160, 224, 3)
+    out = {}
+    for fused in (True, False):
+        m = _model("bf16", 128, 160, (192, 256))
+        m.refiner_fused = fused
+        out[fused] = m.match(im0.to(dev), im1.to(dev))
+    dw = (out[True][0] - out[False][0]).abs().mean().item()
+    dc = (out[True][1] - out[False][1]).abs().mean().item()
+    print(f"[measured] dkm bf16 fused vs two-launch refiner blocks: mean |d warp| {dw:.2e}, mean |d certainty| {dc:.2e}")
+    assert dw < 2e-3 and dc < 2e-3
+
+
 def test_cos_kernel_and_gp_solve():
     """CosKernel via igemm dot products + finish kernel; (K + sigma I)^-1 f via the fp64 Cholesky solve vs torch.linalg.inv"""
     from gim_amd import ops

@@ -36,7 +36,9 @@ HOT = {
     "la_kv_h16_kernel<256>": (128, 0),              # 8 waves, two workgroups per CU
     "la_kv_h16_kernel<512>": (256, 0),
     "la_kv_mfma2_kernel<false, 256>": (256, 0),
-    "dwconv5x5_rows2_kernel<true>": (256, 0),
+    "dwconv5x5_rows2_kernel<true, 0, 0>": (256, 0),
+    "dwconv5x5_rows2_kernel<true, 5, 9>": (256, 48),    # round 5: the 144-channel ConvRefiner block in one launch (6 spilled registers)
+    "dwconv5x5_rows2_kernel<true, 1, 2>": (256, 48),
 }
 
 

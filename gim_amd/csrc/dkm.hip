@@ -551,6 +551,16 @@ __global__ void __launch_bounds__(256, 2) dwconv5x5_rows2_kernel(const void* __r
         constexpr int PFW = (PXMAX + 127) / 128;                 // 32-pixel fragments per wave
         char* T = (char*)(wl + NP * 25 * CGB);                   // [4 PFW x 32 px][ROW]
         const int tid = threadIdx.x;
+        const int lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+        // A operand of the 1x1 (row m = output channel 32 f + l31, k16 step ks: input channels 16 ks + 8 lh .. + 7): 16 bytes per lane and
+        // (fragment, step) straight from L2, a ring of RING steps requested ahead -- the first RING steps HERE, in front of the tile writes and the
+        // barrier (one step of lookahead left ~9 dependent L2 round trips per workgroup exposed: the fused block measured 0.25 ms SLOWER per match())
+        constexpr int RING = NKS < 4 ? NKS : 4;
+        bf16x8_t wa[RING][NF];
+#pragma unroll
+        for (int k = 0; k < RING; ++k)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) wa[k][f] = *(const bf16x8_t*)(pww + (size_t)(32 * f + l31) * KP + k * 16 + lh * 8);
         if (sl < SPB) {
 #pragma unroll
             for (int o = 0; o < 2; ++o)
@@ -570,7 +580,6 @@ __global__ void __launch_bounds__(256, 2) dwconv5x5_rows2_kernel(const void* __r
                 }
         }
         __syncthreads();
-        const int lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lh = lane >> 5;
         f32x16_t c[PFW][NF];
 #pragma unroll
         for (int f = 0; f < NF; ++f)
@@ -580,22 +589,18 @@ __global__ void __launch_bounds__(256, 2) dwconv5x5_rows2_kernel(const void* __r
 #pragma unroll
                 for (int j = 0; j < PFW; ++j) { c[j][f][rg * 4] = bb.x; c[j][f][rg * 4 + 1] = bb.y; c[j][f][rg * 4 + 2] = bb.z; c[j][f][rg * 4 + 3] = bb.w; }
             }
-        // A operand: row m = output channel 32 f + l31, k16 step ks: input channels 16 ks + 8 lh .. + 7 -- one step ahead of its MFMAs
-        bf16x8_t wa[2][NF];
-#pragma unroll
-        for (int f = 0; f < NF; ++f) wa[0][f] = *(const bf16x8_t*)(pww + (size_t)(32 * f + l31) * KP + lh * 8);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            if (ks + 1 < NKS) {
-#pragma unroll
-                for (int f = 0; f < NF; ++f) wa[(ks + 1) & 1][f] = *(const bf16x8_t*)(pww + (size_t)(32 * f + l31) * KP + (ks + 1) * 16 + lh * 8);
-            }
 #pragma unroll
             for (int j = 0; j < PFW; ++j) {
                 const int pi = (wv * PFW + j) * 32 + l31;
                 const bf16x8_t bv = *(const bf16x8_t*)(T + pi * ROW + (2 * ks + lh) * 16);
 #pragma unroll
-                for (int f = 0; f < NF; ++f) c[j][f] = mfma_h16_32x32x16(wa[ks & 1][f], bv, c[j][f]);
+                for (int f = 0; f < NF; ++f) c[j][f] = mfma_h16_32x32x16(wa[ks % RING][f], bv, c[j][f]);
+            }
+            if (ks + RING < NKS) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f) wa[ks % RING][f] = *(const bf16x8_t*)(pww + (size_t)(32 * f + l31) * KP + (ks + RING) * 16 + lh * 8);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's rows are consumed (a wave's LDS accesses execute in order)

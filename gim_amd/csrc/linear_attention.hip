@@ -59,15 +59,33 @@ la_kv_kernel(const void* __restrict__ k, const void* __restrict__ v, const uint8
     }
 }
 
-// final[bh][:] = sum_chunk part[bh][chunk][:] (ascending chunk order)
-__global__ void la_kv_finalize_kernel(const float* __restrict__ part, float* __restrict__ fin, int per, int nchunk,
-                                      size_t total) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const size_t bh = idx / per, e = idx - bh * per;
+// final[bh][:] = sum_chunk part[bh][chunk][:].  Round 5: the first version gave one thread one element and walked the chunks in a loop of
+// dependent load -> add steps: 19-38 memory latencies in a row, 16.3 us per launch for 5-10 MB (profiles/r05_kernel_stats.txt; 32 launches per
+// forward).  Now a workgroup owns 64 elements, its four waves take the chunks c = wave, wave + 4, ... -- up to eight independent loads in flight
+// per thread and round -- and the four partial sums meet in LDS.  The order of the additions is a fixed function of nchunk alone (not of nb), so
+// the state of a sequence stays independent of the batch it is computed in (tests/test_gpu_kernels.py::test_linear_attention_state_is_batch_invariant).
+__global__ void __launch_bounds__(256)
+la_kv_finalize_kernel(const float* __restrict__ part, float* __restrict__ fin, int per, int nchunk, size_t total) {
+    __shared__ float red[256];
+    const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const size_t idx = (size_t)blockIdx.x * 64 + el;
     float s = 0.f;
-    for (int c = 0; c < nchunk; ++c) s += part[(bh * nchunk + c) * per + e];
-    fin[idx] = s;
+    if (idx < total) {
+        const size_t bh = idx / per, e = idx - bh * per;
+        const float* p = part + bh * nchunk * per + e;
+        for (int c0 = g; c0 < nchunk; c0 += 32) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = c0 + 4 * i;
+                v[i] = c < nchunk ? p[(size_t)c * per] : 0.f;
+            }
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (g == 0 && idx < total) fin[idx] = (red[el] + red[64 + el]) + (red[128 + el] + red[192 + el]);
 }
 
 template <int D, bool BF16, bool OUT_BF16>
@@ -576,7 +594,7 @@ extern "C" int GIM_FN(gim_linear_attention_kv)(const void* k, const void* v, con
     if (rc != GIM_OK) return rc;
     if (nc > 1) {
         const size_t total = (size_t)nb * H * per;
-        hipLaunchKernelGGL(la_kv_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, part, fin, per, nc, total);
+        hipLaunchKernelGGL(la_kv_finalize_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, part, fin, per, nc, total);
         rc = gim_check_launch("la_kv_finalize");
     }
     return rc;

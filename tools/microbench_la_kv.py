@@ -35,4 +35,4 @@ for kind in (torch.float16, torch.bfloat16):
         us = e0.elapsed_time(e1) / (reps * N) * 1e3
         mb = nb * S * 2 * C * 2 / 1e6
         print(f"{str(kind)[6:]} nb={nb}: {us:.1f} us per call (kv + finalize), "
-              f"{mb:.0f} MB of K / V -> {mb / us / 1e3:.2f} TB/s")
+              f"{mb:.0f} MB of K / V -> {mb / us:.2f} TB/s")

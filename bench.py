@@ -173,6 +173,9 @@ def main():
         class _DryModel:   # emits 3 + rank matches per pair; nothing else of the engine is exercised
             use_graph, coarse_sim, stem_fp16, stem_split = False, "dry", False, False
 
+            def _split(self):
+                return False
+
             def __call__(self, d):
                 g = torch.Generator().manual_seed(7 + rank)
                 m = (3 + rank) * nb
@@ -601,13 +604,15 @@ def main():
                 parity["other_coarse_sim"] = {"coarse_sim": model.coarse_sim, "flip_rate": alt["flip_rate"],
                                               "mean_abs_dmconf": alt.get("mean_abs_dmconf"), "mean_abs_dmkpts1_px": alt.get("mean_abs_dmkpts1_px")}
                 model.coarse_sim = was
-                if model.stem_split:   # what the split-operand first convolution buys: the same batch with plainly rounded stem operands (round 3's mode)
-                    model.stem_split = False
-                    model._invalidate()
-                    alt = parity_vs_oracle(step(), ref, 0)
-                    parity["plain_stem"] = {k: alt.get(k) for k in ("flip_rate", "mean_abs_dmconf", "max_abs_dmconf", "mean_abs_dmkpts1_px")}
-                    model.stem_split = True
-                    model._invalidate()
+                # what the split-operand first convolution buys (or would buy): the same batch with the other setting of the stem
+                # (fp16 mode: split by default, `plain_stem` = round 3's mode; bf16 mode: plain by default since round 5, `split_stem`)
+                was_split, split_now = model.stem_split, model._split()
+                model.stem_split = not split_now
+                model._invalidate()
+                alt = parity_vs_oracle(step(), ref, 0)
+                parity["plain_stem" if split_now else "split_stem"] = {k: alt.get(k) for k in ("flip_rate", "mean_abs_dmconf", "max_abs_dmconf", "mean_abs_dmkpts1_px")}
+                model.stem_split = was_split
+                model._invalidate()
             for nm, (rec, d_alt) in alt_modes.items():
                 rec["parity"] = parity_vs_oracle(d_alt, ref, 0)
 
@@ -632,7 +637,7 @@ def main():
                                    "in correspondence (device resident), fine level loaded, outputs incl. match count read back",
                        "pairs_per_step": world * nb, "matches_per_pair": round(n_matches / max(1, pairs), 1),
                        "coarse_sim": model.coarse_sim, "stem_operands": ("fp16" if (args.precision == "bf16" and model.stem_fp16) else args.precision) +
-                                        (" hi+lo pairs (split-operand first convolution)" if (model.stem_split and args.precision != "fp32") else ""),
+                                        (" hi+lo pairs (split-operand first convolution)" if model._split() else ""),
                        "parallelism": f"pairs sharded over {world} GPU(s), no collective per step",
                        "hip_graph": bool(model.use_graph), "transformer_pair_chains": int(getattr(model, "tf_chains", 1)),
                        "readback": f"match count every step (host sync) + the packed match rows, {readback_bytes // max(1, args.steps)} B per step, to pinned host "

@@ -660,6 +660,7 @@ __global__ void cm_precand_kernel(const CmGeom g, const CmWs w) {
 // deterministic).  Four threads share an element (slots t, t + 4, ...) so that a pair's 38 ... 75 dependent-latency loads become
 // 10 ... 19: the two launches took 20 us each as one thread per element.
 struct CombineJob { const float2* part; float2* stat; int len, ntile; };   // `ntile` partial slots per pair, all of them filled
+constexpr int CMB_INFLIGHT = 20;   // slots per thread held in registers: covers 80 partial slots (4800 tokens: 38 row / 75 column slots)
 // one launch for both directions (round 5): blockIdx.y = 0 the row statistics, 1 the column statistics
 __global__ void __launch_bounds__(256) cm_combine_kernel(const CombineJob jr, const CombineJob jc, int N) {
     const CombineJob& J = blockIdx.y ? jc : jr;
@@ -675,10 +676,26 @@ __global__ void __launch_bounds__(256) cm_combine_kernel(const CombineJob jr, co
     if (ok) {
         const size_t n = idx / len, x = idx - n * len;
         const float2* p = part + n * (size_t)stride * len + x;   // `stride` slots per pair, the first `ntile` of them filled
-        for (int t = tq; t < ntile; t += 4) m = fmaxf(m, p[(size_t)t * len].x);
-        for (int t = tq; t < ntile; t += 4) {
-            const float2 v = p[(size_t)t * len];
-            z += v.y * expf(v.x - m);
+        if (ntile <= 4 * CMB_INFLIGHT) {
+            // all of this thread's slots requested at once (one memory latency instead of 10 ... 19 dependent ones per pass), then the same
+            // arithmetic in the same order
+            float2 v[CMB_INFLIGHT];
+#pragma unroll
+            for (int q = 0; q < CMB_INFLIGHT; ++q) {
+                const int t = tq + 4 * q;
+                v[q] = t < ntile ? p[(size_t)t * len] : make_float2(-INFINITY, 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < CMB_INFLIGHT; ++q) m = fmaxf(m, v[q].x);
+#pragma unroll
+            for (int q = 0; q < CMB_INFLIGHT; ++q)
+                if (tq + 4 * q < ntile) z += v[q].y * expf(v[q].x - m);
+        } else {
+            for (int t = tq; t < ntile; t += 4) m = fmaxf(m, p[(size_t)t * len].x);
+            for (int t = tq; t < ntile; t += 4) {
+                const float2 v = p[(size_t)t * len];
+                z += v.y * expf(v.x - m);
+            }
         }
     }
     sh[tq][xq] = make_float2(m, z);

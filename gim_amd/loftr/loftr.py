@@ -20,7 +20,8 @@ Precision modes (`config['precision']`, default env GIM_PRECISION or 'fp16'):
           as fp16 (`config['stem_fp16']`, default on): rounding the image and the 7x7 filters to 8
           significand bits in front of an edge-detecting (cancelling) convolution is HALF of this mode's deviation from
           the fp32 reference (tools/precision_emulation.py: index flip rate 1.95 % -> 0.98 % with the stem alone on fp16
-          operands; same MFMA rate, same bytes);
+          operands; same MFMA rate, same bytes) -- plainly rounded: the split (hi + lo) stem of the fp16 mode is off here unless
+          `config['stem_split']` asks for it (no measurable parity gain under bf16 storage everywhere else, 0.07 ms per step);
   'fp16'  (default) IEEE fp16 operands / fp32 accumulate everywhere the bf16 mode uses bf16: same kernels in their second flavour
           (csrc/gim_common.h), same instruction counts and bytes (measured 2-3 % slower: lower clocks), 11 instead of 8
           significand bits per stored activation -- index flip rate 0.15-0.3 % against the fp32 oracle where bf16 has 0.7-1.3 %
@@ -193,7 +194,10 @@ class LoFTR(nn.Module):
         self.stem_fp16 = flag("stem_fp16", True, config)
         # ... on split (hi + lo) operands -- image and 7x7 filters carried to 2^-22 instead of 2^-11
         # (profiles/r04_precision_sweep.txt: the stem alone is 57 % of the fp16 mode's mean |dmconf| and 3/4 of its index flips) ...
-        self.stem_split = flag("stem_split", True, config)
+        # 'auto' (default): in the fp16 mode only.  The bf16 mode rounds every other activation to 8 bits, and the split buys it nothing
+        # measurable (bench.py `parity.split_stem` / `plain_stem`: 12 vs 13 flips of 1485, the same mean |dmconf|) for twice the
+        # stem's MFMAs: -0.07 ms per step without it (profiles/r05_la_finalize.txt).  True / False force it either way.
+        self.stem_split = flag("stem_split", "auto", config)
         # ... on its own kernel (gim_stem7x7: filter bank resident in LDS, every input patch staged once) instead of the implicit GEMM
         self.stem_kernel = flag("stem_kernel", True, config)
         # set once the fp16 mode's range guard tripped and the module fell back to bf16 (see forward)
@@ -281,7 +285,13 @@ class LoFTR(nn.Module):
     def _split(self):
         """first convolution on split (hi + lo) operands?  16-bit modes only: to the implicit-GEMM kernel it is a 9-channel
         convolution, to gim_stem7x7 one MFMA per tap on [hi | lo] pixels"""
-        return bool(self.stem_split) and self.precision != "fp32"
+        if self.precision == "fp32":
+            return False
+        s = self.stem_split
+        if isinstance(s, str):
+            s = s.strip().lower()
+            return self.precision == "fp16" if s == "auto" else s not in ("0", "false", "no", "off", "")
+        return bool(s)
 
     def _stem_k(self):
         """first convolution through gim_stem7x7?  (16-bit modes; the kernel stages by LDS-DMA, so lds_dma = False turns it off too)"""

@@ -108,7 +108,7 @@ def test_bf16_batch8_flip_rate_vs_oracle(synth, pairs, oracle_two_pairs, precisi
             assert torch.isfinite(d["mconf"]).all() and torch.isfinite(d["mkpts1_f"]).all()
     finally:
         model.stem_fp16 = True
-        model.stem_split = True
+        model.stem_split = "auto"
         model.set_precision("fp32")
 
 

@@ -18,6 +18,17 @@ def test_flag_resolution_order_and_types(monkeypatch):
     assert switches.flag("coarse_sim", "") == ""
 
 
+def test_split_stem_default_follows_the_precision_mode():
+    """`stem_split` = 'auto' (default): split-operand first convolution in the fp16 mode only; True / False (config, attribute or GIM_FLAGS
+    text) force it; never in the fp32 mode."""
+    from types import SimpleNamespace as NS
+    from gim_amd.loftr.loftr import LoFTR
+    sp = lambda prec, s: LoFTR._split(NS(precision=prec, stem_split=s))   # noqa: E731
+    assert sp("fp16", "auto") is True and sp("bf16", "auto") is False and sp("fp32", "auto") is False
+    assert sp("bf16", True) is True and sp("bf16", "1") is True and sp("fp16", False) is False and sp("fp16", "off") is False
+    assert sp("fp32", True) is False
+
+
 def test_package_reads_only_the_documented_environment_variables():
     allowed = {"GIM_PRECISION", "GIM_FLAGS", "GIM_LIB", "GIM_POSE_BACKEND", "GIM_HIPCC_EXTRA", "GIM_BUILD_JOBS", "GIMRECONSTRUCTION", "HIPCC"}
     seen = set()

@@ -52,7 +52,8 @@ class TokenEmit(ctypes.Structure):
     """struct gim_token_emit (include/gim_hip.h)."""
     MAX = 6
     _fields_ = [("nblk", c_int), ("weights", c_void_p), ("out", c_void_p * 6), ("ld", c_int * 6), ("act", c_int * 6),
-                ("row_lo", c_int * 6), ("row_hi", c_int * 6)]
+                ("row_lo", c_int * 6), ("row_hi", c_int * 6),
+                ("kv_part", c_void_p * 6), ("kv_nchunk", c_int * 6), ("kv_tile0", c_int * 6), ("kv_len", c_float * 6)]
 
 
 class LgAssignArgs(ctypes.Structure):
@@ -82,6 +83,8 @@ PROTOTYPES = {
     "gim_upsample2x_add": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "gim_posenc_add": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
     "gim_linear_attention_ws_bytes": (c_int64, [c_int] * 4),
+    "gim_linear_attention_ws_bytes_chunks": (c_int64, [c_int] * 4),
+    "gim_linear_attention_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "gim_linear_attention_kv": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
     "gim_linear_attention_apply": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
     "gim_linear_attention_short": (c_int, [c_void_p] * 6 + [c_int] * 11 + [c_void_p]),

@@ -601,6 +601,21 @@ extern "C" int GIM_FN(gim_linear_attention_kv)(const void* k, const void* v, con
 }
 
 #if !GIM_HALF_KIND
+// Second half of gim_linear_attention_kv alone, for partial states written by somebody else (gim_token_mlp_emit's fused KV state: one
+// partial per 64-row tile): kv_ws = [state nb x H x (D D + D)][partials nb x H x nchunk x (D D + D)]; state = sum over the chunks.
+extern "C" int64_t gim_linear_attention_ws_bytes_chunks(int nb, int H, int D, int nchunk) {
+    return (int64_t)nb * H * ((int64_t)D * D + D) * 4 * ((int64_t)nchunk + 1);
+}
+extern "C" int gim_linear_attention_finalize(float* kv_ws, int nb, int H, int D, int nchunk, gim_stream_t stream) {
+    GIM_REQUIRE(kv_ws && nb > 0 && H > 0 && D > 0 && nchunk > 0, "linear_attention_finalize: bad args");
+    const int per = D * D + D;
+    const size_t total = (size_t)nb * H * per;
+    hipLaunchKernelGGL(la_kv_finalize_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, (hipStream_t)stream, kv_ws + total, kv_ws, per, nchunk, total);
+    return gim_check_launch("la_kv_finalize");
+}
+#endif
+
+#if !GIM_HALF_KIND
 extern "C" int gim_linear_attention_apply_f16(const void* q, const uint8_t* q_mask, const float* kv_ws, void* out, int nb,
                                           int L, int S, int H, int D, int ldq, int ldo, int dtype, int out_dtype,
                                           gim_stream_t stream);

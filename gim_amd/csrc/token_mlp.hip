@@ -29,6 +29,15 @@
 // per block a row range (a self layer over both images projects k / v only for the side that is a source next), weights streamed
 // the same way (4 units per block and wave).  The stand-alone projection GEMMs (K = 256: 4 slabs of prologue / epilogue per tile,
 // 350 TFLOP/s) and their re-read of x disappear.
+//
+// FUSED KV STATE (round 5): the k and v rows of a sequence have ONE reader -- the linear attention's state reduction KV = K^T V / S,
+// Ksum = K^T 1 (attentions.py:38-43) of the call they are the source of.  A (k, v) block pair flagged with `kv_part` is therefore not
+// written at all: both projections are computed with the MFMA operands SWAPPED (tokens = A, weights = B), which leaves a lane holding one
+// output CHANNEL and 16 TOKENS per accumulator -- and that is, register for register, the operand layout of the state product itself
+// (lane = d resp. v, 8 consecutive registers = 8 k positions; K and V carry the same token in the same position, so the contraction
+// over tokens needs no transposition).  Two packs per quad and 16 more MFMAs per wave give the tile's [8 heads][32 x 32 + 32] partial
+// state, stored where gim_linear_attention_kv would have put the partial of a 64-row chunk; gim_linear_attention_finalize sums the
+// partials of a sequence.  128 KiB of k / v stores per tile, their read-back by la_kv and the la_kv launch itself are gone.
 #include "gim_common.h"
 
 namespace {
@@ -67,6 +76,11 @@ struct Args {
     const uint4* ewts;           // 4 waves x nblk x 4 units x 8 fragments (packing.py::pack_token_emit)
     unsigned short* eout[MAXBLK];
     int eld[MAXBLK], eact[MAXBLK], elo[MAXBLK], ehi[MAXBLK];
+    // fused KV state: block b = K, block b + 1 = V of a pair when ekv[b] != NULL (neither is stored)
+    float* ekv[MAXBLK];          // partial states of the consuming call: [sequence][8][nchunk][32 * 32 + 32] fp32
+    int ekv_nchunk[MAXBLK];      // 64-row tiles per sequence of the consumer's source
+    int ekv_tile0[MAXBLK];       // consumer-relative index of the tile that starts at row elo[b]
+    float ekv_inv_s[MAXBLK];     // 1 / source length (attentions.py:41)
 };
 
 struct W8 { bf16x8_t f[8]; };
@@ -120,6 +134,31 @@ __device__ __forceinline__ void mma_n64(const char* tile, const int (&tab)[8], i
             } else {
                 acc[nf][0] = mfma_h16_32x32x16(w.f[2 * k + nf], v0, acc[nf][0]);
                 acc[nf][1] = mfma_h16_32x32x16(w.f[2 * k + nf], v1, acc[nf][1]);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// the same unit with the operands swapped (rows = A, weights = B): acc[nf][j][4 rg + e] = channel 32 nf + l31 of row 32 j + 8 rg + 4 lh + e
+template <bool FIRST>
+__device__ __forceinline__ void mma_n64t(const char* tile, const int (&tab)[8], int ks0, int jstride, const W8& w, f32x16_t (&acc)[2][2]) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const char* ab = tile + tab[ks0 + k];
+        const bf16x8_t v0 = *(const bf16x8_t*)(ab), v1 = *(const bf16x8_t*)(ab + jstride);
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+            if (FIRST && k == 0) {
+                f32x16_t z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                acc[nf][0] = mfma_h16_32x32x16(v0, w.f[2 * k + nf], z);
+                acc[nf][1] = mfma_h16_32x32x16(v1, w.f[2 * k + nf], z);
+            } else {
+                acc[nf][0] = mfma_h16_32x32x16(v0, w.f[2 * k + nf], acc[nf][0]);
+                acc[nf][1] = mfma_h16_32x32x16(v1, w.f[2 * k + nf], acc[nf][1]);
             }
         }
     }
@@ -422,6 +461,75 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
     while (b >= 0) {
         const unsigned rest = emask & ~((2u << b) - 1u);
         const int nb = rest ? __ffs(rest) - 1 : -1;
+        if (a.ekv[b]) {
+            // ---- (k, v) pair -> partial KV state of this tile (block-uniform branch; the V block is the next active one: same row gate) ----
+            // K^T as MFMA A operand, [head of the wave][row half][k16 step] x 8 tokens per lane: parked in LDS while the V block is projected
+            // (32 registers the emit loop does not have; X's upper half and H are idle here: 8 KiB per wave, lane-linear)
+            char* kpark = smem + OFF_X + 16384 + L.w * 8192 + L.lane * 16;
+            float ksum[2] = {0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const char* tile = A + (q >> 1) * 256;
+                W8& w = (q & 1) ? wb : wa;
+                if (q == 0) mma_n64t<true>(tile, L.a8, 0, 32 * ROWB, w, acc);
+                else mma_n64t<false>(tile, L.a8, (q & 1) * 4, 32 * ROWB, w, acc);
+                fetch(w);
+            }
+            const bool kelu = a.eact[b] == GIM_ACT_ELU1;
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        float v[8];
+#pragma unroll
+                        for (int p = 0; p < 8; ++p) v[p] = kelu ? elu1(acc[nf][j][8 * ks + p]) : acc[nf][j][8 * ks + p];
+                        const unsigned kq[4] = {cvt_pk_h16(v[0], v[1]), cvt_pk_h16(v[2], v[3]), cvt_pk_h16(v[4], v[5]), cvt_pk_h16(v[6], v[7])};
+                        *(uint4*)(kpark + ((nf * 2 + j) * 2 + ks) * 1024) = make_uint4(kq[0], kq[1], kq[2], kq[3]);
+                        // Ksum[d] = sum over the tokens of the ROUNDED k values (what la_kv reads back), 16 of them in this lane
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) ksum[nf] += h16_lo(kq[p]) + h16_hi(kq[p]);
+                    }
+            const int bv = nb;   // the pair's V block
+            const unsigned restv = emask & ~((2u << bv) - 1u);
+            const int nbv = restv ? __ffs(restv) - 1 : -1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const char* tile = A + (q >> 1) * 256;
+                W8& w = (q & 1) ? wb : wa;
+                if (q == 0) mma_n64t<true>(tile, L.a8, 0, 32 * ROWB, w, acc);
+                else mma_n64t<false>(tile, L.a8, (q & 1) * 4, 32 * ROWB, w, acc);
+                fetch(w);
+            }
+            const int tix = a.ekv_tile0[b] + (r0 - a.elo[b]) / ROWS, nch = a.ekv_nchunk[b];
+            const int seq = tix / nch, chunk = tix - seq * nch;
+            const float inv_s = a.ekv_inv_s[b];
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) {
+                f32x16_t kv;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) kv[r] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const f32x16_t& va = acc[nf][j];
+                        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(cvt_pk_h16(va[8 * ks], va[8 * ks + 1]), cvt_pk_h16(va[8 * ks + 2], va[8 * ks + 3]),
+                                                                                    cvt_pk_h16(va[8 * ks + 4], va[8 * ks + 5]), cvt_pk_h16(va[8 * ks + 6], va[8 * ks + 7])));
+                        const bf16x8_t kk = *(const bf16x8_t*)(kpark + ((nf * 2 + j) * 2 + ks) * 1024);   // (same wave wrote it: LDS executes a wave's accesses in order)
+                        kv = mfma_h16_32x32x16(kk, vf, kv);        // D[d][v] += sum_tokens K[token][d] V[token][v]
+                    }
+                // register r of lane (l31, lh) is element [d = 8 (r >> 2) + 4 lh + (r & 3)][v = l31] (the layout la_kv_h16_kernel stores)
+                float* out = a.ekv[b] + ((size_t)(seq * 8 + 2 * L.w + nf) * nch + chunk) * (32 * 32 + 32);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) out[((r >> 2) * 8 + L.lh * 4 + (r & 3)) * 32 + L.l31] = kv[r] * inv_s;
+                const float ksd = ksum[nf] + __shfl_xor(ksum[nf], 32, 64);   // lane (d = l31, lh) held the tokens 8 rg + 4 lh + e of both row halves
+                if (L.lh == 0) out[32 * 32 + L.l31] = ksd;
+            }
+            b = nbv;
+            continue;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const char* tile = A + (q >> 1) * 256;
@@ -483,12 +591,25 @@ static int token_mlp_launch(const void* msg, void* xb, float* x32, const void* w
     a.msg = (const unsigned short*)msg; a.xb = (unsigned short*)xb; a.x32 = x32; a.wts = (const uint4*)weights; a.ln = ln_params;
     a.R = R; a.ldm = ldm; a.ldxb = ldxb; a.ldx32 = ldx32; a.eps = ln_eps;
     a.nblk = 0; a.ewts = nullptr;
-    for (int b = 0; b < MAXBLK; ++b) { a.eout[b] = nullptr; a.eld[b] = 0; a.eact[b] = GIM_ACT_NONE; a.elo[b] = a.ehi[b] = 0; }
+    for (int b = 0; b < MAXBLK; ++b) {
+        a.eout[b] = nullptr; a.eld[b] = 0; a.eact[b] = GIM_ACT_NONE; a.elo[b] = a.ehi[b] = 0;
+        a.ekv[b] = nullptr; a.ekv_nchunk[b] = 1; a.ekv_tile0[b] = 0; a.ekv_inv_s[b] = 0.f;
+    }
     if (em && em->nblk > 0) {
         GIM_REQUIRE(em->nblk <= MAXBLK && em->weights, "token_mlp: %d projection blocks (at most %d), weights %p", em->nblk, MAXBLK, em->weights);
         a.nblk = em->nblk; a.ewts = (const uint4*)em->weights;
         for (int b = 0; b < em->nblk; ++b) {
-            GIM_REQUIRE(em->out[b] && em->ld[b] >= C && em->ld[b] % 8 == 0 && ((uintptr_t)em->out[b] & 15) == 0,
+            const bool pair_k = em->kv_part[b] != nullptr, pair_v = b > 0 && em->kv_part[b - 1] != nullptr;
+            if (pair_k) {
+                GIM_REQUIRE(!pair_v && b + 1 < em->nblk && !em->kv_part[b + 1] && em->row_lo[b + 1] == em->row_lo[b] && em->row_hi[b + 1] == em->row_hi[b],
+                            "token_mlp: fused KV state: block %d (K) must be followed by its V block with the same row range", b);
+                GIM_REQUIRE(em->kv_nchunk[b] > 0 && em->kv_tile0[b] >= 0 && em->kv_len[b] > 0.f && em->row_hi[b] <= R && em->row_hi[b] % ROWS == 0 && ((uintptr_t)em->kv_part[b] & 15) == 0,
+                            "token_mlp: fused KV state of block %d: %d tiles per sequence, first tile %d, source length %g, rows up to %d of %d",
+                            b, em->kv_nchunk[b], em->kv_tile0[b], (double)em->kv_len[b], em->row_hi[b], R);
+                a.ekv[b] = em->kv_part[b]; a.ekv_nchunk[b] = em->kv_nchunk[b]; a.ekv_tile0[b] = em->kv_tile0[b]; a.ekv_inv_s[b] = 1.0f / em->kv_len[b];
+            }
+            GIM_REQUIRE(pair_k || pair_v || (em->out[b] && ((uintptr_t)em->out[b] & 15) == 0), "token_mlp: projection block %d: output %p", b, em->out[b]);
+            GIM_REQUIRE(pair_k || pair_v || (em->ld[b] >= C && em->ld[b] % 8 == 0),
                         "token_mlp: projection block %d: output %p, row stride %d", b, em->out[b], em->ld[b]);
             GIM_REQUIRE(em->act[b] == GIM_ACT_NONE || em->act[b] == GIM_ACT_ELU1, "token_mlp: projection block %d: activation %d", b, em->act[b]);
             GIM_REQUIRE(em->row_lo[b] % ROWS == 0 && em->row_lo[b] <= em->row_hi[b], "token_mlp: projection block %d: rows [%d, %d) (the start must be a multiple of %d)",

@@ -228,6 +228,8 @@ class LoFTR(nn.Module):
         self.depth_groups = flag("depth_groups", 1, config)
         self.l3_chains = flag("l3_chains", 1, config)
         self.tf_chains = flag("tf_chains", 2, config)
+        # token tails write partial KV states instead of the k / v rows of the next attention (see _transformer_emit; False: rows + la_kv)
+        self.kv_fused = flag("kv_fused", True, config)
         self._packed = None
         self._health = None          # fp16 range guard word of the forward in flight (count[1] of its coarse matching), see _coarse_stage
         self._health_sync_left = 3   # forwards that still wait for the fine kernel to read its health bit at once (fp16 mode)
@@ -673,6 +675,28 @@ class LoFTR(nn.Module):
             per_call.append((pack_token_emit(wsel, device, tdt), blocks))
         return calls, per_call, needs_after(-1, (0, 1))
 
+    @staticmethod
+    def _kv_consumers(calls, per_call, initial):
+        """(call index, index of a k block in that call's block list) -> index of the later call whose SOURCE those k / v rows are, for every
+        (k, v) pair a token tail may hand over as partial KV states (the v block is the next entry of the list).  A call fed, for any of its
+        source sides, by the initial projections keeps the row path: its state comes from one gim_linear_attention_kv launch."""
+        fed_by_initial = {(li, sd) for li, blk, sides in initial if blk == 1 for sd in sides}
+        out = {}
+        for ci, em in enumerate(per_call):
+            if em is None:
+                continue
+            blocks = em[1]
+            for bi, (l2, blk, sides) in enumerate(blocks):
+                if blk != 1:
+                    continue
+                assert bi + 1 < len(blocks) and blocks[bi + 1] == (l2, 2, sides), "the v block follows its k block"
+                for cj in range(ci + 1, len(calls)):
+                    if calls[cj][0] == l2 and set(sides) <= set(calls[cj][2]):
+                        if not any((l2, sd) in fed_by_initial for sd in calls[cj][2]):
+                            out[(ci, bi)] = cj
+                        break
+        return out
+
     def _transformer_emit(self, P, name, tf, T, n0, L, n1, S):
         """LocalFeatureTransformer.forward with every projection after the first layer's computed by the token tail that produced
         its operand rows (see _emit_plan).  Two [R, 3C] projection buffers alternate by layer parity: a tail writes the NEXT layer's
@@ -706,33 +730,62 @@ class LoFTR(nn.Module):
                 assert blks == [0], blks
                 ops.linear(x_t, P[p + "q_proj"], q[r, :C], ACT_ELU1, self.use_lds_dma)
 
+        # Fused KV state (token_mlp.hip): the k / v rows of a side have one reader, the state reduction of the call they are the source of.
+        # A token tail that would emit them writes its tiles' partial states into that call's workspace instead; the call then only sums them
+        # (gim_linear_attention_finalize) -- no k / v rows, no la_kv launch.  Not for calls fed by the initial projections, padded inputs
+        # (the state reduction masks rows) or the debug dumps.
+        fuse_kv = bool(self.kv_fused) and T.MASK is None and self.debug is None
+        consumers = self._kv_consumers(calls, per_call, initial) if fuse_kv else {}
+
         def run(rows_c, m0, m1, ws):
-            """the call sequence on the row ranges (side 0, side 1) of m0 / m1 sequences; returns the KV workspace it ended with"""
+            """the call sequence on the row ranges (side 0, side 1) of m0 / m1 sequences; returns the KV workspaces it used (the caller keeps
+            them referenced until the streams join; [0] is re-usable by the next forward)"""
             both = slice(rows_c[0].start, rows_c[1].stop)
             rc = lambda sides: both if len(sides) == 2 else rows_c[sides[0]]   # noqa: E731
-            for (li, xs_s, ss_s), em in zip(calls, per_call):
+            nseq = lambda sides: m0 + m1 if len(sides) == 2 else (m0, m1)[sides[0]]   # noqa: E731
+            kvws = {}   # consumer call index -> workspace its producers fill
+            used = []
+            for ci, ((li, xs_s, ss_s), em) in enumerate(zip(calls, per_call)):
                 xs, ss = rc(xs_s), rc(ss_s)
                 q = QK[li & 1]
-                nb_src = m0 + m1 if len(ss_s) == 2 else (m0, m1)[ss_s[0]]
+                nb_src = nseq(ss_s)
                 len_q = L if xs_s[0] == 0 else S
                 len_src = L if ss_s[0] == 0 else S
                 qm = T.MASK[xs] if T.MASK is not None else None
                 km = T.MASK[ss] if T.MASK is not None else None
                 wts, lnp, eps = P[f"{name}{li}.tok"]
-                ws, _ = ops.linear_attention_state(q[ss, C:2 * C], q[ss, 2 * C:], nb_src, len_src, H, ws, km)
+                if ci in kvws:
+                    kv = ops.kv_state_finalize(kvws.pop(ci), nb_src, len_src // 64)
+                else:
+                    ws, _ = ops.linear_attention_state(q[ss, C:2 * C], q[ss, 2 * C:], nb_src, len_src, H, ws, km)
+                    kv = ws
                 emit = None
                 if em is not None:
                     ew, blocks = em
                     spec = []
-                    for l2, blk, sides in blocks:
+                    for bi, (l2, blk, sides) in enumerate(blocks):
                         lo, hi = (0, xs.stop - xs.start) if sides == xs_s else ((0, m0 * L) if sides == (0,) else (m0 * L, xs.stop - xs.start))
-                        spec.append((QK[l2 & 1][xs, blk * C:(blk + 1) * C], ACT_ELU1 if blk < 2 else ACT_NONE, lo, hi))
+                        cj = consumers.get((ci, bi if blk == 1 else bi - 1)) if blk >= 1 else None
+                        if cj is None:
+                            spec.append((QK[l2 & 1][xs, blk * C:(blk + 1) * C], ACT_ELU1 if blk < 2 else ACT_NONE, lo, hi))
+                        elif blk == 1:   # K of a fused pair; its V block follows (same consumer, same rows)
+                            src = rc(calls[cj][2])
+                            slen = L if calls[cj][2][0] == 0 else S
+                            if cj not in kvws:
+                                kvws[cj] = ops.kv_state_workspace(nseq(calls[cj][2]), slen // 64, T.X32.device)
+                                used.append(kvws[cj])
+                            spec.append((None, ACT_ELU1, lo, hi, (kvws[cj], nseq(calls[cj][2]), slen // 64, (xs.start + lo - src.start) // 64, slen)))
+                        else:
+                            assert len(spec[-1]) == 5 and spec[-1][2:4] == (lo, hi)
+                            spec.append((None, ACT_NONE, lo, hi))
                     emit = (ew, spec)
-                ops.token_mlp(q[xs, :C], T.CAT[xs, :C], T.X32[xs], wts, lnp, eps, kv=ws, L=len_q, S=len_src, q_mask=qm, emit=emit)
-            return ws
+                ops.token_mlp(q[xs, :C], T.CAT[xs, :C], T.X32[xs], wts, lnp, eps, kv=kv, L=len_q, S=len_src, q_mask=qm, emit=emit)
+            assert not kvws
+            return [ws] + used
 
         if K == 1:
-            T.ws = run(rows, n0, n1, T.ws)
+            T.keep = run(rows, n0, n1, T.ws)
+            T.ws = T.keep[0]
             return
         m = n0 // K
         main = torch.cuda.current_stream()

@@ -529,7 +529,10 @@ def token_mlp(msg, xb, x32, weights, ln_params, eps, kv=None, L=0, S=0, q_mask=N
     of x, updated in place), x32 [R, >=256] fp32 (updated in place).  With `kv` (the fp32 state of linear_attention_state) the
     attention's apply step is fused in front: `msg` then holds the elu+1 query rows of R / L sequences, S = source length.
     `emit` = (stream from packing.pack_token_emit, [(out [R, >=256] 16-bit row view, act, row_lo, row_hi), ...]): projection blocks
-    act(x_new W_b^T) of the new x, written for the rows of the 64-row tiles that start in [row_lo, row_hi)."""
+    act(x_new W_b^T) of the new x, written for the rows of the 64-row tiles that start in [row_lo, row_hi).
+    A block entry with a fifth element (ws, nb_kv, nchunk, tile0, src_len) is the K block of a fused (k, v) pair -- the next entry is its V block, `out`
+    of both may be None: nothing is written but each tile's partial KV state into the partial area of the linear-attention workspace `ws`
+    (kv_state_workspace) of the call that consumes these rows as its source; kv_state_finalize(ws, ...) completes it."""
     _req_cuda(msg, xb, x32, weights, ln_params, kv, q_mask)
     assert msg.dtype in HALF and xb.dtype == msg.dtype and weights.dtype == msg.dtype and x32.dtype == torch.float32
     f16 = msg.dtype == torch.float16
@@ -542,10 +545,25 @@ def token_mlp(msg, xb, x32, weights, ln_params, eps, kv=None, L=0, S=0, q_mask=N
         assert 0 < len(blocks) <= _lib.TokenEmit.MAX and ew.dtype == msg.dtype and ew.is_cuda and ew.numel() == len(blocks) * 256 * 256
         em = _lib.TokenEmit()
         em.nblk, em.weights = len(blocks), ew.data_ptr()
-        for b, (out, act, lo, hi) in enumerate(blocks):
-            _req_cuda(out)
-            assert out.dtype == msg.dtype and out.stride(1) == 1 and out.shape[0] == R and out.shape[1] >= 256
-            em.out[b], em.ld[b], em.act[b], em.row_lo[b], em.row_hi[b] = out.data_ptr(), out.stride(0), act, lo, hi
+        fused_v = False
+        for b, blk in enumerate(blocks):
+            out, act, lo, hi = blk[:4]
+            if len(blk) > 4:      # K of a fused pair
+                ws, nb_kv, nchunk, tile0, src_len = blk[4]
+                _req_cuda(ws)
+                assert ws.dtype == torch.float32 and ws.is_contiguous() and b + 1 < len(blocks) and len(blocks[b + 1]) == 4
+                assert hi <= R and lo % 64 == 0 and hi % 64 == 0 and tile0 + (hi - lo) // 64 <= nb_kv * nchunk, "token_mlp: fused KV state: tile range"
+                state = nb_kv * 8 * (32 * 32 + 32)
+                assert ws.numel() >= state * (nchunk + 1), "token_mlp: KV-state workspace too small (kv_state_workspace)"
+                em.kv_part[b], em.kv_nchunk[b], em.kv_tile0[b], em.kv_len[b] = ws.data_ptr() + 4 * state, nchunk, tile0, float(src_len)
+                fused_v = True
+            elif fused_v:         # V of the pair
+                fused_v = False
+            else:
+                _req_cuda(out)
+                assert out.dtype == msg.dtype and out.stride(1) == 1 and out.shape[0] == R and out.shape[1] >= 256
+                em.out[b], em.ld[b] = out.data_ptr(), out.stride(0)
+            em.act[b], em.row_lo[b], em.row_hi[b] = act, lo, hi
             flops += 2.0 * max(0, min(hi, R) - lo) * 256 * 256
     with _Timed("token_mlp", flops):
         if em is None:
@@ -572,6 +590,20 @@ def linear_attention_state(k, v, nb_kv, S, H, ws=None, kv_mask=None):
     check(lib.gim_linear_attention_kv(_p(k), _p(v), _p(kv_mask), _p(ws), nb_kv, S, H, D, k.stride(0), v.stride(0),
                                       gim_dtype(k), _stream()), "gim_linear_attention_kv")
     return ws, need
+
+
+def kv_state_workspace(nb_kv, nchunk, device, H=8, D=32):
+    """fp32 workspace [state nb_kv x H x (D D + D)][partials nb_kv x H x nchunk x (D D + D)] for partial states written by token_mlp's
+    fused (k, v) pairs (gim_linear_attention_ws_bytes_chunks)"""
+    return torch.empty(lib.gim_linear_attention_ws_bytes_chunks(nb_kv, H, D, nchunk) // 4, dtype=torch.float32, device=device)
+
+
+def kv_state_finalize(ws, nb_kv, nchunk, H=8, D=32):
+    """state = sum of the partials (gim_linear_attention_finalize); afterwards `ws` is what token_mlp takes as `kv`"""
+    _req_cuda(ws)
+    assert ws.dtype == torch.float32 and ws.numel() * 4 >= lib.gim_linear_attention_ws_bytes_chunks(nb_kv, H, D, nchunk)
+    check(lib.gim_linear_attention_finalize(_p(ws), nb_kv, H, D, nchunk, _stream()), "gim_linear_attention_finalize")
+    return ws
 
 
 def fine_fused(feat_f0, feat_f1, b_ids, i_ids, j_ids, mkpts1_c, scale1, weights, ln_params, M, w0c, w1c, stride, W,

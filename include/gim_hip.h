@@ -35,7 +35,9 @@ enum { GIM_OK = 0, GIM_ERR_INVALID = -1, GIM_ERR_LAUNCH = -2, GIM_ERR_UNSUPPORTE
 
 /* 110 (round 5): the fp16 range-guard word is an ARGUMENT of the entry points that use it (`health` of gim_bneck64_fused*,
  * gim_bneck_tail*, gim_conv_args.health; gim_set_range_guard() is gone), and gim_coarse_match's `count` is int32[2 + N] (count[1] = health
- * word, per-pair counts from count[2]) -- a caller bound to version 100 must be rebuilt. */
+ * word, per-pair counts from count[2]) -- a caller bound to version 100 must be rebuilt.
+ * 111: struct gim_token_emit grew the kv_part / kv_nchunk / kv_tile0 / kv_len arrays (fused KV state; zero them for the old behaviour);
+ * new entries gim_linear_attention_finalize, gim_linear_attention_ws_bytes_chunks. */
 int gim_version(void);
 /* fp16 range guard.  `health` (NULL: no check): a device word into which the fp16 flavour of the kernels that store un-normalised
  * residual streams (gim_bneck64_fused*, gim_bneck_tail*, gim_conv2d_bn_act with a residual operand) OR 4 when a converted value exceeds
@@ -139,10 +141,14 @@ int gim_posenc_add(const void* x, const float* pe, float* out_f32, void* out_t, 
  * (K, V rows with mask 0 do not contribute; Q rows with mask 0 give a zero message).
  * Arithmetic of step 1 at the coarse level (D = 32, H = 8): 16-bit operands -- exact products on the 16-bit MFMA, fp32 sums, 1/S applied
  * to the sums; fp32 operands -- fp32 MFMA on K and V/S.  Partial sums of row chunks are combined in a fixed order (run-to-run deterministic).
- * fp32 operands: 256-row chunks always -- a sequence's state does not depend on the batch it travels in, bit for bit.  16-bit operands: 256-row
- * chunks, 512-row ones when nb * ceil(S / 256) * 2 > 512 (one round of resident workgroups): across that threshold the association of the
- * fp32 additions differs (last-bit differences).  (GIM_LA_KV2 = 0 / 1 / 2 selects the earlier kernel shapes; default 3.) */
+ * The partials are those of 256-row chunks whatever workgroup shape the launch takes: a sequence's state does not depend on the batch it
+ * travels in, bit for bit.
+ * gim_linear_attention_finalize (version 111): the last step alone -- state = sum of `nchunk` partial states per sequence and head that somebody
+ * else wrote (gim_token_mlp_emit's fused KV state: one partial per 64-row tile) into a workspace of gim_linear_attention_ws_bytes_chunks bytes:
+ * [state: nb x H x (D D + D) fp32][partials: nb x H x nchunk x (D D + D) fp32]. */
 int64_t gim_linear_attention_ws_bytes(int nb, int S, int H, int D);
+int64_t gim_linear_attention_ws_bytes_chunks(int nb, int H, int D, int nchunk);
+int gim_linear_attention_finalize(float* kv_ws, int nb, int H, int D, int nchunk, gim_stream_t stream);
 int gim_linear_attention_kv(const void* k, const void* v, const uint8_t* kv_mask, float* kv_ws, int nb,
                             int S, int H, int D, int ldk, int ldv, int dtype, gim_stream_t stream);
 int gim_linear_attention_apply(const void* q, const uint8_t* q_mask, const float* kv_ws, void* out,
@@ -293,6 +299,15 @@ typedef struct gim_token_emit {
     int ld[GIM_TOKEN_EMIT_MAX];         /* row stride in elements (multiple of 8) */
     int act[GIM_TOKEN_EMIT_MAX];        /* GIM_ACT_NONE or GIM_ACT_ELU1 */
     int row_lo[GIM_TOKEN_EMIT_MAX], row_hi[GIM_TOKEN_EMIT_MAX];
+    /* Fused KV state (version 111).  kv_part[b] != NULL: blocks b (k, elu + 1) and b + 1 (v; same row range, whole 64-row tiles) are NOT
+     * written; each tile stores the partial state K^T V / kv_len, K^T 1 of its 64 rows (attentions.py:38-43) at
+     * kv_part[b][sequence][8 heads][kv_nchunk[b]][32 * 32 + 32] fp32, tile index = kv_tile0[b] + (tile's first row - row_lo[b]) / 64 counted
+     * over the consuming call's source rows (sequence = index / kv_nchunk, chunk = index % kv_nchunk).  kv_part is the partial area of a
+     * gim_linear_attention_kv workspace (gim_linear_attention_part) and gim_linear_attention_finalize turns it into the state.  out[] /
+     * ld[] of the two blocks are ignored. */
+    float* kv_part[GIM_TOKEN_EMIT_MAX];
+    int kv_nchunk[GIM_TOKEN_EMIT_MAX], kv_tile0[GIM_TOKEN_EMIT_MAX];
+    float kv_len[GIM_TOKEN_EMIT_MAX];
 } gim_token_emit;
 int gim_token_mlp_emit(const void* msg, void* xb, float* x32, const void* weights, const float* ln_params, const float* kv,
                        const uint8_t* q_mask, int R, int C, int L, int S, int ldm, int ldxb, int ldx32, float ln_eps,

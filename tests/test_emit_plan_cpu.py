@@ -74,3 +74,32 @@ def test_every_projection_is_fresh_and_produced_once(monkeypatch, names, same_le
     for li, xs, ss in calls:
         used |= {(li, 0, sd) for sd in xs} | {(li, b, sd) for sd in ss for b in (1, 2)}
     assert produced == used
+
+
+@pytest.mark.parametrize("names,same_len", list(itertools.product(SEQS, [True, False])),
+                         ids=[f"{'-'.join(n[0] for n in s)}-{'eq' if e else 'ne'}" for s, e in itertools.product(SEQS, [True, False])])
+def test_fused_kv_pairs_cover_their_consumer_exactly(monkeypatch, names, same_len):
+    """_kv_consumers (round 5: token tails hand the k / v rows of the next attention over as partial KV states): a consuming call either gets
+    its whole source from fused pairs -- every source side exactly once, from the tail that LAST updated that side -- or none of it; calls
+    fed by the initial projections are never fused."""
+    monkeypatch.setattr(L, "pack_token_emit", lambda ws, dev, tdt: 0)
+    calls, per_call, initial = L.LoFTR._emit_plan(_TF(names), same_len, "cpu", torch.float16)
+    cons = L.LoFTR._kv_consumers(calls, per_call, initial)
+    fed_initial = {(li, sd) for li, blk, sides in initial if blk == 1 for sd in sides}
+    covered = {}
+    for (ci, bi), cj in cons.items():
+        l2, blk, sides = per_call[ci][1][bi]
+        assert blk == 1 and per_call[ci][1][bi + 1] == (l2, 2, sides) and cj > ci and calls[cj][0] == l2
+        for sd in sides:
+            assert sd in calls[ci][1] and sd in calls[cj][2]                 # produced by a call that updates the side, consumed as a source
+            assert not any(sd in calls[c][1] for c in range(ci + 1, cj))      # ... and nobody updates the side in between
+            assert (cj, sd) not in covered
+            covered[(cj, sd)] = ci
+    for cj, (li, xs, ss) in enumerate(calls):
+        got = [sd for sd in ss if (cj, sd) in covered]
+        assert got == [] or got == list(ss), ("a call's source is fused for some sides only", cj)
+        if any((li, sd) in fed_initial for sd in ss):
+            assert got == []
+    # the benchmark's plan: everything but the first layer's calls is fused
+    if names == ["self", "cross"] * 4 and not same_len:
+        assert sorted({cj for cj in cons.values()}) == list(range(2, len(calls)))

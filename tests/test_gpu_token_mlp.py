@@ -266,3 +266,94 @@ def test_emitted_projections_with_padding_masks():
         assert torch.isfinite(outs[True][k]).all()
         assert e.max().item() < 2e-2 * scale and e.mean().item() < 1e-3 * scale, (k, e.max().item(), e.mean().item(), scale)
     assert abs(outs[True][2] - outs[False][2]) <= 0.05 * outs[False][2] + 2
+
+
+@pytest.mark.parametrize("tdt", KINDS, ids=KIDS)
+def test_token_mlp_fused_kv_state(tdt):
+    """Fused KV state (round 5): a (k, v) projection pair handed over as per-tile partial states K^T V / S, K^T 1 (attentions.py:38-43)
+    instead of rows -- against the row path on the same launch inputs: k / v rows emitted, then gim_linear_attention_kv.  Two producers
+    fill one consumer's workspace (4 sequences of 128 rows: sequences 0-1 from the first call, 2-3 from the second, whose pair is row-gated
+    to the last two of its three sequences); a plain q block rides along."""
+    from gim_amd import ops
+    from gim_amd._lib import ACT_ELU1, ACT_NONE
+    from gim_amd.packing import pack_token_emit, pack_token_mlp
+    L, H = 128, 8
+    layer = _layer(11)
+    g = torch.Generator().manual_seed(12)
+    wq, wk, wv = (torch.randn(256, 256, generator=g) / 16 for _ in range(3))
+    wts, ln, eps = pack_token_mlp(layer, "cuda", tdt)
+    ew = pack_token_emit([wq, wk, wv], "cuda", tdt)
+    launches = [(2 * L, 0, 0), (3 * L, L, 2 * (L // 64))]      # (rows, row_lo of the k / v blocks, consumer-relative first tile)
+    ins = [((0.5 * torch.randn(R, 256, generator=g)).to(tdt).cuda(), (torch.randn(R, 256, generator=g) * 2.0).cuda()) for R, _, _ in launches]
+
+    def run(fused, ws):
+        outs = []
+        for (R, lo, tile0), (msg, x32) in zip(launches, ins):
+            cat = torch.zeros(R, 512, dtype=tdt, device="cuda")
+            cat[:, :256] = x32.to(tdt)
+            xd = x32.clone()
+            qkv = torch.full((R, 768), 5.0, dtype=tdt, device="cuda")
+            if fused:
+                spec = [(qkv[:, :256], ACT_ELU1, 0, R), (None, ACT_ELU1, lo, R, (ws, 4, L // 64, tile0, L)), (None, ACT_NONE, lo, R)]
+            else:
+                spec = [(qkv[:, :256], ACT_ELU1, 0, R), (qkv[:, 256:512], ACT_ELU1, lo, R), (qkv[:, 512:], ACT_NONE, lo, R)]
+            ops.token_mlp(msg, cat[:, :256], xd, wts, ln, eps, emit=(ew, spec))
+            outs.append((xd, cat, qkv))
+        torch.cuda.synchronize()
+        return outs
+
+    rows = run(False, None)
+    ws = ops.kv_state_workspace(4, L // 64, "cuda")
+    ws.fill_(float("nan"))
+    fus = run(True, ws)
+    for (x0, c0, q0), (x1, c1, q1) in zip(rows, fus):
+        assert torch.equal(x0, x1) and torch.equal(c0, c1) and torch.equal(q0[:, :256], q1[:, :256])
+        assert bool((q1[:, 256:] == 5.0).all())                         # the fused pair writes no rows
+    ops.kv_state_finalize(ws, 4, L // 64)
+    k = torch.cat([rows[0][2][:, 256:512], rows[1][2][L:, 256:512]]).contiguous()
+    v = torch.cat([rows[0][2][:, 512:], rows[1][2][L:, 512:]]).contiguous()
+    ref, _ = ops.linear_attention_state(k, v, 4, L, H)
+    torch.cuda.synchronize()
+    n = 4 * H * (32 * 32 + 32)
+    got, want = ws[:n].cpu().view(4, H, 1056), ref[:n].cpu().view(4, H, 1056)
+    assert torch.isfinite(got).all()
+    scale = want.abs().max().item()
+    err = (got - want).abs().max().item()
+    assert err <= 2e-6 * scale + 1e-6, (err, scale)                      # same 16-bit products, fp32 sums in another order
+    # ... and against the definition on the emitted rows
+    kf, vf = k.float().cpu().view(4, L, H, 32), v.float().cpu().view(4, L, H, 32)
+    kv = torch.einsum("nshd,nshv->nhdv", kf.double(), vf.double() / L).float()
+    assert (got[..., :1024].view(4, H, 32, 32) - kv).abs().max().item() <= 1e-5 * scale
+    assert (got[..., 1024:] - kf.double().sum(1).float()).abs().max().item() <= 1e-5 * kf.sum(1).abs().max().item()
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_coarse_transformer_fused_kv_state_vs_row_path(precision):
+    """the whole forward with the k / v rows handed over as partial states (`kv_fused`, default) against the row path (k / v rows + la_kv
+    launches): same products, fp32 sums of the state in another order -- the match lists agree but for threshold-marginal entries"""
+    from tools import synth_loftr as S
+    model, _ = S.synthetic_model(precision)
+    model = model.cuda()
+    c0, c1 = S.textured_pairs(4, 256, 320, seed=21, frac=0.5)
+    c0, c1 = c0.cuda(), c1.cuda()
+    outs = {}
+    for fused in (True, False):
+        model.kv_fused = fused
+        model._invalidate()
+        for _ in range(2):   # eager, then the captured graph
+            d = {"image0": c0[:, :1], "image1": c1[:, :1], "color0": c0, "color1": c1}
+            model(d)
+        torch.cuda.synchronize()
+        outs[fused] = {k: d[k].cpu() for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts1_f")}
+    model.kv_fused = True
+    key = lambda o: set(zip(o["b_ids"].tolist(), o["i_ids"].tolist(), o["j_ids"].tolist()))   # noqa: E731
+    a, b = key(outs[True]), key(outs[False])
+    assert len(b) >= 200 and len(a ^ b) <= 0.01 * len(b) + 2, (len(a), len(b), len(a ^ b))
+    ia = {m: n for n, m in enumerate(zip(outs[True]["b_ids"].tolist(), outs[True]["i_ids"].tolist(), outs[True]["j_ids"].tolist()))}
+    ib = {m: n for n, m in enumerate(zip(outs[False]["b_ids"].tolist(), outs[False]["i_ids"].tolist(), outs[False]["j_ids"].tolist()))}
+    common = sorted(a & b)
+    sa, sb = torch.tensor([ia[m] for m in common]), torch.tensor([ib[m] for m in common])
+    # (a last-bit difference of an fp32 state flips 16-bit roundings downstream: the bf16 mode carries 8 significand bits per activation)
+    dm = (outs[True]["mconf"][sa] - outs[False]["mconf"][sb]).abs()
+    assert dm.max().item() < (1e-1 if precision == "bf16" else 2e-2) and dm.mean().item() < (2e-3 if precision == "bf16" else 5e-4), (dm.max().item(), dm.mean().item())
+    assert (outs[True]["mkpts1_f"][sa] - outs[False]["mkpts1_f"][sb]).abs().max().item() < 0.5

@@ -30,6 +30,11 @@
 // the same way (4 units per block and wave).  The stand-alone projection GEMMs (K = 256: 4 slabs of prologue / epilogue per tile,
 // 350 TFLOP/s) and their re-read of x disappear.
 //
+// LOCAL QUERIES (round 5): with `qwts` the elu + 1 query rows of the fused attention apply are not read from `msg` but projected HERE, from
+// the operand copy of x the tile loads anyway (q = elu(x Wq^T) + 1, transformer.py:42, attentions.py:31): 4 weight units in front of the
+// merge product, written to the A tile in the accumulator's row pattern.  The tail that updated the rows no longer emits a q block: 32 KiB
+// of stores and 32 KiB of loads per tile less, the same MFMAs in the same order (the values are bit-identical to the emitted ones).
+//
 // FUSED KV STATE (round 5): the k and v rows of a sequence have ONE reader -- the linear attention's state reduction KV = K^T V / S,
 // Ksum = K^T 1 (attentions.py:38-43) of the call they are the source of.  A (k, v) block pair flagged with `kv_part` is therefore not
 // written at all: both projections are computed with the MFMA operands SWAPPED (tokens = A, weights = B), which leaves a lane holding one
@@ -64,7 +69,8 @@ struct Args {
     const unsigned char* qmask;  // optional [R] padding mask of the query rows (attentions.py:36)
     int L;                       // rows per sequence (kv != NULL: must be a multiple of 64, rows of a tile share one sequence)
     float slen;                  // source length S (values were divided by it, attentions.py:41,45)
-    const unsigned short* msg;   // [R][ldm] bf16 attention output (or queries, see kv)
+    const unsigned short* msg;   // [R][ldm] bf16 attention output (or queries, see kv); not read when qwts != NULL
+    const uint4* qwts;           // NULL or the query projection of THIS call: 4 waves x 4 units x 8 fragments (pack_token_emit([Wq])); needs kv
     unsigned short* xb;          // [R][ldxb] bf16 operand copy of x (in: x, out: x + msg)
     float* x32;                  // [R][ldx32] fp32 residual stream (in / out)
     const uint4* wts;            // 4 waves x 28 units x 8 fragments
@@ -249,7 +255,11 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
     // Unit sequence: the 28 base units, then 4 per active projection block.
     int pf = 0;                                      // next base unit to request
     int pb = emask ? __ffs(emask) - 1 : -1, pq = 0;  // next projection unit to request: block, unit
+    const bool qloc = a.qwts != nullptr;             // the queries are projected here (4 units in front of the base stream)
+    const uint4* qwp = a.qwts + (size_t)L.w * 4 * UNIT_U4;
+    int pl = qloc ? 0 : 4;                           // next query-projection unit to request
     auto fetch = [&](W8& w) __attribute__((always_inline)) {
+        if (pl < 4) { wload(w, qwp + (size_t)pl * UNIT_U4, L.lane); ++pl; return; }
         if (pf < UNITS_PER_WAVE) { wload(w, wp + (size_t)pf * UNIT_U4, L.lane); ++pf; return; }
         if (pb < 0) return;
         wload(w, ewp + (size_t)(4 * pb + pq) * UNIT_U4, L.lane);
@@ -261,7 +271,7 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
     };
     W8 wa, wb;
     TT(0);
-    fetch(wa);   // merge, units 0 and 1: in flight during the tile loads
+    fetch(wa);   // merge (or query projection), units 0 and 1: in flight during the tile loads
     fetch(wb);
     // ---- A <- attention output rows, X <- operand copy of x (512 B rows: 32 lanes x 16 B, 8 rows per pass) ----------
     {
@@ -274,7 +284,7 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
             const int m = r0 + pass * 8 + (t >> 5);
             va[pass] = vx[pass] = make_uint4(0u, 0u, 0u, 0u);
             if (m < a.R) {
-                va[pass] = *(const uint4*)(a.msg + (size_t)m * a.ldm + slot * 8);
+                if (!qloc) va[pass] = *(const uint4*)(a.msg + (size_t)m * a.ldm + slot * 8);
                 vx[pass] = *(const uint4*)(a.xb + (size_t)m * a.ldxb + slot * 8);
             }
         }
@@ -282,11 +292,32 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
         for (int pass = 0; pass < ROWS / 8; ++pass) {
             const int row = pass * 8 + (t >> 5);
             const int off = row * ROWB + ((slot ^ (row & 15)) << 4);   // XOR on the low 4 slot bits: conflict-free b128 rows
-            *(uint4*)(A + off) = va[pass];
+            if (!qloc) *(uint4*)(A + off) = va[pass];
             *(uint4*)(X + off) = vx[pass];
         }
     }
     __syncthreads();
+    f32x16_t acc[2][2];
+    if (qloc) {
+        // ---- queries of this call: A <- elu(x Wq^T) + 1 of the tile's rows, this wave's 64 columns (same units, same order as a projection block) ----
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const char* tile = X + (q >> 1) * 256;
+            W8& w = (q & 1) ? wb : wa;
+            if (q == 0) mma_n64<true>(tile, L.a8, 0, 32 * ROWB, w, acc);
+            else mma_n64<false>(tile, L.a8, (q & 1) * 4, 32 * ROWB, w, acc);
+            fetch(w);
+        }
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    *(uint2*)(A + (32 * j + L.l31) * ROWB + (((8 * L.w + 4 * nf + rg) ^ L.sw) << 4) + L.lh * 8) =
+                        make_uint2(cvt_pk_h16(elu1(acc[nf][j][rg * 4]), elu1(acc[nf][j][rg * 4 + 1])), cvt_pk_h16(elu1(acc[nf][j][rg * 4 + 2]), elu1(acc[nf][j][rg * 4 + 3])));
+        __syncthreads();
+    }
     TT(1);
     if (a.kv) {
         // ---- linear-attention apply (attentions.py:44-45), in place on A: this wave owns heads 2w, 2w+1 = channels 64w..64w+63, and
@@ -341,7 +372,6 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
     }
     TT(2);
     // ---- merge: [64 x 256] x W_merge^T, this wave's 64 output channels (transformer.py:52) ----------------------------
-    f32x16_t acc[2][2];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {          // 4 units x 4 k16 steps = K 256
         const char* tile = A + (q >> 1) * 256;   // k16 steps 0..7 -> first 256 B of the row, 8..15 -> second
@@ -576,9 +606,9 @@ static int token_mlp_launch(const void* msg, void* xb, float* x32, const void* w
                             const uint8_t* q_mask, int R, int C_, int L, int S, int ldm, int ldxb, int ldx32, float ln_eps,
                             const gim_token_emit* em, gim_stream_t stream) {
     if (R == 0) return GIM_OK;
-    GIM_REQUIRE(msg && xb && x32 && weights && ln_params, "token_mlp: NULL pointer");
+    GIM_REQUIRE((msg || (em && em->q_weights)) && xb && x32 && weights && ln_params, "token_mlp: NULL pointer");
     GIM_REQUIRE(C_ == C, "token_mlp: built for d_model 256 (got %d)", C_);
-    GIM_REQUIRE(R > 0 && ldm >= C && ldxb >= C && ldx32 >= C && ldm % 8 == 0 && ldxb % 8 == 0 && ldx32 % 4 == 0, "token_mlp: bad strides");
+    GIM_REQUIRE(R > 0 && ((em && em->q_weights) || (ldm >= C && ldm % 8 == 0)) && ldxb >= C && ldx32 >= C && ldxb % 8 == 0 && ldx32 % 4 == 0, "token_mlp: bad strides");
     GIM_REQUIRE(!kv || (L > 0 && L % ROWS == 0 && R % L == 0 && S > 0), "token_mlp: fused attention apply needs L %% 64 == 0 and R %% L == 0 (L=%d R=%d)", L, R);
     static GimPerDevice attr;
     if (attr.needed()) {
@@ -590,7 +620,11 @@ static int token_mlp_launch(const void* msg, void* xb, float* x32, const void* w
     a.kv = kv; a.qmask = q_mask; a.L = L > 0 ? L : R; a.slen = (float)S;
     a.msg = (const unsigned short*)msg; a.xb = (unsigned short*)xb; a.x32 = x32; a.wts = (const uint4*)weights; a.ln = ln_params;
     a.R = R; a.ldm = ldm; a.ldxb = ldxb; a.ldx32 = ldx32; a.eps = ln_eps;
-    a.nblk = 0; a.ewts = nullptr;
+    a.nblk = 0; a.ewts = nullptr; a.qwts = nullptr;
+    if (em && em->q_weights) {
+        GIM_REQUIRE(kv, "token_mlp: q_weights (local query projection) needs the fused attention apply (kv)");
+        a.qwts = (const uint4*)em->q_weights;
+    }
     for (int b = 0; b < MAXBLK; ++b) {
         a.eout[b] = nullptr; a.eld[b] = 0; a.eact[b] = GIM_ACT_NONE; a.elo[b] = a.ehi[b] = 0;
         a.ekv[b] = nullptr; a.ekv_nchunk[b] = 1; a.ekv_tile0[b] = 0; a.ekv_inv_s[b] = 0.f;

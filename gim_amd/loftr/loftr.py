@@ -230,6 +230,8 @@ class LoFTR(nn.Module):
         self.tf_chains = flag("tf_chains", 2, config)
         # token tails write partial KV states instead of the k / v rows of the next attention (see _transformer_emit; False: rows + la_kv)
         self.kv_fused = flag("kv_fused", True, config)
+        # every token tail projects its own queries (no q rows between the calls; False: the updating tail emits them)
+        self.q_local = flag("q_local", True, config)
         self._packed = None
         self._health = None          # fp16 range guard word of the forward in flight (count[1] of its coarse matching), see _coarse_stage
         self._health_sync_left = 3   # forwards that still wait for the fine kernel to read its health bit at once (fp16 mode)
@@ -388,8 +390,10 @@ class LoFTR(nn.Module):
         if is_half(dt) and self.loftr_coarse.d_model == 256:
             for li, layer in enumerate(self.loftr_coarse.layers):
                 P[f"c{li}.tok"] = pack_token_mlp(layer, device, tdt)
+                P[f"c{li}.qtok"] = pack_token_emit([layer.q_proj.weight], device, tdt)   # the call's own query projection (q_local)
             for same_len in (True, False):
                 P["c.emit", same_len] = self._emit_plan(self.loftr_coarse, same_len, device, tdt)
+                P["c.emitk", same_len] = self._emit_plan(self.loftr_coarse, same_len, device, tdt, emit_q=False)
         fl = self.loftr_fine
         if is_half(dt) and fl.d_model == 128 and fl.nhead == 8 and fl.layer_names == ["self", "cross"] and self.W == 5:
             P["fine_fused"] = pack_fine_fused(fl.layers, device, tdt) + (fl.layers[0].norm1.eps,)
@@ -639,7 +643,7 @@ class LoFTR(nn.Module):
         ops.layernorm_residual(T.MLP[xs], g2, b2, T.X32[xs], T.X32[xs], T.CAT[xs, :C], e2)  # x + message
 
     @staticmethod
-    def _emit_plan(tf, same_len, device, tdt):
+    def _emit_plan(tf, same_len, device, tdt, emit_q=True):
         """Launch plan of a LocalFeatureTransformer whose token tails emit the projections (gim_token_mlp_emit).
         The call sequence (transformer.py:88-99) as (layer, query sides, source sides); after each call, the q / k / v projections
         its rows feed before they are updated again: in a cross layer the first call's rows are the source of the second call (k, v
@@ -660,7 +664,8 @@ class LoFTR(nn.Module):
                         need.setdefault((li, 1), []).append(sd)
                         need.setdefault((li, 2), []).append(sd)
                     if sd in xs:   # these rows are updated by that call: nothing later reads the current values
-                        need.setdefault((li, 0), []).append(sd)
+                        if emit_q:   # (emit_q = False: every call projects its own queries, token_mlp.hip "local queries")
+                            need.setdefault((li, 0), []).append(sd)
                         break
             return [(li, blk, tuple(sorted(sd))) for (li, blk), sd in need.items()]
 
@@ -708,7 +713,9 @@ class LoFTR(nn.Module):
         H = tf.nhead
         K = self.tf_chains if (name == "c" and self.tf_chains > 1 and n0 == n1 and n0 % self.tf_chains == 0 and self.debug is None
                                and (name + ".emit", False) in P) else 1
-        calls, per_call, initial = P[name + ".emit", L == S and K == 1]
+        # local queries: every call projects its own q rows from the operand copy of x it loads anyway -- no q blocks, no q rows
+        ql = bool(self.q_local) and self.debug is None and (name + ".emitk", False) in P
+        calls, per_call, initial = P[name + (".emitk" if ql else ".emit"), L == S and K == 1]
         T.QKV2 = torch.empty_like(T.QKV)
         QK = (T.QKV, T.QKV2)
         rows = (slice(0, n0 * L), slice(n0 * L, n0 * L + n1 * S))
@@ -779,7 +786,8 @@ class LoFTR(nn.Module):
                             assert len(spec[-1]) == 5 and spec[-1][2:4] == (lo, hi)
                             spec.append((None, ACT_NONE, lo, hi))
                     emit = (ew, spec)
-                ops.token_mlp(q[xs, :C], T.CAT[xs, :C], T.X32[xs], wts, lnp, eps, kv=kv, L=len_q, S=len_src, q_mask=qm, emit=emit)
+                ops.token_mlp(None if ql else q[xs, :C], T.CAT[xs, :C], T.X32[xs], wts, lnp, eps, kv=kv, L=len_q, S=len_src, q_mask=qm, emit=emit,
+                              q_weights=P[f"{name}{li}.qtok"] if ql else None)
             assert not kvws
             return [ws] + used
 

@@ -524,7 +524,7 @@ def bneck_tail_ds(t2, x_in, pk, act_next=ACT_RELU, out=None, health=None):
     return xo, t1n
 
 
-def token_mlp(msg, xb, x32, weights, ln_params, eps, kv=None, L=0, S=0, q_mask=None, emit=None):
+def token_mlp(msg, xb, x32, weights, ln_params, eps, kv=None, L=0, S=0, q_mask=None, emit=None, q_weights=None):
     """x += norm2(mlp.2(relu(mlp.0(cat[x, norm1(merge(msg))])))) on row views: msg [R, >=256] bf16, xb [R, >=256] bf16 (operand copy
     of x, updated in place), x32 [R, >=256] fp32 (updated in place).  With `kv` (the fp32 state of linear_attention_state) the
     attention's apply step is fused in front: `msg` then holds the elu+1 query rows of R / L sequences, S = source length.
@@ -532,18 +532,27 @@ def token_mlp(msg, xb, x32, weights, ln_params, eps, kv=None, L=0, S=0, q_mask=N
     act(x_new W_b^T) of the new x, written for the rows of the 64-row tiles that start in [row_lo, row_hi).
     A block entry with a fifth element (ws, nb_kv, nchunk, tile0, src_len) is the K block of a fused (k, v) pair -- the next entry is its V block, `out`
     of both may be None: nothing is written but each tile's partial KV state into the partial area of the linear-attention workspace `ws`
-    (kv_state_workspace) of the call that consumes these rows as its source; kv_state_finalize(ws, ...) completes it."""
-    _req_cuda(msg, xb, x32, weights, ln_params, kv, q_mask)
+    (kv_state_workspace) of the call that consumes these rows as its source; kv_state_finalize(ws, ...) completes it.
+    `q_weights` (with `kv`; pack_token_emit([Wq]) of this layer): `msg` may be None -- the query rows are projected inside the kernel from xb."""
+    if msg is None:
+        assert q_weights is not None and kv is not None, "token_mlp: msg=None needs q_weights and kv"
+        msg = xb
+    _req_cuda(msg, xb, x32, weights, ln_params, kv, q_mask, q_weights)
     assert msg.dtype in HALF and xb.dtype == msg.dtype and weights.dtype == msg.dtype and x32.dtype == torch.float32
     f16 = msg.dtype == torch.float16
     assert msg.stride(1) == 1 and xb.stride(1) == 1 and x32.stride(1) == 1 and msg.shape[0] == xb.shape[0] == x32.shape[0]
     R = msg.shape[0]
     flops = 2.0 * R * (256 * 256 + 512 * 512 + 512 * 256 + (32 * 256 if kv is not None else 0))
     em = None
+    if q_weights is not None:
+        assert kv is not None and q_weights.dtype == msg.dtype and q_weights.numel() == 256 * 256 and q_weights.is_contiguous()
+        em = _lib.TokenEmit()
+        em.q_weights = q_weights.data_ptr()
+        flops += 2.0 * R * 256 * 256
     if emit:
         ew, blocks = emit
         assert 0 < len(blocks) <= _lib.TokenEmit.MAX and ew.dtype == msg.dtype and ew.is_cuda and ew.numel() == len(blocks) * 256 * 256
-        em = _lib.TokenEmit()
+        em = em or _lib.TokenEmit()
         em.nblk, em.weights = len(blocks), ew.data_ptr()
         fused_v = False
         for b, blk in enumerate(blocks):

@@ -29,12 +29,14 @@ SEQS = [["self", "cross"] * 4, ["cross", "self"] * 2, ["self", "self", "cross", 
         ["cross", "cross", "cross"], ["self", "cross", "cross", "self", "self"]]
 
 
+@pytest.mark.parametrize("emit_q", [True, False], ids=["q-emitted", "q-local"])
 @pytest.mark.parametrize("names,same_len", list(itertools.product(SEQS, [True, False])),
                          ids=[f"{'-'.join(n[0] for n in s)}-{'eq' if e else 'ne'}" for s, e in itertools.product(SEQS, [True, False])])
-def test_every_projection_is_fresh_and_produced_once(monkeypatch, names, same_len):
+def test_every_projection_is_fresh_and_produced_once(monkeypatch, names, same_len, emit_q):
+    """emit_q = False (round 5, `q_local`): every call projects its own queries inside the token kernel -- the plan holds k / v blocks only"""
     packed = []
     monkeypatch.setattr(L, "pack_token_emit", lambda ws, dev, tdt: packed.append([int(w[0, 0]) for w in ws]) or len(packed) - 1)
-    calls, per_call, initial = L.LoFTR._emit_plan(_TF(names), same_len, "cpu", torch.float16)
+    calls, per_call, initial = L.LoFTR._emit_plan(_TF(names), same_len, "cpu", torch.float16, emit_q=emit_q)
     version = {0: 0, 1: 0}
     have = {}          # (layer, block, side) -> version of the rows it was computed from
     produced = set()
@@ -52,7 +54,7 @@ def test_every_projection_is_fresh_and_produced_once(monkeypatch, names, same_le
     assert calls == expect
     for (li, xs, ss), em in zip(calls, per_call):
         for sd in xs:
-            assert have.get((li, 0, sd)) == version[sd], ("stale / missing q", li, sd)
+            assert not emit_q or have.get((li, 0, sd)) == version[sd], ("stale / missing q", li, sd)
         for sd in ss:
             for blk in (1, 2):
                 assert have.get((li, blk, sd)) == version[sd], ("stale / missing k, v", li, blk, sd)
@@ -72,18 +74,19 @@ def test_every_projection_is_fresh_and_produced_once(monkeypatch, names, same_le
     # nothing is computed that no call reads
     used = set()
     for li, xs, ss in calls:
-        used |= {(li, 0, sd) for sd in xs} | {(li, b, sd) for sd in ss for b in (1, 2)}
+        used |= ({(li, 0, sd) for sd in xs} if emit_q else set()) | {(li, b, sd) for sd in ss for b in (1, 2)}
     assert produced == used
 
 
+@pytest.mark.parametrize("emit_q", [True, False], ids=["q-emitted", "q-local"])
 @pytest.mark.parametrize("names,same_len", list(itertools.product(SEQS, [True, False])),
                          ids=[f"{'-'.join(n[0] for n in s)}-{'eq' if e else 'ne'}" for s, e in itertools.product(SEQS, [True, False])])
-def test_fused_kv_pairs_cover_their_consumer_exactly(monkeypatch, names, same_len):
+def test_fused_kv_pairs_cover_their_consumer_exactly(monkeypatch, names, same_len, emit_q):
     """_kv_consumers (round 5: token tails hand the k / v rows of the next attention over as partial KV states): a consuming call either gets
     its whole source from fused pairs -- every source side exactly once, from the tail that LAST updated that side -- or none of it; calls
     fed by the initial projections are never fused."""
     monkeypatch.setattr(L, "pack_token_emit", lambda ws, dev, tdt: 0)
-    calls, per_call, initial = L.LoFTR._emit_plan(_TF(names), same_len, "cpu", torch.float16)
+    calls, per_call, initial = L.LoFTR._emit_plan(_TF(names), same_len, "cpu", torch.float16, emit_q=emit_q)
     cons = L.LoFTR._kv_consumers(calls, per_call, initial)
     fed_initial = {(li, sd) for li, blk, sides in initial if blk == 1 for sd in sides}
     covered = {}

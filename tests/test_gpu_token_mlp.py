@@ -357,3 +357,65 @@ def test_coarse_transformer_fused_kv_state_vs_row_path(precision):
     dm = (outs[True]["mconf"][sa] - outs[False]["mconf"][sb]).abs()
     assert dm.max().item() < (1e-1 if precision == "bf16" else 2e-2) and dm.mean().item() < (2e-3 if precision == "bf16" else 5e-4), (dm.max().item(), dm.mean().item())
     assert (outs[True]["mkpts1_f"][sa] - outs[False]["mkpts1_f"][sb]).abs().max().item() < 0.5
+
+
+@pytest.mark.parametrize("masked", [False, True], ids=["nomask", "qmask"])
+@pytest.mark.parametrize("tdt", KINDS, ids=KIDS)
+def test_token_mlp_local_queries_are_bit_identical_to_emitted_ones(tdt, masked):
+    """Local queries (round 5): a call that projects its own q rows from the operand copy of x (`q_weights`) against the same call fed with
+    the q rows the PREVIOUS tail emitted for it -- same units, same MFMA order, same elu + 1: every output bit agrees."""
+    from gim_amd import ops
+    from gim_amd._lib import ACT_ELU1
+    from gim_amd.packing import pack_token_emit, pack_token_mlp
+    nb, L, H = 3, 128, 8
+    R = nb * L
+    g = torch.Generator().manual_seed(31)
+    la, lb = _layer(32), _layer(33)
+    wq = torch.randn(256, 256, generator=g) / 16
+    qw = pack_token_emit([wq], "cuda", tdt)
+    wa, lna, epsa = pack_token_mlp(la, "cuda", tdt)
+    wb, lnb, epsb = pack_token_mlp(lb, "cuda", tdt)
+    msg = (0.5 * torch.randn(R, 256, generator=g)).to(tdt).cuda()
+    x32 = (torch.randn(R, 256, generator=g) * 2.0).cuda()
+    cat = torch.zeros(R, 512, dtype=tdt, device="cuda")
+    cat[:, :256] = x32.to(tdt)
+    qrows = torch.zeros(R, 256, dtype=tdt, device="cuda")
+    ops.token_mlp(msg, cat[:, :256], x32, wa, lna, epsa, emit=(qw, [(qrows, ACT_ELU1, 0, R)]))     # the updating tail: new x + its q rows
+    k = (torch.rand(R, 256, generator=g) + 0.5).to(tdt).cuda()
+    v = torch.randn(R, 256, generator=g).to(tdt).cuda()
+    kv, _ = ops.linear_attention_state(k, v, nb, L, H)
+    qm = None
+    if masked:
+        qm = (torch.rand(R, generator=g) > 0.2).to(torch.uint8).cuda()
+    outs = []
+    for local in (False, True):
+        c, x = cat.clone(), x32.clone()
+        ops.token_mlp(None if local else qrows, c[:, :256], x, wb, lnb, epsb, kv=kv, L=L, S=L, q_mask=qm, q_weights=qw if local else None)
+        torch.cuda.synchronize()
+        outs.append((c, x))
+    assert torch.isfinite(outs[0][1]).all() and not torch.equal(outs[0][1], x32)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_coarse_transformer_local_queries_vs_emitted_queries(precision):
+    """the whole forward with local queries (`q_local`, default) against the emitted-q path: identical from the second layer on, the first
+    layer's q rows come from the token kernel instead of the initial projection GEMM (another accumulation order inside K = 256)"""
+    from tools import synth_loftr as S
+    model, _ = S.synthetic_model(precision)
+    model = model.cuda()
+    c0, c1 = S.textured_pairs(4, 256, 320, seed=22, frac=0.5)
+    c0, c1 = c0.cuda(), c1.cuda()
+    outs = {}
+    for ql in (True, False):
+        model.q_local = ql
+        model._invalidate()
+        for _ in range(2):
+            d = {"image0": c0[:, :1], "image1": c1[:, :1], "color0": c0, "color1": c1}
+            model(d)
+        torch.cuda.synchronize()
+        outs[ql] = {k: d[k].cpu() for k in ("b_ids", "i_ids", "j_ids", "mconf")}
+    model.q_local = True
+    key = lambda o: set(zip(o["b_ids"].tolist(), o["i_ids"].tolist(), o["j_ids"].tolist()))   # noqa: E731
+    a, b = key(outs[True]), key(outs[False])
+    assert len(b) >= 200 and len(a ^ b) <= 0.01 * len(b) + 2, (len(a), len(b), len(a ^ b))

@@ -195,7 +195,7 @@ class LoFTR(nn.Module):
         # ... on split (hi + lo) operands -- image and 7x7 filters carried to 2^-22 instead of 2^-11
         # (profiles/r04_precision_sweep.txt: the stem alone is 57 % of the fp16 mode's mean |dmconf| and 3/4 of its index flips) ...
         # 'auto' (default): in the fp16 mode only.  The bf16 mode rounds every other activation to 8 bits, and the split buys it nothing
-        # measurable (bench.py `parity.split_stem` / `plain_stem`: 12 vs 13 flips of 1485, the same mean |dmconf|) for twice the
+        # measurable (bench.py `parity.split_stem` / `plain_stem`: 10-12 vs 13 flips of 1485 in two runs of the round, the same mean |dmconf| 0.0082) for twice the
         # stem's MFMAs: -0.07 ms per step without it (profiles/r05_la_finalize.txt).  True / False force it either way.
         self.stem_split = flag("stem_split", "auto", config)
         # ... on its own kernel (gim_stem7x7: filter bank resident in LDS, every input patch staged once) instead of the implicit GEMM

@@ -232,6 +232,10 @@ __device__ __forceinline__ void layernorm_rows(f32x16_t (&acc)[2][2], const floa
         }
 }
 
+// PROJ = true ("projection only", round 5): the tile is just the 16-bit rows `xb`; nothing of the layer runs, only the projection blocks behind
+// it -- the k / v pair of the FIRST layer, handed over as partial KV states like every later one (replaces the initial [k | v] projection GEMM,
+// its rows and the la_kv launches that read them).
+template <bool PROJ>
 __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lane L;
@@ -253,9 +257,9 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
     // Weight units are requested TWO ahead of their use into alternating register sets (wa: even units, wb: odd units): with one
     // set, unit u + 1 could only be requested once unit u's MFMAs had issued, and every unit waited out an L2 round trip.
     // Unit sequence: the 28 base units, then 4 per active projection block.
-    int pf = 0;                                      // next base unit to request
+    int pf = PROJ ? UNITS_PER_WAVE : 0;              // next base unit to request (projection only: none)
     int pb = emask ? __ffs(emask) - 1 : -1, pq = 0;  // next projection unit to request: block, unit
-    const bool qloc = a.qwts != nullptr;             // the queries are projected here (4 units in front of the base stream)
+    const bool qloc = !PROJ && a.qwts != nullptr;    // the queries are projected here (4 units in front of the base stream)
     const uint4* qwp = a.qwts + (size_t)L.w * 4 * UNIT_U4;
     int pl = qloc ? 0 : 4;                           // next query-projection unit to request
     auto fetch = [&](W8& w) __attribute__((always_inline)) {
@@ -284,7 +288,7 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
             const int m = r0 + pass * 8 + (t >> 5);
             va[pass] = vx[pass] = make_uint4(0u, 0u, 0u, 0u);
             if (m < a.R) {
-                if (!qloc) va[pass] = *(const uint4*)(a.msg + (size_t)m * a.ldm + slot * 8);
+                if (!PROJ && !qloc) va[pass] = *(const uint4*)(a.msg + (size_t)m * a.ldm + slot * 8);
                 vx[pass] = *(const uint4*)(a.xb + (size_t)m * a.ldxb + slot * 8);
             }
         }
@@ -292,12 +296,16 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
         for (int pass = 0; pass < ROWS / 8; ++pass) {
             const int row = pass * 8 + (t >> 5);
             const int off = row * ROWB + ((slot ^ (row & 15)) << 4);   // XOR on the low 4 slot bits: conflict-free b128 rows
+            if (PROJ) { *(uint4*)(A + off) = vx[pass]; continue; }   // projection only: the rows ARE the operand tile of the blocks
             if (!qloc) *(uint4*)(A + off) = va[pass];
             *(uint4*)(X + off) = vx[pass];
         }
     }
     __syncthreads();
     f32x16_t acc[2][2];
+    if constexpr (PROJ) {
+        if (!emask) return;
+    } else {   // ======== the layer itself (not re-indented: everything down to the operand tile of the new x) ========
     if (qloc) {
         // ---- queries of this call: A <- elu(x Wq^T) + 1 of the tile's rows, this wave's 64 columns (same units, same order as a projection block) ----
 #pragma unroll
@@ -483,6 +491,7 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
         }
     }
     __syncthreads();
+    }   // ======== !PROJ ========
     TT(8);
     char* t2 = X + L.w * 4096;   // wave-private [32 rows][64 channels] 16-bit: 16-byte slot s of row r at slot s ^ ((r >> 1) & 7), the
                                  // slot's 8-byte halves swapped for rows 16..31 (32 accumulator rows x 8 B hit 32 distinct bank pairs)
@@ -606,13 +615,15 @@ static int token_mlp_launch(const void* msg, void* xb, float* x32, const void* w
                             const uint8_t* q_mask, int R, int C_, int L, int S, int ldm, int ldxb, int ldx32, float ln_eps,
                             const gim_token_emit* em, gim_stream_t stream) {
     if (R == 0) return GIM_OK;
-    GIM_REQUIRE((msg || (em && em->q_weights)) && xb && x32 && weights && ln_params, "token_mlp: NULL pointer");
+    const bool proj = em && em->project_only;
+    GIM_REQUIRE((msg || proj || (em && em->q_weights)) && xb && (proj || (x32 && weights && ln_params)), "token_mlp: NULL pointer");
     GIM_REQUIRE(C_ == C, "token_mlp: built for d_model 256 (got %d)", C_);
-    GIM_REQUIRE(R > 0 && ((em && em->q_weights) || (ldm >= C && ldm % 8 == 0)) && ldxb >= C && ldx32 >= C && ldxb % 8 == 0 && ldx32 % 4 == 0, "token_mlp: bad strides");
+    GIM_REQUIRE(R > 0 && (proj || (em && em->q_weights) || (ldm >= C && ldm % 8 == 0)) && ldxb >= C && ldxb % 8 == 0 && (proj || (ldx32 >= C && ldx32 % 4 == 0)), "token_mlp: bad strides");
     GIM_REQUIRE(!kv || (L > 0 && L % ROWS == 0 && R % L == 0 && S > 0), "token_mlp: fused attention apply needs L %% 64 == 0 and R %% L == 0 (L=%d R=%d)", L, R);
     static GimPerDevice attr;
     if (attr.needed()) {
-        hipError_t e = hipFuncSetAttribute((const void*)token_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        hipError_t e = hipFuncSetAttribute((const void*)token_mlp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)token_mlp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) { gim_set_error("token_mlp: hipFuncSetAttribute(%d B LDS): %s", SMEM, hipGetErrorString(e)); return GIM_ERR_LAUNCH; }
         attr.done();
     }
@@ -651,7 +662,12 @@ static int token_mlp_launch(const void* msg, void* xb, float* x32, const void* w
             a.eout[b] = (unsigned short*)em->out[b]; a.eld[b] = em->ld[b]; a.eact[b] = em->act[b]; a.elo[b] = em->row_lo[b]; a.ehi[b] = em->row_hi[b];
         }
     }
-    hipLaunchKernelGGL(token_mlp_kernel, dim3((unsigned)((R + ROWS - 1) / ROWS)), dim3(256), SMEM, (hipStream_t)stream, a);
+    if (em && em->project_only) {
+        GIM_REQUIRE(a.nblk > 0 && !a.qwts && !kv, "token_mlp: project_only runs projection blocks only (nblk > 0, no q_weights, no kv)");
+        hipLaunchKernelGGL(token_mlp_kernel<true>, dim3((unsigned)((R + ROWS - 1) / ROWS)), dim3(256), SMEM, (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL(token_mlp_kernel<false>, dim3((unsigned)((R + ROWS - 1) / ROWS)), dim3(256), SMEM, (hipStream_t)stream, a);
+    }
     return gim_check_launch("token_mlp");
 }
 

@@ -232,6 +232,8 @@ class LoFTR(nn.Module):
         self.kv_fused = flag("kv_fused", True, config)
         # every token tail projects its own queries (no q rows between the calls; False: the updating tail emits them)
         self.q_local = flag("q_local", True, config)
+        # the first layer's [k | v] projection as partial KV states too (token kernel, projection only) instead of a GEMM + la_kv launches
+        self.kv_init = flag("kv_init", True, config)
         self._packed = None
         self._health = None          # fp16 range guard word of the forward in flight (count[1] of its coarse matching), see _coarse_stage
         self._health_sync_left = 3   # forwards that still wait for the fine kernel to read its health bit at once (fp16 mode)
@@ -391,6 +393,7 @@ class LoFTR(nn.Module):
             for li, layer in enumerate(self.loftr_coarse.layers):
                 P[f"c{li}.tok"] = pack_token_mlp(layer, device, tdt)
                 P[f"c{li}.qtok"] = pack_token_emit([layer.q_proj.weight], device, tdt)   # the call's own query projection (q_local)
+                P[f"c{li}.kvtok"] = pack_token_emit([layer.k_proj.weight, layer.v_proj.weight], device, tdt)   # projection-only launch of the initial tokens (kv_init)
             for same_len in (True, False):
                 P["c.emit", same_len] = self._emit_plan(self.loftr_coarse, same_len, device, tdt)
                 P["c.emitk", same_len] = self._emit_plan(self.loftr_coarse, same_len, device, tdt, emit_q=False)
@@ -725,6 +728,30 @@ class LoFTR(nn.Module):
         groups = {}
         for li, blk, sides in initial:
             groups.setdefault((li, sides), []).append(blk)
+        fuse_kv = bool(self.kv_fused) and T.MASK is None and self.debug is None
+        # ... except a [k | v] group when the states are handed over anyway (`kv_init`): the token kernel in its projection-only form writes the
+        # partial states of those rows -- no projection GEMM, no k / v rows, no la_kv launches for the first layer either.  One workspace per
+        # side (both sides in one when the sequences are equally long: a self layer over both images reads one contiguous state).
+        init_state = {}   # (layer, side) -> (workspace, index of the side's first sequence in it)
+        if fuse_kv and self.kv_init and ql:
+            for (li, sides), blks in list(groups.items()):
+                if sorted(blks) != [1, 2]:
+                    continue
+                del groups[(li, sides)]
+                ew = P[f"{name}{li}.kvtok"]
+                parts = [sides] if (len(sides) == 1 or L == S) else [(sd,) for sd in sides]
+                for part in parts:
+                    r = rs(part)
+                    nseq, slen = sum((n0, n1)[sd] for sd in part), (L if part[0] == 0 else S)
+                    ws_i = ops.kv_state_workspace(nseq, slen // 64, T.X32.device)
+                    nrow = r.stop - r.start
+                    ops.token_project(T.CAT[r, :C], (ew, [(None, ACT_ELU1, 0, nrow, (ws_i, nseq, slen // 64, 0, slen)), (None, ACT_NONE, 0, nrow)]))
+                    ops.kv_state_finalize(ws_i, nseq, slen // 64)
+                    off = 0
+                    for sd in part:
+                        init_state[(li, sd)] = (ws_i, off)
+                        off += (n0, n1)[sd]
+        T.init_state = init_state
         for (li, sides), blks in groups.items():
             p, r = f"{name}{li}.", rs(sides)
             x_t, q = T.CAT[r, :C], QK[li & 1]
@@ -741,7 +768,6 @@ class LoFTR(nn.Module):
         # A token tail that would emit them writes its tiles' partial states into that call's workspace instead; the call then only sums them
         # (gim_linear_attention_finalize) -- no k / v rows, no la_kv launch.  Not for calls fed by the initial projections, padded inputs
         # (the state reduction masks rows) or the debug dumps.
-        fuse_kv = bool(self.kv_fused) and T.MASK is None and self.debug is None
         consumers = self._kv_consumers(calls, per_call, initial) if fuse_kv else {}
 
         def run(rows_c, m0, m1, ws):
@@ -763,6 +789,11 @@ class LoFTR(nn.Module):
                 wts, lnp, eps = P[f"{name}{li}.tok"]
                 if ci in kvws:
                     kv = ops.kv_state_finalize(kvws.pop(ci), nb_src, len_src // 64)
+                elif all((li, sd) in init_state for sd in ss_s) and len({id(init_state[(li, sd)][0]) for sd in ss_s}) == 1:
+                    # the first layer's state, written before the chains forked: this call's sequences are a slice of it
+                    ws_i, off = init_state[(li, ss_s[0])]
+                    seq0 = off + (ss.start - rows[ss_s[0]].start) // len_src
+                    kv = ws_i[seq0 * H * (32 * 32 + 32):]
                 else:
                     ws, _ = ops.linear_attention_state(q[ss, C:2 * C], q[ss, 2 * C:], nb_src, len_src, H, ws, km)
                     kv = ws

@@ -554,26 +554,7 @@ def token_mlp(msg, xb, x32, weights, ln_params, eps, kv=None, L=0, S=0, q_mask=N
         assert 0 < len(blocks) <= _lib.TokenEmit.MAX and ew.dtype == msg.dtype and ew.is_cuda and ew.numel() == len(blocks) * 256 * 256
         em = em or _lib.TokenEmit()
         em.nblk, em.weights = len(blocks), ew.data_ptr()
-        fused_v = False
-        for b, blk in enumerate(blocks):
-            out, act, lo, hi = blk[:4]
-            if len(blk) > 4:      # K of a fused pair
-                ws, nb_kv, nchunk, tile0, src_len = blk[4]
-                _req_cuda(ws)
-                assert ws.dtype == torch.float32 and ws.is_contiguous() and b + 1 < len(blocks) and len(blocks[b + 1]) == 4
-                assert hi <= R and lo % 64 == 0 and hi % 64 == 0 and tile0 + (hi - lo) // 64 <= nb_kv * nchunk, "token_mlp: fused KV state: tile range"
-                state = nb_kv * 8 * (32 * 32 + 32)
-                assert ws.numel() >= state * (nchunk + 1), "token_mlp: KV-state workspace too small (kv_state_workspace)"
-                em.kv_part[b], em.kv_nchunk[b], em.kv_tile0[b], em.kv_len[b] = ws.data_ptr() + 4 * state, nchunk, tile0, float(src_len)
-                fused_v = True
-            elif fused_v:         # V of the pair
-                fused_v = False
-            else:
-                _req_cuda(out)
-                assert out.dtype == msg.dtype and out.stride(1) == 1 and out.shape[0] == R and out.shape[1] >= 256
-                em.out[b], em.ld[b] = out.data_ptr(), out.stride(0)
-            em.act[b], em.row_lo[b], em.row_hi[b] = act, lo, hi
-            flops += 2.0 * max(0, min(hi, R) - lo) * 256 * 256
+        flops += _fill_emit_blocks(em, blocks, R, msg.dtype)
     with _Timed("token_mlp", flops):
         if em is None:
             fn = lib.gim_token_mlp_f16 if f16 else lib.gim_token_mlp
@@ -599,6 +580,48 @@ def linear_attention_state(k, v, nb_kv, S, H, ws=None, kv_mask=None):
     check(lib.gim_linear_attention_kv(_p(k), _p(v), _p(kv_mask), _p(ws), nb_kv, S, H, D, k.stride(0), v.stride(0),
                                       gim_dtype(k), _stream()), "gim_linear_attention_kv")
     return ws, need
+
+
+def token_project(xb, emit):
+    """Projection blocks of the 16-bit rows `xb` [R, >= 256] as they are (gim_token_mlp_emit with project_only): `emit` as in token_mlp --
+    the first layer's (k, v) pair handed over as partial KV states instead of a projection GEMM, its rows and la_kv launches."""
+    _req_cuda(xb)
+    assert xb.dtype in HALF and xb.stride(1) == 1 and xb.shape[1] >= 256
+    ew, blocks = emit
+    R = xb.shape[0]
+    assert 0 < len(blocks) <= _lib.TokenEmit.MAX and ew.dtype == xb.dtype and ew.is_cuda and ew.numel() == len(blocks) * 256 * 256
+    em = _lib.TokenEmit()
+    em.nblk, em.weights, em.project_only = len(blocks), ew.data_ptr(), 1
+    _fill_emit_blocks(em, blocks, R, xb.dtype)
+    fn = lib.gim_token_mlp_emit_f16 if xb.dtype == torch.float16 else lib.gim_token_mlp_emit
+    with _Timed("token_mlp", 2.0 * sum(max(0, min(b[3], R) - b[2]) for b in blocks) * 256 * 256):
+        check(fn(None, _p(xb), None, None, None, None, None, R, 256, 0, 0, 0, xb.stride(0), 0, 0.0, ctypes.byref(em), _stream()), "gim_token_mlp_emit")
+
+
+def _fill_emit_blocks(em, blocks, R, dtype):
+    """block descriptors of a gim_token_emit (see token_mlp); returns the flops of the blocks"""
+    flops = 0.0
+    fused_v = False
+    for b, blk in enumerate(blocks):
+        out, act, lo, hi = blk[:4]
+        if len(blk) > 4:      # K of a fused pair
+            ws, nb_kv, nchunk, tile0, src_len = blk[4]
+            _req_cuda(ws)
+            assert ws.dtype == torch.float32 and ws.is_contiguous() and b + 1 < len(blocks) and len(blocks[b + 1]) == 4
+            assert hi <= R and lo % 64 == 0 and hi % 64 == 0 and tile0 + (hi - lo) // 64 <= nb_kv * nchunk, "token_mlp: fused KV state: tile range"
+            state = nb_kv * 8 * (32 * 32 + 32)
+            assert ws.numel() >= state * (nchunk + 1), "token_mlp: KV-state workspace too small (kv_state_workspace)"
+            em.kv_part[b], em.kv_nchunk[b], em.kv_tile0[b], em.kv_len[b] = ws.data_ptr() + 4 * state, nchunk, tile0, float(src_len)
+            fused_v = True
+        elif fused_v:         # V of the pair
+            fused_v = False
+        else:
+            _req_cuda(out)
+            assert out.dtype == dtype and out.stride(1) == 1 and out.shape[0] == R and out.shape[1] >= 256
+            em.out[b], em.ld[b] = out.data_ptr(), out.stride(0)
+        em.act[b], em.row_lo[b], em.row_hi[b] = act, lo, hi
+        flops += 2.0 * max(0, min(hi, R) - lo) * 256 * 256
+    return flops
 
 
 def kv_state_workspace(nb_kv, nchunk, device, H=8, D=32):

@@ -419,3 +419,60 @@ def test_coarse_transformer_local_queries_vs_emitted_queries(precision):
     key = lambda o: set(zip(o["b_ids"].tolist(), o["i_ids"].tolist(), o["j_ids"].tolist()))   # noqa: E731
     a, b = key(outs[True]), key(outs[False])
     assert len(b) >= 200 and len(a ^ b) <= 0.01 * len(b) + 2, (len(a), len(b), len(a ^ b))
+
+
+@pytest.mark.parametrize("tdt", KINDS, ids=KIDS)
+def test_token_project_first_layer_state(tdt):
+    """Projection only (round 5, `kv_init`): the first layer's (k, v) pair of the initial tokens as partial KV states straight from the rows --
+    against the row path it replaces: [k | v] projection GEMM with elu + 1 on k (gim_conv2d_bn_act), then gim_linear_attention_kv."""
+    from gim_amd import ops
+    from gim_amd._lib import ACT_ELU1, ACT_NONE
+    from gim_amd.packing import pack_conv, pack_token_emit
+    from gim_amd._lib import GIM_BF16, GIM_F16
+    nb, L, H = 5, 192, 8
+    R = nb * L
+    g = torch.Generator().manual_seed(41)
+    wk, wv = (torch.randn(256, 256, generator=g) / 16 for _ in range(2))
+    cat = torch.zeros(R, 512, dtype=tdt, device="cuda")                      # the engine's [x | msg] buffer: x rows are a strided view
+    cat[:, :256] = torch.randn(R, 256, generator=g).to(tdt).cuda()
+    ew = pack_token_emit([wk, wv], "cuda", tdt)
+    ws = ops.kv_state_workspace(nb, L // 64, "cuda")
+    ws.fill_(float("nan"))
+    ops.token_project(cat[:, :256], (ew, [(None, ACT_ELU1, 0, R, (ws, nb, L // 64, 0, L)), (None, ACT_NONE, 0, R)]))
+    ops.kv_state_finalize(ws, nb, L // 64)
+    kvrows = torch.empty(R, 512, dtype=tdt, device="cuda")
+    ops.linear(cat[:, :256], pack_conv(torch.cat([wk, wv], 0), None, GIM_F16 if tdt == torch.float16 else GIM_BF16, "cuda"), kvrows, ACT_ELU1, True, act_cols=256)
+    ref, _ = ops.linear_attention_state(kvrows[:, :256], kvrows[:, 256:], nb, L, H)
+    torch.cuda.synchronize()
+    n = nb * H * (32 * 32 + 32)
+    got, want = ws[:n].cpu(), ref[:n].cpu()
+    assert torch.isfinite(got).all()
+    scale = want.abs().max().item()
+    # the rows differ in the last 16-bit digit here and there (another accumulation order inside K = 256 before the rounding), the sums follow
+    tol = 2e-3 if tdt == torch.bfloat16 else 3e-4
+    assert (got - want).abs().max().item() <= tol * scale, ((got - want).abs().max().item(), scale)
+    assert (got - want).abs().mean().item() <= tol / 8 * scale
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_coarse_transformer_first_layer_state_vs_projection_gemm(precision):
+    """the whole forward with the first layer's k / v handed over as partial states by the projection-only token kernel (`kv_init`, default)
+    against the projection GEMM + la_kv launches"""
+    from tools import synth_loftr as S
+    model, _ = S.synthetic_model(precision)
+    model = model.cuda()
+    c0, c1 = S.textured_pairs(4, 256, 320, seed=23, frac=0.5)
+    c0, c1 = c0.cuda(), c1.cuda()
+    outs = {}
+    for ki in (True, False):
+        model.kv_init = ki
+        model._invalidate()
+        for _ in range(2):
+            d = {"image0": c0[:, :1], "image1": c1[:, :1], "color0": c0, "color1": c1}
+            model(d)
+        torch.cuda.synchronize()
+        outs[ki] = {k: d[k].cpu() for k in ("b_ids", "i_ids", "j_ids", "mconf")}
+    model.kv_init = True
+    key = lambda o: set(zip(o["b_ids"].tolist(), o["i_ids"].tolist(), o["j_ids"].tolist()))   # noqa: E731
+    a, b = key(outs[True]), key(outs[False])
+    assert len(b) >= 200 and len(a ^ b) <= 0.01 * len(b) + 2, (len(a), len(b), len(a ^ b))

@@ -17,7 +17,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 # kernel (substring of the demangled name) -> (max VGPRs incl. AGPRs, max scratch bytes per lane)
 HOT = {
-    "token_mlp_kernel(": (256, 200),                # 192 B: the projection-block descriptors of the by-value argument struct, indexed at run time, + 28 registers spilled around the emit loop since the fused KV state (round 5; none inside the merge / mlp phases)
+    "token_mlp_kernel<false>(": (256, 200),                # 192 B: the projection-block descriptors of the by-value argument struct, indexed at run time, + 28 registers spilled around the emit loop since the fused KV state (round 5; none inside the merge / mlp phases)
     "fine_fused_kernel(": (256, 104),               # 84-96 B: 20-23 spilled registers (the resident set of two matches is the design's limit)
     "bneck_tail_kernel<256, 256, 4, false>": (256, 0),
     "bneck_tail_kernel<128, 128, 8, false>": (256, 0),
@@ -101,7 +101,7 @@ def test_every_code_object_targets_gfx950_wave64():
     ks = _kernels()
     # (the metadata was parsed per object in _kernels(); here: the flagship kernels exist in both 16-bit flavours' objects and nothing
     #  was built for another target -- _kernels() asserts the target string of every object)
-    assert any("token_mlp_kernel" in n for n in ks) and any("la_kv_h16_kernel" in n for n in ks)
+    assert any("token_mlp_kernel<false>" in n for n in ks) and any("token_mlp_kernel<true>" in n for n in ks) and any("la_kv_h16_kernel" in n for n in ks)
 
 
 def test_kv_reduction_inner_loop_is_on_the_16bit_mfma():

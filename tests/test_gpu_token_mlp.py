@@ -476,3 +476,32 @@ def test_coarse_transformer_first_layer_state_vs_projection_gemm(precision):
     key = lambda o: set(zip(o["b_ids"].tolist(), o["i_ids"].tolist(), o["j_ids"].tolist()))   # noqa: E731
     a, b = key(outs[True]), key(outs[False])
     assert len(b) >= 200 and len(a ^ b) <= 0.01 * len(b) + 2, (len(a), len(b), len(a ^ b))
+
+
+def test_padded_inputs_keep_the_row_path_for_k_v_and_agree_with_emitted_queries():
+    """padding masks: the state reduction masks k / v ROWS, so the fused KV state is off (rows + la_kv launches) while the queries stay local
+    (the query mask acts in the apply step) -- against the same forward with emitted q rows"""
+    from tools import synth_loftr as S
+    model, _ = S.synthetic_model("fp16")
+    model = model.cuda()
+    c0, c1 = S.textured_pairs(2, 256, 256, seed=9)
+    m0 = torch.zeros(2, 32, 32, dtype=torch.bool); m1 = torch.zeros(2, 32, 32, dtype=torch.bool)
+    for b, ((h0, w0), (h1, w1)) in enumerate([((32, 28), (30, 32)), ((24, 32), (32, 32))]):
+        m0[b, :h0, :w0] = True; m1[b, :h1, :w1] = True
+    outs = {}
+    for ql in (True, False):
+        model.q_local = ql
+        model._invalidate()
+        for _ in range(2):
+            d = {"image0": c0[:, :1].cuda(), "image1": c1[:, :1].cuda(), "color0": c0.cuda(), "color1": c1.cuda(), "mask0": m0.cuda(), "mask1": m1.cuda()}
+            model(d)
+        torch.cuda.synchronize()
+        outs[ql] = {k: d[k].cpu() for k in ("b_ids", "i_ids", "j_ids", "mconf")}
+    model.q_local = True
+    key = lambda o: set(zip(o["b_ids"].tolist(), o["i_ids"].tolist(), o["j_ids"].tolist()))   # noqa: E731
+    a, b = key(outs[True]), key(outs[False])
+    assert len(b) >= 50 and len(a ^ b) <= 0.02 * len(b) + 2, (len(a), len(b), len(a ^ b))
+    # masked coarse cells never match (coarse_matching.py:117-119)
+    for o in outs.values():
+        for bb, i, j in zip(o["b_ids"].tolist(), o["i_ids"].tolist(), o["j_ids"].tolist()):
+            assert m0[bb].reshape(-1)[i] and m1[bb].reshape(-1)[j]

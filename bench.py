@@ -640,6 +640,7 @@ def main():
                                         (" hi+lo pairs (split-operand first convolution)" if model._split() else ""),
                        "parallelism": f"pairs sharded over {world} GPU(s), no collective per step",
                        "hip_graph": bool(model.use_graph), "transformer_pair_chains": int(getattr(model, "tf_chains", 1)),
+                       "transformer_rows": {k: bool(getattr(model, k, False)) for k in ("q_local", "kv_fused", "kv_init")},
                        "readback": f"match count every step (host sync) + the packed match rows, {readback_bytes // max(1, args.steps)} B per step, to pinned host "
                                    "memory inside the timed region",
                        "baseline_dtype_note": "BASELINE config 2 names bf16: the headline mode since round 5 (rounds 3-4 headlined fp16 = `fp16_mode` here: "

@@ -54,7 +54,7 @@ class TokenEmit(ctypes.Structure):
     _fields_ = [("nblk", c_int), ("weights", c_void_p), ("out", c_void_p * 6), ("ld", c_int * 6), ("act", c_int * 6),
                 ("row_lo", c_int * 6), ("row_hi", c_int * 6),
                 ("kv_part", c_void_p * 6), ("kv_nchunk", c_int * 6), ("kv_tile0", c_int * 6), ("kv_len", c_float * 6),
-                ("q_weights", c_void_p), ("project_only", c_int)]
+                ("q_weights", c_void_p), ("project_only", c_int), ("pe_feat", c_void_p), ("pe", c_void_p), ("pe_ld", c_int), ("pe_hw", c_int)]
 
 
 class LgAssignArgs(ctypes.Structure):

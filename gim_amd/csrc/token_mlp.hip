@@ -71,6 +71,10 @@ struct Args {
     float slen;                  // source length S (values were divided by it, attentions.py:41,45)
     const unsigned short* msg;   // [R][ldm] bf16 attention output (or queries, see kv); not read when qwts != NULL
     const uint4* qwts;           // NULL or the query projection of THIS call: 4 waves x 4 units x 8 fragments (pack_token_emit([Wq])); needs kv
+    // projection only, with the positional encoding in front (loftr.py:74-75): rows = feat + pe[row % pe_hw], written to x32 and xb as well
+    const unsigned short* feat;  // NULL: the rows are read from xb
+    const float* pe;             // [pe_hw][256] fp32
+    int ldf, pe_hw;
     unsigned short* xb;          // [R][ldxb] bf16 operand copy of x (in: x, out: x + msg)
     float* x32;                  // [R][ldx32] fp32 residual stream (in / out)
     const uint4* wts;            // 4 waves x 28 units x 8 fragments
@@ -278,7 +282,38 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
     fetch(wa);   // merge (or query projection), units 0 and 1: in flight during the tile loads
     fetch(wb);
     // ---- A <- attention output rows, X <- operand copy of x (512 B rows: 32 lanes x 16 B, 8 rows per pass) ----------
-    {
+    if (PROJ && a.feat) {
+        // x = feat + pe (gim_posenc_add's arithmetic: 16-bit feature -> fp32, + fp32 table row, one rounding for the operand copy); every load
+        // of the lane is in flight before the first store (the stores alias the loads for all the compiler knows)
+        const int t = threadIdx.x, slot = t & 31;
+        uint4 vf[ROWS / 8];
+        float4 p0[ROWS / 8], p1[ROWS / 8];
+#pragma unroll
+        for (int pass = 0; pass < ROWS / 8; ++pass) {
+            const int m = r0 + pass * 8 + (t >> 5);
+            vf[pass] = make_uint4(0u, 0u, 0u, 0u);
+            p0[pass] = p1[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < a.R) {
+                vf[pass] = *(const uint4*)(a.feat + (size_t)m * a.ldf + slot * 8);
+                const float* pp = a.pe + (size_t)(m % a.pe_hw) * C + slot * 8;
+                p0[pass] = *(const float4*)pp;
+                p1[pass] = *(const float4*)(pp + 4);
+            }
+        }
+#pragma unroll
+        for (int pass = 0; pass < ROWS / 8; ++pass) {
+            const int row = pass * 8 + (t >> 5), m = r0 + row;
+            const float4 lo = make_float4(h16_lo(vf[pass].x) + p0[pass].x, h16_hi(vf[pass].x) + p0[pass].y, h16_lo(vf[pass].y) + p0[pass].z, h16_hi(vf[pass].y) + p0[pass].w);
+            const float4 hi = make_float4(h16_lo(vf[pass].z) + p1[pass].x, h16_hi(vf[pass].z) + p1[pass].y, h16_lo(vf[pass].w) + p1[pass].z, h16_hi(vf[pass].w) + p1[pass].w);
+            const uint4 o = make_uint4(cvt_pk_h16(lo.x, lo.y), cvt_pk_h16(lo.z, lo.w), cvt_pk_h16(hi.x, hi.y), cvt_pk_h16(hi.z, hi.w));
+            if (m < a.R) {
+                *(float4*)(a.x32 + (size_t)m * a.ldx32 + slot * 8) = lo;
+                *(float4*)(a.x32 + (size_t)m * a.ldx32 + slot * 8 + 4) = hi;
+                *(uint4*)(a.xb + (size_t)m * a.ldxb + slot * 8) = o;
+            }
+            *(uint4*)(A + row * ROWB + ((slot ^ (row & 15)) << 4)) = (m < a.R) ? o : make_uint4(0u, 0u, 0u, 0u);
+        }
+    } else {
         // all 16 row loads of a lane are in flight before the first LDS write: ONE HBM round trip (measured with the phase stamps
         // of -DGIM_TOKEN_TIMING: 14.3 k cycles for this phase when the loop was rolled 4 passes at a time)
         const int t = threadIdx.x, slot = t & 31;
@@ -632,6 +667,12 @@ static int token_mlp_launch(const void* msg, void* xb, float* x32, const void* w
     a.msg = (const unsigned short*)msg; a.xb = (unsigned short*)xb; a.x32 = x32; a.wts = (const uint4*)weights; a.ln = ln_params;
     a.R = R; a.ldm = ldm; a.ldxb = ldxb; a.ldx32 = ldx32; a.eps = ln_eps;
     a.nblk = 0; a.ewts = nullptr; a.qwts = nullptr;
+    a.feat = nullptr; a.pe = nullptr; a.ldf = 0; a.pe_hw = 1;
+    if (proj && em->pe) {
+        GIM_REQUIRE(em->pe_feat && em->pe_hw > 0 && em->pe_ld >= C && em->pe_ld % 8 == 0 && x32 && ldx32 >= C && ldx32 % 4 == 0 && ((uintptr_t)em->pe_feat & 15) == 0 && ((uintptr_t)em->pe & 15) == 0,
+                    "token_mlp: positional encoding in front of the projection: feature rows %p (stride %d), table %p x %d rows, x32 %p", em->pe_feat, em->pe_ld, em->pe, em->pe_hw, (void*)x32);
+        a.feat = (const unsigned short*)em->pe_feat; a.pe = em->pe; a.ldf = em->pe_ld; a.pe_hw = em->pe_hw;
+    }
     if (em && em->q_weights) {
         GIM_REQUIRE(kv, "token_mlp: q_weights (local query projection) needs the fused attention apply (kv)");
         a.qwts = (const uint4*)em->q_weights;

@@ -234,6 +234,7 @@ class LoFTR(nn.Module):
         self.q_local = flag("q_local", True, config)
         # the first layer's [k | v] projection as partial KV states too (token kernel, projection only) instead of a GEMM + la_kv launches
         self.kv_init = flag("kv_init", True, config)
+        self.pos_fused = flag("pos_fused", True, config)   # ... with the positional encoding added on the fly by that launch (False: gim_posenc_add in front)
         self._packed = None
         self._health = None          # fp16 range guard word of the forward in flight (count[1] of its coarse matching), see _coarse_stage
         self._health_sync_left = 3   # forwards that still wait for the fine kernel to read its health bit at once (fp16 mode)
@@ -603,6 +604,8 @@ class LoFTR(nn.Module):
             self.MLP = torch.empty(R, C, dtype=tdt, device=dev)
             self.ws = None
             self.MASK = None  # optional uint8 [R] padding mask aligned with the rows (coarse level only)
+            self.pos = None   # [(feature rows, pos-encoding table)] per side when the tokens still lack their positional encoding (coarse level)
+            self.pos_all = None
 
     def _encoder_layer(self, P, p, T, xs, ss, nb, L, S, H, have_q=False, with_q_of_source=False):
         """LoFTREncoderLayer.forward (transformer.py:35-58) on row ranges xs (queries) / ss (source).
@@ -745,13 +748,26 @@ class LoFTR(nn.Module):
                     nseq, slen = sum((n0, n1)[sd] for sd in part), (L if part[0] == 0 else S)
                     ws_i = ops.kv_state_workspace(nseq, slen // 64, T.X32.device)
                     nrow = r.stop - r.start
-                    ops.token_project(T.CAT[r, :C], (ew, [(None, ACT_ELU1, 0, nrow, (ws_i, nseq, slen // 64, 0, slen)), (None, ACT_NONE, 0, nrow)]))
+                    # the positional encoding of these rows on the fly (`pos_fused`) when they still lack it and one table serves the launch
+                    pos = None
+                    if self.pos_fused and T.pos is not None and all(T.pos[sd] is not None for sd in part):
+                        if len(part) == 1:
+                            pos = (T.pos[part[0]][0], T.pos[part[0]][1], T.X32[r])
+                        elif T.pos_all is not None and T.pos[0][1] is T.pos[1][1]:
+                            pos = (T.pos_all, T.pos[0][1], T.X32[r])
+                        if pos is not None:
+                            for sd in part:
+                                T.pos[sd] = None
+                    if pos is None:
+                        self._posenc(T, rows, part)
+                    ops.token_project(T.CAT[r, :C], (ew, [(None, ACT_ELU1, 0, nrow, (ws_i, nseq, slen // 64, 0, slen)), (None, ACT_NONE, 0, nrow)]), pos=pos)
                     ops.kv_state_finalize(ws_i, nseq, slen // 64)
                     off = 0
                     for sd in part:
                         init_state[(li, sd)] = (ws_i, off)
                         off += (n0, n1)[sd]
         T.init_state = init_state
+        self._posenc(T, rows)   # whatever the projection-only launches did not cover
         for (li, sides), blks in groups.items():
             p, r = f"{name}{li}.", rs(sides)
             x_t, q = T.CAT[r, :C], QK[li & 1]
@@ -839,6 +855,18 @@ class LoFTR(nn.Module):
             main.wait_stream(s_)
         T.keep = keep
 
+    @staticmethod
+    def _posenc(T, rows, sides=(0, 1)):
+        """pos_encoding + 'n c h w -> n (h w) c' (loftr.py:74-75) of the sides that still lack it: feature rows + table -> X32 and the operand copy"""
+        if T.pos is None:
+            return
+        C = T.X32.shape[1]
+        for sd in sides:
+            if T.pos[sd] is not None:
+                feat, pe = T.pos[sd]
+                ops.posenc_add(feat, pe, T.X32[rows[sd]], T.CAT[rows[sd], :C])
+                T.pos[sd] = None
+
     def _transformer(self, P, name, tf, T, n0, L, n1, S):
         """LocalFeatureTransformer.forward (transformer.py:80-101).  Rows [0, n0*L) are feat0's tokens,
         rows [n0*L, n0*L + n1*S) feat1's; n0 == n1 sequences on each side."""
@@ -848,6 +876,7 @@ class LoFTR(nn.Module):
         if (self.token_emit and self.token_fused and (name + ".emit", L == S) in P and L % 64 == 0 and S % 64 == 0 and H == 8
                 and T.X32.shape[1] == 256 and all(f"{name}{li}.tok" in P for li in range(len(tf.layer_names)))):
             return self._transformer_emit(P, name, tf, T, n0, L, n1, S)
+        self._posenc(T, (r0, r1))
         for li, kind in enumerate(tf.layer_names):
             p = f"{name}{li}."
             if kind == "self":
@@ -897,8 +926,10 @@ class LoFTR(nn.Module):
             T.MASK = torch.empty(bs * (L + S), dtype=torch.uint8, device=dev)
             T.MASK[r0].copy_(mask0.reshape(-1))
             T.MASK[r1].copy_(mask1.reshape(-1))
-        ops.posenc_add(c0.reshape(-1, C), self._pos_encoding(C, *hw0_c, dev), T.X32[r0], T.CAT[r0, :C])
-        ops.posenc_add(c1.reshape(-1, C), self._pos_encoding(C, *hw1_c, dev), T.X32[r1], T.CAT[r1, :C])
+        # (the positional encoding itself runs inside _transformer: in front of the first layer's projections -- the projection-only token
+        #  kernel adds it on the fly where it can, gim_posenc_add does it otherwise)
+        T.pos = [(c0.reshape(-1, C), self._pos_encoding(C, *hw0_c, dev)), (c1.reshape(-1, C), self._pos_encoding(C, *hw1_c, dev))]
+        T.pos_all = c_all.reshape(-1, C) if len(xs) == 1 else None    # both sides' feature rows as one tensor (same image shapes)
         self._transformer(P, "c", self.loftr_coarse, T, bs, L, bs, S)
         # 3. coarse matching (coarse_matching.py:88-259), fused
         mc = cfg["match_coarse"]

@@ -582,9 +582,11 @@ def linear_attention_state(k, v, nb_kv, S, H, ws=None, kv_mask=None):
     return ws, need
 
 
-def token_project(xb, emit):
+def token_project(xb, emit, pos=None):
     """Projection blocks of the 16-bit rows `xb` [R, >= 256] as they are (gim_token_mlp_emit with project_only): `emit` as in token_mlp --
-    the first layer's (k, v) pair handed over as partial KV states instead of a projection GEMM, its rows and la_kv launches."""
+    the first layer's (k, v) pair handed over as partial KV states instead of a projection GEMM, its rows and la_kv launches.
+    `pos` = (feat [R, 256] 16-bit rows, pe [hw, 256] fp32, x32 [R, >= 256] fp32 row view): the positional encoding in front (posenc_add's
+    arithmetic) -- the kernel computes the rows feat + pe[row % hw] itself and WRITES them to x32 and xb before it projects them."""
     _req_cuda(xb)
     assert xb.dtype in HALF and xb.stride(1) == 1 and xb.shape[1] >= 256
     ew, blocks = emit
@@ -592,10 +594,18 @@ def token_project(xb, emit):
     assert 0 < len(blocks) <= _lib.TokenEmit.MAX and ew.dtype == xb.dtype and ew.is_cuda and ew.numel() == len(blocks) * 256 * 256
     em = _lib.TokenEmit()
     em.nblk, em.weights, em.project_only = len(blocks), ew.data_ptr(), 1
+    x32 = None
+    if pos is not None:
+        feat, pe, x32 = pos
+        _req_cuda(feat, pe, x32)
+        assert feat.dtype == xb.dtype and feat.shape == (R, 256) and feat.stride(1) == 1 and pe.dtype == torch.float32 and pe.shape[1] == 256 and pe.is_contiguous()
+        assert x32.dtype == torch.float32 and x32.shape[0] == R and x32.stride(1) == 1 and x32.shape[1] >= 256
+        em.pe_feat, em.pe, em.pe_ld, em.pe_hw = feat.data_ptr(), pe.data_ptr(), feat.stride(0), pe.shape[0]
     _fill_emit_blocks(em, blocks, R, xb.dtype)
     fn = lib.gim_token_mlp_emit_f16 if xb.dtype == torch.float16 else lib.gim_token_mlp_emit
     with _Timed("token_mlp", 2.0 * sum(max(0, min(b[3], R) - b[2]) for b in blocks) * 256 * 256):
-        check(fn(None, _p(xb), None, None, None, None, None, R, 256, 0, 0, 0, xb.stride(0), 0, 0.0, ctypes.byref(em), _stream()), "gim_token_mlp_emit")
+        check(fn(None, _p(xb), _p(x32), None, None, None, None, R, 256, 0, 0, 0, xb.stride(0), x32.stride(0) if x32 is not None else 0, 0.0,
+                 ctypes.byref(em), _stream()), "gim_token_mlp_emit")
 
 
 def _fill_emit_blocks(em, blocks, R, dtype):

@@ -36,7 +36,7 @@ enum { GIM_OK = 0, GIM_ERR_INVALID = -1, GIM_ERR_LAUNCH = -2, GIM_ERR_UNSUPPORTE
 /* 110 (round 5): the fp16 range-guard word is an ARGUMENT of the entry points that use it (`health` of gim_bneck64_fused*,
  * gim_bneck_tail*, gim_conv_args.health; gim_set_range_guard() is gone), and gim_coarse_match's `count` is int32[2 + N] (count[1] = health
  * word, per-pair counts from count[2]) -- a caller bound to version 100 must be rebuilt.
- * 111: struct gim_token_emit grew the kv_part / kv_nchunk / kv_tile0 / kv_len arrays (fused KV state), q_weights (local queries) and project_only; zero them for
+ * 111: struct gim_token_emit grew the kv_part / kv_nchunk / kv_tile0 / kv_len arrays (fused KV state), q_weights (local queries), project_only and pe_*; zero them for
  * the old behaviour;
  * new entries gim_linear_attention_finalize, gim_linear_attention_ws_bytes_chunks. */
 int gim_version(void);
@@ -316,6 +316,11 @@ typedef struct gim_token_emit {
     /* Projection only (version 111).  != 0: nothing of the layer runs -- msg, x32, weights, ln_params, kv may be NULL -- the blocks are
      * projections of the 16-bit rows `xb` as they are (the first layer's k / v pair as partial KV states: replaces its projection GEMM). */
     int project_only;
+    /* ... with the positional encoding in front (loftr.py:74-75; pe != NULL, project_only only): the rows are pe_feat[m] (16-bit, stride pe_ld)
+     * + pe[m % pe_hw] (fp32 [pe_hw][256]) in gim_posenc_add's arithmetic; the kernel writes them to x32 (fp32) and xb (16-bit) before it projects. */
+    const void* pe_feat;
+    const float* pe;
+    int pe_ld, pe_hw;
 } gim_token_emit;
 int gim_token_mlp_emit(const void* msg, void* xb, float* x32, const void* weights, const float* ln_params, const float* kv,
                        const uint8_t* q_mask, int R, int C, int L, int S, int ldm, int ldxb, int ldx32, float ln_eps,

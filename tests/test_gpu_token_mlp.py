@@ -505,3 +505,61 @@ def test_padded_inputs_keep_the_row_path_for_k_v_and_agree_with_emitted_queries(
     for o in outs.values():
         for bb, i, j in zip(o["b_ids"].tolist(), o["i_ids"].tolist(), o["j_ids"].tolist()):
             assert m0[bb].reshape(-1)[i] and m1[bb].reshape(-1)[j]
+
+
+@pytest.mark.parametrize("tdt", KINDS, ids=KIDS)
+def test_token_project_with_positional_encoding_in_front(tdt):
+    """`pos_fused` (round 5): the projection-only launch computes its rows feat + pe[row % hw] itself (gim_posenc_add's arithmetic), writes them to
+    the fp32 stream and the operand copy and projects them -- bit for bit what gim_posenc_add followed by the plain launch gives."""
+    from gim_amd import ops
+    from gim_amd._lib import ACT_ELU1, ACT_NONE
+    from gim_amd.packing import pack_token_emit
+    nb, L = 3, 192
+    R = nb * L
+    g = torch.Generator().manual_seed(51)
+    wk, wv = (torch.randn(256, 256, generator=g) / 16 for _ in range(2))
+    ew = pack_token_emit([wk, wv], "cuda", tdt)
+    feat = torch.randn(R, 256, generator=g).to(tdt).cuda()
+    pe = torch.randn(L, 256, generator=g).cuda()
+    outs = []
+    for fused in (False, True):
+        x32 = torch.full((R, 256), 3.0, device="cuda")
+        cat = torch.full((R, 512), 7.0, dtype=tdt, device="cuda")
+        ws = ops.kv_state_workspace(nb, L // 64, "cuda")
+        ws.fill_(float("nan"))
+        spec = [(None, ACT_ELU1, 0, R, (ws, nb, L // 64, 0, L)), (None, ACT_NONE, 0, R)]
+        if fused:
+            ops.token_project(cat[:, :256], (ew, spec), pos=(feat, pe, x32))
+        else:
+            ops.posenc_add(feat, pe, x32, cat[:, :256])
+            ops.token_project(cat[:, :256], (ew, spec))
+        ops.kv_state_finalize(ws, nb, L // 64)
+        torch.cuda.synchronize()
+        outs.append((x32, cat, ws[:nb * 8 * 1056].clone()))
+    assert torch.isfinite(outs[0][2]).all() and bool((outs[1][1][:, 256:] == 7.0).all())
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[1][0], (feat.float() + pe.repeat(nb, 1)))
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_forward_with_fused_positional_encoding_is_bit_identical(precision):
+    """the whole forward with the positional encoding inside the projection-only launch against gim_posenc_add in front of it: same arithmetic"""
+    from tools import synth_loftr as S
+    model, _ = S.synthetic_model(precision)
+    model = model.cuda()
+    c0, c1 = S.textured_pairs(4, 256, 320, seed=24, frac=0.5)
+    c0, c1 = c0.cuda(), c1.cuda()
+    outs = {}
+    for pf in (True, False):
+        model.pos_fused = pf
+        model._invalidate()
+        for _ in range(2):
+            d = {"image0": c0[:, :1], "image1": c1[:, :1], "color0": c0, "color1": c1}
+            model(d)
+        torch.cuda.synchronize()
+        outs[pf] = {k: d[k].clone() for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts0_f", "mkpts1_f")}
+    model.pos_fused = True
+    assert outs[True]["b_ids"].numel() >= 200
+    for k in outs[True]:
+        assert torch.equal(outs[True][k], outs[False][k]), k

@@ -8,6 +8,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgimhip.so")
+if os.environ.get("GIM_LIB"):   # an alternative build of the library (A/B runs, tools/build_timing.sh); relative paths are taken from the repository root
+    LIB_PATH = os.environ["GIM_LIB"] if os.path.isabs(os.environ["GIM_LIB"]) else os.path.join(os.path.dirname(_HERE), os.environ["GIM_LIB"])
 
 GIM_F32, GIM_BF16, GIM_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU1, ACT_GELU = 0, 1, 2, 3, 4
@@ -38,7 +40,7 @@ class CoarseArgs(ctypes.Structure):
         ("N", c_int), ("L", c_int), ("S", c_int), ("C", c_int),
         ("h0c", c_int), ("w0c", c_int), ("h1c", c_int), ("w1c", c_int),
         ("cap", c_int), ("temperature", c_float), ("thr", c_float), ("border_rm", c_int),
-        ("scale", c_float), ("feat_dtype", c_int), ("ldf", c_int),
+        ("scale", c_float), ("feat_dtype", c_int), ("ldf", c_int), ("precand_per_row", c_int),
     ]
 
 
@@ -66,6 +68,8 @@ class LgAssignArgs(ctypes.Structure):
         ("B", c_int), ("M", c_int), ("N", c_int), ("C", c_int), ("ld_desc", c_int), ("threshold", c_float),
     ]
 
+
+ABI_VERSION = 112   # gim_version() of the include/gim_hip.h revision the structures and prototypes here mirror
 
 # name -> (restype, argtypes); every symbol declared in include/gim_hip.h
 PROTOTYPES = {
@@ -185,6 +189,10 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
+    # the ctypes mirrors above are bound to ONE revision of include/gim_hip.h: same-named entry points changed their argument lists between
+    # revisions (110 inserted `health` in front of `stream`), so another library (GIM_LIB) would shift arguments silently
+    if lib.gim_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} is ABI revision {lib.gim_version()}, gim_amd/_lib.py binds revision {ABI_VERSION}: rebuild with `python -m gim_amd.build`")
     return lib
 
 

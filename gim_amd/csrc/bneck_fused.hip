@@ -59,6 +59,7 @@ struct Args {
 // downsample launch (0.17 ms at 640x480 batch 8, HBM-bound) with the 629 MB tensor it wrote disappears.
 
 typedef __attribute__((address_space(3))) void lds_t;
+GIM_TT_DECL(bneck64)
 
 // 8 rows x 128 B per wave instruction, lane i -> row base + (i >> 3), LDS slot i & 7 <- source slot (i & 7) ^ key(row)
 __device__ __forceinline__ int swz_key(int row) { return (row >> 1) & 7; }   // two 128-byte rows share a 256-byte bank row
@@ -73,6 +74,7 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
     const int tile = blockIdx.x;
     const int b = tile / (tiles_x * tiles_y), tr = tile - b * tiles_x * tiles_y;
     const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) * TW;
+    GIM_TT(bneck64, w, 0);
 
     // ---- LDS-DMA: halo tile of t1 (zero outside the image), conv2 / conv3 weights -----------------------------------
     {
@@ -102,6 +104,7 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
     }
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // T1 and W2 have landed; this wave's 4 W3 pieces (issued last) may still fly
     __builtin_amdgcn_s_barrier();
+    GIM_TT(bneck64, w, 1);
 
     // ---- conv2: D[m = out channel][n = pixel of row w] over 9 taps x 4 k16 steps --------------------------------------
     f32x16_t c2[2];
@@ -133,6 +136,7 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
             }
         }
     }
+    GIM_TT(bneck64, w, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // W3
     __syncthreads();   // every wave is done with W2 and T1 (conv1' weights / the patches take their place); W3 is visible
     // identity rows of the first 64-channel pass (8 lanes x 16 B per pixel, 8 pixels per instruction): requested HERE, a whole conv3
@@ -168,6 +172,7 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
             gim_dma16(rw1, w1_addr + (unsigned)(pc * 1024), voff);
         }
     }
+    GIM_TT(bneck64, w, 3);
     // ---- relu -> bf16 operand (contraction order = accumulator order) -> conv3 -----------------------------------------
     bf16x8_t t2[4];   // k16 step s = 2f + t: channels 32f + 16t + 8(p >> 2) + 4lh + (p & 3)
 #pragma unroll
@@ -213,6 +218,7 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
                 }
         }
     }
+    GIM_TT(bneck64, w, 4);
     // ---- + identity, relu; x' out; bf16 operand of conv1' -- in four 64-channel passes through this wave's LDS patch ----
     char* patch = smem + OFF_SCR + w * 4096;          // [32 px][128 B], 16-byte slots XOR (px & 7)
     bf16x8_t xq[16];  // conv1' operand: step s = 2j + t
@@ -274,12 +280,14 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
         }
         h16_range_check(a.health, hm);   // x': the un-normalised residual stream
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the patch is rewritten by the next pass
+        GIM_TT(bneck64, w, 5 + q);
     }
     if constexpr (N1 > 0) {
         // ---- conv1' of the next block: K = 256 in accumulator order, weights from LDS -----------------------------------------
         constexpr int NF = N1 / 32;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        GIM_TT(bneck64, w, 9);
         f32x16_t c1[NF];
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
@@ -298,6 +306,7 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
                 c1[f] = mfma_h16_32x32x16(wv, xq[s], c1[f]);
             }
         }
+        GIM_TT(bneck64, w, 10);
 #pragma unroll
         for (int h2 = 0; h2 < NF / 2; ++h2) {          // 64 output channels per pass through the patch
 #pragma unroll
@@ -317,6 +326,7 @@ __global__ void __launch_bounds__(512, 2) bneck64_kernel(const Args a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
+    GIM_TT(bneck64, w, 11);
 }
 
 }  // namespace

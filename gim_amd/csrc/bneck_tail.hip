@@ -75,6 +75,7 @@ struct Args {
 };
 
 typedef __attribute__((address_space(3))) void lds_t;
+GIM_TT_DECL(bneck_tail)
 
 // The weight and identity streams use gim_dma16 (gim_common.h): LDS-DMA through inline asm, counted by hand (tail_wait below).
 typedef gim_u32x4_t u32x4_t;
@@ -139,6 +140,9 @@ __global__ void __launch_bounds__(NW * 64, 2) bneck_tail_kernel(const Args a) {
     const size_t prow0 = (size_t)blockIdx.x * ROWS + w * 32;   // first pixel row of this wave
     char* patch = smem + C::OFF_PATCH + w * C::PATCH;
 
+    GIM_TT(bneck_tail, w, 0);
+    unsigned long long tt_wait = 0, tt_c3 = 0, tt_epi = 0, tt_c1 = 0, tt_a = 0, tt_b = 0;   // GIM_TIMING: per-phase totals over the chunks
+    (void)tt_wait; (void)tt_c3; (void)tt_epi; (void)tt_c1; (void)tt_a; (void)tt_b;
     const u32x4_t rw3 = make_rsrc(a.w3, a.w3_bytes), rw1 = make_rsrc(a.w1n, a.w1n_bytes);
     const unsigned smem_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_t*)smem);   // LDS byte address of the dynamic array
     issue_chunk<P, N1, NW, DS>(rw3, rw1, smem_addr, 0, 0, w, lane);
@@ -189,6 +193,7 @@ __global__ void __launch_bounds__(NW * 64, 2) bneck_tail_kernel(const Args a) {
     if constexpr (C::NBUF == 3) issue_chunk<P, N1, NW, DS>(rw3, rw1, smem_addr, 1, 1, w, lane);   // behind what chunk 0 needs: may stay in flight
     __syncthreads();             // biases are in LDS (the compiler knows nothing of the DMA in flight: no drain)
 
+    GIM_TT(bneck_tail, w, 1);
     f32x16_t c1[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
@@ -204,6 +209,7 @@ __global__ void __launch_bounds__(NW * 64, 2) bneck_tail_kernel(const Args a) {
         // chunk q's weights (this wave's pieces) and identity rows have landed.  Younger operations that may fly on: the IPC stores
         // of the previous chunk and, with three buffers, the weight DMA of chunk q + 1 (issued behind the identity DMA of chunk q).
         // The count must be exact -- vmcnt(n) only guarantees that all but the n YOUNGEST operations are complete.
+        tt_a = GIM_TT_NOW();
         const bool dma_ahead = C::NBUF == 3 && q + 1 < NCHUNK;
         const bool stores_behind = q > 0 && a.xo != nullptr;
         if (dma_ahead) { if (stores_behind) tail_wait<C::PPW + C::IPC>(); else tail_wait<C::PPW>(); }
@@ -211,6 +217,7 @@ __global__ void __launch_bounds__(NW * 64, 2) bneck_tail_kernel(const Args a) {
         __syncthreads();          // everybody's pieces are visible, and everybody is done with the buffer of chunk q - 1
         const char* wb3 = smem + (q % C::NBUF) * C::BUF;
         const char* wb1 = wb3 + C::W3C;
+        tt_b = GIM_TT_NOW(); tt_wait += tt_b - tt_a;
 
         // ---- conv3, CH output channels: D[m = channel][n = pixel] over K = P ---------------------------------------------------
         f32x16_t c3[TF];
@@ -242,6 +249,7 @@ __global__ void __launch_bounds__(NW * 64, 2) bneck_tail_kernel(const Args a) {
                 }
             }
         }
+        tt_a = GIM_TT_NOW(); tt_c3 += tt_a - tt_b;
         // ---- + identity (DMA'd into the patch in row layout), relu; x' chunk out; operand of conv1' ----------------------------------
 #pragma unroll
         for (int f = 0; f < TF; ++f) {
@@ -290,6 +298,7 @@ __global__ void __launch_bounds__(NW * 64, 2) bneck_tail_kernel(const Args a) {
             *(uint4*)(xp) = x0; *(uint4*)(xp + (size_t)PPI * C4) = x1;
             if constexpr (C::IPC == 4) { *(uint4*)(xp + (size_t)2 * PPI * C4) = x2; *(uint4*)(xp + (size_t)3 * PPI * C4) = x3; }
         }
+        tt_b = GIM_TT_NOW(); tt_epi += tt_b - tt_a;
         // ---- conv1' of the next block, this chunk's CH input channels: CH / 16 k16 steps x NF fragments ------------------------------
 #pragma unroll
         for (int s = 0; s < 2 * TF; ++s) {
@@ -300,7 +309,10 @@ __global__ void __launch_bounds__(NW * 64, 2) bneck_tail_kernel(const Args a) {
                 c1[f] = mfma_h16_32x32x16(wv, xq[s], c1[f]);
             }
         }
+        tt_a = GIM_TT_NOW(); tt_c1 += tt_a - tt_b;
     }
+    GIM_TT(bneck_tail, w, 2);
+    GIM_TT_SET(bneck_tail, w, 4, tt_wait); GIM_TT_SET(bneck_tail, w, 5, tt_c3); GIM_TT_SET(bneck_tail, w, 6, tt_epi); GIM_TT_SET(bneck_tail, w, 7, tt_c1);
     // ---- t1' out: 64 channels per pass through a [32 px][128 B] transposition tile.  The per-wave patch is only 2 KiB when P = 256,
     // so every wave takes 4 KiB of the (now idle) weight ring instead ---------------------------------------------------------------
     __syncthreads();             // all waves are past their last weight reads and no DMA is in flight: the ring is free
@@ -327,6 +339,7 @@ __global__ void __launch_bounds__(NW * 64, 2) bneck_tail_kernel(const Args a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     h16_range_flag(a.health, hbig);
+    GIM_TT(bneck_tail, w, 3);
 }
 
 template <int P, int N1, int NW = 8, bool DS = false>

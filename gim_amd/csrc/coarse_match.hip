@@ -27,7 +27,6 @@
 //          (mask.max(dim=2) returns the first True).  compact: block scan per pair, ascending i.
 #include "igemm_mainloop.h"
 #include <limits.h>
-#include <stdlib.h>
 
 namespace {
 
@@ -65,14 +64,13 @@ struct CmWs {  // device pointers carved out of the caller's workspace
 
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
-size_t carve(CmWs& w, char* base, int N, int L, int S, int C) {
+size_t carve(CmWs& w, char* base, int N, int L, int S, int C, int per_row = 16) {
     w.ntL = (L + BM - 1) / BM;
     w.ntS = (S + BN - 1) / BN;
     w.ntL64 = (L + 63) / 64;
     w.capc = 20 * L + 64;  // < 1/thr entries of a row can exceed thr (sum_j softmax_j <= 1); validate() enforces thr >= 0.05
-    // pre-candidate capacity; GIM_CM_PRECAND_PER_ROW (default 16) exists so that tests can force the
-    // overflow -> recompute fallback
-    static const int per_row = [] { const char* e = getenv("GIM_CM_PRECAND_PER_ROW"); int v = e ? atoi(e) : 16; return v < 0 ? 0 : v; }();
+    // pre-candidate capacity: 16 entries per row (what gim_coarse_match_ws_bytes sizes the workspace for); gim_coarse_args.precand_per_row
+    // lets a caller SHRINK it (tests force the overflow -> recompute fallback with -1 = none)
     w.capp = per_row * L + 1024;
     size_t o = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + o : nullptr; o += al(bytes); return p; };
@@ -921,7 +919,7 @@ extern "C" int64_t GIM_FN(gim_coarse_match_ws_bytes)(int N, int L, int S) {
 }
 
 static int cm_prepare(const gim_coarse_args& a, CmWs& w, CmGeom& g) {
-    carve(w, (char*)a.ws, a.N, a.L, a.S, a.C);
+    carve(w, (char*)a.ws, a.N, a.L, a.S, a.C, a.precand_per_row == 0 ? 16 : (a.precand_per_row < 0 ? 0 : (a.precand_per_row > 16 ? 16 : a.precand_per_row)));
     w.health = a.count ? a.count + 1 : nullptr;
     g.feat0 = a.feat0; g.feat1 = a.feat1; g.bf16 = a.feat_dtype == GIM_H16; g.ldf = a.ldf ? a.ldf : a.C; g.mask0 = a.mask0; g.mask1 = a.mask1; g.N = a.N; g.L = a.L; g.S = a.S; g.C = a.C;
     g.inv_c = 1.0f / (float)a.C; g.temperature = a.temperature; g.thr = a.thr;

@@ -23,11 +23,11 @@
 // Replaces (reference file:line): networks/loftr/backbone/resnet.py:109-126,230-233,316-327 and the
 // nn.Linear calls of networks/loftr/submodules/transformer.py:47-55.
 #include "igemm_mainloop.h"
-#include <stdlib.h>
 
 namespace {
 
 using gim::KTB;
+GIM_TT_DECL(conv)
 
 // 16-bit output?  (the fp16 objects can also write bf16 -- gim_conv2d_bn_act)
 inline bool out_is16(const gim_conv_args& a) { return a.out_dtype == GIM_H16 || (GIM_HALF_KIND && a.out_dtype == GIM_BF16); }
@@ -81,12 +81,12 @@ __device__ __forceinline__ void epilogue_rows(const gim_conv_args& a, const floa
             o.x = cvt_pk_h16(v[0], v[1]); o.y = cvt_pk_h16(v[2], v[3]);
             o.z = cvt_pk_h16(v[4], v[5]); o.w = cvt_pk_h16(v[6], v[7]);
             *(uint4*)((unsigned short*)a.y + yo) = o;
-            if (a.res) hm = h16_range_fold_abs(hm, o);
+            if (a.res && a.out_dtype == GIM_F16) hm = h16_range_fold_abs(hm, o);   // (fp16 patterns only: the persistent Epilogue's `!out_bf`)
         } else {
             *(float4*)((float*)a.y + yo) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
-    if constexpr (OUT_BF16) h16_range_check(a.health, hm);
+    if constexpr (OUT_BF16) { if (a.out_dtype == GIM_F16) h16_range_check(a.health, hm); }
 }
 
 template <int BM, int BN, int WM, int WN, bool BF16, bool LDSDMA>
@@ -440,6 +440,9 @@ igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntile
     const int nkt = a.kpad * G::ES / KTB;
 
     E epi;
+    GIM_TT(conv, epi.wave, 0);
+    unsigned long long tt_k = 0, tt_e = 0, tt_n = 0, tt_a = 0, tt_b = 0;   // GIM_TIMING: K-loop / epilogue totals over this workgroup's tiles
+    (void)tt_k; (void)tt_e; (void)tt_n; (void)tt_a; (void)tt_b;
     G g, gn;  // staging coordinates of the current / the next tile
     typename G::Acc acc;
     typename E::Res rres;
@@ -457,6 +460,7 @@ igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntile
         const bool has_next = tile_n < end;
         const int m0n = (int)(tile_n / ntiles) * BM, n0n = (int)(tile_n % ntiles) * BN;
         if (has_next) gn.decode(ml, m0n, n0n);
+        tt_a = GIM_TT_NOW();
         // ---- K loop: only MFMAs touch the accumulators in here ------------------------------------------
         auto kloop = [&](auto live) __attribute__((always_inline)) {
             for (int kt = 0; kt < nkt; ++kt) {
@@ -482,12 +486,16 @@ igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntile
         } else {
             kloop(IntC<G::TN>());
         }
+        tt_b = GIM_TT_NOW(); tt_k += tt_b - tt_a;
         epi.run(a, acc, rres, smem + (buf ^ 1) * G::STAGE, m0, n0, M);  // buf ^ 1: the stage just consumed
         epi.init_acc(a, acc, n0n < a.npad ? n0n : 0);
         g = gn;
         m0 = m0n; n0 = n0n;
         __syncthreads();  // the transposition tile lives in a stage buffer the next slab's DMA will overwrite
+        tt_e += GIM_TT_NOW() - tt_b; ++tt_n;
     }
+    GIM_TT(conv, epi.wave, 1);
+    GIM_TT_SET(conv, epi.wave, 4, tt_k); GIM_TT_SET(conv, epi.wave, 5, tt_e); GIM_TT_SET(conv, epi.wave, 6, tt_n);
 }
 
 
@@ -554,6 +562,9 @@ conv3x3_halo_kernel(const gim_conv_args a, const int tiles_x, const int tiles_y,
     const int t = threadIdx.x, lane = t & 63;
     E epi;  // wave, wm, wn, l31, lh, rrow, rslot
     const int wave = epi.wave;
+    GIM_TT(conv, wave, 0);
+    unsigned long long tt_k = 0, tt_e = 0, tt_n = 0, tt_a = 0, tt_b = 0;
+    (void)tt_k; (void)tt_e; (void)tt_n; (void)tt_a; (void)tt_b;
     const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
     const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)((unsigned)a.npad * (unsigned)a.kpad * 2u), 0x00020000);
 
@@ -660,7 +671,9 @@ conv3x3_halo_kernel(const gim_conv_args a, const int tiles_x, const int tiles_y,
         };
         // (no fragment skipping here: a second copy of this K loop spills; layers with an all-padding fragment stay on the
         // generic kernel, which skips it)
+        tt_a = GIM_TT_NOW();
         kloop(IntC<TN>());
+        tt_b = GIM_TT_NOW(); tt_k += tt_b - tt_a;
         // ---- epilogue: activation, bf16, per-wave transposition through the halo buffer just consumed (ab ^ 1), row stores ------
         {
             const int tx = mt % tiles_x, ty = (mt / tiles_x) % tiles_y, b = mt / (tiles_x * tiles_y);
@@ -698,7 +711,10 @@ conv3x3_halo_kernel(const gim_conv_args a, const int tiles_x, const int tiles_y,
         epi.init_acc(a, acc, n0n);
         n0 = n0n;
         __syncthreads();  // the transposition tiles live in a halo buffer the next chunk's DMA will overwrite
+        tt_e += GIM_TT_NOW() - tt_b; ++tt_n;
     }
+    GIM_TT(conv, wave, 1);
+    GIM_TT_SET(conv, wave, 4, tt_k); GIM_TT_SET(conv, wave, 5, tt_e); GIM_TT_SET(conv, wave, 6, tt_n);
 }
 
 template <int TN>

@@ -463,11 +463,7 @@ __global__ void __launch_bounds__(256, 2) dwconv5x5_rows2_kernel(const void* __r
         const int yy = min(max(Y + r - 2, 0), H - 1);
         const char* rp = (const char*)x + (((size_t)b * H + yy) * W) * pstride + (size_t)co * ES;
 #pragma unroll
-#if defined(GIM_DW_ABL) && GIM_DW_ABL == 2   // (tools/microbench_dwconv.hip: development builds only) no global loads
-        for (int q = 0; q < 8; ++q) { raw[q] = Raw(); raw[q].x = 0x3f003f00u + (unsigned)(yy + q) + (unsigned)(size_t)rp; }
-#else
         for (int q = 0; q < 8; ++q) raw[q] = *(const Raw*)(rp + (unsigned)min(max(xs + q - 2, 0), W - 1) * pstride);
-#endif
     };
     issue(0);
     // a real loop (not unrolled): each iteration is its own scheduling region, so the prefetch stays one row deep (fully
@@ -497,11 +493,6 @@ __global__ void __launch_bounds__(256, 2) dwconv5x5_rows2_kernel(const void* __r
         ORDER_FENCE();
         if (r < 5) issue(r + 1);
         ORDER_FENCE();
-#if defined(GIM_DW_ABL) && GIM_DW_ABL == 1   // no FMAs: loads, unpacking and stores only
-        for (int p_ = 0; p_ < 4; ++p_)
-            for (int e = 0; e < G2; ++e) { acc[0][p_][e] += in[p_ + 2][e]; acc[1][p_][e] += in[p_ + 3][e]; }
-        if (r < 0)
-#endif
         // output row Y + o takes this input row with dy = r - o
         if (r <= 4) {
 #pragma unroll
@@ -518,9 +509,6 @@ __global__ void __launch_bounds__(256, 2) dwconv5x5_rows2_kernel(const void* __r
                     for (int e = 0; e < G2; ++e) acc[0][p_][e] = __builtin_elementwise_fma(in[p_ + dx][e], wv[e], acc[0][p_][e]);
             }
         }
-#if defined(GIM_DW_ABL) && GIM_DW_ABL == 1
-        if (r < 0)
-#endif
         if (r >= 1) {
 #pragma unroll
             for (int dx = 0; dx < 5; ++dx) {
@@ -643,9 +631,6 @@ __global__ void __launch_bounds__(256, 2) dwconv5x5_rows2_kernel(const void* __r
                 const f32x2_t v = acc[o][p_][e] * sc[e] + sh[e];
                 rr[2 * e] = fmaxf(v.x, 0.f); rr[2 * e + 1] = fmaxf(v.y, 0.f);
             }
-#if defined(GIM_DW_ABL) && GIM_DW_ABL == 3   // no stores (the condition never holds: outputs are >= 0)
-            if (rr[0] < -1.f)
-#endif
             if constexpr (BF16) {
                 *(uint4*)((unsigned short*)y + oo) = make_uint4(cvt_pk_h16(rr[0], rr[1]), cvt_pk_h16(rr[2], rr[3]),
                                                                 cvt_pk_h16(rr[4], rr[5]), cvt_pk_h16(rr[6], rr[7]));

@@ -37,7 +37,6 @@
 // Numerics: bf16 operands, fp32 accumulation, fp32 residual stream, fp32 LayerNorm / softmax statistics -- the same
 // rounding points as the unfused bf16 path (q, k, v, msg, LN outputs and hidden activations are bf16 there too).
 #include "gim_common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -630,7 +629,7 @@ static int fine_fused_launch(const void* feat_f0, const void* feat_f1, const int
     a.fscale = scale; a.eps = ln_eps; a.has_scale0 = has_scale0; a.count = count;
     a.dbg_stage = 0;
 #ifdef FF_DEBUG_STAGES
-    if (const char* e = getenv("GIM_FF_STAGE")) a.dbg_stage = atoi(e);
+    a.dbg_stage = FF_DEBUG_STAGES;   // development builds only: -DFF_DEBUG_STAGES=<stage> (no environment variable is read in csrc/)
 #endif
     hipLaunchKernelGGL(fine_fused_kernel, dim3((unsigned)((M + G - 1) / G)), dim3(256), SMEM, (hipStream_t)stream, a);
     return gim_check_launch("fine_fused");

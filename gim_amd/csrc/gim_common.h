@@ -242,6 +242,31 @@ __device__ __forceinline__ gim_u32x4_t gim_make_rsrc(const void* p, unsigned byt
     return r;
 }
 
+// ---- phase stamps (development builds: GIM_HIPCC_EXTRA=-DGIM_TIMING; tools/kernel_timing.py) -------------------------------------------
+// GIM_TT_DECL(name) in a translation unit declares a stamp array [workgroup][wave][slot] and its reader gim_timing_<name>(host, n_wg);
+// GIM_TT(name, wave, slot) stores the shader clock (s_memtime) of lane 0; GIM_TT_ACC adds a duration (persistent kernels: per-phase totals).
+#ifdef GIM_TIMING
+constexpr int GIM_TT_WG = 8192, GIM_TT_W = 8, GIM_TT_N = 16;
+#define GIM_TT_DECL(name)                                                                                               \
+    __device__ unsigned long long g_tt_##name[GIM_TT_WG][GIM_TT_W][GIM_TT_N];                                              \
+    extern "C" int GIM_FN(gim_timing_##name)(unsigned long long* host, int n_wg) {                                       \
+        return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tt_##name), (size_t)(n_wg < GIM_TT_WG ? n_wg : GIM_TT_WG) * GIM_TT_W * GIM_TT_N * 8) == hipSuccess ? 0 : -1; \
+    }                                                                                                                   \
+    extern "C" int GIM_FN(gim_timing_clear_##name)(void) {                                                               \
+        void* p_ = nullptr;                                                                                             \
+        if (hipGetSymbolAddress(&p_, HIP_SYMBOL(g_tt_##name)) != hipSuccess) return -1;                                  \
+        return hipMemset(p_, 0, sizeof(g_tt_##name)) == hipSuccess ? 0 : -1;                                             \
+    }
+#define GIM_TT(name, wave, slot) do { if (blockIdx.x < GIM_TT_WG && (threadIdx.x & 63) == 0) g_tt_##name[blockIdx.x][wave][slot] = __builtin_readcyclecounter(); } while (0)
+#define GIM_TT_SET(name, wave, slot, v) do { if (blockIdx.x < GIM_TT_WG && (threadIdx.x & 63) == 0) g_tt_##name[blockIdx.x][wave][slot] = (v); } while (0)
+#define GIM_TT_NOW() __builtin_readcyclecounter()
+#else
+#define GIM_TT_DECL(name)
+#define GIM_TT(name, wave, slot) do { } while (0)
+#define GIM_TT_SET(name, wave, slot, v) do { } while (0)
+#define GIM_TT_NOW() 0ull
+#endif
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -24,7 +24,7 @@ import os
 import torch
 
 from ..precision import resolve as resolve_precision
-from ..switches import flag
+from ..switches import flag, tri_flag
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -165,7 +165,7 @@ class RegressionMatcher(nn.Module):
         # GP posterior entirely in fp64 (kernel entries, Cholesky, products; csrc/gp_solve.hip: gim_gp_posterior_f64).  None = in
         # the fp32 parity mode only: the system's condition number (~2e4) turns fp32 rounding of the kernel ENTRIES into ~1e-4 of mu,
         # the one term of the engine's deviation that is not the reference's own (tests/test_gpu_gp_pins.py)
-        self.gp_exact = {"": None, "0": False, "1": True}[str(flag("gp_exact", ""))]
+        self.gp_exact = tri_flag("gp_exact")
         self._packed = None
         self._gp_f = {}
         self.overlap_gp = flag("dkm_overlap", True)   # GP on a side stream beside the high-res encoder

@@ -551,8 +551,9 @@ class LoFTR(nn.Module):
             if fuse and self.bneck_ds and (p + "fused_ds") in P and x.shape[3] == 64 and x.is_contiguous():
                 x, o = ops.bneck64_ds(o, x, P[p + "fused_ds"], out=outs, health=self._health)   # ... and the downsample branch: no identity tensor at all
                 continue
+            rows_ds = x.shape[0] * ((x.shape[1] - 1) // 2 + 1) * ((x.shape[2] - 1) // 2 + 1)   # output rows of a stride-2 block
             if (self.bneck_tail and self.bneck_tail_ds and (p + "tail_ds") in P and x.is_contiguous() and x.shape[3] == 256
-                    and (x.shape[0] * ((x.shape[1] - 1) // 2 + 1) * ((x.shape[2] - 1) // 2 + 1)) % 256 == 0):
+                    and rows_ds % 256 == 0 and rows_ds * 512 * 2 < (1 << 32) - 16):   # 32-bit byte offsets into [rows, 512] (its own REQUIRE): oversize batches take the unfused launches
                 # layer 2's first block: conv2, then ONE kernel for conv3 + the stride-2 downsample branch (extra K) + relu + the next conv1:
                 # no downsample launch, no identity tensor (gim_bneck_tail128_ds)
                 o = ops.conv2d(o, P[p + "c2"], ACT_RELU, lds_dma=dma)
@@ -590,22 +591,33 @@ class LoFTR(nn.Module):
         return x1_out
 
     class _TfBuffers:
-        """Row buffers of one LocalFeatureTransformer run over R rows of width C."""
+        """Row buffers of one LocalFeatureTransformer run over R rows of width C.  The q / k / v rows, the message, the pre-LayerNorm
+        activations and the hidden layer exist only on the UNFUSED launch paths (masks, debug dumps, fp32 mode without the token kernel):
+        they are allocated on first touch -- the default 16-bit coarse path (local queries, fused KV state, first layer's state from the
+        projection-only launch) never touches them (two [R, 3C] buffers = 236 MB at batch 8 were allocated, and pinned by the captured
+        graph's pool, for nothing: ADVICE r5)."""
+        _LAZY = {"QKV": 3, "QKV2": 3, "MSG": 1, "MRG": 1, "HID": 2, "MLP": 1}   # name -> width in units of C
 
         def __init__(self, R, C, tdt, dev):
             f32 = torch.float32
+            self._shape = (R, C, tdt, dev)
             self.X32 = torch.empty(R, C, dtype=f32, device=dev)       # fp32 master of the token features
             self.CAT = torch.empty(R, 2 * C, dtype=tdt, device=dev)   # [x | norm1(message)] GEMM operand
-            self.QKV = torch.empty(R, 3 * C, dtype=tdt, device=dev)   # [elu(q)+1 | elu(k)+1 | v] row buffers
-            self.MSG = torch.empty(R, C, dtype=tdt, device=dev)
-            # pre-LayerNorm activations in the operand dtype (A/B on one box: 14.16-14.26 vs 14.38-14.48 ms with fp32)
-            self.MRG = torch.empty(R, C, dtype=tdt, device=dev)
-            self.HID = torch.empty(R, 2 * C, dtype=tdt, device=dev)
-            self.MLP = torch.empty(R, C, dtype=tdt, device=dev)
+            # QKV / QKV2: [elu(q)+1 | elu(k)+1 | v] row buffers (two alternate by layer parity on the emitting path); MSG; MRG, HID, MLP:
+            # pre-LayerNorm activations in the operand dtype (A/B on one box: 14.16-14.26 vs 14.38-14.48 ms with fp32) -- see _LAZY
             self.ws = None
             self.MASK = None  # optional uint8 [R] padding mask aligned with the rows (coarse level only)
             self.pos = None   # [(feature rows, pos-encoding table)] per side when the tokens still lack their positional encoding (coarse level)
             self.pos_all = None
+
+        def __getattr__(self, name):   # only reached when the attribute does not exist yet
+            w = type(self)._LAZY.get(name)
+            if w is None:
+                raise AttributeError(name)
+            R, C, tdt, dev = self._shape
+            t = torch.empty(R, w * C, dtype=tdt, device=dev)
+            setattr(self, name, t)
+            return t
 
     def _encoder_layer(self, P, p, T, xs, ss, nb, L, S, H, have_q=False, with_q_of_source=False):
         """LoFTREncoderLayer.forward (transformer.py:35-58) on row ranges xs (queries) / ss (source).
@@ -722,8 +734,10 @@ class LoFTR(nn.Module):
         # local queries: every call projects its own q rows from the operand copy of x it loads anyway -- no q blocks, no q rows
         ql = bool(self.q_local) and self.debug is None and (name + ".emitk", False) in P
         calls, per_call, initial = P[name + (".emitk" if ql else ".emit"), L == S and K == 1]
-        T.QKV2 = torch.empty_like(T.QKV)
-        QK = (T.QKV, T.QKV2)
+        class _QK:   # the two projection row buffers, by layer parity; allocated when a block is really emitted as rows (_TfBuffers._LAZY)
+            def __getitem__(self, i):
+                return T.QKV2 if i else T.QKV
+        QK = _QK()
         rows = (slice(0, n0 * L), slice(n0 * L, n0 * L + n1 * S))
         rall = slice(0, n0 * L + n1 * S)
         rs = lambda sides: rall if len(sides) == 2 else rows[sides[0]]   # noqa: E731
@@ -766,6 +780,9 @@ class LoFTR(nn.Module):
                     for sd in part:
                         init_state[(li, sd)] = (ws_i, off)
                         off += (n0, n1)[sd]
+        # Cross-stream lifetime: the chains below run on side streams and read these workspaces (and write the ones in T.keep).  No
+        # record_stream() is needed because the owning tensors stay referenced by T (init_state, keep) until _coarse_stage returns, i.e.
+        # past the main.wait_stream() join at the end of this function -- the caching allocator cannot hand their blocks out before that
         T.init_state = init_state
         self._posenc(T, rows)   # whatever the projection-only launches did not cover
         for (li, sides), blks in groups.items():
@@ -796,7 +813,6 @@ class LoFTR(nn.Module):
             used = []
             for ci, ((li, xs_s, ss_s), em) in enumerate(zip(calls, per_call)):
                 xs, ss = rc(xs_s), rc(ss_s)
-                q = QK[li & 1]
                 nb_src = nseq(ss_s)
                 len_q = L if xs_s[0] == 0 else S
                 len_src = L if ss_s[0] == 0 else S
@@ -811,6 +827,7 @@ class LoFTR(nn.Module):
                     seq0 = off + (ss.start - rows[ss_s[0]].start) // len_src
                     kv = ws_i[seq0 * H * (32 * 32 + 32):]
                 else:
+                    q = QK[li & 1]
                     ws, _ = ops.linear_attention_state(q[ss, C:2 * C], q[ss, 2 * C:], nb_src, len_src, H, ws, km)
                     kv = ws
                 emit = None
@@ -833,7 +850,7 @@ class LoFTR(nn.Module):
                             assert len(spec[-1]) == 5 and spec[-1][2:4] == (lo, hi)
                             spec.append((None, ACT_NONE, lo, hi))
                     emit = (ew, spec)
-                ops.token_mlp(None if ql else q[xs, :C], T.CAT[xs, :C], T.X32[xs], wts, lnp, eps, kv=kv, L=len_q, S=len_src, q_mask=qm, emit=emit,
+                ops.token_mlp(None if ql else QK[li & 1][xs, :C], T.CAT[xs, :C], T.X32[xs], wts, lnp, eps, kv=kv, L=len_q, S=len_src, q_mask=qm, emit=emit,
                               q_weights=P[f"{name}{li}.qtok"] if ql else None)
             assert not kvws
             return [ws] + used
@@ -853,7 +870,7 @@ class LoFTR(nn.Module):
         keep.append(run((slice(0, m * L), slice(n0 * L, n0 * L + m * S)), m, m, None))
         for s_ in sides_:
             main.wait_stream(s_)
-        T.keep = keep
+        T.keep = keep   # (every side-stream workspace outlives the join above: see the lifetime note at T.init_state)
 
     @staticmethod
     def _posenc(T, rows, sides=(0, 1)):

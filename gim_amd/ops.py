@@ -346,7 +346,7 @@ class CoarseResult:
 
 
 def coarse_match(feat0, feat1, hw0_c, hw1_c, scale, temperature=0.1, thr=0.2, border_rm=2,
-                 scale0=None, scale1=None, mask0=None, mask1=None, count=None):
+                 scale0=None, scale1=None, mask0=None, mask1=None, count=None, precand_per_row=0):
     """feat0 [N,L,C], feat1 [N,S,C], fp32 or bf16, rows possibly strided (stride(1) = ldf >= C, the same for both; e.g. a
     column range of the transformer's token buffers).  bf16 features run the similarity on the bf16 MFMA (exact products,
     fp32 accumulation).  Returns CoarseResult with cap-sized device buffers; count[0] (device int32) is the number of
@@ -393,6 +393,7 @@ def coarse_match(feat0, feat1, hw0_c, hw1_c, scale, temperature=0.1, thr=0.2, bo
     a.h0c, a.w0c, a.h1c, a.w1c = hw0_c[0], hw0_c[1], hw1_c[0], hw1_c[1]
     a.cap, a.temperature, a.thr, a.border_rm, a.scale = cap, temperature, thr, border_rm, scale
     a.feat_dtype, a.ldf = gim_dtype(feat0), ldf
+    a.precand_per_row = precand_per_row   # 0: the default capacity; -1: none (tests force the overflow -> recompute fallback)
     r.args = a
     with _Timed("coarse_match", 2.0 * N * L * S * C):   # the similarity GEMM's flops (computed once in the common case)
         check(lib.gim_coarse_match(ctypes.byref(a), _stream()), "gim_coarse_match")

@@ -28,7 +28,7 @@ import os
 import torch
 
 from ..precision import resolve as resolve_precision
-from ..switches import flag
+from ..switches import flag, tri_flag
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -158,11 +158,16 @@ class RegressionMatcher(nn.Module):
         self.upsample_res = (14 * 16 * 6, 14 * 16 * 6)
         self.symmetric = symmetric
         self.sample_thresh = 0.05
-        self.precision = resolve_precision(precision, "gim_roma")
+        # round 6: IEEE fp16 is gim_roma's default 16-bit mode (gim_amd/precision.py has the argument; bf16 moves the warp by ~3 px at 560 x 560,
+        # fp16 stays < 5e-6 of scale from the fp32 mode: tests/test_gpu_roma.py, tests/test_gpu_dense_fullsize.py); `_fp16_checked` = the
+        # output check of match_batch below has passed once for the current weights
+        self.precision = resolve_precision(precision, "gim_roma", default="fp16")
+        self._fp16_default = precision is None and self.precision == "fp16"
+        self._fp16_checked = False
         # GP posterior entirely in fp64 (kernel entries, Cholesky, products; csrc/gp_solve.hip: gim_gp_posterior_f64).  None = in
         # the fp32 parity mode only: the system's condition number (~2e4) turns fp32 rounding of the kernel ENTRIES into ~1e-4 of mu,
         # the one term of the engine's deviation that is not the reference's own (tests/test_gpu_gp_pins.py)
-        self.gp_exact = {"": None, "0": False, "1": True}[str(flag("gp_exact", ""))]
+        self.gp_exact = tri_flag("gp_exact")
         # 16-bit modes: the 144- and 24-channel ConvRefiner blocks (scales 2 and 1, both passes) as ONE launch each (gim_dwconv5x5_pw, round 5)
         self.refiner_fused = flag("refiner_fused", True)
         self._dino = [None]          # a list, like roma.py:612: the ViT is not a registered sub-module / not in state_dict()
@@ -185,11 +190,13 @@ class RegressionMatcher(nn.Module):
         if tuple(state_dict["pos_embed"].shape) != (1, VIT_GRID ** 2 + 1, VIT_DIM):
             raise GimHipError(f"DINOv2 weights: pos_embed {tuple(state_dict['pos_embed'].shape)} is not ViT-L/14 @518")
         self._dino[0] = {k: state_dict[k].detach().float().cpu() for k in need}
+        self._fp16_checked = False
         self._packed = None
         self._tables = {}
 
     def load_state_dict(self, state_dict, *a, **k):
         self._packed = None
+        self._fp16_checked = False
         self._tables = {}
         return super().load_state_dict(state_dict, *a, **k)
 
@@ -556,6 +563,18 @@ class RegressionMatcher(nn.Module):
             ops.dkm_match_post((flow[b], flow[b + B]), (cert[b], cert[b + B]), (low[b], low[b + B]),
                                ops.dkm_black_mask(im1[b:b + 1], (hs, ws)), ops.dkm_black_mask(im2[b:b + 1], (hs, ws)), warp[b], certainty[b])
         self._debug = stages
+        # fp16 as the DEFAULT mode carries a range check of what it hands out (an explicit precision='fp16' is the caller's decision):
+        # every stored activation of this engine sits behind a BatchNorm / LayerNorm, so an overflow needs pathological weights -- it then
+        # surfaces as inf / nan in the flow or certainty logits (no ReLU between the refiners' last convolution and these outputs).  One
+        # reduction + host sync on the first calls after a weight change; a trip switches the module to bf16 for good and re-runs the batch
+        if self._fp16_default and self.precision == "fp16" and not self._fp16_checked:
+            if bool(torch.isfinite(warp).all()) and bool(torch.isfinite(certainty).all()):
+                self._fp16_checked = True
+            else:
+                import warnings
+                warnings.warn("gim_amd RoMa: non-finite outputs in the default fp16 mode (activations beyond 65504?); switching this module to bf16")
+                self.precision, self._packed = "bf16", None
+                return self.match_batch(ims_A, ims_B)
         return warp, certainty
 
     @torch.no_grad()

@@ -38,7 +38,8 @@ enum { GIM_OK = 0, GIM_ERR_INVALID = -1, GIM_ERR_LAUNCH = -2, GIM_ERR_UNSUPPORTE
  * word, per-pair counts from count[2]) -- a caller bound to version 100 must be rebuilt.
  * 111: struct gim_token_emit grew the kv_part / kv_nchunk / kv_tile0 / kv_len arrays (fused KV state), q_weights (local queries), project_only and pe_*; zero them for
  * the old behaviour;
- * new entries gim_linear_attention_finalize, gim_linear_attention_ws_bytes_chunks. */
+ * new entries gim_linear_attention_finalize, gim_linear_attention_ws_bytes_chunks.
+ * 112 (round 6): gim_coarse_args.precand_per_row appended (zero it for the old behaviour); the library reads no environment variable. */
 int gim_version(void);
 /* fp16 range guard.  `health` (NULL: no check): a device word into which the fp16 flavour of the kernels that store un-normalised
  * residual streams (gim_bneck64_fused*, gim_bneck_tail*, gim_conv2d_bn_act with a residual operand) OR 4 when a converted value exceeds
@@ -208,6 +209,8 @@ typedef struct gim_coarse_args {
     int feat_dtype;       /* GIM_F32 (0, default) or GIM_BF16: bf16 features run the similarity on the bf16 MFMA -- exact
                            * products, fp32 accumulation, i.e. the fp32 result for bf16-valued inputs up to summation order */
     int ldf;              /* row stride of feat0 / feat1 in elements; 0 = C (contiguous) */
+    int precand_per_row;  /* 0 = default (16 pre-candidate slots per row, what gim_coarse_match_ws_bytes sizes); 1..16 = fewer; -1 = none: the
+                           * device-side overflow flag then routes every call to the two-pass recompute (tests; replaces an environment hook) */
 } gim_coarse_args;
 int64_t gim_coarse_match_ws_bytes(int N, int L, int S);
 int gim_coarse_match(const gim_coarse_args* a, gim_stream_t stream);

@@ -165,3 +165,95 @@ def test_dkm_batch4_672x896_vs_single_pair_oracles(monkeypatch):
         _close(W[k], rw, 2e-5, f"dkm batch-4 slot {k} warp vs the fp64-GP oracle", frac=1.0, mean_tol=2e-6)
         _close(C[k], rc, 2e-5, f"dkm batch-4 slot {k} certainty vs the fp64-GP oracle", frac=1.0, mean_tol=2e-6)
     assert torch.equal(W[0], W[3]) and torch.equal(W[1], W[2]) and torch.equal(C[0], C[3]) and torch.equal(C[1], C[2])
+
+
+# ---- round 6: gim_roma at BASELINE config 4's size, and its upsampling pass at size -------------------------------------
+def _roma_vs_oracles(monkeypatch, size, up, tag, pinned=True):
+    """engine (fp32 mode) at `size` x `size` (-> `up` when given) against (a) the pinned reference arithmetic and (b) the same oracle with
+    only the GP step in fp64 -- the two comparisons of test_roma_672_vs_oracle / test_dkm_672x896_upsample_pass_vs_oracle"""
+    import dkm_oracle as DO
+    import roma_oracle as O
+    from gim_amd.roma import RoMa
+    sd, dsd = O.make_state_dicts(0)
+    im0, im1 = DO.seeded_pair(size, size, 3)
+    with torch.no_grad():
+        if pinned:   # (one CPU pass of the upsampling oracle at 1344 x 1344 is ~1.5 min on the GPU box's host)
+            ref_warp, ref_cert = O.match(sd, dsd, im0, im1, size, size, up)
+        monkeypatch.setattr(DO, "GP_FP64", True)
+        x_warp, x_cert = O.match(sd, dsd, im0, im1, size, size, up)
+        monkeypatch.setattr(DO, "GP_FP64", False)
+    m = RoMa([size], precision="fp32", dinov2_weights=dsd)
+    m.load_state_dict(sd)
+    m = m.eval()
+    m.upsample_preds = up is not None
+    if up is not None:
+        m.upsample_res = up
+    warp, cert = m.match(im0.to("cuda:0"), im1.to("cuda:0"))
+    hs, ws = up if up is not None else (size, size)
+    assert warp.shape == (hs, 2 * ws, 4) and cert.shape == (hs, 2 * ws)
+    # (a) the pinned reference arithmetic: the anchor arg-max over 64 x 64 classes (roma.py:94-136) flips at isolated pixels under the
+    # reference's OWN fp32 GP noise, so a fraction + a mean, as at 672 x 672 (bounds = 2 x measured on MI355X, round 6: see the callers)
+    if pinned:
+        _close(warp, ref_warp, 2e-3, f"roma warp {tag} vs the reference arithmetic", frac=0.995, mean_tol=7.5e-4)
+        _close(cert, ref_cert, 1.5e-3, f"roma certainty {tag} vs the reference arithmetic", frac=0.999, mean_tol=1.5e-4)
+    # (b) the exact-GP oracle: EVERY value within 2e-5 of scale (north_star: 1e-4)
+    _close(warp, x_warp, 2e-5, f"roma warp {tag} vs the fp64-GP oracle", frac=1.0, mean_tol=2e-6)
+    _close(cert, x_cert, 2e-5, f"roma certainty {tag} vs the fp64-GP oracle", frac=1.0, mean_tol=4e-6)
+    if pinned:
+        (rw_max, rw_mean), (ew_max, ew_mean) = _dist(ref_warp, x_warp), _dist(warp, x_warp)
+        print(f"roma {tag} warp: reference arithmetic vs fp64-GP oracle max {rw_max:.2e} mean {rw_mean:.2e}; engine vs fp64-GP oracle max {ew_max:.2e} mean {ew_mean:.2e}")
+        assert ew_mean <= rw_mean, "the engine's parity mode must sit closer to the formula than the reference's fp32 arithmetic does"
+
+
+def test_roma_560_vs_oracle(monkeypatch):
+    """BASELINE config 4: gim_roma at 560 x 560 (`RoMa(img_size=[560])`, roma.py:1124-1266; 1600-point GP), low-resolution pass"""
+    _roma_vs_oracles(monkeypatch, 560, None, "560x560")
+
+
+def test_roma_560_upsample_pass_vs_oracle(monkeypatch):
+    """... and with the upsampling pass it runs by default (roma.py:658: upsample_res = 1344 x 1344 whatever img_size; roma.py:836-866: the second
+    encoder pass + the refiners at scales 8 ... 1 on the upsampled flow -- 5.9 of config 4's 10 TFLOP), never compared with the oracle at size before"""
+    _roma_vs_oracles(monkeypatch, 560, (1344, 1344), "560 -> 1344 (upsampling pass)")
+
+
+def test_roma_672_upsample_pass_vs_oracle(monkeypatch):
+    """the configuration gim's own callers run (`RoMa(img_size=[672])`, trainer/lightning.py:38-41, demo.py:332): 672 -> 1344, against the exact-GP
+    oracle (the pinned-arithmetic comparison of this size's low-resolution pass is test_roma_672_vs_oracle, of the upsampling pass the 560 test)"""
+    _roma_vs_oracles(monkeypatch, 672, (1344, 1344), "672 -> 1344 (upsampling pass)", pinned=False)
+
+
+def test_roma_default_mode_is_fp16_and_close_to_the_fp32_mode_at_560():
+    """round 6: gim_roma's DEFAULT 16-bit mode is IEEE fp16 (gim_amd/precision.py).  At config 4's size, with the upsampling pass: the default
+    module against the fp32 parity mode of the same engine, and the bf16 mode on the same pair.  Measured on MI355X (round 6, seeded random
+    weights): fp16 99.43 % of the warp values within 2e-3 of scale, mean 8.0e-4 -- the mean is ALL in the 0.57 % of values behind an anchor
+    arg-max decision (roma.py:94-136, 4096 classes) that 11-bit storage still flips at isolated pixels (max 1.3 of scale); bf16: mean 1.04e-2,
+    13 x further.  VERDICT r5's "< 1e-4" holds for the values outside those flips, not for the mean; fp16 is the default because it is an
+    order of magnitude closer at the same speed, which is what this test holds (bounds = 2 x measured)."""
+    import dkm_oracle as DO
+    import roma_oracle as O
+    from gim_amd.roma import RoMa
+    sd, dsd = O.make_state_dicts(0)
+    im0, im1 = DO.seeded_pair(560, 560, 3)
+    out = {}
+    for prec in (None, "fp32", "bf16"):
+        m = RoMa([560], precision=prec, dinov2_weights=dsd)
+        m.load_state_dict(sd)
+        m = m.eval()
+        if prec is None:
+            assert m.precision == "fp16"
+        w, c = m.match(im0.to("cuda:0"), im1.to("cuda:0"))
+        if prec is None:
+            assert m.precision == "fp16" and m._fp16_checked, "the default mode's output range check must have passed"
+        out[prec] = (w.float().cpu(), c.float().cpu())
+        del m
+        torch.cuda.empty_cache()
+    scale = out["fp32"][0].abs().max().item()
+    e16 = (out[None][0] - out["fp32"][0]).abs() / scale
+    ebf = (out["bf16"][0] - out["fp32"][0]).abs() / scale
+    c16 = (out[None][1] - out["fp32"][1]).abs().mean().item()
+    print(f"roma 560 -> 1344, vs the fp32 mode: default (fp16) warp mean {e16.mean().item():.2e} max {e16.max().item():.2e}, within 2e-3: "
+          f"{100 * (e16 <= 2e-3).float().mean().item():.3f} %, certainty mean {c16:.2e}; bf16 warp mean {ebf.mean().item():.2e}")
+    inside = e16 <= 2e-3
+    print(f"  fp16 values outside 2e-3: {100 * (1 - inside.float().mean().item()):.3f} %; mean over the values inside: {e16[inside].mean().item():.2e}, median {e16.median().item():.2e}")
+    assert inside.float().mean().item() >= 0.988 and e16.mean().item() < 1.6e-3 and e16[inside].mean().item() < 1e-4
+    assert e16.mean().item() * 6 < ebf.mean().item(), "fp16 must be several times closer than bf16 on this pair (measured 13 x)"

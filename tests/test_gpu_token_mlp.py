@@ -329,14 +329,22 @@ def test_token_mlp_fused_kv_state(tdt):
 
 @pytest.mark.parametrize("precision", ["fp16", "bf16"])
 def test_coarse_transformer_fused_kv_state_vs_row_path(precision):
-    """the whole forward with the k / v rows handed over as partial states (`kv_fused`, default) against the row path (k / v rows + la_kv
-    launches): same products, fp32 sums of the state in another order -- the match lists agree but for threshold-marginal entries"""
+    """the whole forward with the k / v rows handed over as partial states (`kv_fused`, default) and on the row path (k / v rows + la_kv launches),
+    EACH AGAINST THE fp32 CPU ORACLE (round 6: until round 5 the two engine paths were compared with each other at "match lists agree to 1 %",
+    an engine-vs-engine bound with a hole; the state itself is pinned at 2e-6 by test_token_mlp_fused_kv_state).  Bounds = the full-size
+    table of tests/test_gpu_loftr_fullsize.py for the mode (index flip rate, mean |d mconf|), over the four pairs together, + 2 flips for the
+    granularity of ~10^3 matches; and the fused path may not sit further from the oracle than the row path does (x 1.5 + noise floor)."""
+    import loftr_oracle as LO
     from tools import synth_loftr as S
-    model, _ = S.synthetic_model(precision)
+    from tools.parity import parity_vs_oracle
+    model, sd = S.synthetic_model(precision)
     model = model.cuda()
     c0, c1 = S.textured_pairs(4, 256, 320, seed=21, frac=0.5)
+    with torch.no_grad():
+        ref = LO.loftr_forward(sd, {"image0": c0[:, :1], "image1": c1[:, :1], "color0": c0, "color1": c1})
     c0, c1 = c0.cuda(), c1.cuda()
-    outs = {}
+    max_flip, max_dconf = {"fp16": (0.004, 0.0025), "bf16": (0.026, 0.018)}[precision]
+    dev = {}
     for fused in (True, False):
         model.kv_fused = fused
         model._invalidate()
@@ -344,19 +352,18 @@ def test_coarse_transformer_fused_kv_state_vs_row_path(precision):
             d = {"image0": c0[:, :1], "image1": c1[:, :1], "color0": c0, "color1": c1}
             model(d)
         torch.cuda.synchronize()
-        outs[fused] = {k: d[k].cpu() for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts1_f")}
+        ps = [parity_vs_oracle(d, ref, b, b) for b in range(4)]
+        n_ref = sum(p["oracle_matches"] for p in ps)
+        flips = sum(round(p["flip_rate"] * max(1, p["oracle_matches"])) for p in ps)
+        dconf = sum(p.get("mean_abs_dmconf", 0.0) * p["common"] for p in ps) / max(1, sum(p["common"] for p in ps))
+        dpx = max(p.get("max_abs_dmkpts1_px", 0.0) for p in ps)
+        print(precision, "kv_fused", fused, "vs oracle:", n_ref, "matches,", flips, "flips, mean |d mconf|", round(dconf, 5), "max |d mkpts1|", dpx)
+        assert n_ref >= 200, n_ref
+        assert flips <= max_flip * n_ref + 2, (fused, flips, n_ref)
+        assert dconf <= max_dconf and dpx <= 1.0, (fused, dconf, dpx)
+        dev[fused] = (flips, dconf)
     model.kv_fused = True
-    key = lambda o: set(zip(o["b_ids"].tolist(), o["i_ids"].tolist(), o["j_ids"].tolist()))   # noqa: E731
-    a, b = key(outs[True]), key(outs[False])
-    assert len(b) >= 200 and len(a ^ b) <= 0.01 * len(b) + 2, (len(a), len(b), len(a ^ b))
-    ia = {m: n for n, m in enumerate(zip(outs[True]["b_ids"].tolist(), outs[True]["i_ids"].tolist(), outs[True]["j_ids"].tolist()))}
-    ib = {m: n for n, m in enumerate(zip(outs[False]["b_ids"].tolist(), outs[False]["i_ids"].tolist(), outs[False]["j_ids"].tolist()))}
-    common = sorted(a & b)
-    sa, sb = torch.tensor([ia[m] for m in common]), torch.tensor([ib[m] for m in common])
-    # (a last-bit difference of an fp32 state flips 16-bit roundings downstream: the bf16 mode carries 8 significand bits per activation)
-    dm = (outs[True]["mconf"][sa] - outs[False]["mconf"][sb]).abs()
-    assert dm.max().item() < (1e-1 if precision == "bf16" else 2e-2) and dm.mean().item() < (2e-3 if precision == "bf16" else 5e-4), (dm.max().item(), dm.mean().item())
-    assert (outs[True]["mkpts1_f"][sa] - outs[False]["mkpts1_f"][sb]).abs().max().item() < 0.5
+    assert dev[True][0] <= 1.5 * dev[False][0] + 3 and dev[True][1] <= 1.5 * dev[False][1] + 1e-4, dev
 
 
 @pytest.mark.parametrize("masked", [False, True], ids=["nomask", "qmask"])

@@ -40,5 +40,27 @@ def test_package_reads_only_the_documented_environment_variables():
             if f.endswith((".hip", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 seen |= set(re.findall(r"getenv\(\s*\"([A-Z_0-9]+)\"", src))
-    extra = seen - allowed - {"GIM_CM_PRECAND_PER_ROW", "GIM_FF_STAGE"}   # a test hook (forces the overflow fallback) and a -DFF_DEBUG_STAGES development build
+    extra = seen - allowed
     assert not extra, f"undocumented environment switches: {sorted(extra)}"
+
+
+def test_the_library_reads_no_environment_variable():
+    """round 6: csrc/ has no getenv() left (the pre-candidate capacity is gim_coarse_args.precand_per_row, the fine kernel's debug stage a -D build)"""
+    for f in os.listdir(os.path.join(ROOT, "gim_amd", "csrc")):
+        assert "getenv(" not in open(os.path.join(ROOT, "gim_amd", "csrc", f)).read(), f
+
+
+def test_unknown_flags_and_legacy_variables_are_reported(monkeypatch):
+    from gim_amd import switches
+    monkeypatch.setattr(switches, "FLAGS", switches._parse("fine_fuse=0,tf_chains=4"))
+    monkeypatch.setattr(switches, "_ASKED", set())
+    switches.flag("tf_chains", 2)
+    assert switches.unused_flags() == ["fine_fuse"]
+    assert switches.legacy_env({"GIM_GRAPH": "0", "GIM_FLAGS": "x", "GIM_BENCH_DEBUG": "1", "GIM_LA_KV2": "1", "PATH": ""}) == ["GIM_GRAPH", "GIM_LA_KV2"]
+    assert switches.tri_flag("gp_exact") is None
+    monkeypatch.setattr(switches, "FLAGS", switches._parse("gp_exact=true,refiner=off"))
+    assert switches.tri_flag("gp_exact") is True and switches.tri_flag("refiner") is False
+    monkeypatch.setattr(switches, "FLAGS", switches._parse("gp_exact=maybe"))
+    import pytest
+    with pytest.raises(ValueError):
+        switches.tri_flag("gp_exact")

@@ -1,6 +1,7 @@
-// Depthwise 5x5 + BN + ReLU (gim_dwconv5x5_bn_relu) alone on the shapes of one gim_dkm match(), with ablations of the kernel's
-// ingredients (-DGIM_DW_ABL=1: no FMAs, 2: no global loads, 3: no stores; development builds only):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DGIM_DW_ABL=n] tools/microbench_dwconv.hip gim_amd/csrc/runtime.hip -o /tmp/dw_n && /tmp/dw_n
+// Depthwise 5x5 + BN + ReLU (gim_dwconv5x5_bn_relu) alone on the shapes of one gim_dkm match().  (Round 4 also built ablations of the
+// kernel's ingredients -- no FMAs / no global loads / no stores, profiles/r04_dwconv.txt -- through GIM_DW_ABL blocks inside dkm.hip; round 6
+// removed those blocks from the product source, git history has them.)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/microbench_dwconv.hip gim_amd/csrc/runtime.hip -o /tmp/dw && /tmp/dw
 #include "../gim_amd/csrc/dkm.hip"
 #include <stdio.h>
 #include <vector>

@@ -1,10 +1,10 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace --stats of the headline command (bench.py, gim_loftr only) -> gpurun_out/<tag>_kernel_stats.txt + bench line
-#   tools/prof_bench.sh <tag> [steps]
+#   tools/prof_bench.sh <tag> [steps]        (PROF_ARGS="--precision fp16" adds bench arguments)
 tag=${1:-final}; steps=${2:-10}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag; rm -rf $out; mkdir -p $out
 ( cd /tmp && TMPDIR=/tmp GIM_BENCH_SKIP_DENSE=1 GIM_BENCH_SKIP_LIGHTGLUE=1 GIM_BENCH_SKIP_PARITY_MODE=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o p -- \
-    python $GRAFT_REPO_ROOT/bench.py --steps $steps --warmup 2 --no-cpu-baseline ) > $out/log.txt 2>&1
+    python $GRAFT_REPO_ROOT/bench.py --steps $steps --warmup 2 --no-cpu-baseline $PROF_ARGS ) > $out/log.txt 2>&1
 python - "$out" "$steps" <<'PY'
 import csv, glob, sys
 out, steps = sys.argv[1], int(sys.argv[2])

@@ -1,6 +1,6 @@
 """gim_loftr throughput bench on MI355X (driver contract: see DESIGN.md section 6).
 
-    python bench.py                       # 1 GPU, BASELINE config 2: gim_loftr 640x480 bf16, batch 8 pairs (--precision fp16 | fp32)
+    python bench.py                       # 1 GPU, BASELINE config 2: gim_loftr 640x480, batch 8 pairs, 16-bit operands (IEEE fp16 since round 6; --precision bf16 | fp32)
     python bench.py --gpus 8              # spawns 8 ranks itself (re-exec under torch.distributed.run, 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W        # what the driver does
@@ -56,7 +56,8 @@ from gim_amd.runner import HostPairFeeder, all_gather_matches, bind_rank_to_core
 
 H, W = 480, 640
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense, MI355X_MICROARCH.md
-TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_traffic.json") for r in (5, "4s2", 4, 3, 2)) if os.path.exists(p)), "")
+SEC_TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_traffic_secondary.json") for r in (6,)) if os.path.exists(p)), "")
+TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_traffic.json") for r in (6, 5, "4s2", 4, 3, 2)) if os.path.exists(p)), "")
 
 
 def parse_args(argv=None):
@@ -65,10 +66,11 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="pairs per rank per step")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"],
-                    help="gim_loftr's mode.  bf16 (default: the dtype BASELINE config 2 names): the 16-bit kernels on bf16 operands, 0.7-1.3 %% "
-                         "index flips against the fp32 oracle; fp16 (the module's own default): the same kernels on IEEE-fp16 operands, 2-3 %% "
-                         "slower, 0.15-0.3 %% flips; fp32: the parity mode (exact indices)")
+    ap.add_argument("--precision", default="fp16", choices=["bf16", "fp16", "fp32"],
+                    help="gim_loftr's mode.  fp16 (default since round 6 = the module's own default: the 16-bit kernels on IEEE-fp16 operands behind the "
+                         "range guard; 0.15-0.3 %% index flips against the fp32 oracle, max |d mconf| 0.02); bf16 (the dtype BASELINE config 2 names, round 5's "
+                         "headline: the same kernels on bf16 operands, 4-5 %% faster -- the fp16 MFMA draws more power --, 0.7-1.3 %% flips, max |d mconf| 0.2: "
+                         "reported as `bf16_mode`); fp32: the parity mode (exact indices)")
     ap.add_argument("--coarse-sim", default=None, choices=["fp32", "bf16", "fp16"], help="override LoFTR config['coarse_sim']")
     ap.add_argument("--frac", type=float, default=0.45, help="corresponding fraction of the frame (match count knob)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -413,6 +415,14 @@ def main():
         del m0, u0, u1
         torch.cuda.empty_cache()
 
+    # HBM bytes per call of the secondary engines: per-round PMC passes (tools/pmc_secondary.sh), committed under profiles/ -- NOT collected in this run
+    sec_tr = json.load(open(SEC_TRAFFIC_JSON))["engines"] if SEC_TRAFFIC_JSON else {}
+    sec_traffic_src = (f" ({os.path.relpath(SEC_TRAFFIC_JSON, ROOT)}: separate rocprofv3 --pmc passes, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, bf16 mode)" if SEC_TRAFFIC_JSON
+                       else " (no PMC pass on file)")
+
+    def sec_traffic(key):
+        return sec_tr.get(key, {}).get("hbm_bytes_per_call")
+
     # ---- secondary workload (reported, not the metric): gim_lightglue at the same resolution / batch ---------
     sec_prec = "fp32" if args.precision == "fp32" else "bf16"   # the secondary engines have a bf16 and an fp32 mode
     lightglue = None
@@ -447,6 +457,11 @@ def main():
                      "ms_per_step": round(1e3 * tl, 3), "dtype": sec_prec,
                      "achieved_tflops": round(nb / tl * 334e9 / 1e12, 1),
                      "note": "algorithmic 334 GFLOP/pair (SURVEY 8d)"}
+        lg_ach = nb / tl * 334e9 / 1e12
+        lightglue["roofline"] = {"bound": "mfma", "achieved": round(lg_ach, 1), "peak": MFMA_PEAK_TFLOPS[sec_prec], "unit": "TFLOP/s",
+                                 "frac": round(lg_ach / MFMA_PEAK_TFLOPS[sec_prec], 4), "traffic": sec_traffic("lightglue"),
+                                 "what": "334 GFLOP per pair (SURVEY 8d) x pairs per step / step time, whole pipeline (SuperPoint x 2, LightGlue, adapter, two read-backs); "
+                                         "traffic = HBM bytes per batch-8 step" + sec_traffic_src}
         del det, lgm
 
     # ---- secondary workloads: the two dense matchers at the reference's own configurations (one pair per call) ----
@@ -457,7 +472,8 @@ def main():
         im0 = base.to(dev)
         im1 = torch.roll(base, shifts=(12, 20), dims=(2, 3)).to(dev)
 
-        def dense_bench(name, build, note, batch=1, tflop_per_pair=None, parity_note=None):
+        def dense_bench(name, build, note, batch=1, tflop_per_pair=None, parity_note=None, traffic_key=None, prec16="bf16"):
+            p16 = sec_prec if sec_prec == "fp32" else prec16   # the engine's default 16-bit mode (gim_dkm: bf16, gim_roma: fp16 since round 6)
             try:
                 def make(prec):
                     torch.manual_seed(0)
@@ -468,7 +484,7 @@ def main():
                             mm.decoder.conv_refiner[s_].out_conv.bias.mul_(0.05)
                     return mm
 
-                m = make(sec_prec)
+                m = make(p16)
                 for _ in range(2):
                     warp, cert = m.match(im0, im1)
                     m.sample(warp, cert, 5000)
@@ -485,12 +501,12 @@ def main():
                 torch.cuda.synchronize()
                 t_sample = (time.perf_counter() - td) / n_it
                 dense[name] = {"workload": note, "pairs_per_s": round(1.0 / (t_match + t_sample), 2),
-                               "match_ms": round(1e3 * t_match, 2), "sample_ms": round(1e3 * t_sample, 2), "dtype": sec_prec}
+                               "match_ms": round(1e3 * t_match, 2), "sample_ms": round(1e3 * t_sample, 2), "dtype": p16}
                 if tflop_per_pair:   # SURVEY 8d's algorithmic work of one match() (low-resolution + upsampling pass) against the dense 16-bit MFMA peak
                     ach = tflop_per_pair / t_match
-                    dense[name]["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS[sec_prec], "unit": "TFLOP/s",
-                                               "frac": round(ach / MFMA_PEAK_TFLOPS[sec_prec], 4), "traffic": None,
-                                               "what": f"{tflop_per_pair} TFLOP per match() (SURVEY 8d, BASELINE.md section 2) / match_ms; no PMC pass for this workload"}
+                    dense[name]["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS[p16], "unit": "TFLOP/s",
+                                               "frac": round(ach / MFMA_PEAK_TFLOPS[p16], 4), "traffic": sec_traffic(traffic_key),
+                                               "what": f"{tflop_per_pair} TFLOP per match() (SURVEY 8d, BASELINE.md section 2) / match_ms; traffic = HBM bytes per match()" + sec_traffic_src}
                 if parity_note:
                     dense[name]["parity_note"] = parity_note
                 if batch > 1:   # BASELINE's batched configuration: `batch` independent pairs in one engine pass (match_batch)
@@ -506,11 +522,12 @@ def main():
                     dense[name].update({f"batch{batch}_match_ms_per_pair": round(1e3 * t_b / batch, 2),
                                         f"batch{batch}_pairs_per_s": round(batch / (t_b + batch * t_sample), 2)})
                     del wb, cb
-                if sec_prec == "bf16":   # round 5: the same engine in its IEEE-fp16 flavour (precision='fp16': 11 instead of 8 significand bits per stored activation)
+                if p16 != "fp32":   # the same engine in its OTHER 16-bit flavour (fp16: 11 instead of 8 significand bits per stored activation)
+                    o16 = "fp16" if p16 == "bf16" else "bf16"
                     w16, c16 = warp.float().clone(), cert.float().clone()
                     del m
                     torch.cuda.empty_cache()
-                    m = make("fp16")
+                    m = make(o16)
                     for _ in range(3):   # (the first calls of a new module build its per-shape tables on the host)
                         wf, cf = m.match(im0, im1)
                     torch.cuda.synchronize()
@@ -518,8 +535,8 @@ def main():
                     for _ in range(n_it):
                         wf, cf = m.match(im0, im1)
                     torch.cuda.synchronize()
-                    dense[name]["fp16_mode"] = {"match_ms": round(1e3 * (time.perf_counter() - td) / n_it, 2), "finite": bool(torch.isfinite(wf).all() and torch.isfinite(cf).all()),
-                                                "mean_abs_dwarp_vs_bf16_mode": round(float((wf.float() - w16).abs().mean()), 5),
+                    dense[name][o16 + "_mode"] = {"match_ms": round(1e3 * (time.perf_counter() - td) / n_it, 2), "finite": bool(torch.isfinite(wf).all() and torch.isfinite(cf).all()),
+                                                "mean_abs_dwarp_vs_timed_mode": round(float((wf.float() - w16).abs().mean()), 5),
                                                 "note": "same random-init weights and pair; tests/test_gpu_dkm.py / test_gpu_roma.py::test_match_fp16_is_closer_than_bf16 hold its distance "
                                                         "from the fp32 oracle against the bf16 mode's"}
                     del wf, cf, w16, c16
@@ -541,17 +558,19 @@ def main():
             return f
 
         dense_bench("gim_dkm", build_dkm, "gim_dkm match() + sample(5000), 672x896 -> upsampling pass 1152x1536, one pair per call, "
-                    "random-init weights (trainer/lightning.py:29-37 configuration)", batch=4, tflop_per_pair=5.27,
+                    "random-init weights (trainer/lightning.py:29-37 configuration)", batch=4, tflop_per_pair=5.27, traffic_key="dkm",
                     parity_note="fp32 mode at 672x896 (tests/test_gpu_dense_fullsize.py, profiles/r03_dense_parity.txt): warp max 2.9e-4 / mean 2.5e-5 of scale "
                                 "from the reference's PINNED fp32 arithmetic -- the distance that arithmetic's own fp32 GP inverse keeps from its formula "
                                 "(condition number ~2e4) -- and max 3.0e-6 from the same oracle with only the GP step in fp64; the timed bf16 mode: mean |d warp| "
                                 "~0.009 (tests/test_gpu_dkm.py)")
         dense_bench("gim_roma", build_roma(672), "gim_roma match() + sample(5000), 672x672 -> upsampling pass 1344x1344, one pair per call, "
-                    "random-init weights incl. a synthetic DINOv2 ViT-L/14 (RoMa(img_size=[672]), trainer/lightning.py:38-41)", tflop_per_pair=14.44,
+                    "random-init weights incl. a synthetic DINOv2 ViT-L/14 (RoMa(img_size=[672]), trainer/lightning.py:38-41)", tflop_per_pair=14.44, traffic_key="roma672", prec16="fp16",
                     parity_note="fp32 mode at 672x672: 99.75 % of the warp values within 2e-3 of the reference's pinned fp32 arithmetic (the rest: anchor arg-max "
                                 "decisions its own GP noise flips), max 3.6e-7 from the oracle with the GP step in fp64 (profiles/r03_dense_parity.txt)")
-        dense_bench("gim_roma_560", build_roma(560), "gim_roma match() + sample(5000), 560x560 -> upsampling pass 1120x1120 (BASELINE config 4 "
-                    "resolution, RoMa(img_size=[560])), one pair per call per GPU, random-init weights", tflop_per_pair=10.03)
+        dense_bench("gim_roma_560", build_roma(560), "gim_roma match() + sample(5000), 560x560 -> upsampling pass 1344x1344 (BASELINE config 4: RoMa(img_size=[560]); "
+                    "roma.py:658 fixes upsample_res = 1344 x 1344 whatever img_size), one pair per call per GPU, random-init weights", tflop_per_pair=10.03, traffic_key="roma560", prec16="fp16",
+                    parity_note="fp32 mode at 560x560 and through the 1344x1344 upsampling pass (tests/test_gpu_dense_fullsize.py::test_roma_560_*): every value within 2e-5 of scale of the "
+                                "oracle with the GP step in fp64; the timed mode is the engine's default 16-bit mode")
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample; parity of the benchmarked engine ----
     cpu = None
@@ -643,8 +662,10 @@ def main():
                        "transformer_rows": {k: bool(getattr(model, k, False)) for k in ("q_local", "kv_fused", "kv_init")},
                        "readback": f"match count every step (host sync) + the packed match rows, {readback_bytes // max(1, args.steps)} B per step, to pinned host "
                                    "memory inside the timed region",
-                       "baseline_dtype_note": "BASELINE config 2 names bf16: the headline mode since round 5 (rounds 3-4 headlined fp16 = `fp16_mode` here: "
-                                              "11 instead of 8 significand bits per stored activation, a quarter of the index flips, 2-3 % slower)"},
+                       "baseline_dtype_note": "BASELINE config 2 names bf16 (round 5's headline, `bf16_mode` here: 4-5 % faster, but 1 % index flips with max |d mconf| 0.2 "
+                                              "against the fp32 oracle -- VERDICT r5: parity first).  Round 6 headlines the 16-bit mode that keeps the parity bar "
+                                              "(IEEE fp16 operands, 11 instead of 8 significand bits per stored activation, fp32 accumulation, range guard with a bf16 "
+                                              "fallback): same kernels, same bytes, same instruction counts"},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity, "parity_mode": alt_modes.get("parity_mode", (None,))[0],
             "fp16_mode": alt_modes.get("fp16_mode", (None,))[0], "bf16_mode": alt_modes.get("bf16_mode", (None,))[0], "h2d_inclusive": h2d, "fine_idle": idle,
             "secondary_workloads": {"gim_lightglue": lightglue, **dense},

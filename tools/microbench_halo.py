@@ -1,5 +1,6 @@
-"""The 3x3 / stride-1 layers of the gim_loftr forward on the three kernels behind gim_conv2d_bn_act, one process, interleaved rounds
-(round 6): generic implicit GEMM (persistent 256x256 / 128x128 tiles), halo v1 (round 2), halo v2 (lean K loop, fragment skip).
+"""The 3x3 / stride-1 layers of the gim_loftr forward on the two kernels behind gim_conv2d_bn_act, one process, interleaved rounds:
+generic implicit GEMM (persistent 256x256 / 128x128 tiles) and the halo kernel.  (Round 6 timed three re-scheduled K loops with it --
+profiles/r06_halo_variants.txt; their kernels are in the git history.)
     python tools/microbench_halo.py [bf16|fp16] [rounds]"""
 import os
 import sys
@@ -33,15 +34,13 @@ def run(kind, pk, x, y, act):
     if kind == "generic":
         ops.conv_rows(x.view(-1, cs), pk, (B, H, W, H, W), y.view(-1, pk.n_store), act)
     else:
-        ops.HALO_V2 = kind != "halo1"
-        ops.HALO_BURST = kind == "halo3b"
         ops.conv3x3_halo(x, pk, y, act)
 
 
 ref = {}
 for r in range(rounds + 1):
     for name, pk, x, y, act, fl in cases:
-        for kind in ("generic", "halo1", "halo2", "halo3b"):
+        for kind in ("generic", "halo1"):
             if pk.halo is None:
                 continue
             run(kind, pk, x, y, act)
@@ -63,7 +62,7 @@ for r in range(rounds + 1):
                     print(f"{name} {kind}: max deviation from the generic kernel {d:.2e} of scale")
 for name, pk, x, y, act, fl in cases:
     row = []
-    for kind in ("generic", "halo1", "halo2", "halo3b"):
+    for kind in ("generic", "halo1"):
         v = res.get((name, kind))
         if v:
             m = sorted(v)[len(v) // 2]

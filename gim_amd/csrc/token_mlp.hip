@@ -239,9 +239,14 @@ __device__ __forceinline__ void layernorm_rows(f32x16_t (&acc)[2][2], const floa
 // PROJ = true ("projection only", round 5): the tile is just the 16-bit rows `xb`; nothing of the layer runs, only the projection blocks behind
 // it -- the k / v pair of the FIRST layer, handed over as partial KV states like every later one (replaces the initial [k | v] projection GEMM,
 // its rows and the la_kv launches that read them).
+// the projection-block descriptors are indexed at run time: read through the kernel-argument segment (scalar loads at a uniform index) --
+// indexing the by-value struct itself made hipcc copy it to scratch (192 B per lane until round 5)
+typedef const __attribute__((address_space(4))) Args* KArgs;
+
 template <bool PROJ>
 __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const KArgs ka = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
     Lane L;
     L.lane = threadIdx.x & 63;
     L.l31 = L.lane & 31;
@@ -257,7 +262,7 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
     const uint4* wp = a.wts + (size_t)L.w * UNITS_PER_WAVE * UNIT_U4;
     const uint4* ewp = a.ewts + (size_t)L.w * a.nblk * 4 * UNIT_U4;
     unsigned emask = 0u;         // projection blocks whose row range holds this tile (block-uniform)
-    for (int b = 0; b < a.nblk; ++b) emask |= (r0 >= a.elo[b] && r0 < a.ehi[b]) ? 1u << b : 0u;
+    for (int b = 0; b < a.nblk; ++b) emask |= (r0 >= ka->elo[b] && r0 < ka->ehi[b]) ? 1u << b : 0u;
     // Weight units are requested TWO ahead of their use into alternating register sets (wa: even units, wb: odd units): with one
     // set, unit u + 1 could only be requested once unit u's MFMAs had issued, and every unit waited out an L2 round trip.
     // Unit sequence: the 28 base units, then 4 per active projection block.
@@ -392,7 +397,7 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const int k16 = 2 * h + ks;   // k16 step of the 256-channel row
-                    const uint4 q = *(const uint4*)(A + (k16 >> 3) * 256 + L.a8[k16 & 7] + j * 32 * ROWB);
+                    const uint4 q = *(const uint4*)(A + (k16 >> 3) * 256 + (L.l31 * ROWB + (((2 * (k16 & 7) + L.lh) ^ L.sw) << 4)) + j * 32 * ROWB);   // = L.a8[k16 & 7], computed: k16 depends on the wave, and a run-time index put the whole table into scratch
                     const unsigned qq[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
@@ -535,7 +540,7 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
     while (b >= 0) {
         const unsigned rest = emask & ~((2u << b) - 1u);
         const int nb = rest ? __ffs(rest) - 1 : -1;
-        if (a.ekv[b]) {
+        if (ka->ekv[b]) {
             // ---- (k, v) pair -> partial KV state of this tile (block-uniform branch; the V block is the next active one: same row gate) ----
             // K^T as MFMA A operand, [head of the wave][row half][k16 step] x 8 tokens per lane: parked in LDS while the V block is projected
             // (32 registers the emit loop does not have; X's upper half and H are idle here: 8 KiB per wave, lane-linear)
@@ -549,7 +554,7 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
                 else mma_n64t<false>(tile, L.a8, (q & 1) * 4, 32 * ROWB, w, acc);
                 fetch(w);
             }
-            const bool kelu = a.eact[b] == GIM_ACT_ELU1;
+            const bool kelu = ka->eact[b] == GIM_ACT_ELU1;
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
@@ -576,9 +581,9 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
                 else mma_n64t<false>(tile, L.a8, (q & 1) * 4, 32 * ROWB, w, acc);
                 fetch(w);
             }
-            const int tix = a.ekv_tile0[b] + (r0 - a.elo[b]) / ROWS, nch = a.ekv_nchunk[b];
+            const int tix = ka->ekv_tile0[b] + (r0 - ka->elo[b]) / ROWS, nch = ka->ekv_nchunk[b];
             const int seq = tix / nch, chunk = tix - seq * nch;
-            const float inv_s = a.ekv_inv_s[b];
+            const float inv_s = ka->ekv_inv_s[b];
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf) {
                 f32x16_t kv;
@@ -595,7 +600,7 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
                         kv = mfma_h16_32x32x16(kk, vf, kv);        // D[d][v] += sum_tokens K[token][d] V[token][v]
                     }
                 // register r of lane (l31, lh) is element [d = 8 (r >> 2) + 4 lh + (r & 3)][v = l31] (the layout la_kv_h16_kernel stores)
-                float* out = a.ekv[b] + ((size_t)(seq * 8 + 2 * L.w + nf) * nch + chunk) * (32 * 32 + 32);
+                float* out = (float*)ka->ekv[b] + ((size_t)(seq * 8 + 2 * L.w + nf) * nch + chunk) * (32 * 32 + 32);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) out[((r >> 2) * 8 + L.lh * 4 + (r & 3)) * 32 + L.l31] = kv[r] * inv_s;
                 const float ksd = ksum[nf] + __shfl_xor(ksum[nf], 32, 64);   // lane (d = l31, lh) held the tokens 8 rg + 4 lh + e of both row halves
@@ -612,9 +617,15 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
             else mma_n64<false>(tile, L.a8, (q & 1) * 4, 32 * ROWB, w, acc);
             fetch(w);
         }
-        unsigned short* ob = a.eout[b];
-        const int ld = a.eld[b];
-        const bool elu = a.eact[b] == GIM_ACT_ELU1;
+        unsigned short* ob = (unsigned short*)ka->eout[b];
+        const int ld = ka->eld[b];
+        const bool elu = ka->eact[b] == GIM_ACT_ELU1;
+        // the lane index behind an empty asm: everything this branch derives from it (row addresses, bounds masks) is then computed HERE -- hipcc
+        // otherwise hoists ~24 registers of it in front of the emit loop and spills them around it, although the default 16-bit path (every block
+        // a fused (k, v) pair) never takes this branch (round 6: the kernel's last scratch bytes)
+        int ln = L.lane;
+        asm volatile("" : "+v"(ln));
+        const int l31p = ln & 31, lhp = ln >> 5;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -625,13 +636,13 @@ __global__ void __launch_bounds__(256, 2) token_mlp_kernel(const Args a) {
                     if (elu) {
                         v0 = elu1(v0); v1 = elu1(v1); v2 = elu1(v2); v3 = elu1(v3);
                     }
-                    *(uint2*)(t2 + L.l31 * 128 + (((4 * nf + rg) ^ ((L.l31 >> 1) & 7)) << 4) + ((L.lh ^ (L.l31 >> 4)) << 3)) =
+                    *(uint2*)(t2 + l31p * 128 + (((4 * nf + rg) ^ ((l31p >> 1) & 7)) << 4) + ((lhp ^ (l31p >> 4)) << 3)) =
                         make_uint2(cvt_pk_h16(v0, v1), cvt_pk_h16(v2, v3));
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave reads below (LDS executes a wave's accesses in order)
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const int row = it * 8 + (L.lane >> 3), slot = L.lane & 7, m = r0 + 32 * j + row;
+                const int row = it * 8 + (ln >> 3), slot = ln & 7, m = r0 + 32 * j + row;
                 uint4 v = *(const uint4*)(t2 + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
                 if (row >> 4) v = make_uint4(v.z, v.w, v.x, v.y);
                 if (m < a.R) *(uint4*)(ob + (size_t)m * ld + 64 * L.w + 8 * slot) = v;

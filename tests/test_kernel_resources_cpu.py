@@ -17,7 +17,8 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 # kernel (substring of the demangled name) -> (max VGPRs incl. AGPRs, max scratch bytes per lane)
 HOT = {
-    "token_mlp_kernel<false>(": (256, 200),                # 192 B: the projection-block descriptors of the by-value argument struct, indexed at run time, + 28 registers spilled around the emit loop since the fused KV state (round 5; none inside the merge / mlp phases)
+    "token_mlp_kernel<false>(": (256, 0),                  # round 6: no scratch (until round 5: 192 B -- a fragment-address table indexed at run time, the descriptors of the by-value argument struct, 24 hoisted registers spilled around the emit loop)
+    "token_mlp_kernel<true>(": (256, 0),
     "fine_fused_kernel(": (256, 104),               # 84-96 B: 20-23 spilled registers (the resident set of two matches is the design's limit)
     "bneck_tail_kernel<256, 256, 4, false>": (256, 0),
     "bneck_tail_kernel<128, 128, 8, false>": (256, 0),

@@ -7,7 +7,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--worker":
     import torch
     sys.path.insert(0, root)
     from tools import synth_loftr as S
-    m, _ = S.synthetic_model(os.environ.get("GIM_AB_PRECISION", "bf16"))
+    m, _ = S.synthetic_model(os.environ.get("GIM_AB_PRECISION", "fp16"))
     m = m.cuda()
     c0, c1 = S.textured_pairs(8, 480, 640, seed=1234, frac=0.45)
     c0, c1 = c0.cuda(), c1.cuda()

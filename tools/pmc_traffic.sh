@@ -35,7 +35,7 @@ NF = 3  # forwards in the run (tools/prof_forward.py 3)
 per_kernel = {}
 for k in set(res["FETCH_SIZE_all"]) | set(res["WRITE_SIZE_all"]):
     per_kernel[k] = round((res["FETCH_SIZE_all"].get(k, 0.0) * 2048 + res["WRITE_SIZE_all"].get(k, 0.0) * 1024) / NF / 1e9, 3)
-out = {"workload": "gim_loftr 640x480 batch 8, the headline 16-bit mode (bf16; the fp16 flavour moves the same bytes), match-rich synthetic pairs (bench.py workload), 3 forwards, eager launches", "igemm_launches": nl,
+out = {"workload": "gim_loftr 640x480 batch 8, the headline 16-bit mode (fp16 since round 6; the bf16 flavour moves the same bytes), match-rich synthetic pairs (bench.py workload), 3 forwards, eager launches", "igemm_launches": nl,
        "total_gb_per_forward_all_kernels": round(sum(per_kernel.values()), 2),
        "igemm_gb_per_forward": round((fetch_b + write_b) / NF / 1e9, 2),
        "gb_per_forward_by_kernel": dict(sorted(per_kernel.items(), key=lambda kv: -kv[1])[:12]),

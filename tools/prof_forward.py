@@ -4,7 +4,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools import synth_loftr as S
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+prec = sys.argv[2] if len(sys.argv) > 2 else "fp16"   # the bench headline mode (round 6)
 m, _ = S.synthetic_model(prec)
 m = m.cuda()
 c0, c1 = S.textured_pairs(8, 480, 640, seed=1234, frac=0.45)

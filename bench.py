@@ -337,22 +337,28 @@ def main():
             torch.cuda.synchronize()
 
         h2d_run(3)
-        n_h = 10
-        th = time.perf_counter()
-        h2d_run(n_h)
-        th = (time.perf_counter() - th) / n_h
+        n_h, th = 10, None
+        for _ in range(3):        # best of three runs of ten steps: a single host hiccup inside ten steps was 40 % of the figure
+            t0 = time.perf_counter()
+            h2d_run(n_h)
+            t0 = (time.perf_counter() - t0) / n_h
+            th = t0 if th is None else min(th, t0)
         for _ in range(2):
             step(p0.to(dev, non_blocking=True), p1.to(dev, non_blocking=True))
         torch.cuda.synchronize()
-        ts = time.perf_counter()
-        for _ in range(5):
-            step(p0.to(dev, non_blocking=True), p1.to(dev, non_blocking=True))
-        torch.cuda.synchronize()
-        ts = (time.perf_counter() - ts) / 5
+        ts = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(5):
+                step(p0.to(dev, non_blocking=True), p1.to(dev, non_blocking=True))
+            torch.cuda.synchronize()
+            t0 = (time.perf_counter() - t0) / 5
+            ts = t0 if ts is None else min(ts, t0)
         h2d = {"pairs_per_s": round(nb / th, 2), "ms_per_step": round(1e3 * th, 3),
                "serial_copy_ms_per_step": round(1e3 * ts, 3),
                "note": f"{2 * c0h.numel() * 4 / 1e6:.0f} MB of fp32 NCHW images per step from pinned host memory, double-buffered on a "
-                       "copy stream so that the transfer of step s+1 overlaps the kernels of step s (incl. the first, exposed copy); "
+                       "copy stream so that the transfer of step s+1 overlaps the kernels of step s (incl. the first, exposed copy); best of "
+                       "three runs of ten steps; "
                        "serial_copy = the same copies issued on the compute stream (round 2's figure)"}
 
     # ---- the other precision modes on the same workload and batch, timed the same way -----------------------------------------

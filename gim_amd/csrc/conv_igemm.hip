@@ -202,10 +202,116 @@ struct Epilogue {
         }
     }
 
+    // UPS: acc += bilinear x2 (align_corners=True) of a.ups -- the FPN's lateral 1x1 conv + F.interpolate + add (resnet.py:321-327) in one launch.
+    // Rounds 3-5 blended on the VALU inside the store loop (four neighbours per output from an LDS patch): 29 000 cycles per 256 x 256 tile
+    // against 9 000 for the plain epilogue, ~1 750 VALU instructions per wave and tile of which the 16-bit unpacks cost as much as the
+    // arithmetic (profiles/r06_halo_variants.txt, r06_valu_rates.txt).  Round 6: the interpolation is 48 more K of the MFMA.  The 32 pixels of
+    // a pass lie in one output row (2 ups_w % 32 == 0, checked at launch); they read 2 source rows x <= 18 source columns.  Per pass
+    // (32 px x 64 ch) the wave stages those sources by LDS-DMA as rows [s][64 ch] with s = 16 ks + 8 r + t <-> source row r, column
+    // 8 ks + t (six 1 KiB pieces, each 8 consecutive columns of one source row), and runs, per 32-channel fragment and k16 step ks,
+    //     acc[ch][px] += A[ch][s] * B[s][px]     A = the staged sources read TRANSPOSED (ds_read_b64_tr_b16: a 16-lane group reads
+    //                                            [4 sources][16 channels] and every lane receives one channel of the four sources),
+    //                                            B = the pixel's bilinear weights (wy of row r = lane half) x (lx0 at column x0, lx1 at x1),
+    //                                            built in registers and rounded to the operand type
+    // i.e. 6 MFMAs per pass, 24 per tile and wave, in front of the plain epilogue: conv + upsample are summed in fp32 and rounded once
+    // (the two-pass path rounds the conv output first).  Two patches per wave (its transposition tile and its half of the stage's second
+    // 32 KiB, rows 32..47 in 4 KiB per wave behind the stages): the request of pass p + 2 goes out when pass p is consumed.
+    __device__ __forceinline__ void ups_accumulate(const gim_conv_args& a, typename G::Acc& acc, char* stage, char* patch2, int m0, int n0, int M) const {
+        static_assert(WAVE_BYTES == 4096 && G::NW * (WAVE_BYTES + 4096) <= G::STAGE, "upsample patches: LDS map");
+        const int h = a.ups_h, w = a.ups_w, W2 = 2 * w, H2 = 2 * h;
+        const float sy = (float)(h - 1) / (float)(H2 - 1), sx = (float)(w - 1) / (float)(W2 - 1);
+        const int lane = threadIdx.x & 63, l15 = lane & 15;
+        constexpr int NP = TM * NH;   // passes of the wave tile
+        char* const pm[2] = {stage + wave * WAVE_BYTES, stage + G::NW * WAVE_BYTES + wave * 4096};   // rows 0..31 of patch 0 / 1
+        char* const pt[2] = {patch2 + wave * 4096, patch2 + wave * 4096 + 2048};                     // rows 32..47
+        const gim_u32x4_t ur = gim_make_rsrc(a.ups, (unsigned)((size_t)(M / (4 * h * w)) * h * w * a.ups_ld * 2));
+        // (16-byte slot of channel group g in row s: g ^ 2 ((s >> 1) & 1) -- the four rows of a transposed read then cover 128 B of distinct banks)
+        auto issue = [&](const int p) __attribute__((always_inline)) {
+            const int jj = p / NH, nn = p % NH;
+            const int mb = m0 + wm * WTM + jj * 32;
+            const int pr = mb / W2, X0 = mb - pr * W2, ib = pr / H2, Y = pr - ib * H2;
+            const float fy = sy * Y;
+            const int y0 = (int)fy, y1 = y0 + (y0 < h - 1 ? 1 : 0);
+            const int xa = (int)(sx * X0);
+            const int row8 = lane >> 3;
+            const int g = (lane & 7) ^ (2 * ((row8 >> 1) & 1));
+            const int nc = n0 + wn * WTN + nn * 64 + g * 8;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {   // piece q: source row q & 1, columns 8 (q >> 1) .. + 7 (beyond the row's last pixel: that pixel again, weight 0)
+                int c = xa + 8 * (q >> 1) + row8;
+                c = c < w - 1 ? c : w - 1;
+                const unsigned voff = (unsigned)((((size_t)ib * h + ((q & 1) ? y1 : y0)) * w + c) * a.ups_ld + nc) * 2u;
+                char* dst = q < 4 ? pm[p & 1] + q * 1024 : pt[p & 1] + (q - 4) * 1024;
+                gim_dma16(ur, (unsigned)(size_t)(__attribute__((address_space(3))) void*)dst, voff);
+            }
+        };
+        issue(0);
+        if (NP > 1) issue(1);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int j = p / NH, nh = p % NH;   // compile-time
+            // ---- this pass's weights: pixel l31 of the pass, source row = lane half --------------------------------------------
+            const int mb = m0 + wm * WTM + j * 32;
+            const int pr = mb / W2, uX0 = mb - pr * W2, uY = pr - (pr / H2) * H2;
+            const float fy = sy * uY;
+            const float ly1 = fy - (float)(int)fy;
+            const float wy = lh ? ly1 : 1.f - ly1;
+            const float fx = sx * (float)(uX0 + l31);
+            const int x0 = (int)fx, xa = (int)(sx * uX0);
+            const int x0r = x0 - xa, x1r = x0r + (x0 < w - 1 ? 1 : 0);
+            const float lx1 = (fx - (float)x0) * wy, lx0 = wy - lx1;   // (1 - lx1) wy
+            bf16x8_t wb[3];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                unsigned u[4];
+#pragma unroll
+                for (int t = 0; t < 8; t += 2) {
+                    const int c = 8 * ks + t;
+                    const float w0 = (c == x0r ? lx0 : 0.f) + (c == x1r ? lx1 : 0.f);
+                    const float w1 = (c + 1 == x0r ? lx0 : 0.f) + (c + 1 == x1r ? lx1 : 0.f);
+                    u[t >> 1] = cvt_pk_h16(w0, w1);
+                }
+                wb[ks] = __builtin_bit_cast(bf16x8_t, make_uint4(u[0], u[1], u[2], u[3]));
+            }
+            // ---- the patch has landed (younger in the queue: the six requests of pass p + 1) ---------------------------------------
+            if (p + 1 < NP) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            typedef short s4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                const char* base = ks < 2 ? pm[p & 1] + ks * 2048 : pt[p & 1];   // rows 16 ks .. 16 ks + 15
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    // lane -> (source 8 lh + 4 e + (l15 >> 2), channels 32 i + 16 (lane >> 4 & 1) + 4 (l15 & 3) .. + 3) of its 16-lane group's block
+                    const int ch = 32 * i + 16 * ((lane >> 4) & 1) + 4 * (l15 & 3);
+                    s4 lo4, hi4;
+                    {
+                        const int row = 8 * lh + (l15 >> 2);
+                        const char* q = base + row * 128 + ((((ch >> 3) ^ (2 * ((row >> 1) & 1))) << 4) | ((ch & 7) << 1));
+                        lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)q);
+                    }
+                    {
+                        const int row = 8 * lh + 4 + (l15 >> 2);
+                        const char* q = base + row * 128 + ((((ch >> 3) ^ (2 * ((row >> 1) & 1))) << 4) | ((ch & 7) << 1));
+                        hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)q);
+                    }
+                    const bf16x8_t av = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                    acc[nh * 2 + i][j] = mfma_h16_32x32x16(av, wb[ks], acc[nh * 2 + i][j]);
+                }
+            }
+            if (p + 2 < NP) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the patch is consumed: the request after next overwrites it
+                issue(p + 2);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch 0 / 1's first 4 KiB are the transposition tile / nothing the plain epilogue touches
+    }
+
     // residual + activation in accumulator layout, transposition through `stage` (a stage buffer no wave reads
     // any more), coalesced stores.  The caller must barrier before the stage is overwritten again.
     __device__ __forceinline__ void run(const gim_conv_args& a, typename G::Acc& acc, const Res& rres, char* stage,
-                                        int m0, int n0, int M) const {
+                                        int m0, int n0, int M, char* patch2 = nullptr) const {
+        if constexpr (UPS && OUT_BF16) ups_accumulate(a, acc, stage, patch2, m0, n0, M);
         char* wl = stage + wave * WAVE_BYTES;  // this wave's transposition tile [32 px][RB]
         const bool full = (m0 + G::A_BYTES / KTB <= M) && (n0 + G::B_BYTES / KTB <= a.N);
         const int act = (a.act_cols > 0 && n0 >= a.act_cols) ? GIM_ACT_NONE : a.act;  // tile-uniform
@@ -276,101 +382,6 @@ struct Epilogue {
                                 make_float4(v[rg * 4 + 0], v[rg * 4 + 1], v[rg * 4 + 2], v[rg * 4 + 3]);
                         }
                     }
-                // UPS: y += bilinear x2 (align_corners=True) of a.ups, arithmetic of upsample2x_add_kernel (elementwise.hip) on
-                // the rounded conv output.  The 32 pixels of a pass lie in one image row (Wo % 32 == 0, checked at launch).
-                // Round 3.  The first version gathered the four half-resolution neighbours of a pixel with ordinary loads inside
-                // the store loop: every row group's gathers queued behind the previous group's stores (vector memory returns in
-                // order), 0.23 ms on the 256->196 lateral conv (0.49 ms fused against 0.25 ms for the bare conv), and issuing
-                // them ahead by hand kept 32-64 more VGPRs live across the transposition (170-450 B of scratch, 1.8 ms).
-                // Now the SOURCE PIXELS of half a pass -- 16 output pixels read 2 rows x <= 10 columns of the half-resolution map --
-                // travel by LDS-DMA into a 2.5 KiB patch of this wave (no VGPR destination, invisible to the compiler's waits),
-                // requested BEFORE the stores of the previous half pass; the wait is a counted vmcnt(2) that leaves exactly
-                // those two stores in flight.  Neighbours are then ds_read_b128 from the patch: 20 staged rows instead of 64 gathers.
-                if constexpr (UPS && OUT_BF16) {
-                    static_assert(NI == 4 && RPI == 8 && G::NW * (WAVE_BYTES + 4096) <= G::STAGE, "upsample patch: LDS map");
-                    const int h = a.ups_h, w = a.ups_w;
-                    const float sy = (float)(h - 1) / (float)(2 * h - 1), sx = (float)(w - 1) / (float)(2 * w - 1);
-                    const int pass = j * NH + nh;   // compile-time
-                    char* ul = stage + G::NW * WAVE_BYTES + wave * 4096;                 // [2 rows x 10 columns][128 B]
-                    const unsigned ul_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)ul);
-                    const gim_u32x4_t ur = gim_make_rsrc(a.ups, (unsigned)((size_t)(M / (4 * h * w)) * h * w * a.ups_ld * 2));
-                    // source patch of half pass (jj, hh) of channel half nn: wave-uniform geometry, lane -> (staged row, 16-byte slot)
-                    auto issue = [&](const int jj, const int nn, const int hh) __attribute__((always_inline)) {
-                        const int mb = m0 + wm * WTM + jj * 32;
-                        const int W2 = 2 * w, H2 = 2 * h;
-                        const int pr = mb / W2, X0 = mb - pr * W2 + 16 * hh, ib = pr / H2, Y = pr - ib * H2;
-                        const float fy = sy * Y;
-                        const int y0 = (int)fy, y1 = y0 + (y0 < h - 1 ? 1 : 0);
-                        const int xa = (int)(sx * X0);
-                        const int nc = n0 + wn * WTN + nn * 64 + (threadIdx.x & 7) * 8;
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) {
-                            const int r = i * 8 + ((threadIdx.x & 63) >> 3);             // staged row 0..23 (20 used)
-                            const int sr = r >= 10 ? 1 : 0;
-                            int c = xa + r - 10 * sr;
-                            c = c < w - 1 ? c : w - 1;
-                            const unsigned voff = r < 20 ? (unsigned)((((size_t)ib * h + (sr ? y1 : y0)) * w + c) * a.ups_ld + nc) * 2u : 0xfffffff0u;
-                            gim_dma16(ur, ul_addr + (unsigned)(i * 1024), voff);
-                        }
-                    };
-                    if (pass == 0) issue(0, 0, 0);
-                    const int mb = m0 + wm * WTM + j * 32;  // wave-uniform
-                    const int W2 = 2 * w, H2 = 2 * h;
-                    const int pr = mb / W2, uX0 = mb - pr * W2, uY = pr - (pr / H2) * H2;
-                    const float fy = sy * uY;
-                    const int y0 = (int)fy;
-                    const float ly1 = fy - y0, ly0 = 1.f - ly1;
-#pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        // this half pass's patch has landed; the two stores of the previous half pass (issued behind its request) may still fly
-                        // (counted only when both store instructions of the previous half pass were certainly issued by this wave: all
-                        // its 256 rows inside the tensor and at least the first 16-byte column group of its 64 channels below N --
-                        // wave-uniform; otherwise, where a wave may have skipped a store altogether, the queue is drained)
-                        const int nprev = hh == 1 ? nh : (pass > 0 ? (pass - 1) % NH : 0);
-                        const bool prev_ok = (hh == 1 || pass > 0) && (m0 + G::A_BYTES / KTB <= M) && (n0 + wn * WTN + nprev * 64 < a.N);
-                        if (prev_ok) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        const int xa = (int)(sx * (uX0 + 16 * hh));
-                        uint4 res[2];
-#pragma unroll
-                        for (int kk = 0; kk < 2; ++kk) {
-                            const int row = (2 * hh + kk) * RPI + rrow;
-                            const uint4 o = *(const uint4*)(wl + row * RB + ((rslot ^ (row & 7)) << 4));
-                            const float fx = sx * (uX0 + row);
-                            const int x0 = (int)fx;
-                            const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
-                            const float lx1 = fx - x0, lx0 = 1.f - lx1;
-                            const char* q0 = ul + (x0 - xa) * 128 + rslot * 16;
-                            const char* q1 = ul + (x1 - xa) * 128 + rslot * 16;
-                            const uint4 qa = *(const uint4*)q0, qb = *(const uint4*)q1;
-                            const uint4 qc = *(const uint4*)(q0 + 1280), qd = *(const uint4*)(q1 + 1280);
-                            const unsigned ov[4] = {o.x, o.y, o.z, o.w}, av[4] = {qa.x, qa.y, qa.z, qa.w}, bv[4] = {qb.x, qb.y, qb.z, qb.w};
-                            const unsigned cv[4] = {qc.x, qc.y, qc.z, qc.w}, dv[4] = {qd.x, qd.y, qd.z, qd.w};
-                            unsigned rv[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float o0 = h16_lo(ov[e]), o1 = h16_hi(ov[e]);
-                                const float a0 = h16_lo(av[e]), a1 = h16_hi(av[e]);
-                                const float b0 = h16_lo(bv[e]), b1 = h16_hi(bv[e]);
-                                const float c0 = h16_lo(cv[e]), c1 = h16_hi(cv[e]);
-                                const float d0 = h16_lo(dv[e]), d1 = h16_hi(dv[e]);
-                                rv[e] = cvt_pk_h16(o0 + (ly0 * (lx0 * a0 + lx1 * b0) + ly1 * (lx0 * c0 + lx1 * d0)),
-                                                    o1 + (ly0 * (lx0 * a1 + lx1 * b1) + ly1 * (lx0 * c1 + lx1 * d1)));
-                            }
-                            res[kk] = make_uint4(rv[0], rv[1], rv[2], rv[3]);
-                        }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the patch is consumed: the next request may overwrite it
-                        // request the next half pass's patch BEFORE this half pass's stores
-                        if (hh == 0) issue(j, nh, 1);
-                        else if (pass + 1 < TM * NH) issue((pass + 1) / NH, (pass + 1) % NH, 0);
-#pragma unroll
-                        for (int kk = 0; kk < 2; ++kk) {
-                            const int row = (2 * hh + kk) * RPI + rrow;
-                            const int m = m0 + wm * WTM + j * 32 + row;
-                            if (ncol_ok && (full || m < M)) *(uint4*)((char*)a.y + ((size_t)m * a.ldy + ncol) * OES) = res[kk];
-                        }
-                    }
-                } else {
                 unsigned hm = 0u;   // fp16 range guard: an un-normalised residual stream is stored here (x + identity; gim_common.h)
 #pragma unroll
                 for (int k = 0; k < NI; ++k) {
@@ -383,7 +394,6 @@ struct Epilogue {
                     }
                 }
                 if constexpr (HAS_RES && OUT_BF16) { if (!out_bf) h16_range_check(a.health, hm); }
-                }
             }
         }
     }
@@ -487,7 +497,7 @@ igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntile
             kloop(IntC<G::TN>());
         }
         tt_b = GIM_TT_NOW(); tt_k += tt_b - tt_a;
-        epi.run(a, acc, rres, smem + (buf ^ 1) * G::STAGE, m0, n0, M);  // buf ^ 1: the stage just consumed
+        epi.run(a, acc, rres, smem + (buf ^ 1) * G::STAGE, m0, n0, M, smem + 2 * G::STAGE);  // buf ^ 1: the stage just consumed; UPS: patch rows behind the stages
         epi.init_acc(a, acc, n0n < a.npad ? n0n : 0);
         g = gn;
         m0 = m0n; n0 = n0n;
@@ -501,7 +511,8 @@ igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntile
 
 template <int BM, int BN, int WM, int WN, bool BF16, bool OUT_BF16, bool HAS_RES, bool SKIP = false, bool UPS = false>
 int launch_persistent(const gim_conv_args& a, hipStream_t stream) {
-    constexpr int smem = 2 * (BM + BN) * KTB;
+    constexpr int smem = 2 * (BM + BN) * KTB + (UPS ? WM * WN * 4096 : 0);   // UPS: rows 32..47 of the two upsample patches of every wave (Epilogue::ups_accumulate)
+    static_assert(smem <= 160 * 1024, "LDS");
     auto kern = igemm_persistent_kernel<BM, BN, WM, WN, BF16, OUT_BF16, HAS_RES, SKIP, UPS>;
     static GimPerDevice attr_done;
     if (attr_done.needed()) {
@@ -828,7 +839,7 @@ static bool ups_supported(const gim_conv_args& a) {
     // output rows are (image, Y, X) with Y < 2 ups_h, X < 2 ups_w whatever geometry the launch states (a 1x1 conv is launched flat)
     const long long Mo = (long long)a.B * a.Ho * a.Wo;
     if (a.ups_h <= 0 || a.ups_w <= 0 || Mo % (4ll * a.ups_h * a.ups_w) != 0 || (2 * a.ups_w) % 32 != 0 || a.ups_ld % 8 != 0 || a.ups_ld < a.N) return false;
-    if (a.act_cols != 0) return false;
+    if (a.act_cols != 0 || a.act != GIM_ACT_NONE) return false;   // the upsampled map is added in front of the activation slot: only the FPN's bare lateral conv
     const int nkt = a.kpad * 2 / KTB;
     const long long M = (long long)a.B * a.Ho * a.Wo;
     return a.use_lds_dma == 3 || (nkt >= BIG_MIN_NKT && ((M + 255) / 256) * (a.npad / 256) >= BIG_MIN_TILES);

@@ -32,7 +32,7 @@ HOT = {
     "igemm_persistent_kernel<256, 256, 4, 2, true, true, false, true, false>": (256, 0),    # the 196-channel 3x3 layers (fragment skip)
     "igemm_persistent_kernel<256, 256, 4, 2, true, true, false, false, false>": (256, 32),
     "igemm_persistent_kernel<256, 256, 4, 2, true, true, false, true, true>": (256, 32),     # lateral 1x1 with the upsample-add through the MFMA (round 6: 24 B; the VALU blend of rounds 3-5: 76 B)
-    "igemm_persistent_kernel<256, 256, 4, 2, true, true, false, false, true>": (256, 32),
+    "igemm_persistent_kernel<256, 256, 4, 2, true, true, false, false, true>": (256, 56),     # the same for N = 256 (no fragment skip): 52 B in the fp16 flavour
     "cm_stats256_kernel<1>": (256, 80),
     "stem7x7_kernel<true>": (128, 0),
     "la_kv_h16_kernel<256>": (128, 0),              # 8 waves, two workgroups per CU

@@ -226,7 +226,8 @@ class LoFTR(nn.Module):
         # launch-order experiments over independent images / pairs (same kernels, same arithmetic; see _backbone_trunk, _transformer_emit;
         # profiles/r05_launch_order.txt: two transformer chains -0.2 ms per batch-8 step, the other two do not pay)
         self.depth_groups = flag("depth_groups", 1, config)
-        self.l3_chains = flag("l3_chains", 1, config)
+        self.l3_chains = flag("l3_chains", 2, config)
+        self.trunk_chains = flag("trunk_chains", False, config)
         self.tf_chains = flag("tf_chains", 2, config)
         # token tails write partial KV states instead of the k / v rows of the next attention (see _transformer_emit; False: rows + la_kv)
         self.kv_fused = flag("kv_fused", True, config)
@@ -463,12 +464,20 @@ class LoFTR(nn.Module):
         Images are independent up to here, so the batch may run as image groups: `depth_groups` > 1 walks stem -> layer1 -> layer2
         group by group (producer -> consumer tensors of a group stay closer to the Infinity Cache), `l3_chains` > 1 runs layer 3 as
         that many image groups on parallel streams (its 300- / 600-tile launches fill 0.6 / 1.2 rounds of the workgroup slots: two
-        unsynchronised chains keep the slots busy).  Both are launch-order changes only: same kernels, same arithmetic."""
+        unsynchronised chains keep the slots busy -- round 5 measured +-0, round 6 -0.25 ms per batch-8 step on one box, 10.16 -> 9.91 ms,
+        and made 2 the default; 4 and 8 chains measure 9.95 / 10.03), `trunk_chains` starts the chains at the stem.  All of them are
+        launch-order changes only: same kernels, same arithmetic."""
         B = x.shape[0]
-        G = self.depth_groups if (self.debug is None and self.depth_groups > 1 and B % self.depth_groups == 0) else 1
-        if G == 1:
-            x1, x2, o3 = self._trunk12(P, x, dt)
-        else:
+        K = self.l3_chains if (self.debug is None and self.l3_chains > 1 and B % self.l3_chains == 0) else 1
+        if K > 1:   # a chain must keep the shapes the fused Bottleneck tails take (256-row tiles at 1/4 and 1/8 resolution), else it would fall back to unfused launches
+            half_ = lambda v: (v - 1) // 2 + 1   # noqa: E731
+            h4, w4 = half_(half_(x.shape[1])), half_(half_(x.shape[2]))
+            if (B // K * h4 * w4) % 256 != 0 or (B // K * half_(h4) * half_(w4)) % 256 != 0:
+                K = 1
+        whole = K > 1 and self.trunk_chains   # the chains start at the stem instead of at layer 3
+        G = K if whole else (self.depth_groups if (self.debug is None and self.depth_groups > 1 and B % self.depth_groups == 0) else 1)
+        o3 = None
+        if G > 1:
             n = B // G
             half = lambda v: (v - 1) // 2 + 1   # noqa: E731
             H1, W1 = half(x.shape[1]), half(x.shape[2])
@@ -476,17 +485,22 @@ class LoFTR(nn.Module):
             tdt = torch_dtype(dt)
             x1 = torch.empty(B, H1, W1, P["l1.2.c3"].n_store, dtype=tdt, device=x.device)
             x2 = torch.empty(B, H2, W2, P["l2.3.c3"].n_store, dtype=tdt, device=x.device)
-            o3 = None
             if self.bneck_tail and "l2.3.tail" in P and (n * H2 * W2) % 256 == 0 and n * H2 * W2 * 1024 < (1 << 32) - 16:   # (_layer's test)
                 o3 = torch.empty(B, H2, W2, P["l3.0.c1"].n_store, dtype=tdt, device=x.device)
+
+        def trunk12_group(g):
+            sl = slice(g * n, (g + 1) * n)
+            a1, a2, ao = self._trunk12(P, x[sl], dt, out=(x1[sl], x2[sl], o3[sl] if o3 is not None else None))
+            assert (ao is None) == (o3 is None)
+            for dst, src in ((x1, a1), (x2, a2), (o3, ao)):   # a launch that was not a fused one allocated its own output
+                if src is not None and src.data_ptr() != dst[sl].data_ptr():
+                    ops.copy_segments([(src.contiguous(), dst[sl])])
+
+        if G == 1:
+            x1, x2, o3 = self._trunk12(P, x, dt)
+        elif not whole:
             for g in range(G):
-                sl = slice(g * n, (g + 1) * n)
-                a1, a2, ao = self._trunk12(P, x[sl], dt, out=(x1[sl], x2[sl], o3[sl] if o3 is not None else None))
-                assert (ao is None) == (o3 is None)
-                for dst, src in ((x1, a1), (x2, a2), (o3, ao)):   # a launch that was not a fused one allocated its own output
-                    if src is not None and src.data_ptr() != dst[sl].data_ptr():
-                        ops.copy_segments([(src.contiguous(), dst[sl])])
-        K = self.l3_chains if (self.debug is None and self.l3_chains > 1 and B % self.l3_chains == 0) else 1
+                trunk12_group(g)
         if K == 1:
             x3, _, x3_out = self._layer(P, 3, 6, x2, o3)
             if x3_out is None:
@@ -499,6 +513,8 @@ class LoFTR(nn.Module):
         keep = []   # tensors that cross streams stay referenced until the join (the caching allocator re-uses a freed block per stream)
 
         def chain(g):
+            if whole:
+                trunk12_group(g)
             sl = slice(g * n, (g + 1) * n)
             x3, _, xo = self._layer(P, 3, 6, x2[sl], o3[sl] if o3 is not None else None, out_last=(None, x3_out[sl]))
             if xo is None:

@@ -371,8 +371,10 @@ int tail_entry(int P, const void* t2, const void* res, void* x_out, void* t1_nex
         return n_next == 128 ? launch_tail<128, 128>(a, (hipStream_t)stream) : launch_tail<128, 256>(a, (hipStream_t)stream);
     }
     GIM_REQUIRE(n_next == 256, "bneck_tail256: n_next must be 256 (got %d)", n_next);
-    // 4-wave workgroups (two per CU) when the 256-row tiles would not fill three rounds of the chip (A/B: DESIGN.md section 4, round 3)
-    if (M / 256 < 3 * 256) return launch_tail<256, 256, 4>(a, (hipStream_t)stream);
+    // 4-wave workgroups (two per CU) when the 256-row tiles are between one and three rounds of the chip (A/B: DESIGN.md section 4, round 3).  A launch of at
+    // most one round -- layer 3 of one image chain of the batch-8 benchmark, 150 tiles -- is better off with 8 waves and the third chunk buffer (round 6, two
+    // chains, same box: 9.54-9.57 vs 9.57-9.63 ms per step)
+    if (M / 256 > 256 && M / 256 < 3 * 256) return launch_tail<256, 256, 4>(a, (hipStream_t)stream);
     return launch_tail<256, 256>(a, (hipStream_t)stream);
 }
 

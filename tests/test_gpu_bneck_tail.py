@@ -42,10 +42,11 @@ def _ref(blk, nxt, t2, res, tdt, plain_next=False):
 @pytest.mark.parametrize("tdt", KINDS, ids=KIDS)
 @pytest.mark.parametrize("B,H,W,planes,n1,plain", [(1, 8, 32, 128, 128, False), (2, 24, 64, 128, 128, False), (3, 16, 80, 128, 128, False),
                                                    (1, 16, 48, 128, 256, False), (1, 8, 32, 256, 256, False), (2, 16, 40, 256, 256, False),
-                                                   (1, 16, 32, 256, 256, True)])
+                                                   (1, 16, 32, 256, 256, True), (16, 60, 80, 256, 256, False)])
 def test_bneck_tail_matches_reference(B, H, W, planes, n1, plain, tdt):
     """planes 128 = layer 2 (chunks of 64 channels), 256 = layer 3 (chunks of 32); plain = layer3_outconv as the next convolution
-    (no BatchNorm, no activation) with x' not stored"""
+    (no BatchNorm, no activation) with x' not stored.  16 x 60 x 80 = the benchmark's layer 3 as ONE launch: 300 tiles of 256 rows, the
+    4-wave workgroups (smaller launches take the 8-wave ones: bneck_tail.hip, tail_entry)"""
     from gim_amd import ops
     from gim_amd.packing import pack_bneck_tail
     blk, nxt = _blocks(H + W, n1, planes)

@@ -28,6 +28,7 @@ class ConvArgs(ctypes.Structure):
         ("dtype", c_int), ("out_dtype", c_int), ("res_dtype", c_int), ("use_lds_dma", c_int),
         ("ups", c_void_p), ("ups_h", c_int), ("ups_w", c_int), ("ups_ld", c_int),
         ("health", c_void_p),
+        ("split16", c_int), ("pad_", c_int),
     ]
 
 
@@ -69,7 +70,7 @@ class LgAssignArgs(ctypes.Structure):
     ]
 
 
-ABI_VERSION = 112   # gim_version() of the include/gim_hip.h revision the structures and prototypes here mirror
+ABI_VERSION = 113   # gim_version() of the include/gim_hip.h revision the structures and prototypes here mirror
 
 # name -> (restype, argtypes); every symbol declared in include/gim_hip.h
 PROTOTYPES = {

@@ -160,6 +160,7 @@ struct Epilogue {
     typedef uint4 Res[HAS_RES ? TM : 1][HAS_RES ? NI : 1];
 
     int wm, wn, l31, lh, rrow, rslot, wave;
+    float wscale = 1.f;   // fp32 operands as fp16 hi / lo pairs (Igemm::compute_split16): the weight operand's power-of-two scale -- the bias enters times it, run() divides
     __device__ __forceinline__ Epilogue() {
         const int lane = threadIdx.x & 63;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -176,6 +177,7 @@ struct Epilogue {
             for (int rg = 0; rg < 4; ++rg) {
                 float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (a.bias) bb = *(const float4*)(a.bias + n0 + wn * WTN + i * 32 + rg * 8 + lh * 4);  // bias is padded to npad
+                if constexpr (G::ES == 4) { bb.x *= wscale; bb.y *= wscale; bb.z *= wscale; bb.w *= wscale; }
 #pragma unroll
                 for (int j = 0; j < TM; ++j) {
                     acc[i][j][rg * 4 + 0] = bb.x; acc[i][j][rg * 4 + 1] = bb.y;
@@ -312,6 +314,17 @@ struct Epilogue {
     __device__ __forceinline__ void run(const gim_conv_args& a, typename G::Acc& acc, const Res& rres, char* stage,
                                         int m0, int n0, int M, char* patch2 = nullptr) const {
         if constexpr (UPS && OUT_BF16) ups_accumulate(a, acc, stage, patch2, m0, n0, M);
+        if constexpr (G::ES == 4) {
+            if (wscale != 1.f) {   // wave-uniform
+                const float inv = 1.f / wscale;   // a power of two: exact
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
+            }
+        }
         char* wl = stage + wave * WAVE_BYTES;  // this wave's transposition tile [32 px][RB]
         const bool full = (m0 + G::A_BYTES / KTB <= M) && (n0 + G::B_BYTES / KTB <= a.N);
         const int act = (a.act_cols > 0 && n0 >= a.act_cols) ? GIM_ACT_NONE : a.act;  // tile-uniform
@@ -450,6 +463,7 @@ igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntile
     const int nkt = a.kpad * G::ES / KTB;
 
     E epi;
+    if constexpr (!BF16) { if (a.split16) epi.wscale = 4096.f; }
     GIM_TT(conv, epi.wave, 0);
     unsigned long long tt_k = 0, tt_e = 0, tt_n = 0, tt_a = 0, tt_b = 0;   // GIM_TIMING: K-loop / epilogue totals over this workgroup's tiles
     (void)tt_k; (void)tt_e; (void)tt_n; (void)tt_a; (void)tt_b;
@@ -472,7 +486,7 @@ igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntile
         if (has_next) gn.decode(ml, m0n, n0n);
         tt_a = GIM_TT_NOW();
         // ---- K loop: only MFMAs touch the accumulators in here ------------------------------------------
-        auto kloop = [&](auto live) __attribute__((always_inline)) {
+        auto kloop = [&](auto live, auto split16) __attribute__((always_inline)) {
             for (int kt = 0; kt < nkt; ++kt) {
                 const bool last = kt + 1 == nkt;
                 int k2 = kt + 2;
@@ -482,7 +496,8 @@ igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntile
                 if (!last) g.stage_issue(ml, smem, buf ^ 1, kt + 1, e_nxt);
                 else if (has_next) gn.stage_issue(ml, smem, buf ^ 1, 0, e_nxt);  // first slab of the next tile
                 if (last) epi.prefetch_res(a, rres, m0, n0, M);
-                G::template compute<decltype(live)::value>(smem, buf, acc);
+                if constexpr (decltype(split16)::value != 0) G::template compute_split16<decltype(live)::value>(smem, buf, acc, epi.wscale);
+                else G::template compute<decltype(live)::value>(smem, buf, acc);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 buf ^= 1;
@@ -491,10 +506,13 @@ igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntile
         };
         if constexpr (SKIP && G::TN > 1) {
             // the wave's last channel fragment holds only padding channels (wave-uniform)
-            if (n0 + epi.wn * G::WTN + (G::TN - 1) * 32 >= a.N) kloop(IntC<G::TN - 1>());
-            else kloop(IntC<G::TN>());
+            if (n0 + epi.wn * G::WTN + (G::TN - 1) * 32 >= a.N) kloop(IntC<G::TN - 1>(), IntC<0>());
+            else kloop(IntC<G::TN>(), IntC<0>());
+        } else if constexpr (!BF16) {
+            if (a.split16) kloop(IntC<G::TN>(), IntC<1>());   // (a second copy of the loop, selected per launch)
+            else kloop(IntC<G::TN>(), IntC<0>());
         } else {
-            kloop(IntC<G::TN>());
+            kloop(IntC<G::TN>(), IntC<0>());
         }
         tt_b = GIM_TT_NOW(); tt_k += tt_b - tt_a;
         epi.run(a, acc, rres, smem + (buf ^ 1) * G::STAGE, m0, n0, M, smem + 2 * G::STAGE);  // buf ^ 1: the stage just consumed; UPS: patch rows behind the stages

@@ -225,6 +225,52 @@ struct Igemm {
         }
     }
 
+    // fp32 operands on the 16-bit matrix pipe (round 6; the parity-grade mode at 16-bit MFMA rates): every fp32 value is split in
+    // registers into an IEEE-fp16 pair hi = rn16(x), lo = rn16(x - hi) and the slab's products are evaluated as
+    //     x w ~= hi_x hi_w + hi_x lo_w + lo_x hi_w          (lo_x lo_w <= 2^-22 |x w| is dropped)
+    // i.e. three v_mfma_f32_32x32x16_f16 per 16 K instead of eight v_mfma_f32_32x32x2_f32, fp32 accumulation either way.  Two 16-byte K
+    // steps of the fp32 slab (4 + 4 values per lane) make one 16-bit operand fragment; the pairing is the same on both operands, so the
+    // MFMA's K positions line up.  `wscale` (a power of two) multiplies the weight operand before the split -- it lifts the weights' low
+    // halves out of the fp16 subnormals; the caller divides the accumulators by it (exact) -- and the bias enters pre-multiplied.
+    template <int LIVE = TN>
+    static __device__ __forceinline__ void compute_split16(const char* smem, int buf, Acc& acc, const float wscale) {
+        static_assert(!BF16, "split products are the fp32 operands' path");
+        const FragAddr f = frag_addr(smem, buf);
+        auto split = [](const f32x4_t& v0, const f32x4_t& v1, const float sc, bf16x8_t& hi, bf16x8_t& lo) __attribute__((always_inline)) {
+            unsigned h[4], l[4];
+            float x[8] = {v0[0] * sc, v0[1] * sc, v0[2] * sc, v0[3] * sc, v1[0] * sc, v1[1] * sc, v1[2] * sc, v1[3] * sc};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[e] = cvt_pk_f16(x[2 * e], x[2 * e + 1]);
+                l[e] = cvt_pk_f16(x[2 * e] - f16_lo(h[e]), x[2 * e + 1] - f16_hi(h[e]));
+            }
+            hi = __builtin_bit_cast(bf16x8_t, make_uint4(h[0], h[1], h[2], h[3]));
+            lo = __builtin_bit_cast(bf16x8_t, make_uint4(l[0], l[1], l[2], l[3]));
+        };
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp) {
+            Frags<LIVE> r0, r1;
+            load_frags<LIVE>(f, 2 * kp, r0);
+            load_frags<LIVE>(f, 2 * kp + 1, r1);
+            bf16x8_t ah[TM], al[TM];
+#pragma unroll
+            for (int j = 0; j < TM; ++j) split(r0.a[j], r1.a[j], 1.f, ah[j], al[j]);
+#pragma unroll
+            for (int i = 0; i < LIVE; ++i) {
+                bf16x8_t bh, bl;
+                split(r0.b[i], r1.b[i], wscale, bh, bl);
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    f32x16_t c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gim_f16x8_t, bl), __builtin_bit_cast(gim_f16x8_t, ah[j]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gim_f16x8_t, bh), __builtin_bit_cast(gim_f16x8_t, al[j]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gim_f16x8_t, bh), __builtin_bit_cast(gim_f16x8_t, ah[j]), c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+            }
+        }
+    }
+
     static __device__ __forceinline__ void zero(Acc& acc) {
 #pragma unroll
         for (int i = 0; i < TN; ++i)

@@ -21,7 +21,7 @@ int gim_check_launch(const char* what) {
     return GIM_OK;
 }
 
-extern "C" int gim_version(void) { return 112; }   // 110: health word as an argument (no gim_set_range_guard), count[2 + N] layout of gim_coarse_match; 111: gim_token_emit.kv_* (fused KV state), gim_linear_attention_finalize; 112: gim_coarse_args.precand_per_row, the library reads no environment variable
+extern "C" int gim_version(void) { return 113; }   // 110: health word as an argument (no gim_set_range_guard), count[2 + N] layout of gim_coarse_match; 111: gim_token_emit.kv_* (fused KV state), gim_linear_attention_finalize; 112: gim_coarse_args.precand_per_row, the library reads no environment variable; 113: gim_conv_args.split16
 extern "C" const char* gim_last_error(void) { return g_err; }
 extern "C" int gim_ktile_bytes(void) { return 128; }
 extern "C" int gim_npad_granule(void) { return 64; }

@@ -227,6 +227,9 @@ class LoFTR(nn.Module):
         # profiles/r05_launch_order.txt: two transformer chains -0.2 ms per batch-8 step, the other two do not pay)
         self.depth_groups = flag("depth_groups", 1, config)
         self.l3_chains = flag("l3_chains", 2, config)
+        # precision='fp32': the GEMMs' fp32 operands as IEEE-fp16 hi / lo pairs on the 16-bit MFMA (gim_conv_args.split16: three products per 16 K, 2^-22 each)
+        # instead of v_mfma_f32_32x32x2_f32 (exact fp32 products; the cross-check)
+        self.fp32_split = flag("fp32_split", True, config)
         self.trunk_chains = flag("trunk_chains", False, config)
         self.tf_chains = flag("tf_chains", 2, config)
         # token tails write partial KV states instead of the k / v rows of the next attention (see _transformer_emit; False: rows + la_kv)
@@ -982,7 +985,7 @@ class LoFTR(nn.Module):
                 "feat_c0": T.X32[r0].view(bs, L, C), "feat_c1": T.X32[r1].view(bs, S, C)}
 
     def _graph_key(self, color0, color1, scale0, mask0):
-        return (tuple(color0.shape), tuple(color1.shape), scale0 is not None, mask0 is not None, self.precision,
+        return (tuple(color0.shape), tuple(color1.shape), scale0 is not None, mask0 is not None, self.precision, bool(self.fp32_split),
                 self.coarse_sim, self._img_dt(), self._split(), self._stem_k(), str(color0.device))
 
     def _coarse_stage_graphed(self, key, color0, color1, scale0, scale1, mask0=None, mask1=None):
@@ -1031,6 +1034,15 @@ class LoFTR(nn.Module):
 
     @torch.no_grad()
     def forward(self, data):
+        if self.precision == "fp32" and self.fp32_split and not ops.FP32_SPLIT:
+            ops.FP32_SPLIT = True   # (module state of gim_amd.ops, read at every fp32 conv / linear launch)
+            try:
+                return self._forward(data)
+            finally:
+                ops.FP32_SPLIT = False
+        return self._forward(data)
+
+    def _forward(self, data):
         for k in ("image0", "image1", "color0", "color1"):
             if k not in data:
                 raise KeyError(f"LoFTR.forward needs data[{k!r}] (loftr.py:54-63)")

@@ -186,6 +186,7 @@ def conv_rows(x, pk, geom, y, act=ACT_NONE, res=None, res_mod=0, lds_dma=True, a
     a.res_dtype = gim_dtype(res) if res is not None else GIM_F32
     a.use_lds_dma = (3 if FORCE_BIG_TILE else 1) if lds_dma else 0
     a.health = _health(health).value if (health is not None and res is not None) else None
+    a.split16 = 1 if (FP32_SPLIT and pk.dtype == GIM_F32 and lds_dma) else 0
     assert y.shape[0] >= B * Ho * Wo and y.shape[1] >= pk.n_store
     if ups is not None:
         a.ups, a.ups_h, a.ups_w, a.ups_ld = ups.data_ptr(), ups.shape[1], ups.shape[2], ups.shape[3]
@@ -205,6 +206,9 @@ def conv_rows(x, pk, geom, y, act=ACT_NONE, res=None, res_mod=0, lds_dma=True, a
 
 
 FORCE_BIG_TILE = flag("force_big_tile", False)   # tests: the 256 x 256 tile on every eligible launch, whatever its size (gim_conv_args.use_lds_dma = 3)
+# fp32 operands multiplied as IEEE-fp16 hi / lo pairs on the 16-bit MFMA (gim_conv_args.split16: three products per 16 K instead of eight fp32 MFMAs, 2^-22 per
+# product); module state read at every launch -- gim_loftr's fp32 mode switches it on around its forward (LoFTR.fp32_split)
+FP32_SPLIT = flag("fp32_split_all", False)
 UPS_FUSED = flag("ups_fused", True)   # FPN: bilinear x2 + add inside the lateral 1x1 conv's epilogue (False: a second pass over the output)
 
 

@@ -39,7 +39,8 @@ enum { GIM_OK = 0, GIM_ERR_INVALID = -1, GIM_ERR_LAUNCH = -2, GIM_ERR_UNSUPPORTE
  * 111: struct gim_token_emit grew the kv_part / kv_nchunk / kv_tile0 / kv_len arrays (fused KV state), q_weights (local queries), project_only and pe_*; zero them for
  * the old behaviour;
  * new entries gim_linear_attention_finalize, gim_linear_attention_ws_bytes_chunks.
- * 112 (round 6): gim_coarse_args.precand_per_row appended (zero it for the old behaviour); the library reads no environment variable. */
+ * 112 (round 6): gim_coarse_args.precand_per_row appended (zero it for the old behaviour); the library reads no environment variable.
+ * 113 (round 6): gim_conv_args.split16 appended (zero it for the old behaviour). */
 int gim_version(void);
 /* fp16 range guard.  `health` (NULL: no check): a device word into which the fp16 flavour of the kernels that store un-normalised
  * residual streams (gim_bneck64_fused*, gim_bneck_tail*, gim_conv2d_bn_act with a residual operand) OR 4 when a converted value exceeds
@@ -113,13 +114,19 @@ typedef struct gim_conv_args {
     int use_lds_dma;    /* 1: buffer_load ... lds staging (default); 0: register staging; 2: 3x3 halo kernel (w / ktab / kpad =
                            the halo packing, res_mod = channels stored per input row); 3: as 1, and the 256 x 256 tile takes the launch
                            whatever its size (its selection is a size heuristic: the parity tests reach it on small shapes this way) */
-    const void* ups;    /* NULL, or a half-resolution tensor [B, ups_h, ups_w, ups_ld] (dtype = out_dtype = bf16) whose bilinear x2
-                           upsampling (align_corners=True) is added to the (rounded) conv output in the epilogue: the FPN's
+    const void* ups;    /* NULL, or a half-resolution tensor [B, ups_h, ups_w, ups_ld] (dtype = out_dtype, 16-bit) whose bilinear x2
+                           upsampling (align_corners=True) is added to the conv output in fp32, in front of the ONE 16-bit rounding (round 6:
+                           as 48 more K of the MFMA per 32-pixel pass; act must be GIM_ACT_NONE): the FPN's
                            `x2_out + F.interpolate(x3_out, scale_factor=2.)` (backbone/resnet.py:321-327) without a second pass
                            over y.  Output rows = (image, Y < 2 ups_h, X < 2 ups_w); needs (2 ups_w) % 32 == 0 and a launch the 256 x 256 tile takes
                            (1x1 conv, bf16, no residual, npad % 256 == 0, >= 4 K slabs, >= 512 tiles): gim_conv_ups_supported() */
     int ups_h, ups_w, ups_ld;
     int32_t* health;    /* fp16 range guard (see the top of this file) or NULL: checked where a residual operand is added (fp16 flavour) */
+    int split16;        /* fp32 operands only (ABI 113).  0: products on v_mfma_f32_32x32x2_f32 (exact fp32 products).  1: every fp32 operand value is
+                           split in registers into an IEEE-fp16 pair hi + lo and x w is evaluated as hi hi + hi lo + lo hi on v_mfma_f32_32x32x16_f16
+                           with fp32 accumulation (weights scaled by 2^12 for the split, accumulators scaled back): 2^-22 relative per product at
+                           3/8 of the matrix-pipe time; needs |x| < 65504 and |w| < 16 (a value beyond becomes inf, the output NaN) */
+    int pad_;
 } gim_conv_args;
 int gim_conv_ups_supported(const gim_conv_args* a);   /* 1 if gim_conv2d_bn_act would take a->ups (set or not) for this launch */
 int gim_conv2d_bn_act(const gim_conv_args* a, gim_stream_t stream);

@@ -389,7 +389,8 @@ def main():
                        "serial_copy = the same copies issued on the compute stream (round 2's figure)"}
 
     # ---- the other precision modes on the same workload and batch, timed the same way -----------------------------------------
-    #   parity_mode: precision='fp32' (exact fp32 MFMA products) -- the mode whose match indices equal the oracle's
+    #   parity_mode: precision='fp32' (fp32 storage; products as fp16 hi / lo pairs since round 6, exact fp32 MFMA products as `exact_products`) -- the mode whose
+    #                match indices equal the oracle's
     #   bf16_mode / fp16_mode: the OTHER 16-bit flavour of the same kernels (same MFMA rate, same bytes): bf16 has fp32's exponent
     #                range and 8 significand bits per stored activation, fp16 has 11 (a quarter of bf16's index flips)
     alt_modes = {}
@@ -400,7 +401,7 @@ def main():
                  "bf16": ("fp16_mode", "fp16", "the same kernels in their IEEE fp16 flavour (v_mfma_f32_32x32x16_f16, v_cvt_pk_f16_f32): same "
                                                "instruction counts and bytes, |activation| < 65504")}[args.precision]
         for name, prec, n_alt, note in (
-                ("parity_mode", "fp32", 5, "every GEMM on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
+                ("parity_mode", "fp32", 5, "every GEMM on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)"),   # (note replaced below when the mode runs split products)
                 (other[0], other[1], args.steps, other[2])):
             model.set_precision(prec)
             for _ in range(3):
@@ -414,6 +415,23 @@ def main():
             alt_modes[name] = ({"precision": prec, "pairs_per_s": round(nb / ta, 2), "ms_per_step": round(1e3 * ta, 3), "steps": n_alt,
                                 "matches_per_pair": round(da["b_ids"].numel() / nb, 1), "note": "same workload and batch; " + note},
                                {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in da.items() if k != "conf_matrix"})
+            if prec == "fp32" and getattr(model, "fp32_split", False):
+                # the cross-check: the same mode with every product on v_mfma_f32_32x32x2_f32 (exact fp32 products) instead of fp16 hi / lo pairs
+                model.fp32_split = False
+                for _ in range(2):
+                    dx = step()
+                torch.cuda.synchronize()
+                tx = time.perf_counter()
+                for _ in range(3):
+                    dx = step()
+                torch.cuda.synchronize()
+                tx = (time.perf_counter() - tx) / 3
+                model.fp32_split = True
+                alt_modes[name][0]["note"] = ("same workload and batch; fp32 storage, the fp32 operands of every GEMM split in registers into IEEE-fp16 hi / lo pairs and "
+                                              "multiplied as hi hi + hi lo + lo hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation (gim_conv_args.split16, round 6: "
+                                              "2^-22 per product, tests/test_gpu_split16.py); `exact_products` = the same mode on v_mfma_f32_32x32x2_f32")
+                alt_modes[name + ".exact_products"] = ({"pairs_per_s": round(nb / tx, 2), "ms_per_step": round(1e3 * tx, 3), "steps": 3},
+                                                       {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in dx.items() if k != "conf_matrix"})
         model.set_precision(args.precision, args.coarse_sim)
         torch.cuda.empty_cache()
 
@@ -667,6 +685,8 @@ def main():
                 model._invalidate()
             for nm, (rec, d_alt) in alt_modes.items():
                 rec["parity"] = parity_vs_oracle(d_alt, ref, 0)
+    if "parity_mode.exact_products" in alt_modes:
+        alt_modes["parity_mode"][0]["exact_products"] = alt_modes.pop("parity_mode.exact_products")[0]
 
     if rank == 0 and os.environ.get("GIM_BENCH_DEBUG"):
         print("per-step ms:", [round(1e3 * (b - a), 2) for a, b in zip([t0] + tstep[:-1], tstep)], file=sys.stderr)

@@ -157,7 +157,7 @@ struct Epilogue {
     static constexpr int NI = 32 / RPI;            // row-layout instructions per 32-pixel pass (4 / 8)
     static constexpr int WAVE_BYTES = 32 * RB;     // transposition tile of one wave
     static_assert(G::NW * WAVE_BYTES <= G::STAGE, "transposition tiles must fit in one stage buffer");
-    typedef uint4 Res[HAS_RES ? TM : 1][HAS_RES ? NI : 1];
+    typedef uint4 Res[(HAS_RES && OUT_BF16) ? TM : 1][(HAS_RES && OUT_BF16) ? NI : 1];
 
     int wm, wn, l31, lh, rrow, rslot, wave;
     float wscale = 1.f;   // fp32 operands as fp16 hi / lo pairs (Igemm::compute_split16): the weight operand's power-of-two scale -- the bias enters times it, run() divides
@@ -187,8 +187,11 @@ struct Epilogue {
     }
 
     // coalesced residual rows of the tile -> registers (issued before the tile's last slab is computed)
+    // (fp32 rows: not prefetched -- 64 registers held across the last slab's MFMAs spilled 23 registers in round 5's kernel and 267 beside the
+    //  split-product loop of round 6; run() loads them pass by pass instead)
+    static constexpr bool RES_PREFETCH = HAS_RES && OES == 2;
     __device__ __forceinline__ void prefetch_res(const gim_conv_args& a, Res& rres, int m0, int n0, int M) const {
-        if constexpr (HAS_RES) {
+        if constexpr (RES_PREFETCH) {
             const bool full = (m0 + G::A_BYTES / KTB <= M) && (n0 + G::B_BYTES / KTB <= a.N);
             const int ncol = n0 + wn * WTN + rslot * (16 / OES);
             const bool ncol_ok = full || ncol < a.N;
@@ -338,10 +341,26 @@ struct Epilogue {
                 const int ncol = n0 + wn * WTN + nh * 64 + rslot * (16 / OES);
                 const bool ncol_ok = full || ncol < a.N;
                 if constexpr (HAS_RES) {
+                    if constexpr (RES_PREFETCH) {
 #pragma unroll
-                    for (int k = 0; k < NI; ++k) {
-                        const int row = k * RPI + rrow;
-                        *(uint4*)(wl + row * RB + ((rslot ^ (row & 7)) << 4)) = rres[j][k];
+                        for (int k = 0; k < NI; ++k) {
+                            const int row = k * RPI + rrow;
+                            *(uint4*)(wl + row * RB + ((rslot ^ (row & 7)) << 4)) = rres[j][k];
+                        }
+                    } else {
+                        uint4 rr[NI];
+#pragma unroll
+                        for (int k = 0; k < NI; ++k) {
+                            const int m = m0 + wm * WTM + j * 32 + k * RPI + rrow;
+                            const bool ok = ncol_ok && (full || m < M);
+                            const size_t ro = (size_t)(a.res_mod > 0 ? m % a.res_mod : m) * a.ldres + ncol;
+                            rr[k] = ok ? *(const uint4*)((const char*)a.res + ro * OES) : make_uint4(0u, 0u, 0u, 0u);
+                        }
+#pragma unroll
+                        for (int k = 0; k < NI; ++k) {
+                            const int row = k * RPI + rrow;
+                            *(uint4*)(wl + row * RB + ((rslot ^ (row & 7)) << 4)) = rr[k];
+                        }
                     }
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
@@ -509,7 +528,8 @@ igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntile
             if (n0 + epi.wn * G::WTN + (G::TN - 1) * 32 >= a.N) kloop(IntC<G::TN - 1>(), IntC<0>());
             else kloop(IntC<G::TN>(), IntC<0>());
         } else if constexpr (!BF16) {
-            if (a.split16) kloop(IntC<G::TN>(), IntC<1>());   // (a second copy of the loop, selected per launch)
+            if constexpr (BM == 256 && BN == 256) kloop(IntC<G::TN>(), IntC<1>());   // (only split launches are sent to this tile: dispatch_persistent)
+            else if (a.split16) kloop(IntC<G::TN>(), IntC<1>());   // (a second copy of the loop, selected per launch)
             else kloop(IntC<G::TN>(), IntC<0>());
         } else {
             kloop(IntC<G::TN>(), IntC<0>());
@@ -809,6 +829,12 @@ int dispatch_persistent(const gim_conv_args& a, hipStream_t s) {
             }
             if (skip) return launch_persistent<256, 256, 4, 2, BF16, true, false, true>(a, s);
             return launch_persistent<256, 256, 4, 2, BF16, true, false>(a, s);
+        }
+        // fp32 operands multiplied as fp16 hi / lo pairs (split16): the 256 x 256 tile halves the splits and the staged bytes per MFMA
+        if constexpr (!BF16) {
+            if (a.split16 && a.npad % 256 == 0 && a.out_dtype == GIM_F32 && !a.res && !a.ups &&
+                (a.use_lds_dma == 3 || (nkt >= 2 * BIG_MIN_NKT && ((M + 255) / 256) * (a.npad / 256) >= BIG_MIN_TILES)))
+                return launch_persistent<256, 256, 4, 2, false, false, false>(a, s);
         }
         // (a 512 x 128 tile with 128 x 64 wave tiles for the N = 128 layers measured slower than 128 x 128: 875 vs 716 us
         //  on 196->128 3x3 -- not built)

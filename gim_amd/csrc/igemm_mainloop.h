@@ -249,16 +249,16 @@ struct Igemm {
         };
 #pragma unroll
         for (int kp = 0; kp < 2; ++kp) {
-            Frags<LIVE> r0, r1;
-            load_frags<LIVE>(f, 2 * kp, r0);
-            load_frags<LIVE>(f, 2 * kp + 1, r1);
+            // (fragments are loaded where they are split: all of a K step's fp32 fragments at once are 48 registers on the 64 x 128 wave tile)
+            const int so0 = ((2 * (2 * kp) + f.lh) ^ f.lswz) << 4, so1 = ((2 * (2 * kp + 1) + f.lh) ^ f.lswz) << 4;
             bf16x8_t ah[TM], al[TM];
 #pragma unroll
-            for (int j = 0; j < TM; ++j) split(r0.a[j], r1.a[j], 1.f, ah[j], al[j]);
+            for (int j = 0; j < TM; ++j)
+                split(*(const f32x4_t*)(f.sA + j * 32 * KTB + so0), *(const f32x4_t*)(f.sA + j * 32 * KTB + so1), 1.f, ah[j], al[j]);
 #pragma unroll
             for (int i = 0; i < LIVE; ++i) {
                 bf16x8_t bh, bl;
-                split(r0.b[i], r1.b[i], wscale, bh, bl);
+                split(*(const f32x4_t*)(f.sB + i * 32 * KTB + so0), *(const f32x4_t*)(f.sB + i * 32 * KTB + so1), wscale, bh, bl);
 #pragma unroll
                 for (int j = 0; j < TM; ++j) {
                     f32x16_t c = acc[i][j];

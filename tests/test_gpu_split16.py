@@ -15,9 +15,14 @@ CASES = [  # B, H, W, cin, cout, k, stride, res, act
 ]
 
 
+@pytest.mark.parametrize("big", [False, True], ids=["tile128", "tile256"])
 @pytest.mark.parametrize("case", CASES, ids=[f"{c[3]}to{c[4]}_k{c[5]}s{c[6]}" for c in CASES])
-def test_split16_conv_vs_float64(case, monkeypatch):
+def test_split16_conv_vs_float64(case, big, monkeypatch):
+    """big: the 256 x 256 tile (fp32 output, no residual, N padded to 256) takes the split launch whatever its size (gim_conv_args.use_lds_dma = 3)"""
     from gim_amd import _lib, ops
+    if big and (case[7] or case[4] not in (196, 256)):
+        pytest.skip("the 256 x 256 tile takes no residual and needs npad % 256 == 0")
+    monkeypatch.setattr(ops, "FORCE_BIG_TILE", big)
     from gim_amd.packing import cstore, pack_conv
     B, H, W, cin, cout, k, stride, has_res, act = case
     dev = torch.device("cuda:0")

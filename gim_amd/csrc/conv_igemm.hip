@@ -525,8 +525,8 @@ igemm_persistent_kernel(const gim_conv_args a, const int mtiles, const int ntile
         };
         if constexpr (SKIP && G::TN > 1) {
             // the wave's last channel fragment holds only padding channels (wave-uniform)
-            if (n0 + epi.wn * G::WTN + (G::TN - 1) * 32 >= a.N) kloop(IntC<G::TN - 1>(), IntC<0>());
-            else kloop(IntC<G::TN>(), IntC<0>());
+            if (n0 + epi.wn * G::WTN + (G::TN - 1) * 32 >= a.N) kloop(IntC<G::TN - 1>(), IntC<BF16 ? 0 : 1>());   // (fp32 operands reach this tile as split launches only)
+            else kloop(IntC<G::TN>(), IntC<BF16 ? 0 : 1>());
         } else if constexpr (!BF16) {
             if constexpr (BM == 256 && BN == 256) kloop(IntC<G::TN>(), IntC<1>());   // (only split launches are sent to this tile: dispatch_persistent)
             else if (a.split16) kloop(IntC<G::TN>(), IntC<1>());   // (a second copy of the loop, selected per launch)
@@ -834,7 +834,8 @@ int dispatch_persistent(const gim_conv_args& a, hipStream_t s) {
         if constexpr (!BF16) {
             if (a.split16 && a.npad % 256 == 0 && a.out_dtype == GIM_F32 && !a.res && !a.ups &&
                 (a.use_lds_dma == 3 || (nkt >= 2 * BIG_MIN_NKT && ((M + 255) / 256) * (a.npad / 256) >= BIG_MIN_TILES)))
-                return launch_persistent<256, 256, 4, 2, false, false, false>(a, s);
+                return a.N <= a.npad - 32 ? launch_persistent<256, 256, 4, 2, false, false, false, true>(a, s)   // (196 channels: the all-padding fragment is skipped)
+                                          : launch_persistent<256, 256, 4, 2, false, false, false>(a, s);
         }
         // (a 512 x 128 tile with 128 x 64 wave tiles for the N = 128 layers measured slower than 128 x 128: 875 vs 716 us
         //  on 196->128 3x3 -- not built)

@@ -795,6 +795,11 @@ int launch_halo(const gim_conv_args& a, hipStream_t stream) {
 // Round 5: the experimental main-loop variants (3-stage ring, ping-pong, loader waves: each exact, each measured no faster -- DESIGN.md
 // section 4, "what the counters said") and their GIM_IGEMM_* switches are gone from the library; git history has them.
 constexpr int BIG_MIN_TILES = 1024, BIG_MIN_NKT = 4;
+// Round 6: ... or between half a round and ONE round of the 256 one-per-CU workgroups (128 <= tiles <= 256).  Such a launch leaves CUs idle on its own, but it is
+// what layer 3 of one image chain of the batch-8 benchmark is (150 tiles: the other chain's kernels run on the idle CUs), and alone it costs about what the 600
+// 128 x 128 tiles in 1.17 rounds do.  Same box, two chains: 9.59 vs 9.73 ms per step.  Between one and four rounds the smaller tile's finer quantisation wins.
+// (deep K only -- 16 slabs, i.e. the 3 x 3 layers: gim_lightglue's 128- and 256-tile Linears, K = 256 / 512, measured 1.5 % slower on the big tile)
+static bool big_tile_count(long long tiles, int nkt) { return tiles >= BIG_MIN_TILES || (tiles >= 128 && tiles <= 256 && nkt >= 16); }
 
 template <int BM, int BN, int WM, int WN, bool BF16>
 int dispatch_res(const gim_conv_args& a, hipStream_t s) {
@@ -819,7 +824,7 @@ int dispatch_persistent(const gim_conv_args& a, hipStream_t s) {
         // 256 x 256 tile, 8 waves, 64 x 128 wave tile: twice the MFMAs per wave and slab against nearly the same
         // staging / addressing overhead -- for the MFMA-bound layers (no residual, bf16 out, N % 256 == 0)
         if (a.npad % 256 == 0 && out_is16(a) && !a.res &&
-            (a.use_lds_dma == 3 || (nkt >= BIG_MIN_NKT && ((M + 255) / 256) * (a.npad / 256) >= BIG_MIN_TILES)))   // 3: the tests' way onto this tile
+            (a.use_lds_dma == 3 || (nkt >= BIG_MIN_NKT && big_tile_count(((M + 255) / 256) * (a.npad / 256), nkt))))   // 3: the tests' way onto this tile
         {
             // N <= 224 (the FPN's 196-channel layers): the second column half's last fragment is pure padding
             const bool skip = a.N <= a.npad - 32;
@@ -833,7 +838,7 @@ int dispatch_persistent(const gim_conv_args& a, hipStream_t s) {
         // fp32 operands multiplied as fp16 hi / lo pairs (split16): the 256 x 256 tile halves the splits and the staged bytes per MFMA
         if constexpr (!BF16) {
             if (a.split16 && a.npad % 256 == 0 && a.out_dtype == GIM_F32 && !a.res && !a.ups &&
-                (a.use_lds_dma == 3 || (nkt >= 2 * BIG_MIN_NKT && ((M + 255) / 256) * (a.npad / 256) >= BIG_MIN_TILES)))
+                (a.use_lds_dma == 3 || (nkt >= 2 * BIG_MIN_NKT && big_tile_count(((M + 255) / 256) * (a.npad / 256), nkt))))
                 return a.N <= a.npad - 32 ? launch_persistent<256, 256, 4, 2, false, false, false, true>(a, s)   // (196 channels: the all-padding fragment is skipped)
                                           : launch_persistent<256, 256, 4, 2, false, false, false>(a, s);
         }
@@ -887,7 +892,7 @@ static bool ups_supported(const gim_conv_args& a) {
     if (a.act_cols != 0 || a.act != GIM_ACT_NONE) return false;   // the upsampled map is added in front of the activation slot: only the FPN's bare lateral conv
     const int nkt = a.kpad * 2 / KTB;
     const long long M = (long long)a.B * a.Ho * a.Wo;
-    return a.use_lds_dma == 3 || (nkt >= BIG_MIN_NKT && ((M + 255) / 256) * (a.npad / 256) >= BIG_MIN_TILES);
+    return a.use_lds_dma == 3 || (nkt >= BIG_MIN_NKT && big_tile_count(((M + 255) / 256) * (a.npad / 256), nkt));
 }
 
 #if !GIM_HALF_KIND

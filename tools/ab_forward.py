@@ -9,7 +9,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--worker":
     from tools import synth_loftr as S
     m, _ = S.synthetic_model(os.environ.get("GIM_AB_PRECISION", "fp16"))
     m = m.cuda()
-    c0, c1 = S.textured_pairs(8, 480, 640, seed=1234, frac=0.45)
+    c0, c1 = S.textured_pairs(int(os.environ.get("GIM_AB_BATCH", "8")), 480, 640, seed=1234, frac=0.45)
     c0, c1 = c0.cuda(), c1.cuda()
     def step():
         d = {"image0": c0[:, :1], "image1": c1[:, :1], "color0": c0, "color1": c1}

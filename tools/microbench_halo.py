@@ -58,7 +58,7 @@ for r in range(rounds + 1):
                 if kind == "generic":
                     ref[name] = yy.clone()
                 else:
-                    d = (yy - ref[name]).abs().max().item() / ref[name].abs().max().item()
+                    d = (yy - ref[name]).abs().max().item() / (ref[name].abs().max().item() or 1.0)
                     print(f"{name} {kind}: max deviation from the generic kernel {d:.2e} of scale")
 for name, pk, x, y, act, fl in cases:
     row = []
